@@ -1,0 +1,67 @@
+"""Builds libreftr_hip.so (the C-ABI kernel library declared in include/reftr_hip.h) for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container as well as on the
+MI355X box.  The .so lives IN-TREE (reftr_amd/libreftr_hip.so): it is git-ignored but travels with
+the gpurun snapshot, and the round-end check sees it among the loaded shared objects.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+OBJ_DIR = os.path.join(_HERE, "build", "obj")
+LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return max(os.path.getmtime(d) for d in deps)
+
+
+def _compile_one(src, hdr_mtime, force):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+            and os.path.getmtime(obj) >= hdr_mtime):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    """Compile every csrc/*.hip for gfx950 and link libreftr_hip.so.  Returns the library path."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = _sources()
+    hdr_mtime = _deps_mtime()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile_one(s, hdr_mtime, force), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(ch for _, ch in results)
+    if rebuilt or not os.path.exists(LIB_PATH) or force:
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[reftr_amd] {LIB_PATH} ({'rebuilt' if rebuilt else 'up to date'}, {len(objs)} objects)")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

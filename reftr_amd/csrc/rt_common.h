@@ -1,0 +1,67 @@
+// Shared device helpers for the RefTR gfx950 kernels (CDNA4, wave64).
+// All kernels in this directory are written for MI355X only: 64-lane waves,
+// MFMA 16x16x32 bf16 fragments, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/reftr_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define RT_WAVE 64
+
+__device__ __forceinline__ float rt_bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t rt_f2bf(float v) { return (bf16_t)v; }
+
+// Counter-based dropout hash: keep element `idx` of site `seed` iff hash >= thresh
+// (thresh = p * 2^32).  Forward and backward regenerate the same mask from
+// (seed, idx); the oracle restates the same integer arithmetic in numpy.
+__device__ __forceinline__ uint32_t rt_hash32(uint32_t seed, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u ^ seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rt_drop_thresh(float p) {
+    return (uint32_t)((double)p * 4294967296.0);
+}
+
+__device__ __forceinline__ float rt_gelu(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float rt_gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float rt_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float rt_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); `sm` holds >= 16 floats.
+__device__ __forceinline__ float rt_block_sum(float v, float* sm) {
+    v = rt_wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sm[i];
+    return r;
+}
+
+#define RT_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,0 +1,261 @@
+// rt_conv_gemm: bf16 MFMA implicit-GEMM for conv forward / backward-data and every Linear on the
+// RefTR path (see include/reftr_hip.h for the reference call sites this replaces).
+//
+// Shape of the computation (per workgroup, 256 threads = 4 waves arranged 2(n) x 2(m)):
+//   D[n, m] = sum_k Wt[n, k] * Xg[m, k]      (weights are the MFMA "A" operand, gathered pixels "B")
+// so that each lane ends up with 4 CONSECUTIVE output channels of one pixel (C/D layout of
+// v_mfma_f32_16x16x32_bf16: col = lane&15 -> pixel, row = 4*(lane>>4)+r -> channel) and the NHWC
+// epilogue store is an 8-byte (bf16x4) / 16-byte (f32x4) contiguous write.
+//
+// K pipeline: 64-wide K tiles, global -> VGPR (predicated 16-B loads: conv padding / ragged M,N read as
+// zero) -> XOR-swizzled LDS (slot ^= row&7, conflict-free for ds_read_b128 fragment reads), LDS double
+// buffered with ONE barrier per K tile; next tile's global loads are in flight under the MFMAs.
+#include "rt_common.h"
+
+namespace {
+
+struct GemmArgs {
+    const bf16_t* src; const bf16_t* wgt;
+    bf16_t* out_bf16; float* out_f32;
+    const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact;
+    int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act;
+    float gate_scale, drop_p; uint32_t drop_seed;
+    int M, K, sshift;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
+    constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 MFMA tiles per wave along m / n
+    constexpr int AJ = BN / 32, BJ = BM / 32;      // 16-B staging chunks per thread
+    constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, BUF_BYTES = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+    const int n0 = tile_n * BN, m0 = tile_m * BM;
+
+    const int chunk = t & 7, srow = t >> 3;
+
+    // Decode the destination pixel of each staged activation row once.
+    int b_pix[BJ], b_y[BJ], b_x[BJ];
+    bool b_ok[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int m = m0 + srow + 32 * j;
+        b_ok[j] = m < p.M;
+        const int mm = b_ok[j] ? m : 0;
+        const int dx = mm % p.DW;
+        const int tmp = mm / p.DW;
+        const int dy = tmp % p.DH;
+        const int b = tmp / p.DH;
+        b_pix[j] = b * p.SH * p.SW;
+        if (!p.transposed) { b_y[j] = dy * p.stride - p.pad; b_x[j] = dx * p.stride - p.pad; }
+        else               { b_y[j] = dy + p.pad;            b_x[j] = dx + p.pad; }
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[AJ], rb[BJ];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int nk = p.K >> 6;
+
+#define RT_LOAD_TILES(kt_)                                                                         \
+    {                                                                                              \
+        const int k0 = (kt_) << 6;                                                                 \
+        const int tap = k0 / p.SC;                                                                 \
+        const int c0 = k0 - tap * p.SC;                                                            \
+        const int kh = tap / p.KW;                                                                 \
+        const int kw = tap - kh * p.KW;                                                            \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                           \
+            const int n = n0 + srow + 32 * j;                                                      \
+            ra[j] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.wgt + (size_t)n * p.K + k0 + chunk * 8) : zero4; \
+        }                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                           \
+            int sy, sx; bool ok = b_ok[j];                                                         \
+            if (!p.transposed) { sy = b_y[j] + kh; sx = b_x[j] + kw; }                             \
+            else {                                                                                 \
+                const int ny = b_y[j] - kh, nx = b_x[j] - kw;                                      \
+                const int msk = p.stride - 1;                                                      \
+                ok = ok && ny >= 0 && nx >= 0 && ((ny & msk) == 0) && ((nx & msk) == 0);           \
+                sy = ny >> p.sshift; sx = nx >> p.sshift;                                          \
+            }                                                                                      \
+            ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;             \
+            rb[j] = ok ? *reinterpret_cast<const uint4*>(p.src + ((size_t)(b_pix[j] + sy * p.SW + sx)) * p.SC + c0 + chunk * 8) : zero4; \
+        }                                                                                          \
+    }
+
+#define RT_STORE_TILES(buf_)                                                                       \
+    {                                                                                              \
+        unsigned char* bA = smem + (buf_) * BUF_BYTES;                                             \
+        unsigned char* bB = bA + A_BYTES;                                                          \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                           \
+            const int row = srow + 32 * j;                                                         \
+            *reinterpret_cast<uint4*>(bA + row * 128 + ((chunk ^ (row & 7)) << 4)) = ra[j];        \
+        }                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                           \
+            const int row = srow + 32 * j;                                                         \
+            *reinterpret_cast<uint4*>(bB + row * 128 + ((chunk ^ (row & 7)) << 4)) = rb[j];        \
+        }                                                                                          \
+    }
+
+    RT_LOAD_TILES(0);
+    RT_STORE_TILES(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool has_next = (kt + 1) < nk;
+        if (has_next) RT_LOAD_TILES(kt + 1);
+
+        const unsigned char* bA = smem + cur * BUF_BYTES;
+        const unsigned char* bB = bA + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TN], bfr[TM];
+            const int slot = ((kk * 4 + lg) ^ (li & 7)) << 4;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int row = wn * (BN / 2) + a * 16 + li;
+                af[a] = *reinterpret_cast<const bf16x8*>(bA + row * 128 + slot);
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int row = wm * (BM / 2) + b * 16 + li;
+                bfr[b] = *reinterpret_cast<const bf16x8*>(bB + row * 128 + slot);
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+        if (has_next) RT_STORE_TILES(cur ^ 1);
+        __syncthreads();
+    }
+#undef RT_LOAD_TILES
+#undef RT_STORE_TILES
+
+    // ---- epilogue: +bias -> act -> dropout -> +res -> *gate -> *gelu'(preact) -> store ----
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float keep_scale = do_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        const int n = n0 + wn * (BN / 2) + a * 16 + lg * 4;
+        if (n >= p.N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = m0 + wm * (BM / 2) + b * 16 + li;
+            if (m >= p.M) continue;
+            f32x4 v = acc[a][b] + bv;
+            if (p.act == RT_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.act == RT_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rt_gelu(v[r]);
+            } else if (p.act == RT_ACT_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            }
+            const size_t o = (size_t)m * p.N + n;
+            if (do_drop) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (rt_hash32(p.drop_seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
+            }
+            if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
+            if (p.res_bf16) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (p.gate) {
+                const bf16x4 gg = *reinterpret_cast<const bf16x4*>(p.gate + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = ((float)gg[r] > 0.f) ? v[r] * p.gate_scale : 0.f;
+            }
+            if (p.preact) {
+                const bf16x4 uu = *reinterpret_cast<const bf16x4*>(p.preact + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= rt_gelu_grad((float)uu[r]);
+            }
+            if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
+            if (p.out_bf16) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(p.out_bf16 + o) = ov;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch_gemm(const GemmArgs& a, hipStream_t s) {
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    const size_t smem = 2 * (size_t)(BM + BN) * 128;
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN>), dim3((unsigned)(mt * nt)), dim3(256), smem, s, a);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
+    if (!d || !d->src || !d->wgt || (!d->out_bf16 && !d->out_f32)) return RT_ERR_BADARG;
+    if (d->SC <= 0 || (d->SC & 63) || (d->N & 3) || d->N <= 0) return RT_ERR_UNSUPPORTED;
+    if (d->stride != 1 && d->stride != 2) return RT_ERR_UNSUPPORTED;
+    if (d->KH <= 0 || d->KW <= 0 || d->B <= 0 || d->DH <= 0 || d->DW <= 0) return RT_ERR_BADARG;
+    GemmArgs a;
+    a.src = (const bf16_t*)d->src; a.wgt = (const bf16_t*)d->wgt;
+    a.out_bf16 = (bf16_t*)d->out_bf16; a.out_f32 = d->out_f32;
+    a.bias = d->bias; a.res_f32 = d->res_f32; a.res_bf16 = (const bf16_t*)d->res_bf16;
+    a.gate = (const bf16_t*)d->gate; a.preact = (const bf16_t*)d->preact;
+    a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed;
+    a.act = d->act; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
+    const long long M = (long long)d->B * d->DH * d->DW;
+    if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
+    a.M = (int)M; a.K = d->KH * d->KW * d->SC; a.sshift = d->stride == 2 ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+
+    int hint = d->tile_hint;
+    if (hint == 0) {
+        const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
+        if (a.N > 64 && t128 >= 384) hint = 1;
+        else if (t12864 >= 256) hint = 2;
+        else hint = 3;
+    }
+    switch (hint) {
+        case 1: return launch_gemm<128, 128>(a, s);
+        case 2: return launch_gemm<128, 64>(a, s);
+        case 3: return launch_gemm<64, 64>(a, s);
+        default: return RT_ERR_BADARG;
+    }
+}
+
+extern "C" int rt_abi_version(void) { return 1; }
+
+extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    if (!buf || buflen <= 0) return RT_ERR_BADARG;
+    int i = 0;
+    for (; i < buflen - 1 && prop.gcnArchName[i]; ++i) buf[i] = prop.gcnArchName[i];
+    buf[i] = 0;
+    return RT_OK;
+}

@@ -1,0 +1,147 @@
+"""GPU parity of rt_conv_gemm / rt_conv_wgrad against a plain torch fp32 reference of the same op
+(floating-point kernels: inputs are bf16-representable, accumulation fp32 -> fp32 outputs must agree to
+~1e-5 rel-L2; bf16 outputs to bf16 rounding)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 2e-5      # fp32-accumulated result vs fp32 CPU reference (summation order only)
+TOL_BF16 = 3e-3     # result rounded to bf16 (2^-9 relative per element)
+
+
+def rel(a, b):
+    a = a.float().cpu()
+    b = b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf(x):
+    return x.bfloat16()
+
+
+def nhwc(x):  # NCHW -> NHWC contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def hash_keep(seed, idx, p):
+    """numpy restatement of rt_hash32 / rt_drop_thresh (csrc/rt_common.h)."""
+    x = (idx.astype(np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    x = x ^ np.uint64(seed)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13); x = (x * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    thresh = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    return x >= thresh
+
+
+@pytest.mark.parametrize("M,K,N,hint", [
+    (200, 256, 256, 0), (200, 256, 256, 1), (200, 256, 256, 2), (200, 256, 256, 3),
+    (3520, 256, 2048, 0), (3520, 2048, 256, 0), (320, 768, 3072, 0), (8, 256, 256, 0),
+    (48, 256, 4, 0), (129, 64, 68, 0),
+])
+def test_linear_fwd(hip, M, K, N, hint):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = bf(torch.randn(M, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g)
+    ref = x.float() @ w.float().T + b
+    ob, of = hip.linear(x.cuda(), w.cuda(), bias=b.cuda(), out_bf16=True, out_f32=True, tile_hint=hint)
+    assert rel(of, ref) < TOL_F32
+    assert rel(ob, ref) < TOL_BF16
+    # asymmetric check against transposition: single row/col spot values
+    assert torch.allclose(of.cpu()[M - 1, N - 1], ref[M - 1, N - 1], rtol=1e-4, atol=1e-4)
+
+
+def test_linear_epilogue(hip):
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 333, 128, 192
+    x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g)
+    rf = torch.randn(M, N, generator=g); rb = bf(torch.randn(M, N, generator=g))
+    gate = bf(torch.randn(M, N, generator=g)); pre = bf(torch.randn(M, N, generator=g))
+    lin = x.float() @ w.float().T + b
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    for act, fn in [(hip.ACT_RELU, torch.relu), (hip.ACT_GELU, F.gelu), (hip.ACT_TANH, torch.tanh)]:
+        _, of = hip.linear(xc, wc, bias=bc, act=act, out_bf16=False, out_f32=True)
+        assert rel(of, fn(lin)) < 1e-4, act
+    _, of = hip.linear(xc, wc, bias=bc, res_f32=rf.cuda(), res_bf16=rb.cuda(), out_bf16=False, out_f32=True)
+    assert rel(of, lin + rf + rb.float()) < TOL_F32
+    _, of = hip.linear(xc, wc, bias=bc, gate=gate.cuda(), gate_scale=1.25, out_bf16=False, out_f32=True)
+    assert rel(of, lin * (gate.float() > 0) * 1.25) < TOL_F32
+    _, of = hip.linear(xc, wc, bias=bc, preact=pre.cuda(), out_bf16=False, out_f32=True)
+    u = pre.float().requires_grad_(True)
+    F.gelu(u).sum().backward()
+    assert rel(of, lin * u.grad) < 1e-4
+    # dropout: mask must be the documented hash of (seed, m*N+n)
+    p, seed = 0.1, 1234
+    _, of = hip.linear(xc, wc, bias=bc, drop_p=p, drop_seed=seed, out_bf16=False, out_f32=True)
+    keep = torch.from_numpy(hash_keep(seed, np.arange(M * N, dtype=np.uint64), p).reshape(M, N))
+    assert rel(of, lin * keep / (1 - np.float32(p))) < TOL_F32
+    assert abs(float(keep.float().mean()) - 0.9) < 0.01
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 20, 20, 64, 64, 3, 1, 1),
+    (2, 20, 24, 128, 128, 3, 2, 1),
+    (2, 20, 20, 256, 512, 1, 2, 0),
+    (2, 10, 14, 512, 128, 1, 1, 0),
+    (1, 13, 17, 64, 128, 3, 2, 1),
+    (3, 9, 9, 64, 64, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(hip, B, H, W, Ci, Co, k, s, p):
+    g = torch.Generator().manual_seed(B * 100 + H + Ci)
+    x = bf(torch.randn(B, Ci, H, W, generator=g)).float().requires_grad_(True)
+    w = bf(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).float().requires_grad_(True)
+    bias = torch.randn(Co, generator=g)
+    y = F.conv2d(x, w, bias, stride=s, padding=p)
+    Ho, Wo = y.shape[-2:]
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy.float())
+    x_nhwc = nhwc(x.detach()).bfloat16().cuda()
+    w_k = w.detach().permute(0, 2, 3, 1).contiguous().bfloat16().cuda()        # [Co][kh][kw][Ci]
+    geom = (B, H, W, Ci, Ho, Wo, Co, k, k, s, p)
+    ob, of = hip.conv_gemm(x_nhwc, w_k, geom=geom, bias=bias.cuda(), out_bf16=True, out_f32=True)
+    ref = nhwc(y.detach()).reshape(-1, Co)
+    assert rel(of, ref) < TOL_F32
+    assert rel(ob, ref) < TOL_BF16
+    # backward-data: transposed gather over dy with [Ci][kh][kw][Co] weights
+    w_t = w.detach().permute(1, 2, 3, 0).contiguous().bfloat16().cuda()
+    dy_nhwc = nhwc(dy).cuda()
+    geom_t = (B, Ho, Wo, Co, H, W, Ci, k, k, s, p)
+    _, dxf = hip.conv_gemm(dy_nhwc, w_t, geom=geom_t, transposed=True, out_bf16=False, out_f32=True)
+    assert rel(dxf, nhwc(x.grad).reshape(-1, Ci)) < TOL_F32
+    # weight gradient (+ per-channel scale)
+    scale = torch.rand(Co, generator=g) + 0.5
+    dw = torch.zeros(Co, k, k, Ci, device="cuda")
+    hip.conv_wgrad(dy_nhwc, x_nhwc, dw, geom=geom, scale=scale.cuda())
+    ref_dw = w.grad.permute(0, 2, 3, 1) * scale.view(-1, 1, 1, 1)
+    assert rel(dw, ref_dw) < TOL_F32
+    # accumulation semantics + explicit split
+    hip.conv_wgrad(dy_nhwc, x_nhwc, dw, geom=geom, scale=scale.cuda(), msplit=3)
+    assert rel(dw, 2 * ref_dw) < TOL_F32
+
+
+@pytest.mark.parametrize("M,K,N", [(200, 256, 256), (3520, 256, 2048), (3520, 2048, 256), (8, 256, 256),
+                                   (48, 256, 4), (320, 768, 768), (77, 64, 68)])
+def test_linear_wgrad(hip, M, K, N):
+    g = torch.Generator().manual_seed(M + N)
+    x = bf(torch.randn(M, K, generator=g)); dy = bf(torch.randn(M, N, generator=g))
+    dw = torch.zeros(N, K, device="cuda")
+    hip.linear_wgrad(dy.cuda(), x.cuda(), dw)
+    assert rel(dw, dy.float().T @ x.float()) < TOL_F32
+
+
+def test_errors_are_loud(hip):
+    x = torch.zeros(4, 48, dtype=torch.bfloat16, device="cuda")      # K not a multiple of 64
+    w = torch.zeros(8, 48, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        hip.linear(x, w)
+    with pytest.raises(RuntimeError):
+        hip.linear(x.cpu(), w.cpu())
