@@ -23,8 +23,11 @@ struct GemmArgs {
     int M, K, sshift;
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
+// MODE 0: dense rows (1x1, stride 1, pad 0: every Linear and most bottleneck convs)
+// MODE 1: forward conv gather       MODE 2: transposed (backward-data) gather
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict__ src,
+                                                        const bf16_t* __restrict__ wgt, const GemmArgs p) {
     constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 MFMA tiles per wave along m / n
     constexpr int AJ = BN / 32, BJ = BM / 32;      // 16-B staging chunks per thread
     constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, BUF_BYTES = A_BYTES + B_BYTES;
@@ -41,21 +44,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
 
     const int chunk = t & 7, srow = t >> 3;
 
-    // Decode the destination pixel of each staged activation row once.
-    int b_pix[BJ], b_y[BJ], b_x[BJ];
-    bool b_ok[BJ];
+    // Per staged row: element offset of its (tap 0, channel chunk) source address, validity, and for the
+    // gather modes the pixel coordinates the per-tap bounds test needs.
+    int a_off[AJ]; bool a_ok[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int n = n0 + srow + 32 * j;
+        a_ok[j] = n < p.N;
+        a_off[j] = a_ok[j] ? n * p.K + chunk * 8 : 0;
+    }
+    int b_off[BJ], b_y[BJ], b_x[BJ]; bool b_ok[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int m = m0 + srow + 32 * j;
         b_ok[j] = m < p.M;
         const int mm = b_ok[j] ? m : 0;
-        const int dx = mm % p.DW;
-        const int tmp = mm / p.DW;
-        const int dy = tmp % p.DH;
-        const int b = tmp / p.DH;
-        b_pix[j] = b * p.SH * p.SW;
-        if (!p.transposed) { b_y[j] = dy * p.stride - p.pad; b_x[j] = dx * p.stride - p.pad; }
-        else               { b_y[j] = dy + p.pad;            b_x[j] = dx + p.pad; }
+        if (MODE == 0) {
+            b_off[j] = mm * p.SC + chunk * 8; b_y[j] = 0; b_x[j] = 0;
+        } else {
+            const int dx = mm % p.DW;
+            const int tmp = mm / p.DW;
+            const int dy = tmp % p.DH;
+            const int b = tmp / p.DH;
+            if (MODE == 1) { b_y[j] = dy * p.stride - p.pad; b_x[j] = dx * p.stride - p.pad; }
+            else           { b_y[j] = dy + p.pad;            b_x[j] = dx + p.pad; }
+            b_off[j] = b * p.SH * p.SW * p.SC + chunk * 8;
+        }
     }
 
     f32x4 acc[TN][TM];
@@ -64,59 +78,62 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[AJ], rb[BJ];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int nk = p.K >> 6;
+    // running K-tile position: k0 = kt*64 = ((kh*KW)+kw)*SC + c0
+    int c0 = 0, kw = 0, kh = 0;
 
-#define RT_LOAD_TILES(kt_)                                                                         \
-    {                                                                                              \
-        const int k0 = (kt_) << 6;                                                                 \
-        const int tap = k0 / p.SC;                                                                 \
-        const int c0 = k0 - tap * p.SC;                                                            \
-        const int kh = tap / p.KW;                                                                 \
-        const int kw = tap - kh * p.KW;                                                            \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                           \
-            const int n = n0 + srow + 32 * j;                                                      \
-            ra[j] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.wgt + (size_t)n * p.K + k0 + chunk * 8) : zero4; \
-        }                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                           \
-            int sy, sx; bool ok = b_ok[j];                                                         \
-            if (!p.transposed) { sy = b_y[j] + kh; sx = b_x[j] + kw; }                             \
-            else {                                                                                 \
-                const int ny = b_y[j] - kh, nx = b_x[j] - kw;                                      \
-                const int msk = p.stride - 1;                                                      \
-                ok = ok && ny >= 0 && nx >= 0 && ((ny & msk) == 0) && ((nx & msk) == 0);           \
-                sy = ny >> p.sshift; sx = nx >> p.sshift;                                          \
-            }                                                                                      \
-            ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;             \
-            rb[j] = ok ? *reinterpret_cast<const uint4*>(p.src + ((size_t)(b_pix[j] + sy * p.SW + sx)) * p.SC + c0 + chunk * 8) : zero4; \
-        }                                                                                          \
-    }
+    uint4 ra[AJ], rb[BJ];
 
-#define RT_STORE_TILES(buf_)                                                                       \
-    {                                                                                              \
-        unsigned char* bA = smem + (buf_) * BUF_BYTES;                                             \
-        unsigned char* bB = bA + A_BYTES;                                                          \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                           \
-            const int row = srow + 32 * j;                                                         \
-            *reinterpret_cast<uint4*>(bA + row * 128 + ((chunk ^ (row & 7)) << 4)) = ra[j];        \
-        }                                                                                          \
-        _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                           \
-            const int row = srow + 32 * j;                                                         \
-            *reinterpret_cast<uint4*>(bB + row * 128 + ((chunk ^ (row & 7)) << 4)) = rb[j];        \
-        }                                                                                          \
-    }
-
-    RT_LOAD_TILES(0);
-    RT_STORE_TILES(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool has_next = (kt + 1) < nk;
-        if (has_next) RT_LOAD_TILES(kt + 1);
-
-        const unsigned char* bA = smem + cur * BUF_BYTES;
+    auto load_tiles = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4*>(wgt + (a_off[j] + (a_ok[j] ? k0 : 0)));
+            ra[j] = a_ok[j] ? v : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            bool ok = b_ok[j];
+            int off;
+            if (MODE == 0) {
+                off = b_off[j] + k0;
+            } else {
+                int sy, sx;
+                if (MODE == 1) { sy = b_y[j] + kh; sx = b_x[j] + kw; }
+                else {
+                    const int ny = b_y[j] - kh, nx = b_x[j] - kw;
+                    const int msk = p.stride - 1;
+                    ok = ok && ((ny | nx) >= 0) && (((ny | nx) & msk) == 0);
+                    sy = ny >> p.sshift; sx = nx >> p.sshift;
+                }
+                ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
+                off = b_off[j] + (sy * p.SW + sx) * p.SC + c0;
+            }
+            const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? off : 0));
+            rb[j] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto advance_k = [&]() __attribute__((always_inline)) {
+        if (MODE != 0) {
+            c0 += 64;
+            if (c0 >= p.SC) { c0 = 0; ++kw; if (kw >= p.KW) { kw = 0; ++kh; } }
+        }
+    };
+    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* bA = smem + buf * BUF_BYTES;
+        unsigned char* bB = bA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int row = srow + 32 * j;
+            *reinterpret_cast<uint4*>(bA + row * 128 + ((chunk ^ (row & 7)) << 4)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = srow + 32 * j;
+            *reinterpret_cast<uint4*>(bB + row * 128 + ((chunk ^ (row & 7)) << 4)) = rb[j];
+        }
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* bA = smem + buf * BUF_BYTES;
         const unsigned char* bB = bA + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -138,11 +155,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
                 for (int b = 0; b < TM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
-        if (has_next) RT_STORE_TILES(cur ^ 1);
+    };
+
+    load_tiles(0);
+    advance_k();
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        load_tiles((kt + 1) << 6);      // next tile's global loads fly under this tile's MFMAs
+        advance_k();
+        compute(kt & 1);
+        store_tiles((kt & 1) ^ 1);
         __syncthreads();
     }
-#undef RT_LOAD_TILES
-#undef RT_STORE_TILES
+    compute((nk - 1) & 1);
 
     // ---- epilogue: +bias -> act -> dropout -> +res -> *gate -> *gelu'(preact) -> store ----
     const bool do_drop = p.drop_p > 0.f;
@@ -206,7 +232,14 @@ template <int BM, int BN>
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const size_t smem = 2 * (size_t)(BM + BN) * 128;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN>), dim3((unsigned)(mt * nt)), dim3(256), smem, s, a);
+    const dim3 grid((unsigned)(mt * nt)), block(256);
+    const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0);
+    if (dense)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 0>), grid, block, smem, s, a.src, a.wgt, a);
+    else if (!a.transposed)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 1>), grid, block, smem, s, a.src, a.wgt, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 2>), grid, block, smem, s, a.src, a.wgt, a);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
@@ -228,6 +261,8 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.act = d->act; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
+    // 32-bit element offsets inside the kernel
+    if ((long long)d->B * d->SH * d->SW * d->SC >= 0x7fffffffLL || (long long)d->N * d->KH * d->KW * d->SC >= 0x7fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.K = d->KH * d->KW * d->SC; a.sshift = d->stride == 2 ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
 

@@ -30,13 +30,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off0, i
     return u.v;
 }
 
-template <int BN, int BC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+// SIMPLE: 1x1 / stride 1 / pad 0 (x row = m).  NVEC: N % 8 == 0 (16-B dy loads).
+template <int BN, int BC, bool SIMPLE, bool NVEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restrict__ dyp,
+                                                         const bf16_t* __restrict__ xp, const WgradArgs p) {
     constexpr int TN = BN / 32, TC = BC / 32;       // MFMA tiles per wave (waves 2(n) x 2(c))
     constexpr int SA = BN * 2 + 32, SB = BC * 2 + 32;   // LDS row strides (bytes)
     constexpr int A_BYTES = 32 * SA, B_BYTES = 32 * SB, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int ACH = BN / 8, BCH = BC / 8;       // 16-B chunks per row
     constexpr int AJ = (32 * ACH) / 256, BJ = (32 * BCH) / 256;   // chunks per thread (>=1)
+    constexpr int A_RSTEP = 256 / ACH, B_RSTEP = 256 / BCH;
     static_assert(AJ >= 1 && BJ >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -59,11 +62,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     if (chunk_end > total_chunks) chunk_end = total_chunks;
     if (chunk_begin >= chunk_end) return;
 
-    const int a_chunk = t % ACH, a_row = t / ACH;          // rows a_row + (256/ACH)*j
+    const int a_chunk = t % ACH, a_row = t / ACH;          // rows a_row + A_RSTEP*j
     const int b_chunk = t % BCH, b_row = t / BCH;
-    constexpr int A_RSTEP = 256 / ACH, B_RSTEP = 256 / BCH;
-    const bool simple = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
-    const bool n_vec = (p.N & 7) == 0;
+    const int a_n = n0 + a_chunk * 8;
+    const bool a_nok = a_n < p.N;
+    const int b_c = c0 + b_chunk * 8;
+    const bool b_cok = b_c < p.SC;
+
+    // running (batch, y, x) of each staged x-row for the gather modes (advanced by 32 rows per chunk)
+    int gb[BJ], gy[BJ], gx[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int m = (chunk_begin << 5) + b_row + B_RSTEP * j;
+        gx[j] = m % p.DW; const int tmp = m / p.DW; gy[j] = tmp % p.DH; gb[j] = tmp / p.DH;
+    }
 
     f32x4 acc[TN][TC];
 #pragma unroll
@@ -72,64 +84,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         for (int b = 0; b < TC; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[AJ], rb[BJ];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-#define RT_WG_LOAD(ch_)                                                                             \
-    {                                                                                               \
-        const int mbase = (ch_) << 5;                                                               \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                            \
-            const int m = mbase + a_row + A_RSTEP * j;                                              \
-            const int n = n0 + a_chunk * 8;                                                         \
-            if (n_vec) {                                                                            \
-                ra[j] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.N + n) : zero4; \
-            } else { /* ragged N (e.g. the 4-wide box head): element loads, zero fill */             \
-                union { uint4 q; bf16_t e[8]; } u; u.q = zero4;                                     \
-                if (m < p.M) { _Pragma("unroll") for (int e = 0; e < 8; ++e)                         \
-                    if (n + e < p.N) u.e[e] = p.dy[(size_t)m * p.N + n + e]; }                       \
-                ra[j] = u.q;                                                                        \
-            }                                                                                       \
-        }                                                                                         \
-        _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                            \
-            const int m = mbase + b_row + B_RSTEP * j;                                              \
-            const int c = c0 + b_chunk * 8;                                                         \
-            bool ok = (m < p.M) && (c < p.SC);                                                      \
-            size_t pix;                                                                             \
-            if (simple) { pix = (size_t)m; }                                                        \
-            else {                                                                                  \
-                const int mm = ok ? m : 0;                                                          \
-                const int dx = mm % p.DW; const int tmp = mm / p.DW;                                \
-                const int dy_ = tmp % p.DH; const int bb = tmp / p.DH;                              \
-                const int sy = dy_ * p.stride - p.pad + kh, sx = dx * p.stride - p.pad + kw;        \
-                ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;          \
-                pix = (size_t)((bb * p.SH + sy) * p.SW + sx);                                       \
-            }                                                                                       \
-            rb[j] = ok ? *reinterpret_cast<const uint4*>(p.x + pix * p.SC + c) : zero4;             \
-        }                                                                                           \
-    }
-
-#define RT_WG_STORE(buf_)                                                                           \
-    {                                                                                               \
-        unsigned char* bA = smem + (buf_) * BUF_BYTES;                                              \
-        unsigned char* bB = bA + A_BYTES;                                                           \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                              \
-            *reinterpret_cast<uint4*>(bA + (a_row + A_RSTEP * j) * SA + a_chunk * 16) = ra[j];      \
-        _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                              \
-            *reinterpret_cast<uint4*>(bB + (b_row + B_RSTEP * j) * SB + b_chunk * 16) = rb[j];      \
-    }
-
-    RT_WG_LOAD(chunk_begin);
-    RT_WG_STORE(0);
-    __syncthreads();
-
+    auto load_tiles = [&](int ch) __attribute__((always_inline)) {
+        const int mbase = ch << 5;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = mbase + a_row + A_RSTEP * j;
+            const bool ok = a_nok && m < p.M;
+            if (NVEC) {
+                const uint4 v = *reinterpret_cast<const uint4*>(dyp + (ok ? m * p.N + a_n : 0));
+                ra[j] = ok ? v : make_uint4(0, 0, 0, 0);
+            } else {   // ragged N (e.g. the 4-wide box head): element loads, zero fill
+                union { uint4 q; unsigned short e[8]; } u; u.q = make_uint4(0, 0, 0, 0);
+                const unsigned short* d16 = reinterpret_cast<const unsigned short*>(dyp);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ok && a_n + e < p.N) u.e[e] = d16[m * p.N + a_n + e];
+                ra[j] = u.q;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int m = mbase + b_row + B_RSTEP * j;
+            bool ok = b_cok && m < p.M;
+            int pix;
+            if (SIMPLE) pix = m;
+            else {
+                const int sy = gy[j] * p.stride - p.pad + kh, sx = gx[j] * p.stride - p.pad + kw;
+                ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
+                pix = (gb[j] * p.SH + sy) * p.SW + sx;
+                gx[j] += 32;
+                while (gx[j] >= p.DW) { gx[j] -= p.DW; if (++gy[j] >= p.DH) { gy[j] = 0; ++gb[j]; } }
+            }
+            const uint4 v = *reinterpret_cast<const uint4*>(xp + (ok ? pix * p.SC + b_c : 0));
+            rb[j] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* bA = smem + buf * BUF_BYTES;
+        unsigned char* bB = bA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+            *reinterpret_cast<uint4*>(bA + (a_row + A_RSTEP * j) * SA + a_chunk * 16) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            *reinterpret_cast<uint4*>(bB + (b_row + B_RSTEP * j) * SB + b_chunk * 16) = rb[j];
+    };
     // per-lane byte offsets of the two transpose reads inside a 16-channel column block
     const int tr_row0 = 4 * lg + (li >> 2);
     const int tr_col = (li & 3) * 8;
-
-    int cur = 0;
-    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
-        const bool has_next = (ch + 1) < chunk_end;
-        if (has_next) RT_WG_LOAD(ch + 1);
-        const unsigned char* bA = smem + cur * BUF_BYTES;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* bA = smem + buf * BUF_BYTES;
         const unsigned char* bB = bA + A_BYTES;
         bf16x8 af[TN], bfr[TC];
 #pragma unroll
@@ -147,12 +152,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int b = 0; b < TC; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-        if (has_next) RT_WG_STORE(cur ^ 1);
+    };
+
+    load_tiles(chunk_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ch = chunk_begin; ch < chunk_end - 1; ++ch) {
+        load_tiles(ch + 1);
+        compute(cur);
+        store_tiles(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
-#undef RT_WG_LOAD
-#undef RT_WG_STORE
+    compute(cur);
 
     const int taps = p.KH * p.KW;
 #pragma unroll
@@ -194,7 +207,13 @@ int launch_wgrad(WgradArgs a, int msplit, hipStream_t s) {
     a.chunks_per_block = (total_chunks + msplit - 1) / msplit;
     const int gy = (total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
     constexpr size_t smem = 2 * (size_t)(32 * (BN * 2 + 32) + 32 * (BC * 2 + 32));
-    hipLaunchKernelGGL((conv_wgrad_kernel<BN, BC>), dim3((unsigned)base_blocks, (unsigned)gy), dim3(256), smem, s, a);
+    const dim3 grid((unsigned)base_blocks, (unsigned)gy), block(256);
+    const bool simple = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0);
+    const bool nvec = (a.N & 7) == 0;
+    if (simple && nvec)       hipLaunchKernelGGL((conv_wgrad_kernel<BN, BC, true, true>), grid, block, smem, s, a.dy, a.x, a);
+    else if (simple)          hipLaunchKernelGGL((conv_wgrad_kernel<BN, BC, true, false>), grid, block, smem, s, a.dy, a.x, a);
+    else if (nvec)            hipLaunchKernelGGL((conv_wgrad_kernel<BN, BC, false, true>), grid, block, smem, s, a.dy, a.x, a);
+    else                      hipLaunchKernelGGL((conv_wgrad_kernel<BN, BC, false, false>), grid, block, smem, s, a.dy, a.x, a);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
@@ -211,6 +230,7 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
+    if (M * d->N >= 0x7fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x7fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0;
     hipStream_t s = (hipStream_t)stream;
     if (a.N >= 128 && a.SC >= 128) return launch_wgrad<128, 128>(a, d->msplit, s);
