@@ -1,0 +1,495 @@
+"""CPU oracle: a plain-torch fp32 restatement of the RefTR training hot path.
+
+TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+file; nothing under reftr_amd/ does, and the product path has no CPU fallback.
+
+Every function restates one piece of the reference (ubc-vision/RefTR, /root/reference) and cites the
+file:line it follows.  Parameters are a flat dict keyed by the REFERENCE's state_dict names, so the dict
+of the imported reference model can be fed in directly: oracle/gen_golden.py does exactly that inside the
+build container and pins this file against the reference's own outputs (tests/golden/*.npz, checked by
+tests/test_oracle_golden.py).  Arithmetic that lives outside the reference tree (torchvision ResNet,
+HF BertModel, nn.MultiheadAttention) is restated from its public definition — SURVEY.md Appendix A.
+
+`q=True` turns on the bf16 rounding points of the HIP path (GEMM operands and stored backbone
+activations rounded to bf16, FrozenBN scale folded into the rounded weight) so the GPU result can be
+compared at the 1e-3 level the north star asks for; `q=False` is the reference's fp32 arithmetic.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration (defaults = main_vg.py:26-164 as used by configs/refcoco/RefTR_refcoco.sh)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class BertCfg:
+    vocab_size: int = 30522
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    inter: int = 3072
+    max_pos: int = 512
+    type_vocab: int = 2
+    eps: float = 1e-12
+    dropout: float = 0.1
+
+
+@dataclass
+class Cfg:
+    hidden: int = 256
+    nheads: int = 8
+    enc_layers: int = 6
+    dec_layers: int = 6
+    ffn: int = 2048
+    dropout: float = 0.1
+    max_lang_seq: int = 128
+    n_q: int = 1
+    aux_loss: bool = True
+    resnet_layers: tuple = (3, 4, 6, 3)
+    bert: BertCfg = field(default_factory=BertCfg)
+    bbox_loss_coef: float = 1.0   # main_vg.py:134 (default 1)
+    giou_loss_coef: float = 1.0   # main_vg.py:135 (default 1)
+
+
+class _Round(torch.autograd.Function):
+    """bf16 rounding point, applied to the value going forward and to the gradient coming back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def rq(x, q):
+    return _Round.apply(x) if q else x
+
+
+def rq_fwd(x, q):
+    """rounding of a weight / constant: forward only (the fp32 master weight receives the full gradient)."""
+    return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach() if q else x
+
+
+# ----------------------------------------------------------------------------------------------
+# backbone: torchvision ResNet v1.5 body + FrozenBatchNorm2d (models/modeling/backbone.py:43-125)
+# ----------------------------------------------------------------------------------------------
+def frozen_bn_affine(P, pfx, eps=1e-5):
+    """backbone.py:70-80: scale = w * rsqrt(rv + eps); shift = b - rm * scale (all buffers, no grad)."""
+    scale = P[pfx + "weight"] * (P[pfx + "running_var"] + eps).rsqrt()
+    shift = P[pfx + "bias"] - P[pfx + "running_mean"] * scale
+    return scale.detach(), shift.detach()
+
+
+def conv_bn(x, P, conv, bn, stride=1, padding=0, q=False, relu=True, residual=None):
+    w = P[conv + "weight"]
+    scale, shift = frozen_bn_affine(P, bn)
+    if q:   # HIP path: scale folded into the bf16 weight, output stored as bf16
+        y = F.conv2d(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, stride, padding) + shift.view(1, -1, 1, 1)
+    else:
+        y = F.conv2d(x, w, None, stride, padding) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = F.relu(y)
+    return rq(y, q)
+
+
+def bottleneck(x, P, pfx, stride, q=False):
+    """ResNet v1.5 bottleneck (stride on the 3x3), SURVEY.md A1."""
+    idt = x
+    if (pfx + "downsample.0.weight") in P:
+        idt = conv_bn(x, P, pfx + "downsample.0.", pfx + "downsample.1.", stride, 0, q, relu=False)
+    y = conv_bn(x, P, pfx + "conv1.", pfx + "bn1.", 1, 0, q)
+    y = conv_bn(y, P, pfx + "conv2.", pfx + "bn2.", stride, 1, q)
+    return conv_bn(y, P, pfx + "conv3.", pfx + "bn3.", 1, 0, q, relu=True, residual=idt)
+
+
+def resnet_body(x, P, pfx="img_backbone.0.body.", layers=(3, 4, 6, 3), q=False):
+    """conv1 7x7/2 + FrozenBN + ReLU + maxpool 3x3/2, then layer1..4 (backbone.py:99,119-121).
+    Returns the four stage outputs (strides 4, 8, 16, 32)."""
+    scale, shift = frozen_bn_affine(P, pfx + "bn1.")
+    w = P[pfx + "conv1.weight"]
+    if q:
+        y = F.conv2d(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, 2, 3) + shift.view(1, -1, 1, 1)
+    else:
+        y = F.conv2d(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = rq(F.relu(y), q)
+    y = F.max_pool2d(y, 3, 2, 1)
+    outs = []
+    for li, n in enumerate(layers):
+        for bi in range(n):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            y = bottleneck(y, P, f"{pfx}layer{li + 1}.{bi}.", stride, q)
+        outs.append(y)
+    return outs
+
+
+def mask_downsample(mask, size):
+    """backbone.py:107: F.interpolate(m[None].float(), size) (nearest): src = floor(dst * in / out)."""
+    H, W = mask.shape[-2:]
+    h, w = size
+    iy = torch.floor(torch.arange(h, dtype=torch.float32) * (H / h)).long().clamp(max=H - 1)
+    ix = torch.floor(torch.arange(w, dtype=torch.float32) * (W / w)).long().clamp(max=W - 1)
+    return mask[:, iy][:, :, ix]
+
+
+def sine_pos(mask, num_pos_feats=128, temperature=10000.0):
+    """models/modeling/position_encoding.py:36-56 (normalize=True, scale=2*pi, eps=1e-6)."""
+    not_mask = ~mask
+    y_embed = not_mask.cumsum(1, dtype=torch.float32)
+    x_embed = not_mask.cumsum(2, dtype=torch.float32)
+    eps, scale = 1e-6, 2 * math.pi
+    y_embed = (y_embed - 0.5) / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = (x_embed - 0.5) / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)   # [B, 256, h, w]
+
+
+# ----------------------------------------------------------------------------------------------
+# small building blocks
+# ----------------------------------------------------------------------------------------------
+def linear(x, P, pfx, q=False):
+    return F.linear(rq(x, q), rq_fwd(P[pfx + "weight"], q), P[pfx + "bias"])
+
+
+def layer_norm(x, P, pfx, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), P[pfx + "weight"], P[pfx + "bias"], eps)
+
+
+def drop(x, p, train):
+    return F.dropout(x, p, train) if (train and p > 0) else x
+
+
+def mlp_mapping(x, P, pfx, q=False, train=False):
+    """models/reftr_transformer.py:14-23: Linear-LN-ReLU-Dropout(0.1)-Linear-LN-ReLU."""
+    y = F.relu(layer_norm(linear(x, P, pfx + "0.", q), P, pfx + "1."))
+    y = drop(y, 0.1, train)
+    return F.relu(layer_norm(linear(y, P, pfx + "4.", q), P, pfx + "5."))
+
+
+def mha(P, pfx, query, key, value, key_padding_mask, nheads, p_drop=0.0, train=False, q=False):
+    """nn.MultiheadAttention as the reference uses it (models/modeling/transformer.py:151,174-175,
+    211-212,239-246): packed in_proj [3E,E], q scaled by 1/sqrt(dh), key_padding_mask -> -inf,
+    softmax, dropout on the probabilities, out_proj.  Inputs are [L, B, E] (seq-first)."""
+    E = query.shape[-1]
+    dh = E // nheads
+    W, bias = P[pfx + "in_proj_weight"], P[pfx + "in_proj_bias"]
+    Lq, B, _ = query.shape
+    Lk = key.shape[0]
+    qh = F.linear(rq(query, q), rq_fwd(W[:E], q), bias[:E]) * (dh ** -0.5)
+    kh = F.linear(rq(key, q), rq_fwd(W[E:2 * E], q), bias[E:2 * E])
+    vh = F.linear(rq(value, q), rq_fwd(W[2 * E:], q), bias[2 * E:])
+    qh = rq(qh, q).reshape(Lq, B * nheads, dh).transpose(0, 1)
+    kh = rq(kh, q).reshape(Lk, B * nheads, dh).transpose(0, 1)
+    vh = rq(vh, q).reshape(Lk, B * nheads, dh).transpose(0, 1)
+    scores = torch.bmm(qh, kh.transpose(1, 2))
+    if key_padding_mask is not None:
+        scores = scores.view(B, nheads, Lq, Lk).masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+        scores = scores.view(B * nheads, Lq, Lk)
+    attn = drop(F.softmax(scores, dim=-1), p_drop, train)
+    out = torch.bmm(attn, vh).transpose(0, 1).reshape(Lq, B, E)
+    return F.linear(rq(out, q), rq_fwd(P[pfx + "out_proj.weight"], q), P[pfx + "out_proj.bias"])
+
+
+def encoder_layer(x, pos, kpm, P, pfx, cfg, train=False, q=False):
+    """TransformerEncoderLayer.forward_post, models/modeling/transformer.py:168-181."""
+    qk = x + pos
+    a = mha(P, pfx + "self_attn.", qk, qk, x, kpm, cfg.nheads, cfg.dropout, train, q)
+    x = layer_norm(x + drop(a, cfg.dropout, train), P, pfx + "norm1.")
+    h = drop(F.relu(linear(x, P, pfx + "linear1.", q)), cfg.dropout, train)
+    f = linear(h, P, pfx + "linear2.", q)
+    return layer_norm(x + drop(f, cfg.dropout, train), P, pfx + "norm2.")
+
+
+def decoder_layer(t, memory, qpos, pos, tgt_kpm, mem_kpm, P, pfx, cfg, train=False, q=False):
+    """TransformerDecoderLayer.forward_post, models/modeling/transformer.py:231-252."""
+    qk = t + qpos
+    a = mha(P, pfx + "self_attn.", qk, qk, t, tgt_kpm, cfg.nheads, cfg.dropout, train, q)
+    t = layer_norm(t + drop(a, cfg.dropout, train), P, pfx + "norm1.")
+    a = mha(P, pfx + "multihead_attn.", t + qpos, memory + pos, memory, mem_kpm, cfg.nheads, cfg.dropout, train, q)
+    t = layer_norm(t + drop(a, cfg.dropout, train), P, pfx + "norm2.")
+    h = drop(F.relu(linear(t, P, pfx + "linear1.", q)), cfg.dropout, train)
+    f = linear(h, P, pfx + "linear2.", q)
+    return layer_norm(t + drop(f, cfg.dropout, train), P, pfx + "norm3.")
+
+
+# ----------------------------------------------------------------------------------------------
+# BERT (HF BertModel, post-LN, erf-GELU, eps 1e-12, tanh pooler) — SURVEY.md A5
+# ----------------------------------------------------------------------------------------------
+def bert_forward(P, ids, attn_mask, bc: BertCfg, pfx="lang_backbone.", train=False, q=False):
+    B, L = ids.shape
+    e = pfx + "embeddings."
+    h = P[e + "word_embeddings.weight"][ids] + P[e + "position_embeddings.weight"][:L][None] \
+        + P[e + "token_type_embeddings.weight"][0][None, None]
+    h = drop(layer_norm(h, P, e + "LayerNorm.", bc.eps), bc.dropout, train)
+    dh = bc.hidden // bc.heads
+    # HF extended mask: (1 - mask) * finfo.min added to the scores
+    add_mask = (1.0 - attn_mask.to(torch.float32))[:, None, None, :] * torch.finfo(torch.float32).min
+    for i in range(bc.layers):
+        lp = f"{pfx}encoder.layer.{i}."
+        qh = rq(linear(h, P, lp + "attention.self.query.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
+        kh = rq(linear(h, P, lp + "attention.self.key.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
+        vh = rq(linear(h, P, lp + "attention.self.value.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
+        s = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(dh) + add_mask
+        a = drop(F.softmax(s, dim=-1), bc.dropout, train)
+        ctx = torch.matmul(a, vh).transpose(1, 2).reshape(B, L, bc.hidden)
+        o = drop(linear(ctx, P, lp + "attention.output.dense.", q), bc.dropout, train)
+        h = layer_norm(h + o, P, lp + "attention.output.LayerNorm.", bc.eps)
+        f = F.gelu(linear(h, P, lp + "intermediate.dense.", q))
+        f = drop(linear(f, P, lp + "output.dense.", q), bc.dropout, train)
+        h = layer_norm(h + f, P, lp + "output.LayerNorm.", bc.eps)
+    pooled = torch.tanh(linear(h[:, 0], P, pfx + "pooler.dense.", q))
+    return h, pooled
+
+
+# ----------------------------------------------------------------------------------------------
+# RefTR model (models/reftr_transformer.py:159-297, models/reftr.py:51-120)
+# ----------------------------------------------------------------------------------------------
+def query_encoder(P, ctx, phrase_feat, mask_ctx, cfg, pfx="query_encoder.", train=False, q=False):
+    """QueryEncoder.forward, models/reftr_transformer.py:41-66.  ctx [B,L,E], phrase_feat [B,n_ph,E],
+    mask_ctx [B,n_ph,L] (True = ignore).  NOTE: attention logits are NOT scaled by 1/sqrt(d) (:51)."""
+    B, n_ph, E = phrase_feat.shape
+    k = linear(ctx[:, 0:1, :], P, pfx + "linear1.", q)
+    qs = linear(ctx, P, pfx + "linear2.", q).transpose(1, 2)
+    v = linear(ctx, P, pfx + "linear3.", q).unsqueeze(1)
+    w = torch.bmm(k, qs).expand(-1, n_ph, -1).masked_fill(mask_ctx, float("-inf"))
+    w = F.softmax(w, dim=-1).unsqueeze(-1)
+    c = (v * w).sum(dim=-2)
+    c = layer_norm(linear(c, P, pfx + "context_out.0.", q), P, pfx + "context_out.1.")
+    c = ctx[:, None, 0, :] + c
+    f = mlp_mapping(torch.cat([c, phrase_feat], dim=-1), P, pfx + "fuse_encoder_query.", q, train)
+    emb = P[pfx + "query_embed.weight"]                       # [n_q, 2E]
+    n_q = emb.shape[0]
+    pq = f.view(B, n_ph, 1, -1).repeat(1, 1, 1, 2) + emb.view(1, 1, n_q, -1)
+    pq = pq.view(B, n_ph * n_q, -1).transpose(0, 1)           # [n_ph*n_q, B, 2E]
+    return pq[..., :E], pq[..., E:]
+
+
+def context_masks(samples):
+    """models/reftr_transformer.py:206-248 — integer/bool only.  Returns (mask_context [B,n_ph,L] True=ignore,
+    query_mask [B, n_ph] True=ignore (before the n_q expand))."""
+    sm = samples["sentence_mask"].to(torch.bool)
+    B, L = sm.shape
+    if "phrase" in samples:
+        pl, pr = samples["phrase_pos_l"], samples["phrase_pos_r"]
+        ar = torch.arange(L)[None, None, :]
+        mask_context = ~((ar >= pl[..., None]) & (ar < pr[..., None]))
+        query_mask = ~samples["phrase_mask"].to(torch.bool)[:, :, 2]
+    else:
+        slen = sm.to(torch.int32).sum(-1)
+        mask_context = (~sm).view(B, 1, L).clone()
+        mask_context[:, :, 0] = True
+        mask_context[torch.arange(B), 0, slen - 1] = True
+        query_mask = torch.zeros((B, 1), dtype=torch.bool)
+    return mask_context, query_mask
+
+
+def reftr_forward(P, samples, cfg: Cfg, train=False, q=False):
+    """RefTR.forward.  samples = {'img' [B,3,H,W] f32, 'img_mask' [B,H,W] bool (True = pad),
+    'sentence' int64 [B,L], 'sentence_mask' [B,L], optional phrase fields}.  Returns a dict with the
+    reference outputs plus intermediates used by the parity tests."""
+    img, img_mask = samples["img"], samples["img_mask"]
+    B = img.shape[0]
+    E = cfg.hidden
+    feats = resnet_body(img, P, layers=cfg.resnet_layers, q=q)
+    c5 = feats[-1]
+    m5 = mask_downsample(img_mask, c5.shape[-2:])
+    pos5 = sine_pos(m5, E // 2)
+    # input_proj: 1x1 conv + GroupNorm(32) (models/reftr_transformer.py:121-125,174)
+    src = F.conv2d(rq(c5, q), rq_fwd(P["input_proj.0.0.weight"], q), P["input_proj.0.0.bias"])
+    src = F.group_norm(src, 32, P["input_proj.0.1.weight"], P["input_proj.0.1.bias"], 1e-5)
+
+    sent, smask = samples["sentence"], samples["sentence_mask"]
+    L = sent.shape[1]
+    seq, pooled = bert_forward(P, sent, smask, cfg.bert, train=train, q=q)
+    sent_feat = mlp_mapping(seq, P, "map_sentence.", q, train)                     # :201
+    n_q = cfg.n_q
+    mask_context, query_mask = context_masks(samples)
+    if "phrase" in samples:
+        ph = samples["phrase"]
+        n_ph = ph.shape[1]
+        _, ph_pooled = bert_forward(P, ph.view(B * n_ph, -1), samples["phrase_mask"].view(B * n_ph, -1),
+                                    cfg.bert, train=train, q=q)                     # :217
+    else:
+        n_ph = 1
+        ph_pooled = pooled
+    query_mask = query_mask[:, :, None].expand(-1, -1, n_q).reshape(B, n_ph * n_q)
+    ph_feat = mlp_mapping(ph_pooled, P, "map_phrase.", q, train).view(B, n_ph, -1)   # :250
+
+    # VLTransformer.encode (models/reftr.py:51-120): [lang; img] along S, seq-first layout
+    vt = "vl_transformer."
+    img_src = src.flatten(2).permute(2, 0, 1)                                       # [HW, B, E]
+    img_pos = pos5.flatten(2).permute(2, 0, 1) + P[vt + "level_embed"][0].view(1, 1, -1) \
+        + P[vt + "token_type_embeddings.weight"][1].view(1, 1, -1)
+    lang_src = sent_feat.transpose(0, 1)                                            # [L, B, E]
+    lang_pos = (P[vt + "lang_pos_embeddings.weight"][:L] + P[vt + "token_type_embeddings.weight"][0][None])
+    lang_pos = lang_pos[:, None, :].expand(-1, B, -1)
+    kpm = torch.cat([~smask.to(torch.bool), m5.flatten(1)], dim=1)                  # [B, S] True = ignore
+    x = torch.cat([lang_src, img_src], dim=0)
+    pos = torch.cat([lang_pos, img_pos], dim=0)
+    for i in range(cfg.enc_layers):
+        x = encoder_layer(x, pos, kpm, P, f"{vt}encoder.layers.{i}.", cfg, train, q)
+    memory = x
+
+    tgt, qpos = query_encoder(P, memory[:L].transpose(0, 1), ph_feat, mask_context, cfg, train=train, q=q)
+    hs = []
+    t = tgt
+    for i in range(cfg.dec_layers):
+        t = decoder_layer(t, memory, qpos, pos, query_mask, kpm, P, f"{vt}decoder.layers.{i}.", cfg, train, q)
+        hs.append(layer_norm(t, P, vt + "decoder.norm."))                           # transformer.py:131-138
+    hs = torch.stack(hs).transpose(1, 2)                                            # [nl, B, n_ph*n_q, E]
+    hs = hs.reshape(len(hs), B, n_ph, n_q, -1)
+    y = F.relu(linear(hs, P, "bbox_embed.layers.0.", q))
+    y = F.relu(linear(y, P, "bbox_embed.layers.1.", q))
+    logits = linear(y, P, "bbox_embed.layers.2.", q)                                 # backbone.py:26-38
+    boxes = logits.sigmoid()
+    phrase_mask = ~query_mask
+    out = {"pred_boxes": boxes[-1], "phrase_mask": phrase_mask, "logits": logits, "memory": memory,
+           "c5": c5, "src": src, "pos5": pos5, "kpm": kpm, "feats": feats, "hs": hs}
+    if cfg.aux_loss:
+        out["aux_outputs"] = [{"pred_boxes": b, "phrase_mask": phrase_mask} for b in boxes[:-1]]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# criterion (models/criterion.py:113-202, util/box_ops.py:17-69)
+# ----------------------------------------------------------------------------------------------
+def cxcywh_to_xyxy(b):
+    cx, cy, w, h = b.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+def giou_diag(a, b):
+    """diag(generalized_box_iou(a, b)) (util/box_ops.py:32-69) for xyxy boxes a[i], b[i]."""
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(a[:, :2], b[:, :2]); rb = torch.min(a[:, 2:], b[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
+    union = area_a + area_b - inter
+    iou = inter / union
+    lt2 = torch.min(a[:, :2], b[:, :2]); rb2 = torch.max(a[:, 2:], b[:, 2:])
+    wh2 = (rb2 - lt2).clamp(min=0)
+    area = wh2[:, 0] * wh2[:, 1]
+    return iou - (area - union) / area
+
+
+def loss_boxes(pred_boxes, phrase_mask, targets, num_boxes):
+    """CriterionVGMultiPhrase.loss_boxes, models/criterion.py:113-153.  pred_boxes [B,n_ph,k,4],
+    phrase_mask [B, n_ph*k] (True = valid), targets list of {'boxes': [n,4]}."""
+    B, n_ph, k, _ = pred_boxes.shape
+    m = phrase_mask.view(B, n_ph, k)
+    preds, tgts = [], []
+    for i in range(B):
+        pi = pred_boxes[i][m[i]].view(-1, k, 4)       # masked_select keeps phrase order
+        assert pi.shape[0] == targets[i]["boxes"].shape[0]
+        preds.append(pi); tgts.append(targets[i]["boxes"])
+    p = torch.cat(preds, 0)
+    t = torch.cat(tgts, 0).unsqueeze(1).expand(-1, k, -1)
+    p = p.reshape(-1, 4); t = t.reshape(-1, 4)
+    l1 = (p - t).abs().sum() / (num_boxes * k)
+    gi = (1 - giou_diag(cxcywh_to_xyxy(p), cxcywh_to_xyxy(t))).sum() / (num_boxes * k)
+    return {"loss_bbox": l1, "loss_giou": gi}
+
+
+def criterion(out, targets, world_size=1, global_num_boxes=None):
+    """CriterionVGMultiPhrase.forward, models/criterion.py:166-202 (num_boxes all-reduce modelled by
+    `global_num_boxes` / world_size)."""
+    nb = sum(len(t["labels"]) for t in targets) if global_num_boxes is None else global_num_boxes
+    nb = max(nb / world_size, 1.0)
+    losses = dict(loss_boxes(out["pred_boxes"], out["phrase_mask"], targets, nb))
+    for i, aux in enumerate(out.get("aux_outputs", [])):
+        for k_, v in loss_boxes(aux["pred_boxes"], aux["phrase_mask"], targets, nb).items():
+            losses[f"{k_}_{i}"] = v
+    return losses
+
+
+def weight_dict(cfg: Cfg):
+    """models/reftr_transformer.py:320-329."""
+    wd = {"loss_giou": cfg.giou_loss_coef, "loss_bbox": cfg.bbox_loss_coef}
+    if cfg.aux_loss:
+        aux = {}
+        for i in range(cfg.dec_layers - 1):
+            aux.update({f"{k}_{i}": v for k, v in wd.items()})
+        aux.update({k + "_enc": v for k, v in wd.items()})
+        wd.update(aux)
+    return wd
+
+
+def total_loss(losses, wd):
+    """engine_vg.py:43."""
+    return sum(losses[k] * wd[k] for k in losses if k in wd)
+
+
+# ----------------------------------------------------------------------------------------------
+# training step (engine_vg.py:40-72, main_vg.py:234-270)
+# ----------------------------------------------------------------------------------------------
+def is_trainable(name):
+    """backbone.py:87-89: conv1 / layer1 frozen; FrozenBN tensors are buffers."""
+    if name.startswith("img_backbone."):
+        if any(s in name for s in ("running_mean", "running_var", ".bn", "downsample.1.")):
+            return False
+        return any(s in name for s in ("layer2", "layer3", "layer4"))
+    return True
+
+
+def lr_group(name, lr=1e-4, lr_backbone=1e-5, lr_bert=1e-5):
+    """main_vg.py:29-33,234-262: backbone names -> lr_backbone, lang_backbone -> lr_bert."""
+    if "img_backbone.0" in name:
+        return lr_backbone
+    if "lang_backbone" in name:
+        return lr_bert
+    return lr
+
+
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (engine_vg.py:63): total = ||(||g_i||)||, coef = min(1, max/(total+1e-6))."""
+    total = torch.sqrt(sum((g.detach().float() ** 2).sum() for g in grads.values()))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return total, {k: g * coef for k, g in grads.items()}
+
+
+def adamw_step(P, grads, state, step, lrs, betas=(0.9, 0.999), eps=1e-8, wd=1e-4):
+    """torch.optim.AdamW, decoupled weight decay (main_vg.py:264-268); SURVEY.md A16."""
+    b1, b2 = betas
+    for k, g in grads.items():
+        p = P[k]
+        st = state.setdefault(k, {"m": torch.zeros_like(p), "v": torch.zeros_like(p)})
+        lr = lrs[k]
+        p.mul_(1 - lr * wd)
+        st["m"].mul_(b1).add_(g, alpha=1 - b1)
+        st["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1 ** step
+        bc2 = 1 - b2 ** step
+        denom = (st["v"].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(st["m"], denom, value=-lr / bc1)
+
+
+def train_step(P, samples, targets, cfg, state, step, max_norm=0.1, train=True, q=False,
+               lr=1e-4, lr_backbone=1e-5, lr_bert=1e-5):
+    """One iteration of engine_vg.train_one_epoch's loop body (engine_vg.py:40-72).  P is updated in place;
+    returns (losses dict, total weighted loss, grad norm, grads)."""
+    names = [k for k in P if is_trainable(k) and torch.is_floating_point(P[k])]
+    leaves = {k: P[k].detach().requires_grad_(True) for k in names}
+    Pl = dict(P); Pl.update(leaves)
+    out = reftr_forward(Pl, samples, cfg, train=train, q=q)
+    losses = criterion(out, targets)
+    loss = total_loss(losses, weight_dict(cfg))
+    gl = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(P[k])) for k, g in zip(names, gl)}
+    gnorm, grads_c = clip_grad_norm(grads, max_norm) if max_norm > 0 else (None, grads)
+    lrs = {k: lr_group(k, lr, lr_backbone, lr_bert) for k in names}
+    with torch.no_grad():
+        adamw_step(P, grads_c, state, step, lrs)
+    return {k: float(v) for k, v in losses.items()}, float(loss), (float(gnorm) if gnorm is not None else None), grads

@@ -1,0 +1,101 @@
+"""CPU: the oracle (oracle/reftr_oracle.py) against the golden vectors minted from the imported reference
+(oracle/gen_golden.py, tests/golden/*.npz).  This is what pins the oracle; it runs without a GPU and
+without /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reftr_oracle as O
+from oracle.shapes import param_shapes
+from oracle.synth import make_inputs
+from oracle.weights import formula_state
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).float(); b = torch.as_tensor(b).float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def small_cfg():
+    return O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2))
+
+
+def test_sine_pos_golden():
+    g = gold("sine_pos")
+    assert rel(O.sine_pos(torch.from_numpy(g["mask"])), g["pos"]) < 1e-6
+
+
+def test_criterion_golden_and_known_answer():
+    g = gold("criterion")
+    pm = torch.from_numpy(g["mask"])
+    tg = [{"boxes": torch.from_numpy(g[f"t{i}"]), "labels": torch.zeros(int(pm[i].sum()))} for i in range(3)]
+    out = {"pred_boxes": torch.from_numpy(g["pred"]), "phrase_mask": pm,
+           "aux_outputs": [{"pred_boxes": torch.from_numpy(g["aux"]), "phrase_mask": pm}]}
+    losses = O.criterion(out, tg)
+    for k in ("loss_bbox", "loss_giou", "loss_bbox_0", "loss_giou_0"):
+        assert abs(float(losses[k]) - float(g[k])) < 1e-6, k
+    # BASELINE.md §2 known answer: zero-init head -> boxes 0.5; target (.4,.5,.3,.4): 0.40 + 0.52 per layer
+    ka = O.criterion({"pred_boxes": torch.full((1, 1, 1, 4), 0.5), "phrase_mask": torch.ones(1, 1, dtype=torch.bool)},
+                     [{"boxes": torch.tensor([[0.4, 0.5, 0.3, 0.4]]), "labels": torch.zeros(1)}])
+    assert abs(float(ka["loss_bbox"]) - 0.40) < 1e-6 and abs(float(ka["loss_giou"]) - 0.52) < 1e-6
+
+
+@pytest.mark.parametrize("tag,n_phrase", [("e2e_single", 0), ("e2e_multi", 3)])
+def test_end_to_end_golden(tag, n_phrase):
+    g = gold(tag)
+    cfg = small_cfg()
+    P = formula_state(param_shapes(cfg))
+    samples, targets = make_inputs(tag, B=2, H=96, W=128, L=12, n_phrase=n_phrase)
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(names) == sorted(k for k in P if O.is_trainable(k))
+    leaves = {k: P[k].requires_grad_(True) for k in names}
+    out = O.reftr_forward(P, samples, cfg)
+    assert rel(out["logits"].sigmoid(), g["boxes"]) < 1e-5
+    assert np.array_equal(out["phrase_mask"].numpy(), g["phrase_mask"])          # bool: exact
+    losses = O.criterion(out, targets)
+    for k, v in losses.items():
+        assert abs(float(v) - float(g["loss." + k])) < 1e-5 * max(1.0, abs(float(g["loss." + k]))), k
+    total = O.total_loss(losses, O.weight_dict(cfg))
+    assert abs(float(total) - float(g["total_loss"])) < 1e-5 * abs(float(g["total_loss"]))
+    grads = dict(zip(names, torch.autograd.grad(total, [leaves[k] for k in names])))
+    norms = np.array([float(grads[k].norm()) for k in names])
+    assert np.max(np.abs(norms - g["grad_norms"]) / (g["grad_norms"] + 1e-12)) < 1e-3
+    assert rel(grads["bbox_embed.layers.2.weight"], g["grad_bbox2_w"]) < 1e-5
+    assert rel(grads["vl_transformer.level_embed"], g["grad_level_embed"]) < 1e-5
+    assert rel(grads["img_backbone.0.body.layer4.2.conv3.weight"][:8], g["grad_l4_conv3"]) < 1e-5
+    assert rel(grads["img_backbone.0.body.layer2.0.conv1.weight"][:8], g["grad_l2_conv1"]) < 1e-5
+    assert rel(grads["lang_backbone.encoder.layer.0.attention.self.query.weight"][:8], g["grad_bert_q0"]) < 1e-5
+    assert rel(grads["lang_backbone.embeddings.word_embeddings.weight"][[101, 102]], g["grad_word_emb_rows"]) < 1e-5
+
+
+def test_three_optimizer_steps_golden():
+    g = gold("steps_single")
+    cfg = small_cfg()
+    P = formula_state(param_shapes(cfg))
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    state = {}
+    for it in range(3):
+        _, tot, gnorm, _ = O.train_step(P, samples, targets, cfg, state, it + 1, max_norm=0.1, train=False)
+        assert abs(tot - float(g["loss"][it])) < 2e-5 * abs(float(g["loss"][it]))
+        assert abs(gnorm - float(g["gnorm"][it])) < 1e-3 * abs(float(g["gnorm"][it]))
+    assert rel(P["bbox_embed.layers.2.weight"], g["bbox2_w_after"]) < 1e-5
+    assert rel(P["img_backbone.0.body.layer4.2.conv3.weight"][:4], g["l4_conv3_after"]) < 1e-5
+
+
+def test_bf16_point_mode_stays_close():
+    """q=True (the HIP path's rounding points) must stay a small perturbation of the fp32 arithmetic."""
+    cfg = small_cfg()
+    P = formula_state(param_shapes(cfg))
+    samples, _ = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    with torch.no_grad():
+        a = O.reftr_forward(P, samples, cfg)["logits"]
+        b = O.reftr_forward(P, samples, cfg, q=True)["logits"]
+    assert rel(b, a) < 5e-2
