@@ -79,6 +79,7 @@ typedef struct rt_conv_gemm_desc {
     float    drop_p;
     uint32_t drop_seed;
     int32_t  tile_hint;     /* 0 = auto; otherwise 1: 128x128, 2: 128(m)x64(n), 3: 64x64 */
+    void*    out_preact;    /* bf16 [M, N] or NULL: value after +bias, BEFORE act (saved for GELU backward) */
 } rt_conv_gemm_desc;
 int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream);
 
@@ -103,6 +104,234 @@ typedef struct rt_conv_wgrad_desc {
     int32_t msplit;
 } rt_conv_wgrad_desc;
 int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * rt_layernorm_fwd / rt_layernorm_bwd — nn.LayerNorm over the last axis, fp32 statistics, one wave per row.
+ * Replaces: encoder/decoder norm1-3 and decoder.norm (models/modeling/transformer.py:157-158,217-219,
+ * 176-180,243-251,131-138), BERT LayerNorms (eps 1e-12), the LayerNorms inside mlp_mapping
+ * (models/reftr_transformer.py:14-23) and QueryEncoder.context_out (:36-39).
+ * Fused around it: post-norm ReLU (+dropout) of mlp_mapping, bf16 operand copy for the next GEMM,
+ * bf16(y + pos) for the q/k input of the next attention (with_pos_embed, transformer.py:165-166,172).
+ * Output rows can be re-mapped so that per-image token blocks land inside the [B, S, D] sequence buffer:
+ *   out_row = (r / grp_rows) * grp_stride + grp_off + r % grp_rows      (grp_rows = 0: identity)
+ * Backward: dx (fp32) plus bf16(dx * dropout2-mask) — the gradient entering the GEMM whose output was
+ * dropped-out and added to the residual before this norm; dgamma/dbeta accumulated with atomics.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_layernorm_desc {
+    const float* x;        /* [M, D] */
+    const float* gamma;    /* [D] */
+    const float* beta;     /* [D] */
+    float*       y_f32;    /* row-mapped, or NULL */
+    void*        y_bf16;   /* row-mapped, or NULL */
+    const float* pos;      /* row-mapped like the outputs, or NULL */
+    void*        ypos_bf16;/* bf16(y + pos), or NULL */
+    float*       mean;     /* [M] or NULL */
+    float*       rstd;     /* [M] or NULL */
+    int32_t M, D;
+    float   eps;
+    int32_t act;           /* RT_ACT_NONE | RT_ACT_RELU (after the affine) */
+    float    drop_p;       /* dropout after act, index r*D + c */
+    uint32_t drop_seed;
+    int32_t grp_rows, grp_stride, grp_off;
+} rt_layernorm_desc;
+int rt_layernorm_fwd(const rt_layernorm_desc* d, rt_stream_t stream);
+
+typedef struct rt_layernorm_bwd_desc {
+    const float* dy;       /* row-mapped grad of the LN output */
+    const float* dy2;      /* optional second grad (same mapping) added to dy, or NULL */
+    const float* x;        /* [M, D] LN input */
+    const float* gamma;
+    const float* beta;     /* needed when act == RELU */
+    const float* mean;
+    const float* rstd;
+    float*       dx_f32;   /* [M, D] or NULL */
+    void*        dx_bf16;  /* [M, D] bf16(dx * mask2 / (1-p2)) or NULL */
+    float*       dgamma;   /* [D] accumulated, or NULL */
+    float*       dbeta;    /* [D] accumulated, or NULL */
+    int32_t M, D;
+    int32_t act;
+    float    drop_p;  uint32_t drop_seed;    /* the LN's own post-act dropout */
+    float    drop2_p; uint32_t drop2_seed;   /* dropout of the producing sub-layer (index r*D + c) */
+    int32_t grp_rows, grp_stride, grp_off;
+} rt_layernorm_bwd_desc;
+int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * rt_groupnorm_fwd / rt_groupnorm_bwd — nn.GroupNorm(G, C) of input_proj (models/reftr_transformer.py:
+ * 121-125,174) on the token-major image x[b][pixel][c]; statistics per (image, group) over HW * C/G values.
+ * Output rows go to (b * out_rows_per_img + out_row_off + pixel) so the image tokens land behind the
+ * language tokens of the [B, S, C] sequence (models/reftr.py:115-117).  stats/bstats: [B, G, 2] workspaces.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_groupnorm_desc {
+    const float* x;        /* [B, HW, C] */
+    const float* gamma; const float* beta;
+    float*       stats;    /* [B, G, 2] workspace: sum, sumsq (kept for backward) */
+    float*       y_f32; void* y_bf16;
+    const float* pos; void* ypos_bf16;
+    int32_t B, HW, C, G;
+    float   eps;
+    int32_t out_rows_per_img, out_row_off;
+} rt_groupnorm_desc;
+int rt_groupnorm_fwd(const rt_groupnorm_desc* d, rt_stream_t stream);
+
+typedef struct rt_groupnorm_bwd_desc {
+    const float* dy; const float* dy2;   /* sequence-mapped like the forward outputs */
+    const float* x; const float* gamma;
+    const float* stats;    /* from forward */
+    float*       bstats;   /* [B, G, 2] workspace */
+    float*       dx_f32; void* dx_bf16;  /* [B, HW, C] */
+    float*       dgamma; float* dbeta;
+    int32_t B, HW, C, G;
+    float   eps;
+    int32_t out_rows_per_img, out_row_off;
+} rt_groupnorm_bwd_desc;
+int rt_groupnorm_bwd(const rt_groupnorm_bwd_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * rt_attn_fwd / rt_attn_bwd — softmax(scale * Q K^T + key_padding_mask) V per (batch, head), the core of
+ * nn.MultiheadAttention (models/modeling/transformer.py:174-175,234-246) and of HF BertSelfAttention.
+ * Element (b, i, h, d) of q/k/v/out lives at ptr[(b*S + i)*ld + h*dh + d] so packed projection outputs are
+ * consumed in place.  kpm: uint8 [B, Sk], 1 = ignore (-inf); a fully masked row yields NaN like the
+ * reference.  Dropout acts on the probabilities (index ((b*H+h)*Sq + i)*Sk + j).  lse = log-sum-exp per row
+ * (saved for backward); delta is a [B,H,Sq] fp32 workspace.  dh in {32, 64}; Sq, Sk <= 768.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_attn_desc {
+    const void* q; const void* k; const void* v;
+    void*  out;
+    float* lse;            /* [B, H, Sq] or NULL */
+    const uint8_t* kpm;    /* [B, Sk] or NULL */
+    int32_t B, H, Sq, Sk, dh;
+    int32_t ldq, ldk, ldv, ldo;
+    float    scale;
+    float    drop_p; uint32_t drop_seed;
+} rt_attn_desc;
+int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream);
+
+typedef struct rt_attn_bwd_desc {
+    const void* q; const void* k; const void* v; const void* out; const void* dout;
+    const float* lse;
+    float* delta;          /* [B, H, Sq] workspace */
+    const uint8_t* kpm;
+    void* dq; void* dk; void* dv;
+    int32_t B, H, Sq, Sk, dh;
+    int32_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    float    scale;
+    float    drop_p; uint32_t drop_seed;
+} rt_attn_bwd_desc;
+int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Backbone-side kernels (models/modeling/backbone.py:83-125 + torchvision ResNet stem).
+ * rt_img_pack        NCHW fp32 [B,3,H,W] -> NHWC4 bf16 [B,Hp,Wp,4] with a 3-pixel zero halo on top/left
+ *                    (Hp >= H+6, Wp >= W+6; the 4th channel and the halo are zero)
+ * rt_stem_conv       conv1 7x7/2 pad 3 + FrozenBN + ReLU on MFMA: per kernel row one K=32 step
+ *                    (8 taps x 4 channels); w bf16 [64][7][8][4] (BN scale folded), bias = BN shift;
+ *                    out bf16 NHWC [B,Ho,Wo,64]; needs Wp >= 32*ceil(Wo/16)+6, Hp >= 2*Ho+5
+ * rt_maxpool3x3s2    nn.MaxPool2d(3, 2, 1) on NHWC bf16
+ * rt_weight_prep     fp32 master weight [N][T][C] (T = KH*KW, channels-last) -> bf16 [N][T][C] (dst) and/or
+ *                    bf16 [C][T][N] (dst_t, the backward-data operand), times scale[n] (FrozenBN) if given
+ * rt_stem_weight_prep fp32 [64][7][7][3] -> bf16 [64][7][8][4]
+ * rt_bn_fold         FrozenBatchNorm2d (backbone.py:70-80): scale = w*rsqrt(rv+eps), shift = b - rm*scale
+ * ------------------------------------------------------------------------------------------ */
+int rt_img_pack(const float* img, void* out, int B, int H, int W, int Hp, int Wp, rt_stream_t stream);
+int rt_stem_conv(const void* xp, const void* w, const float* bias, void* out,
+                 int B, int Hp, int Wp, int Ho, int Wo, rt_stream_t stream);
+int rt_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, rt_stream_t stream);
+int rt_weight_prep(const float* src, const float* scale, void* dst, void* dst_t, int N, int T, int C, rt_stream_t stream);
+int rt_stem_weight_prep(const float* src, const float* scale, void* dst, rt_stream_t stream);
+int rt_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps,
+               float* scale, float* shift, int n, rt_stream_t stream);
+
+/* rt_mask_posenc — pad-mask nearest downsample (backbone.py:107, exact/integer) + PositionEmbeddingSine
+ * (models/modeling/position_encoding.py:36-56: normalize, scale 2*pi, T=1e4, eps 1e-6) + add_vec[c]
+ * (level_embed[0] + token_type_embeddings[1], models/reftr.py:60,70-73).  mask uint8 [B,H,W] (1 = pad).
+ * kpm_out[b*kpm_stride + kpm_off + pix] = downsampled mask; pos_out row = b*pos_rows_per_img + pos_row_off + pix. */
+typedef struct rt_mask_posenc_desc {
+    const uint8_t* mask;
+    uint8_t* kpm_out;
+    float*   pos_out;
+    const float* add_vec;   /* [C] or NULL */
+    int32_t B, H, W, h, w, C;
+    int32_t kpm_stride, kpm_off;
+    int32_t pos_rows_per_img, pos_row_off;
+} rt_mask_posenc_desc;
+int rt_mask_posenc(const rt_mask_posenc_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Small fused memory-bound kernels around the GEMMs.
+ * rt_colsum          db[n] += sum_m dy[m,n]   (bias gradients of every nn.Linear / input_proj conv)
+ * rt_rows_add        out[map_o(r)] (=|+=) alpha * (a[map_a(r)] + b[map_b(r)]), fp32 and/or bf16 out;
+ *                    row maps as in rt_layernorm (grp_rows = 0: identity).  Used for with_pos_embed
+ *                    (transformer.py:165-166), residual-gradient accumulation, CLS-row gather/scatter.
+ * rt_bert_embed_*    HF BertEmbeddings lookup word[ids] + pos[l] + type[0] and its scatter-add backward
+ * rt_context_mask    models/reftr_transformer.py:224-248 (bool only): context mask + query mask
+ * rt_qenc_attn_*     QueryEncoder CLS-key attention (models/reftr_transformer.py:48-55), fp32
+ * ------------------------------------------------------------------------------------------ */
+int rt_colsum(const void* dy, int is_bf16, float* db, int M, int N, rt_stream_t stream);
+
+typedef struct rt_rows_add_desc {
+    const float* a_f32; const void* a_bf16; const float* b_f32;
+    float* out_f32; void* out_bf16;
+    int32_t rows, D;
+    float   alpha;
+    int32_t accumulate;     /* out_f32 += instead of = */
+    int32_t a_grp_rows, a_grp_stride, a_grp_off;
+    int32_t b_grp_rows, b_grp_stride, b_grp_off;
+    int32_t o_grp_rows, o_grp_stride, o_grp_off;
+} rt_rows_add_desc;
+int rt_rows_add(const rt_rows_add_desc* d, rt_stream_t stream);
+
+int rt_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
+                      float* out, int rows, int L, int D, rt_stream_t stream);
+int rt_bert_embed_bwd(const int64_t* ids, const float* de, float* dword, float* dpos, float* dtype0,
+                      int rows, int L, int D, rt_stream_t stream);
+int rt_context_mask(const uint8_t* smask, const uint8_t* phrase_mask, const int64_t* pos_l, const int64_t* pos_r,
+                    uint8_t* ctx, uint8_t* qmask, int B, int L, int P, int Lp, rt_stream_t stream);
+int rt_qenc_attn_fwd(const float* k, const float* qs, const float* vs, const uint8_t* ctx, float* w, float* c,
+                     int B, int P, int L, int E, rt_stream_t stream);
+int rt_qenc_attn_bwd(const float* k, const float* qs, const float* vs, const float* w, const float* dc,
+                     float* dk, float* dqs, float* dvs, int B, int P, int L, int E, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * rt_box_loss — CriterionVGMultiPhrase.loss_boxes for all NL decoder layers at once
+ * (models/criterion.py:113-202, util/box_ops.py:17-69).  logits fp32 [NL,B,P,K,4] (pre-sigmoid),
+ * valid uint8 [B,P*K] (phrase_mask, 1 = valid), targets fp32 [sum n_b, 4] cxcywh with tgt_off int32 [B+1],
+ * num_boxes: DEVICE fp32 scalar (already all-reduced / world, clamp >= 1 applied here).
+ * losses[l*2+0] = loss_bbox of layer l, losses[l*2+1] = loss_giou; total = sum_l w_bbox*l1 + w_giou*giou;
+ * dlogits = d total / d logits (0 for invalid phrases).  Selection/ordering is exact.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_box_loss_desc {
+    const float*   logits;
+    const uint8_t* valid;
+    const float*   targets;
+    const int32_t* tgt_off;
+    const float*   num_boxes;
+    float* losses; float* total; float* dlogits;
+    int32_t NL, B, P, K;
+    float   w_bbox, w_giou;
+} rt_box_loss_desc;
+int rt_box_loss(const rt_box_loss_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Optimizer step over the flat parameter / gradient buffers (engine_vg.py:62-67, main_vg.py:234-268).
+ * rt_sqnorm      out[0] = sum g^2
+ * rt_adamw_flat  g' = g * grad_scale; total = sqrt(gnorm_sq) * grad_scale; coef = min(1, max_norm/(total+1e-6))
+ *                (clip_grad_norm_, skipped when max_norm <= 0); AdamW with decoupled weight decay, bias
+ *                correction at `step` (1-based); per-range lr / wd = the reference's param groups.
+ * ------------------------------------------------------------------------------------------ */
+int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stream);
+
+typedef struct rt_adamw_desc {
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    const float* gnorm_sq;  /* device scalar from rt_sqnorm, or NULL */
+    float* gnorm_out;       /* device scalar: total norm (after grad_scale), or NULL */
+    float grad_scale, max_norm, beta1, beta2, eps;
+    int32_t step, n_ranges;
+    int64_t range_begin[8], range_end[8];
+    float   range_lr[8], range_wd[8];
+} rt_adamw_desc;
+int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,266 @@
+// Backbone-side kernels that are not the generic implicit GEMM:
+//   rt_img_pack      NCHW fp32 image -> zero-haloed NHWC4 bf16 (the stem's input layout)
+//   rt_stem_conv     7x7/2 conv + FrozenBN + ReLU on MFMA (K = 7 rows x (8 taps x 4 ch) = 7 x 32)
+//   rt_maxpool3x3s2  NHWC bf16 max-pool 3x3 / stride 2 / pad 1
+//   rt_weight_prep   fp32 master weight -> bf16 GEMM operand(s): [N][T][C] (x FrozenBN scale) and [C][T][N]
+//   rt_mask_posenc   pad-mask nearest downsample + DETR sine position encoding (+ level / token-type embeds)
+#include "rt_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- image pack
+__global__ __launch_bounds__(256) void img_pack_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
+                                                       int B, int H, int W, int Hp, int Wp) {
+    const size_t total = (size_t)B * Hp * Wp;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int xp = (int)(i % Wp);
+        const size_t t = i / Wp;
+        const int yp = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        const int y = yp - 3, x = xp - 3;
+        bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const size_t base = ((size_t)b * 3 * H + y) * W + x;
+            v[0] = (bf16_t)img[base];
+            v[1] = (bf16_t)img[base + (size_t)H * W];
+            v[2] = (bf16_t)img[base + 2 * (size_t)H * W];
+        }
+        *reinterpret_cast<bf16x4*>(out + i * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------- stem conv
+// One wave per output row (b, oh): the 64x224 folded weight lives in registers as 7 x 4 bf16x8 MFMA A
+// fragments; for every 16-pixel tile and kernel row kh the B fragment is ONE 16-byte global load per lane:
+// lane (i, g) needs taps 2g, 2g+1 of output pixel ow0+i = padded input columns 2*(ow0+i) + 2g, +1 (8 bf16).
+__global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict__ xp, const bf16_t* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                        int B, int Hp, int Wp, int Ho, int Wo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int row = blockIdx.x * 4 + wave;          // (b, oh)
+    if (row >= B * Ho) return;
+    const int b = row / Ho, oh = row % Ho;
+    bf16x8 wf[7][4];
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            wf[kh][nt] = *reinterpret_cast<const bf16x8*>(w + ((size_t)(nt * 16 + li) * 7 + kh) * 32 + lg * 8);
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(bias + nt * 16 + lg * 4);
+    const bf16_t* xrow = xp + ((size_t)b * Hp + 2 * oh) * Wp * 4;
+    const int tiles = (Wo + 15) >> 4;
+    for (int tile = 0; tile < tiles; ++tile) {
+        const int ow = tile * 16 + li;
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + ((size_t)kh * Wp + 2 * ow + 2 * lg) * 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][nt], xf, acc[nt], 0, 0, 0);
+        }
+        if (ow < Wo) {
+            bf16_t* o = out + (((size_t)b * Ho + oh) * Wo + ow) * 64;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)fmaxf(acc[nt][r] + bv[nt][r], 0.f);
+                *reinterpret_cast<bf16x4*>(o + nt * 16 + lg * 4) = ov;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- max pool
+__global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                      int B, int H, int W, int C, int Ho, int Wo) {
+    const int cch = C / 8;
+    const size_t total = (size_t)B * Ho * Wo * cch;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cc = (int)(i % cch);
+        size_t t = i / cch;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((size_t)b * H + iy) * W + ix) * C + cc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)m[e];
+        *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------- weight prep
+// src fp32 [N][T][C] -> dst bf16 [N][T][Cpad] (C padded with zeros; used by the stem with T=7x8 taps) and/or
+// dst_t bf16 [C][T][N]; both multiplied by scale[n] when given.
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                          bf16_t* __restrict__ dst, bf16_t* __restrict__ dst_t,
+                                                          int N, int T, int C) {
+    const size_t total = (size_t)N * T * C;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        const int t = (int)(r % T);
+        const int n = (int)(r / T);
+        float v = src[i];
+        if (scale) v *= scale[n];
+        const bf16_t bvv = (bf16_t)v;
+        if (dst) dst[i] = bvv;
+        if (dst_t) dst_t[((size_t)c * T + t) * N + n] = bvv;
+    }
+}
+
+// stem: src fp32 [64][7][7][3] (channels_last view of [64,3,7,7]) -> bf16 [64][7][8][4], zero padded
+__global__ __launch_bounds__(256) void stem_weight_prep_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                               bf16_t* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 64 * 7 * 8 * 4) return;
+    const int c = i & 3, kw = (i >> 2) & 7, kh = (i >> 5) % 7, n = i / 224;
+    float v = 0.f;
+    if (c < 3 && kw < 7) v = src[((n * 7 + kh) * 7 + kw) * 3 + c] * (scale ? scale[n] : 1.f);
+    dst[i] = (bf16_t)v;
+}
+
+// FrozenBN fold: scale = w * rsqrt(rv + eps), shift = b - rm * scale (backbone.py:70-80)
+__global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float s = w[i] * rsqrtf(rv[i] + eps); scale[i] = s; shift[i] = b[i] - rm[i] * s; }
+}
+
+// ---------------------------------------------------------------- mask + position encoding
+// One block per image.  mask_out[b][y][x] = mask[b][floor(y*H/h)][floor(x*W/w)] (nearest, backbone.py:107);
+// pos = sine encoding of the cumulative not-mask counts (position_encoding.py:36-56) + add_vec[c]
+// (level_embed[0] + token_type_emb[1], models/reftr.py:60,70-73), written token-major into the sequence.
+__global__ __launch_bounds__(256) void mask_posenc_kernel(const rt_mask_posenc_desc p) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x;
+    const int hw = p.h * p.w;
+    unsigned char* sm_mask = reinterpret_cast<unsigned char*>(sm);             // [hw]
+    float* ycum = sm + ((hw + 3) / 4);                                         // [hw]
+    float* xcum = ycum + hw;                                                   // [hw]
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        const int y = i / p.w, x = i % p.w;
+        int sy = (int)floorf((float)y * ((float)p.H / (float)p.h));
+        int sx = (int)floorf((float)x * ((float)p.W / (float)p.w));
+        sy = min(sy, p.H - 1); sx = min(sx, p.W - 1);
+        const unsigned char m = p.mask[((size_t)b * p.H + sy) * p.W + sx];
+        sm_mask[i] = m;
+        p.kpm_out[(size_t)b * p.kpm_stride + p.kpm_off + i] = m;
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < p.w; x += 256) {
+        float c = 0.f;
+        for (int y = 0; y < p.h; ++y) { c += sm_mask[y * p.w + x] ? 0.f : 1.f; ycum[y * p.w + x] = c; }
+    }
+    for (int y = threadIdx.x; y < p.h; y += 256) {
+        float c = 0.f;
+        for (int x = 0; x < p.w; ++x) { c += sm_mask[y * p.w + x] ? 0.f : 1.f; xcum[y * p.w + x] = c; }
+    }
+    __syncthreads();
+    const int npf = p.C / 2;
+    const float scale = 6.283185307179586f, eps = 1e-6f;
+    for (int i = threadIdx.x; i < hw * p.C; i += 256) {
+        const int c = i % p.C, pix = i / p.C;
+        const int y = pix / p.w, x = pix % p.w;
+        float e;
+        int cc;
+        if (c < npf) { cc = c; e = (ycum[pix] - 0.5f) / (ycum[(p.h - 1) * p.w + x] + eps) * scale; }
+        else         { cc = c - npf; e = (xcum[pix] - 0.5f) / (xcum[y * p.w + (p.w - 1)] + eps) * scale; }
+        const float dim_t = powf(10000.f, (float)(2 * (cc / 2)) / (float)npf);
+        const float a = e / dim_t;
+        float v = (cc & 1) ? cosf(a) : sinf(a);
+        if (p.add_vec) v += p.add_vec[c];
+        p.pos_out[((size_t)b * p.pos_rows_per_img + p.pos_row_off + pix) * p.C + c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int rt_img_pack(const float* img, void* out, int B, int H, int W, int Hp, int Wp, rt_stream_t stream) {
+    if (!img || !out || Hp < H + 6 || Wp < W + 6) return RT_ERR_BADARG;
+    const size_t total = (size_t)B * Hp * Wp;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(img_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, B, H, W, Hp, Wp);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_stem_conv(const void* xp, const void* w, const float* bias, void* out,
+                            int B, int Hp, int Wp, int Ho, int Wo, rt_stream_t stream) {
+    if (!xp || !w || !bias || !out) return RT_ERR_BADARG;
+    // the last tile of a row reads padded columns up to 2*(16*ceil(Wo/16)-1) + 7
+    if (Wp < 2 * (((Wo + 15) / 16) * 16) + 6 || Hp < 2 * (Ho - 1) + 7) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((B * Ho + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)xp, (const bf16_t*)w, bias, (bf16_t*)out, B, Hp, Wp, Ho, Wo);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, rt_stream_t stream) {
+    if (!x || !y || (C & 7)) return RT_ERR_BADARG;
+    const size_t total = (size_t)B * Ho * Wo * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_weight_prep(const float* src, const float* scale, void* dst, void* dst_t, int N, int T, int C,
+                              rt_stream_t stream) {
+    if (!src || (!dst && !dst_t)) return RT_ERR_BADARG;
+    const size_t total = (size_t)N * T * C;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       src, scale, (bf16_t*)dst, (bf16_t*)dst_t, N, T, C);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_stem_weight_prep(const float* src, const float* scale, void* dst, rt_stream_t stream) {
+    if (!src || !dst) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(stem_weight_prep_kernel, dim3((64 * 224 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       src, scale, (bf16_t*)dst);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps,
+                          float* scale, float* shift, int n, rt_stream_t stream) {
+    if (!w || !b || !rm || !rv || !scale || !shift) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, b, rm, rv, eps, scale, shift, n);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_mask_posenc(const rt_mask_posenc_desc* d, rt_stream_t stream) {
+    if (!d || !d->mask || !d->kpm_out || !d->pos_out || (d->C & 3)) return RT_ERR_BADARG;
+    const int hw = d->h * d->w;
+    const size_t smem = sizeof(float) * ((hw + 3) / 4 + 2 * (size_t)hw);
+    if (smem > 64 * 1024) return RT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(mask_posenc_kernel, dim3(d->B), dim3(256), smem, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}

@@ -16,7 +16,7 @@ namespace {
 
 struct GemmArgs {
     const bf16_t* src; const bf16_t* wgt;
-    bf16_t* out_bf16; float* out_f32;
+    bf16_t* out_bf16; float* out_f32; bf16_t* out_preact;
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act;
     float gate_scale, drop_p; uint32_t drop_seed;
@@ -185,6 +185,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
             const int m = m0 + wm * (BM / 2) + b * 16 + li;
             if (m >= p.M) continue;
             f32x4 v = acc[a][b] + bv;
+            if (p.out_preact) {
+                bf16x4 pv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x4*>(p.out_preact + (size_t)m * p.N + n) = pv;
+            }
             if (p.act == RT_ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -253,7 +259,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     if (d->KH <= 0 || d->KW <= 0 || d->B <= 0 || d->DH <= 0 || d->DW <= 0) return RT_ERR_BADARG;
     GemmArgs a;
     a.src = (const bf16_t*)d->src; a.wgt = (const bf16_t*)d->wgt;
-    a.out_bf16 = (bf16_t*)d->out_bf16; a.out_f32 = d->out_f32;
+    a.out_bf16 = (bf16_t*)d->out_bf16; a.out_f32 = d->out_f32; a.out_preact = (bf16_t*)d->out_preact;
     a.bias = d->bias; a.res_f32 = d->res_f32; a.res_bf16 = (const bf16_t*)d->res_bf16;
     a.gate = (const bf16_t*)d->gate; a.preact = (const bf16_t*)d->preact;
     a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
@@ -282,7 +288,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     }
 }
 
-extern "C" int rt_abi_version(void) { return 1; }
+extern "C" int rt_abi_version(void) { return 2; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

@@ -1,0 +1,281 @@
+// LayerNorm / GroupNorm forward + backward as wave-reduction kernels (fp32 statistics).
+// One 64-lane wave owns one token row (D <= 1024); the epilogue emits everything the next GEMM needs
+// (fp32 residual stream, bf16 operand copy, bf16 copy of y + pos) so no separate cast/add kernels run.
+#include "rt_common.h"
+
+namespace {
+
+constexpr int LN_MAX_PER_LANE = 16;   // D <= 1024
+
+__device__ __forceinline__ int map_row(int r, int grp_rows, int grp_stride, int grp_off) {
+    return grp_rows > 0 ? (r / grp_rows) * grp_stride + grp_off + (r % grp_rows) : r;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const rt_layernorm_desc p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int D = p.D;
+    const int nper = (D + 63) >> 6;
+    const float* xr = p.x + (size_t)row * D;
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + (i << 6);
+        v[i] = (i < nper && c < D) ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = rt_wave_sum(s) / D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + (i << 6);
+        const float d = (i < nper && c < D) ? v[i] - mean : 0.f;
+        ss += d * d;
+    }
+    const float rstd = rsqrtf(rt_wave_sum(ss) / D + p.eps);
+    if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
+    const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    bf16_t* yb = (bf16_t*)p.y_bf16;
+    bf16_t* ypb = (bf16_t*)p.ypos_bf16;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + (i << 6);
+        if (i < nper && c < D) {
+            float y = (v[i] - mean) * rstd * p.gamma[c] + p.beta[c];
+            if (p.act == RT_ACT_RELU) y = fmaxf(y, 0.f);
+            if (do_drop) y = (rt_hash32(p.drop_seed, (uint32_t)(row * D + c)) >= thresh) ? y * ks : 0.f;
+            const size_t o = (size_t)orow * D + c;
+            if (p.y_f32) p.y_f32[o] = y;
+            if (yb) yb[o] = (bf16_t)y;
+            if (ypb) ypb[o] = (bf16_t)(y + p.pos[o]);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma  (dy already through act/dropout)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const rt_layernorm_bwd_desc p) {
+    __shared__ float sm_g[4][1024];
+    __shared__ float sm_b[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = p.D;
+    const int nper = (D + 63) >> 6;
+    float dg[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const bool do_drop2 = p.drop2_p > 0.f;
+    const uint32_t thresh2 = rt_drop_thresh(p.drop2_p);
+    const float ks2 = do_drop2 ? 1.f / (1.f - p.drop2_p) : 1.f;
+    bf16_t* dxb = (bf16_t*)p.dx_bf16;
+
+    for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
+        const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        const float* xr = p.x + (size_t)row * D;
+        float xh[LN_MAX_PER_LANE], g[LN_MAX_PER_LANE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + (i << 6);
+            xh[i] = 0.f; g[i] = 0.f;
+            if (i < nper && c < D) {
+                const size_t o = (size_t)orow * D + c;
+                float d = p.dy[o];
+                if (p.dy2) d += p.dy2[o];
+                xh[i] = (xr[c] - mean) * rstd;
+                const float gam = p.gamma[c];
+                if (do_drop) d = (rt_hash32(p.drop_seed, (uint32_t)(row * D + c)) >= thresh) ? d * ks : 0.f;
+                if (p.act == RT_ACT_RELU) { if (xh[i] * gam + p.beta[c] <= 0.f) d = 0.f; }
+                dg[i] += d * xh[i]; db[i] += d;
+                g[i] = d * gam;
+                s1 += g[i]; s2 += g[i] * xh[i];
+            }
+        }
+        s1 = rt_wave_sum(s1) / D; s2 = rt_wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + (i << 6);
+            if (i < nper && c < D) {
+                const float dx = rstd * (g[i] - s1 - xh[i] * s2);
+                const size_t o = (size_t)row * D + c;
+                if (p.dx_f32) p.dx_f32[o] = dx;
+                if (dxb) {
+                    float d2 = dx;
+                    if (do_drop2) d2 = (rt_hash32(p.drop2_seed, (uint32_t)o) >= thresh2) ? dx * ks2 : 0.f;
+                    dxb[o] = (bf16_t)d2;
+                }
+            }
+        }
+    }
+    if (!p.dgamma && !p.dbeta) return;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + (i << 6);
+        if (i < nper && c < D) { sm_g[wave][c] = dg[i]; sm_b[wave][c] = db[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float a = sm_g[0][c] + sm_g[1][c] + sm_g[2][c] + sm_g[3][c];
+        const float b = sm_b[0][c] + sm_b[1][c] + sm_b[2][c] + sm_b[3][c];
+        if (p.dgamma) atomicAdd(p.dgamma + c, a);
+        if (p.dbeta) atomicAdd(p.dbeta + c, b);
+    }
+}
+
+// ---------------- GroupNorm over token-major images x[b][p][c], groups of C/G channels ----------------
+// stats[b][g] = {sum, sumsq}; a block covers (b, 64-pixel chunk) with one thread per channel.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                       int HW, int C, int G) {
+    const int b = blockIdx.y, c = threadIdx.x;
+    const int p0 = blockIdx.x * 64;
+    const int p1 = min(p0 + 64, HW);
+    float s = 0.f, ss = 0.f;
+    if (c < C)
+        for (int pix = p0; pix < p1; ++pix) { const float v = x[((size_t)b * HW + pix) * C + c]; s += v; ss += v * v; }
+    const int cpg = C / G;             // channels per group (power of two <= 64 assumed)
+    for (int o = cpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (c < C && (c % cpg) == 0) {
+        atomicAdd(stats + ((size_t)b * G + c / cpg) * 2, s);
+        atomicAdd(stats + ((size_t)b * G + c / cpg) * 2 + 1, ss);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const rt_groupnorm_desc p) {
+    const size_t total = (size_t)p.B * p.HW * p.C;
+    const int cpg = p.C / p.G;
+    const float inv_n = 1.f / (float)(cpg * p.HW);
+    bf16_t* yb = (bf16_t*)p.y_bf16; bf16_t* ypb = (bf16_t*)p.ypos_bf16;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % p.C);
+        const size_t pixg = i / p.C;
+        const int b = (int)(pixg / p.HW);
+        const int pix = (int)(pixg % p.HW);
+        const float* st = p.stats + ((size_t)b * p.G + c / cpg) * 2;
+        const float mean = st[0] * inv_n;
+        const float var = fmaxf(st[1] * inv_n - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        const float y = (p.x[i] - mean) * rstd * p.gamma[c] + p.beta[c];
+        const size_t o = ((size_t)b * p.out_rows_per_img + p.out_row_off + pix) * p.C + c;
+        if (p.y_f32) p.y_f32[o] = y;
+        if (yb) yb[o] = (bf16_t)y;
+        if (ypb) ypb[o] = (bf16_t)(y + p.pos[o]);
+    }
+}
+
+// backward pass 1: per (b, g): sums of g=dy*gamma and g*xhat; per channel dgamma/dbeta
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const rt_groupnorm_bwd_desc p) {
+    const int b = blockIdx.y, c = threadIdx.x;
+    const int p0 = blockIdx.x * 64, p1 = min(p0 + 64, p.HW);
+    const int cpg = p.C / p.G;
+    const float inv_n = 1.f / (float)(cpg * p.HW);
+    float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f;
+    if (c < p.C) {
+        const float* st = p.stats + ((size_t)b * p.G + c / cpg) * 2;
+        const float mean = st[0] * inv_n;
+        const float rstd = rsqrtf(fmaxf(st[1] * inv_n - mean * mean, 0.f) + p.eps);
+        const float gam = p.gamma[c];
+        for (int pix = p0; pix < p1; ++pix) {
+            const size_t o = ((size_t)b * p.out_rows_per_img + p.out_row_off + pix) * p.C + c;
+            float d = p.dy[o];
+            if (p.dy2) d += p.dy2[o];
+            const float xh = (p.x[((size_t)b * p.HW + pix) * p.C + c] - mean) * rstd;
+            dg += d * xh; db += d;
+            s1 += d * gam; s2 += d * gam * xh;
+        }
+    }
+    for (int o = cpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (c < p.C) {
+        if ((c % cpg) == 0) {
+            atomicAdd(p.bstats + ((size_t)b * p.G + c / cpg) * 2, s1);
+            atomicAdd(p.bstats + ((size_t)b * p.G + c / cpg) * 2 + 1, s2);
+        }
+        if (p.dgamma) atomicAdd(p.dgamma + c, dg);
+        if (p.dbeta) atomicAdd(p.dbeta + c, db);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const rt_groupnorm_bwd_desc p) {
+    const size_t total = (size_t)p.B * p.HW * p.C;
+    const int cpg = p.C / p.G;
+    const float inv_n = 1.f / (float)(cpg * p.HW);
+    bf16_t* dxb = (bf16_t*)p.dx_bf16;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % p.C);
+        const size_t pixg = i / p.C;
+        const int b = (int)(pixg / p.HW);
+        const int pix = (int)(pixg % p.HW);
+        const int g = c / cpg;
+        const float* st = p.stats + ((size_t)b * p.G + g) * 2;
+        const float mean = st[0] * inv_n;
+        const float rstd = rsqrtf(fmaxf(st[1] * inv_n - mean * mean, 0.f) + p.eps);
+        const float xh = (p.x[i] - mean) * rstd;
+        const size_t o = ((size_t)b * p.out_rows_per_img + p.out_row_off + pix) * p.C + c;
+        float d = p.dy[o];
+        if (p.dy2) d += p.dy2[o];
+        const float m1 = p.bstats[((size_t)b * p.G + g) * 2] * inv_n;
+        const float m2 = p.bstats[((size_t)b * p.G + g) * 2 + 1] * inv_n;
+        const float dx = rstd * (d * p.gamma[c] - m1 - xh * m2);
+        if (p.dx_f32) p.dx_f32[i] = dx;
+        if (dxb) dxb[i] = (bf16_t)dx;
+    }
+}
+
+}  // namespace
+
+extern "C" int rt_layernorm_fwd(const rt_layernorm_desc* d, rt_stream_t stream) {
+    if (!d || !d->x || !d->gamma || !d->beta) return RT_ERR_BADARG;
+    if (d->D <= 0 || d->D > 64 * LN_MAX_PER_LANE || d->M <= 0) return RT_ERR_UNSUPPORTED;
+    if (d->ypos_bf16 && !d->pos) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((d->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stream) {
+    if (!d || !d->dy || !d->x || !d->gamma || !d->mean || !d->rstd) return RT_ERR_BADARG;
+    if (d->D <= 0 || d->D > 64 * LN_MAX_PER_LANE || d->M <= 0) return RT_ERR_UNSUPPORTED;
+    if (d->act == RT_ACT_RELU && !d->beta) return RT_ERR_BADARG;
+    int blocks = (d->M + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_groupnorm_fwd(const rt_groupnorm_desc* d, rt_stream_t stream) {
+    if (!d || !d->x || !d->gamma || !d->beta || !d->stats) return RT_ERR_BADARG;
+    if (d->C <= 0 || d->C > 256 || d->G <= 0 || (d->C % d->G) || (d->C / d->G) > 64 || ((d->C / d->G) & (d->C / d->G - 1)))
+        return RT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d->stats, 0, sizeof(float) * 2 * (size_t)d->B * d->G, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((d->HW + 63) / 64, d->B), dim3(256), 0, s, d->x, d->stats, d->HW, d->C, d->G);
+    RT_CHECK_LAUNCH();
+    const size_t total = (size_t)d->B * d->HW * d->C;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_groupnorm_bwd(const rt_groupnorm_bwd_desc* d, rt_stream_t stream) {
+    if (!d || !d->x || !d->dy || !d->gamma || !d->stats || !d->bstats) return RT_ERR_BADARG;
+    if (d->C <= 0 || d->C > 256 || d->G <= 0 || (d->C % d->G) || (d->C / d->G) > 64) return RT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d->bstats, 0, sizeof(float) * 2 * (size_t)d->B * d->G, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((d->HW + 63) / 64, d->B), dim3(256), 0, s, *d);
+    RT_CHECK_LAUNCH();
+    const size_t total = (size_t)d->B * d->HW * d->C;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}

@@ -1,0 +1,79 @@
+// Optimizer side of the step (engine_vg.py:62-67, main_vg.py:234-268) over ONE flat fp32 parameter buffer:
+//   rt_sqnorm      global L2 norm^2 of the flat gradient (clip_grad_norm_'s total norm)
+//   rt_adamw_flat  gradient scale (1/world) + clip coefficient + decoupled-weight-decay AdamW, 28 B/param of
+//                  HBM traffic in a single streaming pass, per-range learning rates (param groups)
+#include "rt_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (size_t i = (n4 << 2) + blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+    s = rt_block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p) {
+    const float total = sqrtf(p.gnorm_sq ? p.gnorm_sq[0] : 0.f) * p.grad_scale;
+    float coef = 1.f;
+    if (p.max_norm > 0.f) coef = fminf(1.f, p.max_norm / (total + 1e-6f));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.gnorm_out) p.gnorm_out[0] = total;
+    const float gs = p.grad_scale * coef;
+    const float bc1 = 1.f - powf(p.beta1, (float)p.step);
+    const float bc2 = 1.f - powf(p.beta2, (float)p.step);
+    const float inv_sqrt_bc2 = rsqrtf(bc2);
+    const size_t n4 = p.n >> 2;
+    float4* P4 = reinterpret_cast<float4*>(p.p);
+    const float4* G4 = reinterpret_cast<const float4*>(p.g);
+    float4* M4 = reinterpret_cast<float4*>(p.m);
+    float4* V4 = reinterpret_cast<float4*>(p.v);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i << 2;
+        float lr = 0.f, wd = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < p.n_ranges && e >= (size_t)p.range_begin[r] && e < (size_t)p.range_end[r]) { lr = p.range_lr[r]; wd = p.range_wd[r]; }
+        float4 pv = P4[i]; const float4 gv = G4[i]; float4 mv = M4[i]; float4 vv = V4[i];
+        float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float g = gp[c] * gs;
+            pp[c] *= (1.f - lr * wd);
+            mp[c] = p.beta1 * mp[c] + (1.f - p.beta1) * g;
+            vp[c] = p.beta2 * vp[c] + (1.f - p.beta2) * g * g;
+            const float denom = sqrtf(vp[c]) * inv_sqrt_bc2 + p.eps;
+            pp[c] -= (lr / bc1) * (mp[c] / denom);
+        }
+        P4[i] = pv; M4[i] = mv; V4[i] = vv;
+    }
+}
+
+}  // namespace
+
+extern "C" int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stream) {
+    if (!g || !out || n <= 0) return RT_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    int blocks = (int)(((size_t)n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, s, g, (size_t)n, out);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream) {
+    if (!d || !d->p || !d->g || !d->m || !d->v || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8 || d->step < 1)
+        return RT_ERR_BADARG;
+    for (int r = 0; r < d->n_ranges; ++r) if ((d->range_begin[r] & 3) || (d->range_end[r] & 3)) return RT_ERR_BADARG;
+    int blocks = (int)(((size_t)d->n / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}

@@ -6,13 +6,13 @@ an error, a RuntimeError is raised.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -28,6 +28,7 @@ class ConvGemmDesc(Structure):
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
         ("transposed", c_int32), ("act", c_int32),
         ("gate_scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32), ("tile_hint", c_int32),
+        ("out_preact", c_void_p),
     ]
 
 
@@ -41,6 +42,101 @@ class ConvWgradDesc(Structure):
     ]
 
 
+class LayerNormDesc(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("y_f32", c_void_p), ("y_bf16", c_void_p),
+        ("pos", c_void_p), ("ypos_bf16", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+        ("M", c_int32), ("D", c_int32), ("eps", c_float), ("act", c_int32),
+        ("drop_p", c_float), ("drop_seed", c_uint32),
+        ("grp_rows", c_int32), ("grp_stride", c_int32), ("grp_off", c_int32),
+    ]
+
+
+class LayerNormBwdDesc(Structure):
+    _fields_ = [
+        ("dy", c_void_p), ("dy2", c_void_p), ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+        ("mean", c_void_p), ("rstd", c_void_p), ("dx_f32", c_void_p), ("dx_bf16", c_void_p),
+        ("dgamma", c_void_p), ("dbeta", c_void_p),
+        ("M", c_int32), ("D", c_int32), ("act", c_int32),
+        ("drop_p", c_float), ("drop_seed", c_uint32), ("drop2_p", c_float), ("drop2_seed", c_uint32),
+        ("grp_rows", c_int32), ("grp_stride", c_int32), ("grp_off", c_int32),
+    ]
+
+
+class GroupNormDesc(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("stats", c_void_p),
+        ("y_f32", c_void_p), ("y_bf16", c_void_p), ("pos", c_void_p), ("ypos_bf16", c_void_p),
+        ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
+        ("out_rows_per_img", c_int32), ("out_row_off", c_int32),
+    ]
+
+
+class GroupNormBwdDesc(Structure):
+    _fields_ = [
+        ("dy", c_void_p), ("dy2", c_void_p), ("x", c_void_p), ("gamma", c_void_p), ("stats", c_void_p),
+        ("bstats", c_void_p), ("dx_f32", c_void_p), ("dx_bf16", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
+        ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
+        ("out_rows_per_img", c_int32), ("out_row_off", c_int32),
+    ]
+
+
+class AttnDesc(Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p), ("kpm", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Sk", c_int32), ("dh", c_int32),
+        ("ldq", c_int32), ("ldk", c_int32), ("ldv", c_int32), ("ldo", c_int32),
+        ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32),
+    ]
+
+
+class AttnBwdDesc(Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("dout", c_void_p),
+        ("lse", c_void_p), ("delta", c_void_p), ("kpm", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Sk", c_int32), ("dh", c_int32),
+        ("ldq", c_int32), ("ldk", c_int32), ("ldv", c_int32), ("ldo", c_int32),
+        ("lddq", c_int32), ("lddk", c_int32), ("lddv", c_int32),
+        ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32),
+    ]
+
+
+class MaskPosencDesc(Structure):
+    _fields_ = [
+        ("mask", c_void_p), ("kpm_out", c_void_p), ("pos_out", c_void_p), ("add_vec", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("h", c_int32), ("w", c_int32), ("C", c_int32),
+        ("kpm_stride", c_int32), ("kpm_off", c_int32), ("pos_rows_per_img", c_int32), ("pos_row_off", c_int32),
+    ]
+
+
+class RowsAddDesc(Structure):
+    _fields_ = [
+        ("a_f32", c_void_p), ("a_bf16", c_void_p), ("b_f32", c_void_p), ("out_f32", c_void_p), ("out_bf16", c_void_p),
+        ("rows", c_int32), ("D", c_int32), ("alpha", c_float), ("accumulate", c_int32),
+        ("a_grp_rows", c_int32), ("a_grp_stride", c_int32), ("a_grp_off", c_int32),
+        ("b_grp_rows", c_int32), ("b_grp_stride", c_int32), ("b_grp_off", c_int32),
+        ("o_grp_rows", c_int32), ("o_grp_stride", c_int32), ("o_grp_off", c_int32),
+    ]
+
+
+class BoxLossDesc(Structure):
+    _fields_ = [
+        ("logits", c_void_p), ("valid", c_void_p), ("targets", c_void_p), ("tgt_off", c_void_p),
+        ("num_boxes", c_void_p), ("losses", c_void_p), ("total", c_void_p), ("dlogits", c_void_p),
+        ("NL", c_int32), ("B", c_int32), ("P", c_int32), ("K", c_int32), ("w_bbox", c_float), ("w_giou", c_float),
+    ]
+
+
+class AdamWDesc(Structure):
+    _fields_ = [
+        ("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64),
+        ("gnorm_sq", c_void_p), ("gnorm_out", c_void_p),
+        ("grad_scale", c_float), ("max_norm", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+        ("step", c_int32), ("n_ranges", c_int32),
+        ("range_begin", c_int64 * 8), ("range_end", c_int64 * 8), ("range_lr", c_float * 8), ("range_wd", c_float * 8),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/reftr_hip.h declares must be listed here
 # (tests/test_abi.py cross-checks this table against the header).
 _SIGNATURES = {
@@ -48,6 +144,29 @@ _SIGNATURES = {
     "rt_device_arch": (c_int, [c_int, c_char_p, c_int]),
     "rt_conv_gemm": (c_int, [POINTER(ConvGemmDesc), c_void_p]),
     "rt_conv_wgrad": (c_int, [POINTER(ConvWgradDesc), c_void_p]),
+    "rt_layernorm_fwd": (c_int, [POINTER(LayerNormDesc), c_void_p]),
+    "rt_layernorm_bwd": (c_int, [POINTER(LayerNormBwdDesc), c_void_p]),
+    "rt_groupnorm_fwd": (c_int, [POINTER(GroupNormDesc), c_void_p]),
+    "rt_groupnorm_bwd": (c_int, [POINTER(GroupNormBwdDesc), c_void_p]),
+    "rt_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p]),
+    "rt_attn_bwd": (c_int, [POINTER(AttnBwdDesc), c_void_p]),
+    "rt_img_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_stem_conv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_weight_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rt_stem_weight_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rt_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "rt_mask_posenc": (c_int, [POINTER(MaskPosencDesc), c_void_p]),
+    "rt_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "rt_rows_add": (c_int, [POINTER(RowsAddDesc), c_void_p]),
+    "rt_bert_embed_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rt_bert_embed_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rt_context_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_qenc_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_qenc_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_box_loss": (c_int, [POINTER(BoxLossDesc), c_void_p]),
+    "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
 }
 
 _lib = None
@@ -107,10 +226,11 @@ def _req(t, dtype, name):
 # --------------------------------------------------------------------------------------------
 def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=None, gate_scale=1.0,
               preact=None, act=ACT_NONE, drop_p=0.0, drop_seed=0, transposed=False,
-              out_bf16=True, out_f32=False, tile_hint=0):
+              out_bf16=True, out_f32=False, out_preact=False, tile_hint=0):
     """out[B,DH,DW,N] = epilogue(implicit_gemm(src[B,SH,SW,SC], wgt[N,KH,KW,SC])).
 
-    geom = (B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad).  Returns (out_bf16 | None, out_f32 | None).
+    geom = (B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad).  Returns (out_bf16 | None, out_f32 | None)
+    (+ the bf16 pre-activation as a third value when out_preact=True).
     """
     B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
     _req(src, torch.bfloat16, "src"); _req(wgt, torch.bfloat16, "wgt")
@@ -124,8 +244,14 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
     of = torch.empty((M, N), dtype=torch.float32, device=src.device) if out_f32 else None
     d = ConvGemmDesc(_p(src), _p(wgt), _p(ob), _p(of), _p(bias), _p(res_f32), _p(res_bf16), _p(gate),
                      _p(preact), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad,
-                     1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint)
+                     1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint, None)
+    op = None
+    if out_preact:
+        op = torch.empty((M, N), dtype=torch.bfloat16, device=src.device)
+        d.out_preact = _p(op)
     _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm")
+    if out_preact:
+        return ob, of, op
     return ob, of
 
 
@@ -151,3 +277,263 @@ def linear_wgrad(dy, x, dw, **kw):
     M, N = dy.shape
     K = x.shape[1]
     return conv_wgrad(dy, x, dw, geom=(M, 1, 1, K, 1, 1, N, 1, 1, 1, 0), **kw)
+
+
+# --------------------------------------------------------------------------------------------
+# norms
+# --------------------------------------------------------------------------------------------
+def _new(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, *, act=ACT_NONE, drop_p=0.0, drop_seed=0, pos=None,
+                  y_f32=None, y_bf16=None, ypos_bf16=None, want_f32=True, want_bf16=True,
+                  rowmap=(0, 0, 0), save_stats=True):
+    """y = [drop][relu](LN(x)); returns (y_f32, y_bf16, ypos_bf16, mean, rstd).  Output buffers may be passed
+    in (row-mapped writes into a larger sequence buffer) or are allocated [M, D]."""
+    M, D = x.shape
+    _req(x, torch.float32, "x"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    _req(pos, torch.float32, "pos")
+    if y_f32 is None and want_f32:
+        y_f32 = _new((M, D), torch.float32, x)
+    if y_bf16 is None and want_bf16:
+        y_bf16 = _new((M, D), torch.bfloat16, x)
+    if pos is not None and ypos_bf16 is None:
+        ypos_bf16 = _new((M, D), torch.bfloat16, x)
+    mean = _new((M,), torch.float32, x) if save_stats else None
+    rstd = _new((M,), torch.float32, x) if save_stats else None
+    d = LayerNormDesc(_p(x), _p(gamma), _p(beta), _p(y_f32), _p(y_bf16), _p(pos), _p(ypos_bf16), _p(mean), _p(rstd),
+                      M, D, eps, act, drop_p, drop_seed & 0xFFFFFFFF, *rowmap)
+    _check(lib().rt_layernorm_fwd(ctypes.byref(d), _stream()), "rt_layernorm_fwd")
+    return y_f32, y_bf16, ypos_bf16, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy2=None, act=ACT_NONE, drop_p=0.0,
+                  drop_seed=0, drop2_p=0.0, drop2_seed=0, rowmap=(0, 0, 0), want_f32=True, want_bf16=True):
+    """Returns (dx_f32 [M,D], dx_bf16 [M,D] = bf16(dx * dropout2-mask)); dgamma/dbeta accumulated in place."""
+    M, D = x.shape
+    _req(dy, torch.float32, "dy"); _req(dy2, torch.float32, "dy2"); _req(x, torch.float32, "x")
+    dx_f32 = _new((M, D), torch.float32, x) if want_f32 else None
+    dx_bf16 = _new((M, D), torch.bfloat16, x) if want_bf16 else None
+    d = LayerNormBwdDesc(_p(dy), _p(dy2), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx_f32), _p(dx_bf16),
+                         _p(dgamma), _p(dbeta), M, D, act, drop_p, drop_seed & 0xFFFFFFFF, drop2_p,
+                         drop2_seed & 0xFFFFFFFF, *rowmap)
+    _check(lib().rt_layernorm_bwd(ctypes.byref(d), _stream()), "rt_layernorm_bwd")
+    return dx_f32, dx_bf16
+
+
+def groupnorm_fwd(x, gamma, beta, G, eps, *, y_f32=None, y_bf16=None, pos=None, ypos_bf16=None,
+                  rows_per_img=None, row_off=0):
+    """x fp32 [B, HW, C]; outputs are sequence buffers [B*rows_per_img, C] written at row_off + pixel."""
+    B, HW, C = x.shape
+    _req(x, torch.float32, "x")
+    rows_per_img = HW if rows_per_img is None else rows_per_img
+    stats = _new((B, G, 2), torch.float32, x)
+    d = GroupNormDesc(_p(x), _p(gamma), _p(beta), _p(stats), _p(y_f32), _p(y_bf16), _p(pos), _p(ypos_bf16),
+                      B, HW, C, G, eps, rows_per_img, row_off)
+    _check(lib().rt_groupnorm_fwd(ctypes.byref(d), _stream()), "rt_groupnorm_fwd")
+    return stats
+
+
+def groupnorm_bwd(dy, x, gamma, stats, dgamma, dbeta, G, eps, *, dy2=None, rows_per_img=None, row_off=0,
+                  want_f32=False, want_bf16=True):
+    B, HW, C = x.shape
+    rows_per_img = HW if rows_per_img is None else rows_per_img
+    bstats = _new((B, G, 2), torch.float32, x)
+    dx_f32 = _new((B, HW, C), torch.float32, x) if want_f32 else None
+    dx_bf16 = _new((B, HW, C), torch.bfloat16, x) if want_bf16 else None
+    d = GroupNormBwdDesc(_p(dy), _p(dy2), _p(x), _p(gamma), _p(stats), _p(bstats), _p(dx_f32), _p(dx_bf16),
+                         _p(dgamma), _p(dbeta), B, HW, C, G, eps, rows_per_img, row_off)
+    _check(lib().rt_groupnorm_bwd(ctypes.byref(d), _stream()), "rt_groupnorm_bwd")
+    return dx_f32, dx_bf16
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "attention operands are 2-D row views with unit inner stride"
+    return t.stride(0)
+
+
+def attn_fwd(q, k, v, kpm, *, B, H, Sq, Sk, dh, scale, drop_p=0.0, drop_seed=0, out=None):
+    """q [B*Sq, >=H*dh], k/v [B*Sk, >=H*dh] bf16 row views (head h at columns h*dh..); kpm uint8 [B, Sk] or None.
+    Returns (out bf16 [B*Sq, H*dh], lse fp32 [B, H, Sq])."""
+    if out is None:
+        out = _new((B * Sq, H * dh), torch.bfloat16, q)
+    lse = _new((B, H, Sq), torch.float32, q)
+    d = AttnDesc(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(kpm), B, H, Sq, Sk, dh, _ld(q), _ld(k), _ld(v), _ld(out),
+                 scale, drop_p, drop_seed & 0xFFFFFFFF)
+    _check(lib().rt_attn_fwd(ctypes.byref(d), _stream()), "rt_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, dout, lse, kpm, *, B, H, Sq, Sk, dh, scale, drop_p=0.0, drop_seed=0,
+             dq=None, dk=None, dv=None):
+    """Returns (dq, dk, dv) bf16; output row views may be supplied (e.g. halves of one packed buffer)."""
+    if dq is None:
+        dq = _new((B * Sq, H * dh), torch.bfloat16, q)
+    if dk is None:
+        dk = _new((B * Sk, H * dh), torch.bfloat16, q)
+    if dv is None:
+        dv = _new((B * Sk, H * dh), torch.bfloat16, q)
+    delta = _new((B, H, Sq), torch.float32, q)
+    d = AttnBwdDesc(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(delta), _p(kpm), _p(dq), _p(dk), _p(dv),
+                    B, H, Sq, Sk, dh, _ld(q), _ld(k), _ld(v), _ld(out), _ld(dq), _ld(dk), _ld(dv),
+                    scale, drop_p, drop_seed & 0xFFFFFFFF)
+    assert _ld(dout) == _ld(out)
+    _check(lib().rt_attn_bwd(ctypes.byref(d), _stream()), "rt_attn_bwd")
+    return dq, dk, dv
+
+
+# --------------------------------------------------------------------------------------------
+# backbone-side
+# --------------------------------------------------------------------------------------------
+def stem_geometry(H, W):
+    """conv1 7x7/2 pad 3 output size and the padded NHWC4 input size rt_stem_conv needs."""
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp = max(H + 6, 2 * Ho + 5)
+    Wp = max(W + 6, 32 * ((Wo + 15) // 16) + 6)
+    return Ho, Wo, Hp, Wp
+
+
+def img_pack(img):
+    B, C, H, W = img.shape
+    assert C == 3
+    _req(img, torch.float32, "img")
+    _, _, Hp, Wp = stem_geometry(H, W)
+    out = _new((B, Hp, Wp, 4), torch.bfloat16, img)
+    _check(lib().rt_img_pack(_p(img), _p(out), B, H, W, Hp, Wp, _stream()), "rt_img_pack")
+    return out
+
+
+def stem_conv(xp, w, bias, Ho, Wo):
+    B, Hp, Wp, _ = xp.shape
+    out = _new((B, Ho, Wo, 64), torch.bfloat16, xp)
+    _check(lib().rt_stem_conv(_p(xp), _p(w), _p(bias), _p(out), B, Hp, Wp, Ho, Wo, _stream()), "rt_stem_conv")
+    return out
+
+
+def maxpool3x3s2(x):
+    B, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = _new((B, Ho, Wo, C), torch.bfloat16, x)
+    _check(lib().rt_maxpool3x3s2(_p(x), _p(y), B, H, W, C, Ho, Wo, _stream()), "rt_maxpool3x3s2")
+    return y
+
+
+def weight_prep(src, N, T, C, *, scale=None, dst=None, dst_t=None):
+    """fp32 [N][T][C] master -> bf16 dst [N][T][C] and/or dst_t [C][T][N] (both * scale[n])."""
+    _req(src, torch.float32, "src")
+    _check(lib().rt_weight_prep(_p(src), _p(scale), _p(dst), _p(dst_t), N, T, C, _stream()), "rt_weight_prep")
+
+
+def stem_weight_prep(src, scale, dst):
+    _check(lib().rt_stem_weight_prep(_p(src), _p(scale), _p(dst), _stream()), "rt_stem_weight_prep")
+
+
+def bn_fold(w, b, rm, rv, eps, scale, shift):
+    _check(lib().rt_bn_fold(_p(w), _p(b), _p(rm), _p(rv), eps, _p(scale), _p(shift), w.numel(), _stream()), "rt_bn_fold")
+
+
+def mask_posenc(mask_u8, h, w, C, add_vec, kpm_out, kpm_off, pos_out, rows_per_img, row_off):
+    """mask uint8 [B,H,W]; writes kpm_out[b, kpm_off + pix] and pos_out[b*rows_per_img + row_off + pix, :]."""
+    B, H, W = mask_u8.shape
+    d = MaskPosencDesc(_p(mask_u8), _p(kpm_out), _p(pos_out), _p(add_vec), B, H, W, h, w, C,
+                       kpm_out.shape[1], kpm_off, rows_per_img, row_off)
+    _check(lib().rt_mask_posenc(ctypes.byref(d), _stream()), "rt_mask_posenc")
+
+
+# --------------------------------------------------------------------------------------------
+# small fused ops
+# --------------------------------------------------------------------------------------------
+def colsum(dy, db):
+    """db[n] += sum_m dy[m, n] (dy bf16 or fp32, 2-D contiguous)."""
+    M, N = dy.shape
+    _check(lib().rt_colsum(_p(dy), 1 if dy.dtype == torch.bfloat16 else 0, _p(db), M, N, _stream()), "rt_colsum")
+
+
+def rows_add(rows, D, *, a_f32=None, a_bf16=None, b_f32=None, out_f32=None, out_bf16=None, alpha=1.0,
+             accumulate=False, a_map=(0, 0, 0), b_map=(0, 0, 0), o_map=(0, 0, 0)):
+    d = RowsAddDesc(_p(a_f32), _p(a_bf16), _p(b_f32), _p(out_f32), _p(out_bf16), rows, D, alpha,
+                    1 if accumulate else 0, *a_map, *b_map, *o_map)
+    _check(lib().rt_rows_add(ctypes.byref(d), _stream()), "rt_rows_add")
+
+
+def bert_embed_fwd(ids, word, pos, type_emb, L):
+    rows = ids.numel()
+    D = word.shape[1]
+    out = _new((rows, D), torch.float32, word)
+    _check(lib().rt_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type_emb), _p(out), rows, L, D, _stream()),
+           "rt_bert_embed_fwd")
+    return out
+
+
+def bert_embed_bwd(ids, de, dword, dpos, dtype_emb, L):
+    rows, D = de.shape
+    _check(lib().rt_bert_embed_bwd(_p(ids), _p(de), _p(dword), _p(dpos), _p(dtype_emb), rows, L, D, _stream()),
+           "rt_bert_embed_bwd")
+
+
+def context_mask(smask_u8, phrase_mask_u8=None, pos_l=None, pos_r=None):
+    """Returns (ctx uint8 [B,P,L] 1 = ignore, qmask uint8 [B,P] 1 = ignore) — models/reftr_transformer.py:224-248."""
+    B, L = smask_u8.shape
+    if phrase_mask_u8 is None:
+        P, Lp = 1, 0
+    else:
+        _, P, Lp = phrase_mask_u8.shape
+    ctx = _new((B, P, L), torch.uint8, smask_u8)
+    qmask = _new((B, P), torch.uint8, smask_u8)
+    _check(lib().rt_context_mask(_p(smask_u8), _p(phrase_mask_u8), _p(pos_l), _p(pos_r), _p(ctx), _p(qmask),
+                                 B, L, P, Lp, _stream()), "rt_context_mask")
+    return ctx, qmask
+
+
+def qenc_attn_fwd(k, qs, vs, ctx):
+    """k [B,E], qs/vs [B,L,E] fp32, ctx uint8 [B,P,L] -> (w [B,P,L], c [B,P,E])."""
+    B, L, E = qs.shape
+    P = ctx.shape[1]
+    w = _new((B, P, L), torch.float32, qs)
+    c = _new((B, P, E), torch.float32, qs)
+    _check(lib().rt_qenc_attn_fwd(_p(k), _p(qs), _p(vs), _p(ctx), _p(w), _p(c), B, P, L, E, _stream()), "rt_qenc_attn_fwd")
+    return w, c
+
+
+def qenc_attn_bwd(k, qs, vs, w, dc):
+    B, L, E = qs.shape
+    P = w.shape[1]
+    dk = torch.zeros((B, E), dtype=torch.float32, device=qs.device)
+    dqs = torch.zeros((B, L, E), dtype=torch.float32, device=qs.device)
+    dvs = torch.zeros((B, L, E), dtype=torch.float32, device=qs.device)
+    _check(lib().rt_qenc_attn_bwd(_p(k), _p(qs), _p(vs), _p(w), _p(dc), _p(dk), _p(dqs), _p(dvs), B, P, L, E, _stream()),
+           "rt_qenc_attn_bwd")
+    return dk, dqs, dvs
+
+
+def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox, w_giou, want_grad=True):
+    """logits fp32 [NL,B,P,K,4]; returns (losses [NL,2], total [1], dlogits | None)."""
+    NL, B, P, K, _ = logits.shape
+    losses = _new((NL, 2), torch.float32, logits)
+    total = _new((1,), torch.float32, logits)
+    dl = _new(tuple(logits.shape), torch.float32, logits) if want_grad else None
+    d = BoxLossDesc(_p(logits), _p(valid_u8), _p(targets), _p(tgt_off), _p(num_boxes), _p(losses), _p(total), _p(dl),
+                    NL, B, P, K, w_bbox, w_giou)
+    _check(lib().rt_box_loss(ctypes.byref(d), _stream()), "rt_box_loss")
+    return losses, total, dl
+
+
+def sqnorm(g, out):
+    _check(lib().rt_sqnorm(_p(g), g.numel(), _p(out), _stream()), "rt_sqnorm")
+
+
+def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_scale=1.0, max_norm=0.0,
+               beta1=0.9, beta2=0.999, eps=1e-8):
+    """ranges = [(begin, end, lr, wd), ...] element ranges of the flat buffers (multiples of 4)."""
+    d = AdamWDesc()
+    d.p, d.g, d.m, d.v, d.n = _p(p), _p(g), _p(m), _p(v), p.numel()
+    d.gnorm_sq, d.gnorm_out = _p(gnorm_sq), _p(gnorm_out)
+    d.grad_scale, d.max_norm, d.beta1, d.beta2, d.eps = grad_scale, max_norm, beta1, beta2, eps
+    d.step, d.n_ranges = step, len(ranges)
+    for i, (b, e, lr, wd) in enumerate(ranges):
+        d.range_begin[i], d.range_end[i], d.range_lr[i], d.range_wd[i] = b, e, lr, wd
+    _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")
