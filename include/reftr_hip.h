@@ -57,7 +57,7 @@ int rt_device_arch(int dev, char* buf, int buflen);
  * out   [B, DH, DW, N] written as bf16 (out_bf16) and/or fp32 (out_f32)
  * forward gather   : src pixel = (dy*stride - pad + kh, dx*stride - pad + kw)
  * transposed gather: src pixel = ((dy + pad - kh)/stride, (dx + pad - kw)/stride) where divisible
- * epilogue order   : +bias[n] -> act -> dropout(drop_p, drop_seed; index m*N+n) -> +res -> *gate -> *gelu'(preact)
+ * epilogue order   : +bias[n] -> act -> dropout(drop_p, drop_seed; index m*N+n) -> +res -> *gate -> *gelu'(preact) -> *(1-dtanh^2)
  * constraints      : SC % 64 == 0, N % 4 == 0, stride in {1,2}
  * ------------------------------------------------------------------------------------------ */
 typedef struct rt_conv_gemm_desc {
@@ -80,6 +80,8 @@ typedef struct rt_conv_gemm_desc {
     uint32_t drop_seed;
     int32_t  tile_hint;     /* 0 = auto; otherwise 1: 128x128, 2: 128(m)x64(n), 3: 64x64 */
     void*    out_preact;    /* bf16 [M, N] or NULL: value after +bias, BEFORE act (saved for GELU backward) */
+    const void* dtanh;      /* bf16 [M, N] or NULL: out *= (1 - dtanh^2)  (backward of a tanh output, BERT pooler) */
+    int32_t  res_first;     /* 1: add res_* BEFORE act (bottleneck tail relu(bn(conv) + identity)); 0: after dropout */
 } rt_conv_gemm_desc;
 int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream);
 
@@ -261,7 +263,8 @@ int rt_mask_posenc(const rt_mask_posenc_desc* d, rt_stream_t stream);
  * Small fused memory-bound kernels around the GEMMs.
  * rt_colsum          db[n] += sum_m dy[m,n]   (bias gradients of every nn.Linear / input_proj conv)
  * rt_rows_add        out[map_o(r)] (=|+=) alpha * (a[map_a(r)] + b[map_b(r)]), fp32 and/or bf16 out;
- *                    row maps as in rt_layernorm (grp_rows = 0: identity).  Used for with_pos_embed
+ *                    row maps as in rt_layernorm (grp_rows = 0: identity; grp_rows < 0: broadcast
+ *                    (r / -grp_rows) * stride + off); accumulate = 2 uses atomics.  Used for with_pos_embed
  *                    (transformer.py:165-166), residual-gradient accumulation, CLS-row gather/scatter.
  * rt_bert_embed_*    HF BertEmbeddings lookup word[ids] + pos[l] + type[0] and its scatter-add backward
  * rt_context_mask    models/reftr_transformer.py:224-248 (bool only): context mask + query mask
@@ -309,8 +312,17 @@ typedef struct rt_box_loss_desc {
     float* losses; float* total; float* dlogits;
     int32_t NL, B, P, K;
     float   w_bbox, w_giou;
+    const float* weights;   /* optional DEVICE [NL,2] per-layer (bbox, giou) weights overriding w_bbox / w_giou */
 } rt_box_loss_desc;
 int rt_box_loss(const rt_box_loss_desc* d, rt_stream_t stream);
+
+/* rt_small_dgrad — backward-data of a Linear with N <= 8 outputs (the 4-wide bbox_embed.layers.2,
+ * backbone.py:26-38): dx[m,k] = sum_n dy[m,n] w[n,k], optional ReLU gate (gate > 0), bf16 out.
+ * rt_pos_grad    — reduces the gradient of the `pos` sequence (models/reftr.py:60-89) onto
+ * lang_pos_embeddings [L,E], token_type_embeddings [2,E] and level_embed [1,E] (accumulated). */
+int rt_small_dgrad(const float* dy, const float* w, const void* gate, void* dx, int M, int N, int K, rt_stream_t stream);
+int rt_pos_grad(const float* dpos, float* d_lang_pos, float* d_type, float* d_level, int B, int S, int L, int E,
+                rt_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Optimizer step over the flat parameter / gradient buffers (engine_vg.py:62-67, main_vg.py:234-268).

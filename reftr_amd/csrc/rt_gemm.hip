@@ -17,8 +17,8 @@ namespace {
 struct GemmArgs {
     const bf16_t* src; const bf16_t* wgt;
     bf16_t* out_bf16; float* out_f32; bf16_t* out_preact;
-    const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact;
-    int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act;
+    const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
+    int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed;
     int M, K, sshift;
 };
@@ -191,6 +191,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
                 for (int r = 0; r < 4; ++r) pv[r] = (bf16_t)v[r];
                 *reinterpret_cast<bf16x4*>(p.out_preact + (size_t)m * p.N + n) = pv;
             }
+            const size_t o = (size_t)m * p.N + n;
+            if (p.res_first) {
+                if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
+                if (p.res_bf16) {
+                    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                }
+            }
             if (p.act == RT_ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -201,17 +210,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
             }
-            const size_t o = (size_t)m * p.N + n;
             if (do_drop) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     v[r] = (rt_hash32(p.drop_seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
             }
-            if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
-            if (p.res_bf16) {
-                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
+            if (!p.res_first) {
+                if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
+                if (p.res_bf16) {
+                    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                }
             }
             if (p.gate) {
                 const bf16x4 gg = *reinterpret_cast<const bf16x4*>(p.gate + o);
@@ -222,6 +232,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
                 const bf16x4 uu = *reinterpret_cast<const bf16x4*>(p.preact + o);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= rt_gelu_grad((float)uu[r]);
+            }
+            if (p.dtanh) {
+                const bf16x4 tt = *reinterpret_cast<const bf16x4*>(p.dtanh + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (1.f - (float)tt[r] * (float)tt[r]);
             }
             if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
             if (p.out_bf16) {
@@ -261,10 +276,10 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.src = (const bf16_t*)d->src; a.wgt = (const bf16_t*)d->wgt;
     a.out_bf16 = (bf16_t*)d->out_bf16; a.out_f32 = d->out_f32; a.out_preact = (bf16_t*)d->out_preact;
     a.bias = d->bias; a.res_f32 = d->res_f32; a.res_bf16 = (const bf16_t*)d->res_bf16;
-    a.gate = (const bf16_t*)d->gate; a.preact = (const bf16_t*)d->preact;
+    a.gate = (const bf16_t*)d->gate; a.preact = (const bf16_t*)d->preact; a.dtanh = (const bf16_t*)d->dtanh;
     a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed;
-    a.act = d->act; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
+    a.act = d->act; a.res_first = d->res_first; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     // 32-bit element offsets inside the kernel
@@ -288,7 +303,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     }
 }
 
-extern "C" int rt_abi_version(void) { return 2; }
+extern "C" int rt_abi_version(void) { return 5; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

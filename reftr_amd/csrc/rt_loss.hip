@@ -23,6 +23,8 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const rt_box_loss_desc p)
             if (dl) { dl[0] = 0.f; dl[1] = 0.f; dl[2] = 0.f; dl[3] = 0.f; }
         } else {
             layer = l;
+            const float wb = p.weights ? p.weights[l * 2] : p.w_bbox;
+            const float wg = p.weights ? p.weights[l * 2 + 1] : p.w_giou;
             int rank = 0;      // masked_select keeps phrase order (criterion.py:126)
             for (int q = 0; q < ph; ++q) rank += p.valid[(size_t)b * p.P * p.K + q * p.K] ? 1 : 0;
             const float* tg = p.targets + ((size_t)p.tgt_off[b] + rank) * 4;
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const rt_box_loss_desc p)
             for (int c = 0; c < 4; ++c) {
                 const float d = s[c] - t[c];
                 l1_sum += fabsf(d);
-                g[c] = p.w_bbox * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) / nb;
+                g[c] = wb * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) / nb;
             }
             // GIoU on xyxy
             const float x0 = s[0] - 0.5f * s[2], y0 = s[1] - 0.5f * s[3], x1 = s[0] + 0.5f * s[2], y1 = s[1] + 0.5f * s[3];
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const rt_box_loss_desc p)
                 const float diou = (di[c] * uni - inter * du) / (uni * uni);
                 dg[c] = diou + (du * C - uni * dC[c]) / (C * C);     // d giou / d coord
             }
-            const float sc = -p.w_giou / nb;                          // loss = (1 - giou) / nb
+            const float sc = -wg / nb;                          // loss = (1 - giou) / nb
             g[0] += sc * (dg[0] + dg[2]);
             g[1] += sc * (dg[1] + dg[3]);
             g[2] += sc * 0.5f * (dg[2] - dg[0]);
@@ -73,9 +75,11 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const rt_box_loss_desc p)
         }
     }
     if (layer >= 0) {
+        const float wb = p.weights ? p.weights[layer * 2] : p.w_bbox;
+        const float wg = p.weights ? p.weights[layer * 2 + 1] : p.w_giou;
         atomicAdd(p.losses + layer * 2, l1_sum / nb);
         atomicAdd(p.losses + layer * 2 + 1, gi_sum / nb);
-        atomicAdd(p.total, (p.w_bbox * l1_sum + p.w_giou * gi_sum) / nb);
+        atomicAdd(p.total, (wb * l1_sum + wg * gi_sum) / nb);
     }
 }
 

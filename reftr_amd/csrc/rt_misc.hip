@@ -4,8 +4,11 @@
 
 namespace {
 
+// grp_rows > 0: (r / g) * stride + off + r % g;  grp_rows < 0: broadcast (r / -g) * stride + off;  0: identity
 __device__ __forceinline__ int map_row(int r, int grp_rows, int grp_stride, int grp_off) {
-    return grp_rows > 0 ? (r / grp_rows) * grp_stride + grp_off + (r % grp_rows) : r;
+    if (grp_rows > 0) return (r / grp_rows) * grp_stride + grp_off + (r % grp_rows);
+    if (grp_rows < 0) return (r / (-grp_rows)) * grp_stride + grp_off;
+    return r;
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
@@ -40,7 +43,11 @@ __global__ __launch_bounds__(256) void rows_add_kernel(const rt_rows_add_desc p)
         if (p.b_f32) v += p.b_f32[(size_t)map_row(r, p.b_grp_rows, p.b_grp_stride, p.b_grp_off) * p.D + c];
         v *= p.alpha;
         const size_t o = (size_t)map_row(r, p.o_grp_rows, p.o_grp_stride, p.o_grp_off) * p.D + c;
-        if (p.out_f32) { if (p.accumulate) p.out_f32[o] += v; else p.out_f32[o] = v; }
+        if (p.out_f32) {
+            if (p.accumulate == 2) atomicAdd(p.out_f32 + o, v);
+            else if (p.accumulate) p.out_f32[o] += v;
+            else p.out_f32[o] = v;
+        }
         if (ob) ob[o] = (bf16_t)v;
     }
 }
@@ -174,6 +181,44 @@ __global__ __launch_bounds__(256) void qenc_attn_bwd_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------- tiny-N backward-data (the 4-wide box head)
+// dx[m, k] = gate(sum_{n<N} dy[m, n] * w[n, k]),  N <= 8, fp32 dy / w, bf16 out
+__global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          const bf16_t* __restrict__ gate, bf16_t* __restrict__ dx,
+                                                          int M, int N, int K) {
+    const size_t total = (size_t)M * K;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        const int m = (int)(i / K);
+        float a = 0.f;
+        for (int n = 0; n < N; ++n) a += dy[(size_t)m * N + n] * w[(size_t)n * K + k];
+        if (gate && !((float)gate[i] > 0.f)) a = 0.f;
+        dx[i] = (bf16_t)a;
+    }
+}
+
+// ---------------------------------------------------------------- gradients of the positional embeddings
+// dpos fp32 [B*S, E] (gradient w.r.t. the `pos` sequence, models/reftr.py:51-120):
+//   d lang_pos_embeddings[l] += sum_b dpos[b, l];  d token_type[0] += sum over language rows;
+//   d level_embed[0], d token_type[1] += sum over image rows.
+__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dpos, float* __restrict__ d_lang_pos,
+                                                       float* __restrict__ d_type, float* __restrict__ d_level,
+                                                       int B, int S, int L, int E) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= E) return;
+    float t0 = 0.f, t1 = 0.f;
+    for (int l = 0; l < L; ++l) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dpos[((size_t)b * S + l) * E + c];
+        d_lang_pos[(size_t)l * E + c] += a;
+        t0 += a;
+    }
+    for (int b = 0; b < B; ++b)
+        for (int r = L; r < S; ++r) t1 += dpos[((size_t)b * S + r) * E + c];
+    d_type[c] += t0; d_type[E + c] += t1; d_level[c] += t1;
+}
+
 }  // namespace
 
 extern "C" int rt_colsum(const void* dy, int is_bf16, float* db, int M, int N, rt_stream_t stream) {
@@ -239,6 +284,23 @@ extern "C" int rt_qenc_attn_bwd(const float* k, const float* qs, const float* vs
     if (!k || !qs || !vs || !w || !dc || !dk || !dqs || !dvs) return RT_ERR_BADARG;
     if (L > 128 || L <= 0) return RT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(qenc_attn_bwd_kernel, dim3(B * P), dim3(256), 0, (hipStream_t)stream, k, qs, vs, w, dc, dk, dqs, dvs, P, L, E);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_small_dgrad(const float* dy, const float* w, const void* gate, void* dx, int M, int N, int K, rt_stream_t stream) {
+    if (!dy || !w || !dx || N <= 0 || N > 8) return RT_ERR_BADARG;
+    const size_t total = (size_t)M * K;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(small_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, w, (const bf16_t*)gate, (bf16_t*)dx, M, N, K);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_pos_grad(const float* dpos, float* d_lang_pos, float* d_type, float* d_level, int B, int S, int L, int E,
+                           rt_stream_t stream) {
+    if (!dpos || !d_lang_pos || !d_type || !d_level) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(pos_grad_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpos, d_lang_pos, d_type, d_level, B, S, L, E);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

@@ -8,7 +8,9 @@ namespace {
 constexpr int LN_MAX_PER_LANE = 16;   // D <= 1024
 
 __device__ __forceinline__ int map_row(int r, int grp_rows, int grp_stride, int grp_off) {
-    return grp_rows > 0 ? (r / grp_rows) * grp_stride + grp_off + (r % grp_rows) : r;
+    if (grp_rows > 0) return (r / grp_rows) * grp_stride + grp_off + (r % grp_rows);
+    if (grp_rows < 0) return (r / (-grp_rows)) * grp_stride + grp_off;
+    return r;
 }
 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const rt_layernorm_desc p) {

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 5
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -28,7 +28,7 @@ class ConvGemmDesc(Structure):
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
         ("transposed", c_int32), ("act", c_int32),
         ("gate_scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32), ("tile_hint", c_int32),
-        ("out_preact", c_void_p),
+        ("out_preact", c_void_p), ("dtanh", c_void_p), ("res_first", c_int32),
     ]
 
 
@@ -124,6 +124,7 @@ class BoxLossDesc(Structure):
         ("logits", c_void_p), ("valid", c_void_p), ("targets", c_void_p), ("tgt_off", c_void_p),
         ("num_boxes", c_void_p), ("losses", c_void_p), ("total", c_void_p), ("dlogits", c_void_p),
         ("NL", c_int32), ("B", c_int32), ("P", c_int32), ("K", c_int32), ("w_bbox", c_float), ("w_giou", c_float),
+        ("weights", c_void_p),
     ]
 
 
@@ -165,6 +166,8 @@ _SIGNATURES = {
     "rt_qenc_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_qenc_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_box_loss": (c_int, [POINTER(BoxLossDesc), c_void_p]),
+    "rt_small_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rt_pos_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
 }
@@ -225,12 +228,13 @@ def _req(t, dtype, name):
 # op wrappers
 # --------------------------------------------------------------------------------------------
 def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=None, gate_scale=1.0,
-              preact=None, act=ACT_NONE, drop_p=0.0, drop_seed=0, transposed=False,
+              preact=None, dtanh=None, res_first=False, act=ACT_NONE, drop_p=0.0, drop_seed=0, transposed=False,
               out_bf16=True, out_f32=False, out_preact=False, tile_hint=0):
     """out[B,DH,DW,N] = epilogue(implicit_gemm(src[B,SH,SW,SC], wgt[N,KH,KW,SC])).
 
     geom = (B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad).  Returns (out_bf16 | None, out_f32 | None)
-    (+ the bf16 pre-activation as a third value when out_preact=True).
+    (+ the bf16 pre-activation as a third value when out_preact=True).  out_bf16 / out_f32 may be True (allocate
+    [M, N]) or an existing tensor to write into (in-place accumulation when it is also `res_f32`).
     """
     B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
     _req(src, torch.bfloat16, "src"); _req(wgt, torch.bfloat16, "wgt")
@@ -240,11 +244,14 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
     assert src.numel() == B * SH * SW * SC, (src.shape, geom)
     assert wgt.numel() == N * KH * KW * SC, (wgt.shape, geom)
     M = B * DH * DW
-    ob = torch.empty((M, N), dtype=torch.bfloat16, device=src.device) if out_bf16 else None
-    of = torch.empty((M, N), dtype=torch.float32, device=src.device) if out_f32 else None
+    _req(dtanh, torch.bfloat16, "dtanh")
+    ob = out_bf16 if torch.is_tensor(out_bf16) else (torch.empty((M, N), dtype=torch.bfloat16, device=src.device) if out_bf16 else None)
+    of = out_f32 if torch.is_tensor(out_f32) else (torch.empty((M, N), dtype=torch.float32, device=src.device) if out_f32 else None)
+    _req(ob, torch.bfloat16, "out_bf16"); _req(of, torch.float32, "out_f32")
+    assert (ob is None or ob.numel() == M * N) and (of is None or of.numel() == M * N)
     d = ConvGemmDesc(_p(src), _p(wgt), _p(ob), _p(of), _p(bias), _p(res_f32), _p(res_bf16), _p(gate),
                      _p(preact), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad,
-                     1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint, None)
+                     1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint, None, _p(dtanh), 1 if res_first else 0)
     op = None
     if out_preact:
         op = torch.empty((M, N), dtype=torch.bfloat16, device=src.device)
@@ -456,7 +463,7 @@ def colsum(dy, db):
 def rows_add(rows, D, *, a_f32=None, a_bf16=None, b_f32=None, out_f32=None, out_bf16=None, alpha=1.0,
              accumulate=False, a_map=(0, 0, 0), b_map=(0, 0, 0), o_map=(0, 0, 0)):
     d = RowsAddDesc(_p(a_f32), _p(a_bf16), _p(b_f32), _p(out_f32), _p(out_bf16), rows, D, alpha,
-                    1 if accumulate else 0, *a_map, *b_map, *o_map)
+                    int(accumulate), *a_map, *b_map, *o_map)
     _check(lib().rt_rows_add(ctypes.byref(d), _stream()), "rt_rows_add")
 
 
@@ -510,14 +517,15 @@ def qenc_attn_bwd(k, qs, vs, w, dc):
     return dk, dqs, dvs
 
 
-def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox, w_giou, want_grad=True):
-    """logits fp32 [NL,B,P,K,4]; returns (losses [NL,2], total [1], dlogits | None)."""
+def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox=1.0, w_giou=1.0, want_grad=True, weights=None):
+    """logits fp32 [NL,B,P,K,4]; returns (losses [NL,2], total [1], dlogits | None).  `weights` (device fp32
+    [NL,2]) overrides the scalar weights per layer."""
     NL, B, P, K, _ = logits.shape
     losses = _new((NL, 2), torch.float32, logits)
     total = _new((1,), torch.float32, logits)
     dl = _new(tuple(logits.shape), torch.float32, logits) if want_grad else None
     d = BoxLossDesc(_p(logits), _p(valid_u8), _p(targets), _p(tgt_off), _p(num_boxes), _p(losses), _p(total), _p(dl),
-                    NL, B, P, K, w_bbox, w_giou)
+                    NL, B, P, K, w_bbox, w_giou, _p(weights))
     _check(lib().rt_box_loss(ctypes.byref(d), _stream()), "rt_box_loss")
     return losses, total, dl
 
@@ -537,3 +545,17 @@ def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_
     for i, (b, e, lr, wd) in enumerate(ranges):
         d.range_begin[i], d.range_end[i], d.range_lr[i], d.range_wd[i] = b, e, lr, wd
     _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")
+
+
+def small_dgrad(dy_f32, w_f32, gate=None):
+    """dx bf16 [M,K] = gate(dy[M,N<=8] @ w[N,K])."""
+    M, N = dy_f32.shape
+    K = w_f32.shape[1]
+    dx = _new((M, K), torch.bfloat16, dy_f32)
+    _check(lib().rt_small_dgrad(_p(dy_f32), _p(w_f32), _p(gate), _p(dx), M, N, K, _stream()), "rt_small_dgrad")
+    return dx
+
+
+def pos_grad(dpos, d_lang_pos, d_type, d_level, B, S, L):
+    E = dpos.shape[1]
+    _check(lib().rt_pos_grad(_p(dpos), _p(d_lang_pos), _p(d_type), _p(d_level), B, S, L, E, _stream()), "rt_pos_grad")

@@ -1,0 +1,145 @@
+"""ResNet-50/101 v1.5 body with FrozenBatchNorm folded into the convolutions — forward and hand-written
+backward over the HIP implicit-GEMM kernels (NHWC bf16 activations).
+
+Mirrors models/modeling/backbone.py:83-125 of the reference (torchvision resnet + FrozenBatchNorm2d
+:43-80, conv1/layer1 frozen :87-89, pad-mask interpolation :107).  Every conv+BN(+ReLU)(+residual) is ONE
+rt_conv_gemm launch: BN scale is folded into the bf16 weight, BN shift is the epilogue bias.
+
+Backward convention: every gradient tensor that flows between blocks is dL/d(pre-ReLU value) — the ReLU
+mask of a tensor is applied by the kernel that PRODUCES its gradient (`gate=` epilogue), so no separate
+elementwise backward kernels run.
+"""
+from .. import hip as H
+from . import layout as L
+
+
+class ConvSpec:
+    __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "pad", "trainable")
+
+    def __init__(self, name, bn, cin, cout, k, stride, trainable):
+        self.name, self.bn, self.cin, self.cout, self.k, self.stride = name, bn, cin, cout, k, stride
+        self.pad = k // 2
+        self.trainable = trainable
+
+
+class BlockSpec:
+    __slots__ = ("conv1", "conv2", "conv3", "down", "trainable", "first_trainable")
+
+
+class ResNetBody:
+    PFX = "img_backbone.0.body."
+
+    def __init__(self, store, cfg):
+        self.store = store
+        self.cfg = cfg
+        self.blocks = []          # list of stages, each a list of BlockSpec
+        inpl = 64
+        for li, n in enumerate(cfg.resnet_layers):
+            planes = 64 * 2 ** li
+            tr = li > 0
+            stage = []
+            for bi in range(n):
+                p = f"{self.PFX}layer{li + 1}.{bi}."
+                s = 2 if (bi == 0 and li > 0) else 1
+                b = BlockSpec()
+                b.conv1 = ConvSpec(p + "conv1.weight", p + "bn1.", inpl, planes, 1, 1, tr)
+                b.conv2 = ConvSpec(p + "conv2.weight", p + "bn2.", planes, planes, 3, s, tr)
+                b.conv3 = ConvSpec(p + "conv3.weight", p + "bn3.", planes, planes * 4, 1, 1, tr)
+                b.down = ConvSpec(p + "downsample.0.weight", p + "downsample.1.", inpl, planes * 4, 1, s, tr) if bi == 0 else None
+                b.trainable = tr
+                b.first_trainable = (li == 1 and bi == 0)     # its input (layer1 output) needs no gradient
+                stage.append(b)
+                inpl = planes * 4
+            self.blocks.append(stage)
+        self.W = {}      # bf16 operands: name -> [N][T][C]; name + '.t' -> [C][T][N]
+        self.bn = {}     # bn prefix -> (scale, shift) fp32
+        self.all_convs = [c for st in self.blocks for b in st for c in (b.conv1, b.conv2, b.conv3, b.down) if c is not None]
+
+    # ------------------------------------------------------------------ operands
+    def refresh(self, full):
+        """Rebuild bf16 operands from the fp32 masters.  full=True also re-folds the FrozenBN buffers and the
+        frozen weights (needed after load_state_dict / device moves); the per-step call only touches the
+        trainable convolutions."""
+        st, P, dev = self.store, self.store.P, self.store.device
+        import torch
+        if full:
+            bns = [self.PFX + "bn1."] + [c.bn for c in self.all_convs]
+            for bn in bns:
+                c = P[bn + "weight"].numel()
+                sc = torch.empty(c, dtype=torch.float32, device=dev); sh = torch.empty(c, dtype=torch.float32, device=dev)
+                H.bn_fold(P[bn + "weight"], P[bn + "bias"], P[bn + "running_mean"], P[bn + "running_var"], 1e-5, sc, sh)
+                self.bn[bn] = (sc, sh)
+            self.W["stem"] = torch.empty(64, 7, 8, 4, dtype=torch.bfloat16, device=dev)
+            H.stem_weight_prep(st.phys(self.PFX + "conv1.weight"), self.bn[self.PFX + "bn1."][0], self.W["stem"])
+        for c in self.all_convs:
+            if not (full or c.trainable):
+                continue
+            T = c.k * c.k
+            if c.name not in self.W:
+                self.W[c.name] = torch.empty(c.cout, T, c.cin, dtype=torch.bfloat16, device=dev)
+                if c.trainable:
+                    self.W[c.name + ".t"] = torch.empty(c.cin, T, c.cout, dtype=torch.bfloat16, device=dev)
+            H.weight_prep(st.phys(c.name), c.cout, T, c.cin, scale=self.bn[c.bn][0], dst=self.W[c.name],
+                          dst_t=self.W.get(c.name + ".t"))
+
+    # ------------------------------------------------------------------ forward
+    def _conv(self, x, shp, c, relu, res=None):
+        B, Hh, Ww = shp
+        Ho = (Hh + 2 * c.pad - c.k) // c.stride + 1
+        Wo = (Ww + 2 * c.pad - c.k) // c.stride + 1
+        geom = (B, Hh, Ww, c.cin, Ho, Wo, c.cout, c.k, c.k, c.stride, c.pad)
+        y, _ = H.conv_gemm(x, self.W[c.name], geom=geom, bias=self.bn[c.bn][1], res_bf16=res, res_first=True,
+                           act=H.ACT_RELU if relu else H.ACT_NONE)
+        return y, (B, Ho, Wo), geom
+
+    def forward(self, img):
+        """img fp32 [B,3,H,W] -> (list of the 4 stage outputs as ([M, C] bf16, (B,h,w))), saved-for-backward)."""
+        B, _, Hh, Ww = img.shape
+        Ho, Wo, _, _ = H.stem_geometry(Hh, Ww)
+        xp = H.img_pack(img)
+        y = H.stem_conv(xp, self.W["stem"], self.bn[self.PFX + "bn1."][1], Ho, Wo)
+        y = H.maxpool3x3s2(y)
+        shp = (B, y.shape[1], y.shape[2])
+        x = y.view(-1, 64)
+        feats, saved = [], []
+        for stage in self.blocks:
+            for b in stage:
+                rec = {"x": x, "shp": shp}
+                idt = x
+                if b.down is not None:
+                    idt, _, rec["gd"] = self._conv(x, shp, b.down, relu=False)
+                h1, s1, rec["g1"] = self._conv(x, shp, b.conv1, relu=True)
+                h2, s2, rec["g2"] = self._conv(h1, s1, b.conv2, relu=True)
+                out, s3, rec["g3"] = self._conv(h2, s2, b.conv3, relu=True, res=idt)
+                if b.trainable:
+                    rec.update(h1=h1, h2=h2, out=out)
+                    saved.append((b, rec))
+                x, shp = out, s3
+            feats.append((x, shp))
+        return feats, saved
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, g, x, c, geom):
+        H.conv_wgrad(g, x, self.store.phys(c.name, grad=True), geom=geom, scale=self.bn[c.bn][0])
+
+    def _dgrad(self, g, c, geom, res=None, gate=None):
+        B, SH, SW, SC, DH, DW, N, KH, KW, s, p = geom
+        geom_t = (B, DH, DW, N, SH, SW, SC, KH, KW, s, p)
+        y, _ = H.conv_gemm(g, self.W[c.name + ".t"], geom=geom_t, transposed=True, res_bf16=res, gate=gate)
+        return y
+
+    def backward(self, saved, g_out):
+        """g_out: bf16 [M, 2048] = dL/d(pre-ReLU of the layer4 output) (already gated by the producer)."""
+        for b, rec in reversed(saved):
+            x, h1, h2 = rec["x"], rec["h1"], rec["h2"]
+            self._wgrad(g_out, h2, b.conv3, rec["g3"])
+            g_h2 = self._dgrad(g_out, b.conv3, rec["g3"], gate=h2)
+            self._wgrad(g_h2, h1, b.conv2, rec["g2"])
+            g_h1 = self._dgrad(g_h2, b.conv2, rec["g2"], gate=h1)
+            self._wgrad(g_h1, x, b.conv1, rec["g1"])
+            if b.down is not None:
+                self._wgrad(g_out, x, b.down, rec["gd"])
+            if b.first_trainable:
+                break                                   # layer1 is frozen: no gradient w.r.t. its output
+            g_idt = self._dgrad(g_out, b.down, rec["gd"]) if b.down is not None else g_out
+            g_out = self._dgrad(g_h1, b.conv1, rec["g1"], res=g_idt, gate=x)

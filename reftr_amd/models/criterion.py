@@ -1,0 +1,70 @@
+"""CriterionVGMultiPhrase on the fused box-loss kernel.
+
+Same constructor / forward contract and loss keys as the reference (models/criterion.py:100-202):
+`criterion(outputs, targets) -> {'loss_bbox', 'loss_giou', 'loss_bbox_i', 'loss_giou_i', ...}`, `.weight_dict`.
+All decoder layers are evaluated by ONE rt_box_loss launch over outputs['pred_logits'] (the model's
+pre-sigmoid stack); its backward is a second launch of the same kernel weighted by the incoming gradient of
+every loss entry, so any weight_dict the training loop applies (engine_vg.py:43) is honoured.
+"""
+import torch
+from torch import nn
+
+from .. import hip as H
+from ..util.misc import get_world_size, is_dist_avail_and_initialized
+
+
+class _BoxLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, valid_u8, targets, tgt_off, num_boxes):
+        losses, _, _ = H.box_loss(logits, valid_u8, targets, tgt_off, num_boxes, want_grad=False)
+        ctx.save_for_backward(logits, valid_u8, targets, tgt_off, num_boxes)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, valid_u8, targets, tgt_off, num_boxes = ctx.saved_tensors
+        _, _, dl = H.box_loss(logits, valid_u8, targets, tgt_off, num_boxes, want_grad=True,
+                              weights=g.contiguous().to(torch.float32))
+        return dl, None, None, None, None
+
+
+class CriterionVGMultiPhrase(nn.Module):
+    def __init__(self, weight_dict, losses):
+        super().__init__()
+        self.weight_dict = weight_dict
+        self.losses = losses
+        self._off_cache = {}
+
+    def _targets(self, targets, device):
+        lens = tuple(int(t["boxes"].shape[0]) for t in targets)
+        if lens not in self._off_cache:
+            off = [0]
+            for n in lens:
+                off.append(off[-1] + n)
+            self._off_cache[lens] = torch.tensor(off, dtype=torch.int32, device=device)
+        boxes = torch.cat([t["boxes"].to(device, torch.float32) for t in targets], dim=0).contiguous()
+        return boxes, self._off_cache[lens]
+
+    def forward(self, outputs, targets):
+        assert "boxes" in self.losses and "pred_logits" in outputs, \
+            "the HIP criterion consumes the model's pre-sigmoid logits (outputs['pred_logits'])"
+        logits = outputs["pred_logits"]                       # [NL, B, P, K, 4]
+        if "aux_outputs" not in outputs:
+            logits = logits[-1:]
+        logits = logits.contiguous()
+        device = logits.device
+        # criterion.py:176-180: number of target boxes averaged over ranks, clamp >= 1 (in the kernel); kept on
+        # the device so no host sync is needed
+        num_boxes = torch.tensor([float(sum(len(t["labels"]) for t in targets))], dtype=torch.float32, device=device)
+        if is_dist_avail_and_initialized():
+            torch.distributed.all_reduce(num_boxes)
+            num_boxes = num_boxes / get_world_size()
+        boxes, off = self._targets(targets, device)
+        valid = outputs["phrase_mask"].to(torch.uint8).contiguous()
+        losses = _BoxLossFunction.apply(logits, valid, boxes, off, num_boxes)     # [NL, 2]
+        nl = losses.shape[0]
+        out = {"loss_bbox": losses[nl - 1, 0], "loss_giou": losses[nl - 1, 1]}
+        for i in range(nl - 1):
+            out[f"loss_bbox_{i}"] = losses[i, 0]
+            out[f"loss_giou_{i}"] = losses[i, 1]
+        return out

@@ -1,0 +1,156 @@
+"""Parameter layout of the RefTR model: names, shapes, storage order.
+
+The NAMES are the reference's checkpoint contract (state_dict keys of ubc-vision/RefTR):
+torchvision ResNet names under `img_backbone.0.body`, HuggingFace BertModel names under `lang_backbone`,
+DETR-style names under `vl_transformer` (models/reftr.py:22-41, models/modeling/transformer.py:148-158,
+208-219), plus the RefTR heads (models/reftr_transformer.py:82-125).  The ORDER is ours: all trainable
+tensors live in one flat fp32 buffer, grouped by learning-rate group (main_vg.py:29-33,234-262) so the
+fused AdamW kernel needs only three ranges, with BERT's query/key/value tensors adjacent so that the packed
+[3H, H] projection is a free view of the master weights and of their gradients.
+"""
+from dataclasses import dataclass, field
+
+
+@dataclass
+class BertConfig:
+    vocab_size: int = 30522
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    inter: int = 3072
+    max_pos: int = 512
+    type_vocab: int = 2
+    eps: float = 1e-12
+    dropout: float = 0.1
+
+
+@dataclass
+class ModelConfig:
+    hidden: int = 256
+    nheads: int = 8
+    enc_layers: int = 6
+    dec_layers: int = 6
+    ffn: int = 2048
+    dropout: float = 0.1
+    max_lang_seq: int = 128
+    n_q: int = 1                       # num_queries_per_phrase
+    aux_loss: bool = True
+    resnet_layers: tuple = (3, 4, 6, 3)   # resnet50; resnet101 = (3, 4, 23, 3)
+    bert: BertConfig = field(default_factory=BertConfig)
+
+
+GROUP_MAIN, GROUP_BACKBONE, GROUP_BERT = 0, 1, 2
+
+
+def lr_group(name):
+    """main_vg.py:29-33: lr_backbone_names=['img_backbone.0'], lr_bert_names=['lang_backbone']."""
+    if "img_backbone.0" in name:
+        return GROUP_BACKBONE
+    if "lang_backbone" in name:
+        return GROUP_BERT
+    return GROUP_MAIN
+
+
+def _bn(pfx, c, out):
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        out.append((pfx + k, (c,), "buffer"))
+
+
+def resnet_table(pfx, layers):
+    """Returns [(name, shape, kind)], kind in {'param', 'frozen', 'buffer'} (backbone.py:87-89: conv1 and
+    layer1 never train; FrozenBatchNorm2d tensors are buffers, backbone.py:52-57)."""
+    t = [(pfx + "conv1.weight", (64, 3, 7, 7), "frozen")]
+    _bn(pfx + "bn1.", 64, t)
+    inpl = 64
+    for li, n in enumerate(layers):
+        planes = 64 * 2 ** li
+        kind = "frozen" if li == 0 else "param"
+        for bi in range(n):
+            p = f"{pfx}layer{li + 1}.{bi}."
+            t.append((p + "conv1.weight", (planes, inpl, 1, 1), kind)); _bn(p + "bn1.", planes, t)
+            t.append((p + "conv2.weight", (planes, planes, 3, 3), kind)); _bn(p + "bn2.", planes, t)
+            t.append((p + "conv3.weight", (planes * 4, planes, 1, 1), kind)); _bn(p + "bn3.", planes * 4, t)
+            if bi == 0:
+                t.append((p + "downsample.0.weight", (planes * 4, inpl, 1, 1), kind)); _bn(p + "downsample.1.", planes * 4, t)
+            inpl = planes * 4
+    return t
+
+
+def bert_table(pfx, bc: BertConfig):
+    t = []
+    e = pfx + "embeddings."
+    t += [(e + "word_embeddings.weight", (bc.vocab_size, bc.hidden), "param"),
+          (e + "position_embeddings.weight", (bc.max_pos, bc.hidden), "param"),
+          (e + "token_type_embeddings.weight", (bc.type_vocab, bc.hidden), "param"),
+          (e + "LayerNorm.weight", (bc.hidden,), "param"), (e + "LayerNorm.bias", (bc.hidden,), "param")]
+    for i in range(bc.layers):
+        lp = f"{pfx}encoder.layer.{i}."
+        # q, k, v adjacent (weights then biases): packed [3H, H] / [3H] views
+        for n in ("query", "key", "value"):
+            t.append((lp + f"attention.self.{n}.weight", (bc.hidden, bc.hidden), "param"))
+        for n in ("query", "key", "value"):
+            t.append((lp + f"attention.self.{n}.bias", (bc.hidden,), "param"))
+        t += [(lp + "attention.output.dense.weight", (bc.hidden, bc.hidden), "param"),
+              (lp + "attention.output.dense.bias", (bc.hidden,), "param"),
+              (lp + "attention.output.LayerNorm.weight", (bc.hidden,), "param"),
+              (lp + "attention.output.LayerNorm.bias", (bc.hidden,), "param"),
+              (lp + "intermediate.dense.weight", (bc.inter, bc.hidden), "param"),
+              (lp + "intermediate.dense.bias", (bc.inter,), "param"),
+              (lp + "output.dense.weight", (bc.hidden, bc.inter), "param"),
+              (lp + "output.dense.bias", (bc.hidden,), "param"),
+              (lp + "output.LayerNorm.weight", (bc.hidden,), "param"),
+              (lp + "output.LayerNorm.bias", (bc.hidden,), "param")]
+    t += [(pfx + "pooler.dense.weight", (bc.hidden, bc.hidden), "param"), (pfx + "pooler.dense.bias", (bc.hidden,), "param")]
+    return t
+
+
+def main_table(cfg: ModelConfig):
+    E, F_ = cfg.hidden, cfg.ffn
+    t = []
+
+    def lin(p, o, i):
+        t.append((p + "weight", (o, i), "param")); t.append((p + "bias", (o,), "param"))
+
+    def ln(p, d):
+        t.append((p + "weight", (d,), "param")); t.append((p + "bias", (d,), "param"))
+
+    def mha(p):
+        t.append((p + "in_proj_weight", (3 * E, E), "param")); t.append((p + "in_proj_bias", (3 * E,), "param"))
+        lin(p + "out_proj.", E, E)
+
+    def mlp_mapping(p, i, o):
+        lin(p + "0.", o, i); ln(p + "1.", o); lin(p + "4.", o, o); ln(p + "5.", o)
+
+    for i, (o, k) in enumerate(((E, E), (E, E), (4, E))):
+        lin(f"bbox_embed.layers.{i}.", o, k)
+    vt = "vl_transformer."
+    if cfg.dec_layers > 0:
+        ln(vt + "decoder.norm.", E)
+    for i in reversed(range(cfg.dec_layers)):
+        p = f"{vt}decoder.layers.{i}."
+        mha(p + "self_attn."); mha(p + "multihead_attn.")
+        lin(p + "linear1.", F_, E); lin(p + "linear2.", E, F_)
+        ln(p + "norm1.", E); ln(p + "norm2.", E); ln(p + "norm3.", E)
+    q = "query_encoder."
+    t.append((q + "query_embed.weight", (cfg.n_q, 2 * E), "param"))
+    lin(q + "linear1.", E, E); lin(q + "linear2.", E, E); lin(q + "linear3.", E, E)
+    mlp_mapping(q + "fuse_encoder_query.", 2 * E, E)
+    lin(q + "context_out.0.", E, E); ln(q + "context_out.1.", E)
+    for i in reversed(range(cfg.enc_layers)):
+        p = f"{vt}encoder.layers.{i}."
+        mha(p + "self_attn."); lin(p + "linear1.", F_, E); lin(p + "linear2.", E, F_)
+        ln(p + "norm1.", E); ln(p + "norm2.", E)
+    t.append((vt + "level_embed", (1, E), "param"))
+    t.append((vt + "lang_pos_embeddings.weight", (cfg.max_lang_seq, E), "param"))
+    t.append((vt + "token_type_embeddings.weight", (2, E), "param"))
+    mlp_mapping("map_sentence.", cfg.bert.hidden, E)
+    mlp_mapping("map_phrase.", cfg.bert.hidden, E)
+    t.append(("input_proj.0.0.weight", (E, 2048, 1, 1), "param")); t.append(("input_proj.0.0.bias", (E,), "param"))
+    ln("input_proj.0.1.", E)
+    return t
+
+
+def full_table(cfg: ModelConfig):
+    """All tensors of the model.  Trainable ones are listed group by group (main, backbone, bert) in the
+    order they are laid out in the flat parameter buffer."""
+    return main_table(cfg) + resnet_table("img_backbone.0.body.", cfg.resnet_layers) + bert_table("lang_backbone.", cfg.bert)

@@ -1,0 +1,361 @@
+"""Forward and hand-written backward of the language / visual-language side of RefTR on the HIP kernels:
+HF-style BERT encoder, mlp_mapping, VLTransformer encoder + decoder, QueryEncoder, bbox head.
+
+Reference arithmetic (all fp32 there): models/reftr_transformer.py:14-66,159-297, models/reftr.py:51-120,
+models/modeling/transformer.py:81-143,168-181,231-252, models/modeling/backbone.py:26-38, HF BertModel
+(SURVEY.md Appendix A5-A12).  Here: bf16 GEMM operands / fp32 accumulation on MFMA, fp32 residual stream,
+fp32 LayerNorm / softmax statistics.  Token layout is BATCH-major ([B*S, E]; the reference is [S, B, E]),
+language tokens first inside every image's S = L + h*w rows (models/reftr.py:115-117).
+
+Backward is explicit: each `*_bwd` consumes the context its `*_fwd` returned; weight gradients are
+accumulated by the kernels straight into the flat gradient buffer (ParamStore.G).
+"""
+import math
+
+import torch
+
+from .. import hip as H
+
+RELU, GELU, TANH, NONE = H.ACT_RELU, H.ACT_GELU, H.ACT_TANH, H.ACT_NONE
+
+
+class Lin:
+    """One nn.Linear as the kernels see it: bf16 operand W [N,K] (forward), WT [K,N] (backward-data),
+    fp32 master / gradient views for the weight-prep and weight-gradient kernels."""
+    __slots__ = ("w32", "b32", "gw", "gb", "W", "WT", "N", "K")
+
+    def __init__(self, w32, b32, gw, gb, device):
+        self.w32, self.b32, self.gw, self.gb = w32, b32, gw, gb
+        self.N, self.K = w32.shape
+        self.W = torch.empty(self.N, self.K, dtype=torch.bfloat16, device=device)
+        self.WT = torch.empty(self.K, self.N, dtype=torch.bfloat16, device=device)
+
+    def refresh(self):
+        H.weight_prep(self.w32, self.N, 1, self.K, dst=self.W, dst_t=self.WT)
+
+
+class Net:
+    def __init__(self, store, cfg):
+        self.store, self.cfg = store, cfg
+        self.lins = {}
+        self.training = True
+        self._seed_base = 0x1234567
+        self._site = 0
+        self._build_lins()
+
+    # ------------------------------------------------------------------ operand bank
+    def _lin(self, key, wname, bname, rows=None):
+        P, G = self.store.P, self.store.G
+        w, gw, b, gb = P[wname], G[wname], P[bname], G[bname]
+        if rows is not None:
+            a, e = rows
+            w, gw, b, gb = w[a:e], gw[a:e], b[a:e], gb[a:e]
+        self.lins[key] = Lin(w, b, gw, gb, self.store.device)
+
+    def _build_lins(self):
+        cfg, st = self.cfg, self.store
+        E = cfg.hidden
+        for i in range(cfg.bert.layers):
+            lp = f"lang_backbone.encoder.layer.{i}."
+            q = lp + "attention.self.query."
+            self.lins[lp + "qkv"] = Lin(st.packed(q + "weight", 3), st.packed(q + "bias", 3),
+                                        st.packed(q + "weight", 3, grad=True), st.packed(q + "bias", 3, grad=True), st.device)
+            for n in ("attention.output.dense.", "intermediate.dense.", "output.dense."):
+                self._lin(lp + n, lp + n + "weight", lp + n + "bias")
+        self._lin("lang_backbone.pooler.dense.", "lang_backbone.pooler.dense.weight", "lang_backbone.pooler.dense.bias")
+        for m in ("map_sentence.", "map_phrase.", "query_encoder.fuse_encoder_query."):
+            for j in ("0.", "4."):
+                self._lin(m + j, m + j + "weight", m + j + "bias")
+        for n in ("linear1.", "linear2.", "linear3.", "context_out.0."):
+            self._lin("query_encoder." + n, "query_encoder." + n + "weight", "query_encoder." + n + "bias")
+        vt = "vl_transformer."
+        for i in range(cfg.enc_layers):
+            p = f"{vt}encoder.layers.{i}."
+            self._mha(p + "self_attn.", split_qk=False)
+            self._lin(p + "linear1.", p + "linear1.weight", p + "linear1.bias")
+            self._lin(p + "linear2.", p + "linear2.weight", p + "linear2.bias")
+        for i in range(cfg.dec_layers):
+            p = f"{vt}decoder.layers.{i}."
+            self._mha(p + "self_attn.", split_qk=False)
+            self._mha(p + "multihead_attn.", split_qk=True)
+            self._lin(p + "linear1.", p + "linear1.weight", p + "linear1.bias")
+            self._lin(p + "linear2.", p + "linear2.weight", p + "linear2.bias")
+        for i in range(3):
+            p = f"bbox_embed.layers.{i}."
+            self._lin(p, p + "weight", p + "bias")
+        # input_proj 1x1 conv [E, 2048, 1, 1] used as a Linear over pixels
+        w = st.phys("input_proj.0.0.weight").view(E, 2048)
+        gw = st.phys("input_proj.0.0.weight", grad=True).view(E, 2048)
+        self.lins["input_proj.0.0."] = Lin(w, st.P["input_proj.0.0.bias"], gw, st.G["input_proj.0.0.bias"], st.device)
+
+    def _mha(self, p, split_qk):
+        E = self.cfg.hidden
+        wn, bn = p + "in_proj_weight", p + "in_proj_bias"
+        if split_qk:
+            self._lin(p + "q", wn, bn, rows=(0, E)); self._lin(p + "k", wn, bn, rows=(E, 2 * E))
+        else:
+            self._lin(p + "qk", wn, bn, rows=(0, 2 * E))
+        self._lin(p + "v", wn, bn, rows=(2 * E, 3 * E))
+        self._lin(p + "out_proj.", p + "out_proj.weight", p + "out_proj.bias")
+
+    def refresh(self):
+        for l in self.lins.values():
+            l.refresh()
+
+    # ------------------------------------------------------------------ helpers
+    def begin_step(self, training, seed):
+        self.training, self._seed_base, self._site = training, int(seed) & 0x7FFFFFFF, 0
+
+    def _drop(self, p):
+        """(p, seed) of the next dropout site; p = 0 in eval mode."""
+        self._site += 1
+        if not self.training or p <= 0:
+            return 0.0, 0
+        return float(p), (self._seed_base * 2654435761 + self._site * 40503) & 0xFFFFFFFF
+
+    def lin_fwd(self, key, x, **kw):
+        l = self.lins[key]
+        return H.linear(x, l.W, bias=l.b32, **kw)
+
+    def lin_bwd(self, key, dy, x, need_dx=True, **kw):
+        """weight + bias gradient of a Linear (accumulated) and, if asked, its input gradient."""
+        l = self.lins[key]
+        H.linear_wgrad(dy, x, l.gw)
+        H.colsum(dy, l.gb)
+        if need_dx:
+            return H.linear(dy, l.WT, **kw)
+        return None
+
+    def P(self, name):
+        return self.store.P[name]
+
+    def G(self, name):
+        return self.store.G[name]
+
+    def ln_fwd(self, x, pfx, eps=1e-5, **kw):
+        return H.layernorm_fwd(x, self.P(pfx + "weight"), self.P(pfx + "bias"), eps, **kw)
+
+    def ln_bwd(self, dy, x, pfx, mean, rstd, **kw):
+        return H.layernorm_bwd(dy, x, self.P(pfx + "weight"), self.P(pfx + "bias"), mean, rstd,
+                               self.G(pfx + "weight"), self.G(pfx + "bias"), **kw)
+
+    # ------------------------------------------------------------------ BERT
+    def bert_fwd(self, ids, mask_u8):
+        """ids int64 [B, L], mask uint8 [B, L] (1 = token).  Returns (seq bf16 [B*L, Hd], pooled bf16 [B, Hd], ctx)."""
+        bc = self.cfg.bert
+        B, L = ids.shape
+        M, Hd = B * L, bc.hidden
+        pfx = "lang_backbone."
+        e = pfx + "embeddings."
+        kpm = (mask_u8 == 0).to(torch.uint8)
+        emb = H.bert_embed_fwd(ids, self.P(e + "word_embeddings.weight"), self.P(e + "position_embeddings.weight"),
+                               self.P(e + "token_type_embeddings.weight"), L)
+        dp, ds = self._drop(bc.dropout)
+        h32, h16, _, mean, rstd = self.ln_fwd(emb, e + "LayerNorm.", bc.eps, drop_p=dp, drop_seed=ds)
+        ctx = {"ids": ids, "kpm": kpm, "B": B, "L": L, "emb": emb, "emb_stats": (mean, rstd, dp, ds), "layers": []}
+        dh = Hd // bc.heads
+        scale = 1.0 / math.sqrt(dh)
+        for i in range(bc.layers):
+            lp = f"{pfx}encoder.layer.{i}."
+            r = {"h16": h16}
+            qkv, _ = self.lin_fwd(lp + "qkv", h16)
+            r["qkv"] = qkv
+            r["adrop"] = self._drop(bc.dropout)
+            o, lse = H.attn_fwd(qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:], kpm, B=B, H=bc.heads, Sq=L, Sk=L, dh=dh,
+                                scale=scale, drop_p=r["adrop"][0], drop_seed=r["adrop"][1])
+            r["o"], r["lse"] = o, lse
+            r["d1"] = self._drop(bc.dropout)
+            _, t = self.lin_fwd(lp + "attention.output.dense.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=h32,
+                                out_bf16=False, out_f32=True)
+            h32, h16, _, m1, r1 = self.ln_fwd(t, lp + "attention.output.LayerNorm.", bc.eps)
+            r["t"], r["st1"], r["h1_16"] = t, (m1, r1), h16
+            g, _, u = self.lin_fwd(lp + "intermediate.dense.", h16, act=GELU, out_preact=True)
+            r["g"], r["u"] = g, u
+            r["d2"] = self._drop(bc.dropout)
+            _, t2 = self.lin_fwd(lp + "output.dense.", g, drop_p=r["d2"][0], drop_seed=r["d2"][1], res_f32=h32,
+                                 out_bf16=False, out_f32=True)
+            h32, h16, _, m2, r2 = self.ln_fwd(t2, lp + "output.LayerNorm.", bc.eps)
+            r["t2"], r["st2"] = t2, (m2, r2)
+            ctx["layers"].append(r)
+        cls = torch.empty(B, Hd, dtype=torch.bfloat16, device=h16.device)
+        H.rows_add(B, Hd, a_bf16=h16, a_map=(1, L, 0), out_bf16=cls)
+        pooled, _ = self.lin_fwd(pfx + "pooler.dense.", cls, act=TANH)
+        ctx["cls"], ctx["pooled"] = cls, pooled
+        return h16, pooled, ctx
+
+    def bert_bwd(self, ctx, d_seq, d_pooled_bf16):
+        """d_seq fp32 [B*L, Hd] = dL/d(sequence output) or None; d_pooled_bf16 [B, Hd] = dL/d(pooler PRE-tanh
+        output) (callers fold tanh' with the GEMM's dtanh epilogue) or None."""
+        bc = self.cfg.bert
+        B, L, Hd = ctx["B"], ctx["L"], bc.hidden
+        pfx = "lang_backbone."
+        dev = ctx["emb"].device
+        if d_seq is None:
+            d_seq = torch.zeros(B * L, Hd, dtype=torch.float32, device=dev)
+        if d_pooled_bf16 is not None:
+            _, dcls = self.lin_bwd(pfx + "pooler.dense.", d_pooled_bf16, ctx["cls"], out_bf16=False, out_f32=True)
+            H.rows_add(B, Hd, a_f32=dcls, out_f32=d_seq, accumulate=True, o_map=(1, L, 0))
+        dh = Hd // bc.heads
+        scale = 1.0 / math.sqrt(dh)
+        dh32 = d_seq
+        for i in reversed(range(bc.layers)):
+            lp = f"{pfx}encoder.layer.{i}."
+            r = ctx["layers"][i]
+            dt2, dt2b = self.ln_bwd(dh32, r["t2"], lp + "output.LayerNorm.", *r["st2"], drop2_p=r["d2"][0], drop2_seed=r["d2"][1])
+            du, _ = self.lin_bwd(lp + "output.dense.", dt2b, r["g"], preact=r["u"])
+            _, dh1 = self.lin_bwd(lp + "intermediate.dense.", du, r["h1_16"], res_f32=dt2, out_bf16=False, out_f32=True)
+            dt, dtb = self.ln_bwd(dh1, r["t"], lp + "attention.output.LayerNorm.", *r["st1"], drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
+            do, _ = self.lin_bwd(lp + "attention.output.dense.", dtb, r["o"])
+            qkv = r["qkv"]
+            dqkv = torch.empty_like(qkv)
+            H.attn_bwd(qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:], r["o"], do, r["lse"], ctx["kpm"], B=B, H=bc.heads,
+                       Sq=L, Sk=L, dh=dh, scale=scale, drop_p=r["adrop"][0], drop_seed=r["adrop"][1],
+                       dq=dqkv[:, :Hd], dk=dqkv[:, Hd:2 * Hd], dv=dqkv[:, 2 * Hd:])
+            _, dh32 = self.lin_bwd(lp + "qkv", dqkv, r["h16"], res_f32=dt, out_bf16=False, out_f32=True)
+        e = pfx + "embeddings."
+        mean, rstd, dp, ds = ctx["emb_stats"]
+        de, _ = self.ln_bwd(dh32, ctx["emb"], e + "LayerNorm.", mean, rstd, drop_p=dp, drop_seed=ds, want_bf16=False)
+        H.bert_embed_bwd(ctx["ids"], de, self.G(e + "word_embeddings.weight"), self.G(e + "position_embeddings.weight"),
+                         self.G(e + "token_type_embeddings.weight"), L)
+
+    # ------------------------------------------------------------------ mlp_mapping (reftr_transformer.py:14-23)
+    def mlp_fwd(self, x16, pfx, **out_kw):
+        """Linear-LN-ReLU-Dropout(.1)-Linear-LN-ReLU.  out_kw go to the final LayerNorm launch (output buffers,
+        row map, pos).  Returns (outputs of that launch, ctx)."""
+        _, t1 = self.lin_fwd(pfx + "0.", x16, out_bf16=False, out_f32=True)
+        dp, ds = self._drop(0.1)
+        _, a16, _, m1, r1 = self.ln_fwd(t1, pfx + "1.", act=RELU, drop_p=dp, drop_seed=ds, want_f32=False)
+        _, t2 = self.lin_fwd(pfx + "4.", a16, out_bf16=False, out_f32=True)
+        outs = self.ln_fwd(t2, pfx + "5.", act=RELU, **out_kw)
+        ctx = {"x16": x16, "t1": t1, "st1": (m1, r1, dp, ds), "a16": a16, "t2": t2, "st2": (outs[3], outs[4])}
+        return outs, ctx
+
+    def mlp_bwd(self, ctx, dy, pfx, dy_rowmap=(0, 0, 0), dy2=None, need_dx=True, dx_f32=True, **dx_kw):
+        _, dt2b = self.ln_bwd(dy, ctx["t2"], pfx + "5.", *ctx["st2"], act=RELU, rowmap=dy_rowmap, dy2=dy2, want_f32=False)
+        _, da = self.lin_bwd(pfx + "4.", dt2b, ctx["a16"], out_bf16=False, out_f32=True)
+        m1, r1, dp, ds = ctx["st1"]
+        _, dt1b = self.ln_bwd(da, ctx["t1"], pfx + "1.", m1, r1, act=RELU, drop_p=dp, drop_seed=ds, want_f32=False)
+        if not need_dx:
+            self.lin_bwd(pfx + "0.", dt1b, ctx["x16"], need_dx=False)
+            return None
+        ob, of = self.lin_bwd(pfx + "0.", dt1b, ctx["x16"], out_bf16=not dx_f32, out_f32=dx_f32, **dx_kw)
+        return of if dx_f32 else ob
+
+    # ------------------------------------------------------------------ encoder layer (transformer.py:168-181)
+    def enc_layer_fwd(self, p, x32, x16, xp16, pos, kpm, B, S):
+        cfg = self.cfg
+        E, Hh = cfg.hidden, cfg.nheads
+        dh = E // Hh
+        r = {"x16": x16, "xp16": xp16}
+        qk, _ = self.lin_fwd(p + "self_attn.qk", xp16)
+        v, _ = self.lin_fwd(p + "self_attn.v", x16)
+        r["ad"] = self._drop(cfg.dropout)
+        o, lse = H.attn_fwd(qk[:, :E], qk[:, E:], v, kpm, B=B, H=Hh, Sq=S, Sk=S, dh=dh, scale=dh ** -0.5,
+                            drop_p=r["ad"][0], drop_seed=r["ad"][1])
+        r.update(qk=qk, v=v, o=o, lse=lse)
+        r["d1"] = self._drop(cfg.dropout)
+        _, t = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=x32,
+                            out_bf16=False, out_f32=True)
+        x1_32, x1_16, _, m1, r1 = self.ln_fwd(t, p + "norm1.")
+        r.update(t=t, st1=(m1, r1), x1_16=x1_16)
+        r["dh"] = self._drop(cfg.dropout)
+        hdn, _ = self.lin_fwd(p + "linear1.", x1_16, act=RELU, drop_p=r["dh"][0], drop_seed=r["dh"][1])
+        r["hdn"] = hdn
+        r["d2"] = self._drop(cfg.dropout)
+        _, t2 = self.lin_fwd(p + "linear2.", hdn, drop_p=r["d2"][0], drop_seed=r["d2"][1], res_f32=x1_32,
+                             out_bf16=False, out_f32=True)
+        x2_32, x2_16, x2p16, m2, r2 = self.ln_fwd(t2, p + "norm2.", pos=pos)
+        r.update(t2=t2, st2=(m2, r2))
+        return x2_32, x2_16, x2p16, r
+
+    def enc_layer_bwd(self, p, r, dx2, dx2b, kpm, B, S, dpos_acc):
+        """dx2 (+ optional dx2b) = gradient w.r.t. this layer's output.  Returns gradient w.r.t. its input x;
+        the q/k-input gradient is also accumulated into dpos_acc (pos is re-added at every layer)."""
+        cfg = self.cfg
+        E, Hh = cfg.hidden, cfg.nheads
+        dh = E // Hh
+        M = B * S
+        dt2, dt2b = self.ln_bwd(dx2, r["t2"], p + "norm2.", *r["st2"], dy2=dx2b, drop2_p=r["d2"][0], drop2_seed=r["d2"][1])
+        gs = 1.0 / (1.0 - r["dh"][0]) if r["dh"][0] > 0 else 1.0
+        dhdn, _ = self.lin_bwd(p + "linear2.", dt2b, r["hdn"], gate=r["hdn"], gate_scale=gs)
+        _, dx1 = self.lin_bwd(p + "linear1.", dhdn, r["x1_16"], res_f32=dt2, out_bf16=False, out_f32=True)
+        dt, dtb = self.ln_bwd(dx1, r["t"], p + "norm1.", *r["st1"], drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
+        do, _ = self.lin_bwd(p + "self_attn.out_proj.", dtb, r["o"])
+        qk, v = r["qk"], r["v"]
+        dqk = torch.empty_like(qk)
+        _, _, dv = H.attn_bwd(qk[:, :E], qk[:, E:], v, r["o"], do, r["lse"], kpm, B=B, H=Hh, Sq=S, Sk=S, dh=dh,
+                              scale=dh ** -0.5, drop_p=r["ad"][0], drop_seed=r["ad"][1], dq=dqk[:, :E], dk=dqk[:, E:])
+        _, dxa = self.lin_bwd(p + "self_attn.v", dv, r["x16"], res_f32=dt, out_bf16=False, out_f32=True)
+        _, dxp = self.lin_bwd(p + "self_attn.qk", dqk, r["xp16"], out_bf16=False, out_f32=True)
+        H.rows_add(M, E, a_f32=dxp, out_f32=dpos_acc, accumulate=True)
+        return dxa, dxp          # sum of the two = gradient w.r.t. the layer input
+
+    # ------------------------------------------------------------------ decoder layer (transformer.py:231-252)
+    def dec_layer_fwd(self, p, t32, t16, tq16, qpos, mem16, memp16, qmask, kpm, B, T, S):
+        cfg = self.cfg
+        E, Hh = cfg.hidden, cfg.nheads
+        dh = E // Hh
+        sc = dh ** -0.5
+        r = {"t16": t16, "tq16": tq16}
+        qk, _ = self.lin_fwd(p + "self_attn.qk", tq16)
+        v, _ = self.lin_fwd(p + "self_attn.v", t16)
+        r["ad"] = self._drop(cfg.dropout)
+        o, lse = H.attn_fwd(qk[:, :E], qk[:, E:], v, qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh, scale=sc,
+                            drop_p=r["ad"][0], drop_seed=r["ad"][1])
+        r.update(qk=qk, v=v, o=o, lse=lse)
+        r["d1"] = self._drop(cfg.dropout)
+        _, u = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=t32,
+                            out_bf16=False, out_f32=True)
+        t1_32, t1_16, t1q16, m1, r1 = self.ln_fwd(u, p + "norm1.", pos=qpos)
+        r.update(u=u, st1=(m1, r1), t1q16=t1q16)
+        q2, _ = self.lin_fwd(p + "multihead_attn.q", t1q16)
+        k2, _ = self.lin_fwd(p + "multihead_attn.k", memp16)
+        v2, _ = self.lin_fwd(p + "multihead_attn.v", mem16)
+        r["ad2"] = self._drop(cfg.dropout)
+        o2, lse2 = H.attn_fwd(q2, k2, v2, kpm, B=B, H=Hh, Sq=T, Sk=S, dh=dh, scale=sc, drop_p=r["ad2"][0], drop_seed=r["ad2"][1])
+        r.update(q2=q2, k2=k2, v2=v2, o2=o2, lse2=lse2)
+        r["d2"] = self._drop(cfg.dropout)
+        _, u2 = self.lin_fwd(p + "multihead_attn.out_proj.", o2, drop_p=r["d2"][0], drop_seed=r["d2"][1], res_f32=t1_32,
+                             out_bf16=False, out_f32=True)
+        t2_32, t2_16, _, m2, r2 = self.ln_fwd(u2, p + "norm2.")
+        r.update(u2=u2, st2=(m2, r2), t2_16=t2_16)
+        r["dh"] = self._drop(cfg.dropout)
+        hdn, _ = self.lin_fwd(p + "linear1.", t2_16, act=RELU, drop_p=r["dh"][0], drop_seed=r["dh"][1])
+        r["hdn"] = hdn
+        r["d3"] = self._drop(cfg.dropout)
+        _, u3 = self.lin_fwd(p + "linear2.", hdn, drop_p=r["d3"][0], drop_seed=r["d3"][1], res_f32=t2_32,
+                             out_bf16=False, out_f32=True)
+        t3_32, t3_16, t3q16, m3, r3 = self.ln_fwd(u3, p + "norm3.", pos=qpos)
+        r.update(u3=u3, st3=(m3, r3))
+        return t3_32, t3_16, t3q16, r
+
+    def dec_layer_bwd(self, p, r, g_a, g_b, mem16, memp16, qmask, kpm, B, T, S, dmem_acc, dmemp_acc, dqpos_acc):
+        """g_a (+ g_b) = gradient w.r.t. this layer's output t3.  Returns (dt_a, dt_q): their sum is the
+        gradient w.r.t. the layer input t; dt_q (gradient w.r.t. t + query_pos) is also added to dqpos_acc."""
+        cfg = self.cfg
+        E, Hh = cfg.hidden, cfg.nheads
+        dh = E // Hh
+        sc = dh ** -0.5
+        N = B * T
+        du3, du3b = self.ln_bwd(g_a, r["u3"], p + "norm3.", *r["st3"], dy2=g_b, drop2_p=r["d3"][0], drop2_seed=r["d3"][1])
+        gs = 1.0 / (1.0 - r["dh"][0]) if r["dh"][0] > 0 else 1.0
+        dhdn, _ = self.lin_bwd(p + "linear2.", du3b, r["hdn"], gate=r["hdn"], gate_scale=gs)
+        _, dt2 = self.lin_bwd(p + "linear1.", dhdn, r["t2_16"], res_f32=du3, out_bf16=False, out_f32=True)
+        du2, du2b = self.ln_bwd(dt2, r["u2"], p + "norm2.", *r["st2"], drop2_p=r["d2"][0], drop2_seed=r["d2"][1])
+        do2, _ = self.lin_bwd(p + "multihead_attn.out_proj.", du2b, r["o2"])
+        dq2, dk2, dv2 = H.attn_bwd(r["q2"], r["k2"], r["v2"], r["o2"], do2, r["lse2"], kpm, B=B, H=Hh, Sq=T, Sk=S, dh=dh,
+                                   scale=sc, drop_p=r["ad2"][0], drop_seed=r["ad2"][1])
+        self.lin_bwd(p + "multihead_attn.v", dv2, mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc)
+        self.lin_bwd(p + "multihead_attn.k", dk2, memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc)
+        _, dt1q = self.lin_bwd(p + "multihead_attn.q", dq2, r["t1q16"], out_bf16=False, out_f32=True)
+        H.rows_add(N, E, a_f32=dt1q, out_f32=dqpos_acc, accumulate=True)
+        du, dub = self.ln_bwd(du2, r["u"], p + "norm1.", *r["st1"], dy2=dt1q, drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
+        do, _ = self.lin_bwd(p + "self_attn.out_proj.", dub, r["o"])
+        qk, v = r["qk"], r["v"]
+        dqk = torch.empty_like(qk)
+        _, _, dv = H.attn_bwd(qk[:, :E], qk[:, E:], v, r["o"], do, r["lse"], qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh,
+                              scale=sc, drop_p=r["ad"][0], drop_seed=r["ad"][1], dq=dqk[:, :E], dk=dqk[:, E:])
+        _, dta = self.lin_bwd(p + "self_attn.v", dv, r["t16"], res_f32=du, out_bf16=False, out_f32=True)
+        _, dtq = self.lin_bwd(p + "self_attn.qk", dqk, r["tq16"], out_bf16=False, out_f32=True)
+        H.rows_add(N, E, a_f32=dtq, out_f32=dqpos_acc, accumulate=True)
+        return dta, dtq

@@ -1,0 +1,390 @@
+"""RefTR (transformer_single_phrase / multi-phrase REC model) on the MI355X kernel library.
+
+Host-side mirror of the reference's models/reftr_transformer.py: same constructor role, same
+`forward(samples) -> {'pred_boxes', 'phrase_mask', 'aux_outputs'}` contract (:159-304), same state_dict
+keys (built from models/layout.py), same `build_reftr(args)` factory (:307-347).  Underneath, forward and
+backward are explicit sequences of libreftr_hip.so launches (backbone.py / net.py); torch.autograd only
+sees ONE node for the whole model (`_RefTRFunction`), whose backward runs the hand-written backward pass
+and leaves every parameter gradient in the flat gradient buffer.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import hip as H
+from ..util.misc import NestedTensor, nested_tensor_from_tensor_list
+from . import layout as L
+from .backbone import ResNetBody
+from .net import Net, RELU
+from .store import ParamStore, build_module_tree, rebind
+
+
+class _RefTRFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, samples):
+        ctx.model = model
+        return model._forward_impl(samples)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.model._backward_impl(dlogits.contiguous())
+        return None, None, None
+
+
+class RefTR(nn.Module):
+    def __init__(self, cfg: L.ModelConfig, device="cuda", aux_loss=True):
+        super().__init__()
+        assert cfg.n_q == 1, "num_queries_per_phrase = 1 (every reference config); n_q > 1 is not wired yet"
+        self.cfg = cfg
+        self.aux_loss = aux_loss
+        self.num_queries_per_phrase = cfg.n_q
+        self.hidden_dim = cfg.hidden
+        self.store = ParamStore(cfg, device)
+        build_module_tree(self, self.store)
+        self.body = ResNetBody(self.store, cfg)
+        self.net = Net(self.store, cfg)
+        self._anchor = torch.zeros((), device=device, requires_grad=True)
+        self._operands_dirty = True       # bf16 operands must be rebuilt (after init / load / optimizer step)
+        self._full_refresh = True
+        self._step = 0
+        self._saved = None
+        self._post_backward_hooks = []
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ init / state
+    @torch.no_grad()
+    def reset_parameters(self, seed=0):
+        """Random init with the reference's distributions (models/reftr.py:45-49 xavier on every VLTransformer
+        matrix, level_embed ~ N(0,1); reftr_transformer.py:131-135 zero last bbox layer, xavier input_proj;
+        BERT-style N(0, 0.02); kaiming for convs; identity FrozenBN)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for name, shape, kind in self.store.table:
+            t = self.store.P[name]
+            leaf = name.rsplit(".", 1)[-1]
+            if kind == "buffer":
+                t.fill_(1.0 if leaf in ("weight", "running_var") else 0.0)
+                continue
+            is_norm = ("LayerNorm" in name or ".norm" in name or name.startswith("input_proj.0.1")
+                       or (len(shape) == 1 and name.split(".")[-2] in ("1", "5") and leaf in ("weight", "bias")
+                           and any(s in name for s in ("map_sentence", "map_phrase", "fuse_encoder_query", "context_out"))))
+            if is_norm:
+                t.fill_(1.0 if leaf == "weight" else 0.0)
+            elif len(shape) == 1:
+                t.zero_()
+            else:
+                fan_out, fan_in = shape[0], 1
+                for s in shape[1:]:
+                    fan_in *= s
+                rf = 1
+                for s in shape[2:]:
+                    rf *= s
+                v = torch.empty(shape, dtype=torch.float32)
+                if name.startswith("lang_backbone."):
+                    v.normal_(0.0, 0.02, generator=g)
+                elif name.startswith("img_backbone."):
+                    v.normal_(0.0, math.sqrt(2.0 / (fan_out * rf)), generator=g)
+                elif name == "vl_transformer.level_embed":
+                    v.normal_(0.0, 1.0, generator=g)
+                elif name.startswith("vl_transformer.") or name.startswith("input_proj.0.0"):
+                    a = math.sqrt(6.0 / (fan_in + fan_out * rf))
+                    v.uniform_(-a, a, generator=g)
+                else:
+                    a = 1.0 / math.sqrt(fan_in)
+                    v.uniform_(-a, a, generator=g)
+                t.copy_(v)
+        self.store.P["bbox_embed.layers.2.weight"].zero_()
+        self.store.P["bbox_embed.layers.2.bias"].zero_()
+        self.mark_dirty(full=True)
+
+    def mark_dirty(self, full=False):
+        self._operands_dirty = True
+        self._full_refresh = self._full_refresh or full
+
+    def refresh_operands(self):
+        """fp32 masters -> bf16 GEMM operands (weights [N,K] and [K,N], BN-folded conv weights)."""
+        if not self._operands_dirty:
+            return
+        self.body.refresh(self._full_refresh)
+        self.net.refresh()
+        self._operands_dirty, self._full_refresh = False, False
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        for k in list(sd.keys()):     # views of the flat buffer -> standalone, contiguous tensors
+            sd[k] = sd[k].detach().clone(memory_format=torch.contiguous_format)
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}   # backbone.py:59-63
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self.mark_dirty(full=True)
+        return out
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, device=self.store.device))
+        if probe.device != self.store.device:
+            old = self.store.flat
+            self.store.allocate(probe.device, src=old)
+            rebind(self, self.store)
+            self.body = ResNetBody(self.store, self.cfg)
+            self.net = Net(self.store, self.cfg)
+            self._anchor = torch.zeros((), device=probe.device, requires_grad=True)
+            self.mark_dirty(full=True)
+        return self
+
+    def init_from_pretrained_detr(self, state_dict):
+        """models/reftr_transformer.py:137-146."""
+        bb = {"img_backbone." + k.split(".", 1)[1]: v for k, v in state_dict.items() if k.split(".", 1)[0] == "backbone"}
+        enc = {"vl_transformer.encoder." + k.split(".", 2)[2]: v for k, v in state_dict.items() if "transformer.encoder" in k}
+        bb.update(enc)
+        self.load_state_dict(bb, strict=False)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, samples):
+        self.refresh_operands()
+        logits = _RefTRFunction.apply(self._anchor, self, samples)          # [NL, B, P, K, 4]
+        boxes = logits.sigmoid()
+        phrase_mask = self._saved["phrase_mask"]
+        out = {"pred_boxes": boxes[-1], "phrase_mask": phrase_mask, "pred_logits": logits}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_boxes": b, "phrase_mask": phrase_mask} for b in boxes[:-1]]
+        return out
+
+    def _forward_impl(self, samples):
+        cfg, net, st = self.cfg, self.net, self.store
+        dev = st.device
+        E = cfg.hidden
+        img = samples["img"]
+        if not isinstance(img, NestedTensor):
+            img = nested_tensor_from_tensor_list(img)
+        x, mask = img.decompose()
+        x = x.to(dev, torch.float32).contiguous()
+        mask_u8 = mask.to(dev).to(torch.uint8).contiguous()
+        B = x.shape[0]
+        self._step += 1
+        net.begin_step(self.training, self._step * 7919 + 13)
+
+        feats, bb_saved = self.body.forward(x)
+        c5, (_, h, w) = feats[-1]
+        HW = h * w
+        ids = samples["sentence"].to(dev).contiguous()
+        smask_u8 = samples["sentence_mask"].to(dev).to(torch.uint8).contiguous()
+        Lq = ids.shape[1]
+        assert Lq <= cfg.max_lang_seq                                       # models/reftr.py:81
+        S = Lq + HW
+        M = B * S
+        x32 = torch.empty(M, E, dtype=torch.float32, device=dev)
+        x16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
+        xp16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
+        pos = torch.empty(M, E, dtype=torch.float32, device=dev)
+        kpm = torch.empty(B, S, dtype=torch.uint8, device=dev)
+        kpm[:, :Lq] = (smask_u8 == 0)                                       # models/reftr.py:92
+        vt = "vl_transformer."
+        H.rows_add(B * Lq, E, a_f32=st.P[vt + "lang_pos_embeddings.weight"], a_map=(Lq, 0, 0),
+                   b_f32=st.P[vt + "token_type_embeddings.weight"], b_map=(-(B * Lq), 0, 0),
+                   out_f32=pos, o_map=(Lq, S, 0))
+        addv = torch.empty(E, dtype=torch.float32, device=dev)
+        H.rows_add(1, E, a_f32=st.P[vt + "level_embed"], b_f32=st.P[vt + "token_type_embeddings.weight"],
+                   b_map=(-1, 0, 1), out_f32=addv)
+        H.mask_posenc(mask_u8, h, w, E, addv, kpm, Lq, pos, S, Lq)
+
+        seq16, pooled16, bctx = net.bert_fwd(ids, smask_u8)
+        _, ms_ctx = net.mlp_fwd(seq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos, rowmap=(Lq, S, 0))
+        _, ip = net.lin_fwd("input_proj.0.0.", c5, out_bf16=False, out_f32=True)
+        gn_stats = H.groupnorm_fwd(ip.view(B, HW, E), st.P["input_proj.0.1.weight"], st.P["input_proj.0.1.bias"], 32, 1e-5,
+                                   y_f32=x32, y_bf16=x16, pos=pos, ypos_bf16=xp16, rows_per_img=S, row_off=Lq)
+
+        pctx = None
+        if "phrase" in samples:
+            ph = samples["phrase"].to(dev)
+            Pn, Lp = ph.shape[1], ph.shape[2]
+            pm_u8 = samples["phrase_mask"].to(dev).to(torch.uint8).contiguous()
+            _, ph_pooled16, pctx = net.bert_fwd(ph.reshape(B * Pn, Lp).contiguous(), pm_u8.view(B * Pn, Lp))
+            ctxmask, qmask = H.context_mask(smask_u8, pm_u8, samples["phrase_pos_l"].to(dev).contiguous(),
+                                            samples["phrase_pos_r"].to(dev).contiguous())
+        else:
+            Pn = 1
+            ph_pooled16 = pooled16
+            ctxmask, qmask = H.context_mask(smask_u8)
+        N = B * Pn
+        cat16 = torch.empty(N, 2 * E, dtype=torch.bfloat16, device=dev)
+        cat_rows = cat16.view(2 * N, E)
+        _, mp_ctx = net.mlp_fwd(ph_pooled16, "map_phrase.", y_bf16=cat_rows, want_f32=False, rowmap=(1, 2, 1))
+
+        enc = []
+        for i in range(cfg.enc_layers):
+            x32, x16, xp16, r = net.enc_layer_fwd(f"{vt}encoder.layers.{i}.", x32, x16, xp16, pos, kpm, B, S)
+            enc.append(r)
+        mem32, mem16, memp16 = x32, x16, xp16
+
+        # ---- QueryEncoder (models/reftr_transformer.py:41-66)
+        qe = "query_encoder."
+        cls16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
+        lang16 = torch.empty(B * Lq, E, dtype=torch.bfloat16, device=dev)
+        H.rows_add(B, E, a_bf16=mem16, a_map=(1, S, 0), out_bf16=cls16)
+        H.rows_add(B * Lq, E, a_bf16=mem16, a_map=(Lq, S, 0), out_bf16=lang16)
+        _, kq = net.lin_fwd(qe + "linear1.", cls16, out_bf16=False, out_f32=True)
+        _, qs = net.lin_fwd(qe + "linear2.", lang16, out_bf16=False, out_f32=True)
+        _, vs = net.lin_fwd(qe + "linear3.", lang16, out_bf16=False, out_f32=True)
+        qw, qc = H.qenc_attn_fwd(kq, qs.view(B, Lq, E), vs.view(B, Lq, E), ctxmask)
+        c16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
+        H.rows_add(N, E, a_f32=qc.view(N, E), out_bf16=c16)
+        _, co = net.lin_fwd(qe + "context_out.0.", c16, out_bf16=False, out_f32=True)
+        cn32, _, _, cm, cr = net.ln_fwd(co, qe + "context_out.1.", want_bf16=False)
+        H.rows_add(N, E, a_f32=cn32, b_f32=mem32, b_map=(-Pn, S, 0), out_bf16=cat_rows, o_map=(1, 2, 0))
+        (f32, _, _, _, _), fq_ctx = net.mlp_fwd(cat16, qe + "fuse_encoder_query.", want_bf16=False)
+        emb = st.P[qe + "query_embed.weight"].view(2, E)                   # n_q = 1: rows [tgt part | query_pos part]
+        tgt32 = torch.empty(N, E, dtype=torch.float32, device=dev); tgt16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
+        qpos = torch.empty(N, E, dtype=torch.float32, device=dev); tgtq16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
+        H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 0), out_f32=tgt32, out_bf16=tgt16)
+        H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 1), out_f32=qpos)
+        H.rows_add(N, E, a_f32=tgt32, b_f32=qpos, out_bf16=tgtq16)
+
+        # ---- decoder (models/modeling/transformer.py:105-143) + shared norm on every layer's output
+        T = Pn * cfg.n_q
+        NL = cfg.dec_layers
+        hs16 = torch.empty(NL * N, E, dtype=torch.bfloat16, device=dev)
+        dec, hs_stats, t3s = [], [], []
+        t32, t16, tq16 = tgt32, tgt16, tgtq16
+        for i in range(NL):
+            t32, t16, tq16, r = net.dec_layer_fwd(f"{vt}decoder.layers.{i}.", t32, t16, tq16, qpos, mem16, memp16,
+                                                  qmask, kpm, B, T, S)
+            dec.append(r)
+            _, _, _, hm, hr = net.ln_fwd(t32, vt + "decoder.norm.", y_bf16=hs16[i * N:(i + 1) * N], want_f32=False)
+            hs_stats.append((hm, hr)); t3s.append(t32)
+        y1, _ = net.lin_fwd("bbox_embed.layers.0.", hs16, act=RELU)
+        y2, _ = net.lin_fwd("bbox_embed.layers.1.", y1, act=RELU)
+        _, logits = net.lin_fwd("bbox_embed.layers.2.", y2, out_bf16=False, out_f32=True)
+
+        self._saved = dict(
+            B=B, S=S, Lq=Lq, HW=HW, Pn=Pn, N=N, T=T, NL=NL, bb_saved=bb_saved, c5=c5, bctx=bctx, pctx=pctx, ms_ctx=ms_ctx,
+            mp_ctx=mp_ctx, ip=ip, gn_stats=gn_stats, kpm=kpm, qmask=qmask, ctxmask=ctxmask, enc=enc, mem16=mem16,
+            memp16=memp16, mem32=mem32, cls16=cls16, lang16=lang16, kq=kq, qs=qs, vs=vs, qw=qw, c16=c16, co=co,
+            cst=(cm, cr), fq_ctx=fq_ctx, dec=dec, hs_stats=hs_stats, t3s=t3s, hs16=hs16, y1=y1, y2=y2, pooled16=pooled16,
+            phrase_mask=(qmask == 0).view(B, T), memory=mem32)
+        return logits.view(NL, B, Pn, cfg.n_q, 4)
+
+    # ------------------------------------------------------------------ backward
+    def _backward_impl(self, dlogits):
+        cfg, net, st, sv = self.cfg, self.net, self.store, self._saved
+        E = cfg.hidden
+        dev = st.device
+        B, S, Lq, HW, Pn, N, T, NL = (sv[k] for k in ("B", "S", "Lq", "HW", "Pn", "N", "T", "NL"))
+        vt, qe = "vl_transformer.", "query_encoder."
+        M = B * S
+        f32z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)     # noqa: E731
+
+        # ---- bbox head (backbone.py:26-38)
+        dl = dlogits.reshape(NL * N, 4)
+        dl16 = torch.empty(NL * N, 4, dtype=torch.bfloat16, device=dev)
+        H.rows_add(NL * N, 4, a_f32=dl, out_bf16=dl16)
+        l2 = net.lins["bbox_embed.layers.2."]
+        H.linear_wgrad(dl16, sv["y2"], l2.gw)
+        H.colsum(dl, l2.gb)
+        dy2 = H.small_dgrad(dl, l2.w32, gate=sv["y2"])
+        dy1, _ = net.lin_bwd("bbox_embed.layers.1.", dy2, sv["y1"], gate=sv["y1"])
+        _, dhs = net.lin_bwd("bbox_embed.layers.0.", dy1, sv["hs16"], out_bf16=False, out_f32=True)
+
+        # ---- decoder
+        dmem = f32z(M, E); dmemp = f32z(M, E); dqpos = f32z(N, E)
+        ga = gb = None
+        for i in reversed(range(NL)):
+            hm, hr = sv["hs_stats"][i]
+            dnorm, _ = net.ln_bwd(dhs[i * N:(i + 1) * N], sv["t3s"][i], vt + "decoder.norm.", hm, hr, want_bf16=False)
+            extra = None
+            if ga is not None:
+                extra = torch.empty(N, E, dtype=torch.float32, device=dev)
+                H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=extra)
+            ga, gb = net.dec_layer_bwd(f"{vt}decoder.layers.{i}.", sv["dec"][i], dnorm, extra, sv["mem16"], sv["memp16"],
+                                       sv["qmask"], sv["kpm"], B, T, S, dmem, dmemp, dqpos)
+
+        # ---- QueryEncoder backward
+        gqe = st.G[qe + "query_embed.weight"].view(2, E)
+        H.colsum(ga, gqe[0]); H.colsum(gb, gqe[0]); H.colsum(dqpos, gqe[1])
+        df = torch.empty(N, E, dtype=torch.float32, device=dev)
+        H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=df)
+        H.rows_add(N, E, a_f32=dqpos, out_f32=df, accumulate=True)
+        dcat = net.mlp_bwd(sv["fq_ctx"], df, qe + "fuse_encoder_query.")            # fp32 [N, 2E]
+        dcat_rows = dcat.view(2 * N, E)
+        _, dcob = net.ln_bwd(dcat_rows, sv["co"], qe + "context_out.1.", *sv["cst"], rowmap=(1, 2, 0), want_f32=False)
+        _, dc = net.lin_bwd(qe + "context_out.0.", dcob, sv["c16"], out_bf16=False, out_f32=True)
+        H.rows_add(N, E, a_f32=dcat_rows, a_map=(1, 2, 0), out_f32=dmem, accumulate=2, o_map=(-Pn, S, 0))
+        dk, dqs, dvs = H.qenc_attn_bwd(sv["kq"], sv["qs"].view(B, Lq, E), sv["vs"].view(B, Lq, E), sv["qw"], dc.view(B, Pn, E))
+        dk16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
+        dqs16 = torch.empty(B * Lq, E, dtype=torch.bfloat16, device=dev); dvs16 = torch.empty_like(dqs16)
+        H.rows_add(B, E, a_f32=dk, out_bf16=dk16)
+        H.rows_add(B * Lq, E, a_f32=dqs.view(B * Lq, E), out_bf16=dqs16)
+        H.rows_add(B * Lq, E, a_f32=dvs.view(B * Lq, E), out_bf16=dvs16)
+        _, dcls = net.lin_bwd(qe + "linear1.", dk16, sv["cls16"], out_bf16=False, out_f32=True)
+        H.rows_add(B, E, a_f32=dcls, out_f32=dmem, accumulate=True, o_map=(1, S, 0))
+        _, dla = net.lin_bwd(qe + "linear2.", dqs16, sv["lang16"], out_bf16=False, out_f32=True)
+        _, dlang = net.lin_bwd(qe + "linear3.", dvs16, sv["lang16"], res_f32=dla, out_bf16=False, out_f32=True)
+        H.rows_add(B * Lq, E, a_f32=dlang, out_f32=dmem, accumulate=True, o_map=(Lq, S, 0))
+        # map_phrase: gradient rows 2r+1 of dcat; its input is BERT's pooled output (tanh) -> fold tanh'
+        if sv["pctx"] is None:
+            dpool = net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False, dtanh=sv["pooled16"])
+        else:
+            dpool = net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False,
+                                dtanh=sv["pctx"]["pooled"])
+
+        # ---- encoder
+        H.rows_add(M, E, a_f32=dmemp, out_f32=dmem, accumulate=True)      # K-side input of every cross-attention = memory + pos
+        dpos = dmemp
+        dmem_dbg = dmem.clone() if getattr(self, "_debug", False) else None
+        dxa, dxb = dmem, None
+        for i in reversed(range(cfg.enc_layers)):
+            dxa, dxb = net.enc_layer_bwd(f"{vt}encoder.layers.{i}.", sv["enc"][i], dxa, dxb, sv["kpm"], B, S, dpos)
+        H.pos_grad(dpos, st.G[vt + "lang_pos_embeddings.weight"], st.G[vt + "token_type_embeddings.weight"],
+                   st.G[vt + "level_embed"], B, S, Lq)
+
+        # ---- sequence inputs: map_sentence (language rows) and input_proj + GroupNorm (image rows)
+        d_seq = net.mlp_bwd(sv["ms_ctx"], dxa, "map_sentence.", dy_rowmap=(Lq, S, 0), dy2=dxb)
+        _, dip16 = H.groupnorm_bwd(dxa, sv["ip"].view(B, HW, E), st.P["input_proj.0.1.weight"], sv["gn_stats"],
+                                   st.G["input_proj.0.1.weight"], st.G["input_proj.0.1.bias"], 32, 1e-5, dy2=dxb,
+                                   rows_per_img=S, row_off=Lq)
+        g_c5, _ = net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], gate=sv["c5"])
+        if getattr(self, "_debug", False):
+            self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=g_c5.clone())
+        self.body.backward(sv["bb_saved"], g_c5)
+
+        # ---- BERT (sentence pass; phrase pass for multi-phrase inputs)
+        if sv["pctx"] is None:
+            net.bert_bwd(sv["bctx"], d_seq, dpool)
+        else:
+            net.bert_bwd(sv["bctx"], d_seq, None)
+            net.bert_bwd(sv["pctx"], None, dpool)
+        for hook in self._post_backward_hooks:
+            hook()
+
+
+def build_config(args):
+    bc = L.BertConfig()
+    layers = (3, 4, 23, 3) if getattr(args, "backbone", "resnet50") == "resnet101" else (3, 4, 6, 3)
+    for k in ("bert_layers",):
+        if hasattr(args, k):
+            bc.layers = getattr(args, k)
+    return L.ModelConfig(hidden=args.hidden_dim, nheads=args.nheads, enc_layers=args.enc_layers,
+                         dec_layers=0 if getattr(args, "no_decoder", False) else args.dec_layers,
+                         ffn=args.dim_feedforward, dropout=args.dropout, max_lang_seq=args.max_lang_seq,
+                         n_q=args.num_queries_per_phrase, aux_loss=args.aux_loss, resnet_layers=layers, bert=bc)
+
+
+def build_reftr(args):
+    """Same role as models/reftr_transformer.py:307-347: returns (model, criterion, postprocessors)."""
+    from .criterion import CriterionVGMultiPhrase
+    from .post_process import PostProcessVGMultiPhrase
+    device = torch.device(args.device)
+    cfg = build_config(args)
+    model = RefTR(cfg, device=device, aux_loss=args.aux_loss)
+    weight_dict = {"loss_giou": args.giou_loss_coef, "loss_bbox": args.bbox_loss_coef}
+    if args.aux_loss:
+        aux = {}
+        for i in range(cfg.dec_layers - 1):
+            aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
+        aux.update({k + "_enc": v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    criterion = CriterionVGMultiPhrase(weight_dict, losses=["boxes"])
+    postprocessors = {"bbox": PostProcessVGMultiPhrase()}
+    criterion.to(device)
+    return model, criterion, postprocessors

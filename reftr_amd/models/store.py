@@ -1,0 +1,136 @@
+"""Flat parameter storage + the nn.Module tree that exposes it under the reference's state_dict names.
+
+All trainable tensors are views of ONE fp32 buffer (`flat_p`), their gradients views of `flat_g`:
+  * the optimizer is a single streaming kernel over the buffer (rt_adamw_flat), gradient clipping a single
+    reduction (rt_sqnorm), the data-parallel exchange a handful of large all-reduces over `flat_g`;
+  * weight-gradient kernels accumulate straight into `flat_g` views (zeroed once per step by one memset).
+Conv weights are stored channels-last ([Cout][kh][kw][Cin], the implicit-GEMM operand order) but exposed
+with the reference's logical shape [Cout, Cin, kh, kw] through strides, so state_dict()/load_state_dict()
+keep working against reference checkpoints.
+"""
+import torch
+from torch import nn
+
+from . import layout as L
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+class ParamStore:
+    """Owns the flat buffers and the name -> view tables."""
+
+    ALIGN = 4096   # lr-group ranges start on multiples of this (AdamW kernel needs multiples of 4)
+
+    def __init__(self, cfg, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.table = L.full_table(cfg)
+        self.shapes = {n: s for n, s, _ in self.table}
+        self.kinds = {n: k for n, _, k in self.table}
+        # ---- offsets
+        self.offset = {}          # name -> (buffer id, offset)
+        self.group_range = {}     # lr group -> (begin, end)
+        off = 0
+        for grp in (L.GROUP_MAIN, L.GROUP_BACKBONE, L.GROUP_BERT):
+            begin = off
+            for n, s, k in self.table:
+                if k == "param" and L.lr_group(n) == grp:
+                    assert _numel(s) % 4 == 0, (n, s)
+                    self.offset[n] = ("p", off)
+                    off += _numel(s)
+            off = _pad(off, self.ALIGN)
+            self.group_range[grp] = (begin, off)
+        self.n_train = off
+        off = 0
+        for n, s, k in self.table:
+            if k == "frozen":
+                self.offset[n] = ("f", off); off += _pad(_numel(s), 4)
+        self.n_frozen = off
+        off = 0
+        for n, s, k in self.table:
+            if k == "buffer":
+                self.offset[n] = ("b", off); off += _pad(_numel(s), 4)
+        self.n_buffer = off
+        self.allocate(self.device)
+
+    def allocate(self, device, src=None):
+        self.device = torch.device(device)
+        new = {"p": torch.zeros(self.n_train, dtype=torch.float32, device=device),
+               "f": torch.zeros(max(self.n_frozen, 4), dtype=torch.float32, device=device),
+               "b": torch.zeros(max(self.n_buffer, 4), dtype=torch.float32, device=device)}
+        if src is not None:
+            for k in new:
+                new[k].copy_(src[k])
+        self.flat = new
+        self.flat_p = new["p"]
+        self.flat_g = torch.zeros(self.n_train, dtype=torch.float32, device=device)
+        self.P = {n: self._view(self.flat[b], n, o) for n, (b, o) in self.offset.items()}
+        self.G = {n: self._view(self.flat_g, n, o) for n, (b, o) in self.offset.items() if b == "p"}
+
+    def _view(self, buf, name, off):
+        shape = self.shapes[name]
+        flat = buf[off:off + _numel(shape)]
+        if len(shape) == 4:     # conv weight: physical [Cout][kh][kw][Cin], logical [Cout, Cin, kh, kw]
+            co, ci, kh, kw = shape
+            return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat.view(shape)
+
+    def phys(self, name, grad=False):
+        """Physical (contiguous) tensor of a conv weight / its gradient: [Cout, kh*kw, Cin]."""
+        t = (self.G if grad else self.P)[name]
+        co, ci, kh, kw = self.shapes[name]
+        return t.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)    # a view: permute back to storage order
+
+    def packed(self, first, n_parts, grad=False):
+        """View of `n_parts` adjacent, equally-shaped tensors starting at `first` as one stacked tensor."""
+        b, off = self.offset[first]
+        shape = self.shapes[first]
+        buf = self.flat_g if grad else self.flat[b]
+        n = _numel(shape)
+        return buf[off:off + n_parts * n].view((n_parts * shape[0],) + tuple(shape[1:]))
+
+
+def build_module_tree(root: nn.Module, store: ParamStore):
+    """Registers every tensor of the store on `root` under its dotted reference name (containers are plain
+    nn.Module objects), so named_parameters()/state_dict() produce the reference's keys."""
+    for name, shape, kind in store.table:
+        parts = name.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        leaf = parts[-1]
+        if kind == "buffer":
+            mod.register_buffer(leaf, store.P[name])
+        else:
+            par = nn.Parameter(store.P[name], requires_grad=(kind == "param"))
+            if kind == "param":
+                par.grad = store.G[name]
+            mod.register_parameter(leaf, par)
+
+
+def rebind(root: nn.Module, store: ParamStore):
+    """After the flat buffers moved (device change), point every Parameter / buffer at the new views."""
+    for name, shape, kind in store.table:
+        parts = name.split(".")
+        mod = root
+        for p in parts[:-1]:
+            mod = mod._modules[p]
+        leaf = parts[-1]
+        if kind == "buffer":
+            mod._buffers[leaf] = store.P[name]
+        else:
+            par = mod._parameters[leaf]
+            par.data = store.P[name]
+            if kind == "param":
+                par.grad = store.G[name]

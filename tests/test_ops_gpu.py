@@ -187,7 +187,14 @@ def test_mask_posenc_against_golden(hip):
     hip.mask_posenc(up.to(torch.uint8).cuda(), h, w, C, add.cuda(), kpm, L, pos, S, L)
     assert torch.equal(kpm.cpu()[:, L:].bool(), mask.flatten(1))                 # bool: exact
     ref = torch.from_numpy(gd["pos"]).flatten(2).permute(0, 2, 1) + add          # [B, hw, C]
-    assert rel(pos.view(B, S, C)[:, L:], ref) < 2e-5
+    got = pos.view(B, S, C)[:, L:].cpu()
+    # Columns / rows that are entirely padding divide by (0 + 1e-6): arguments of ~3e6 rad whose sine is
+    # ulp-sensitive.  Those positions are masked keys (never attended); compare every other position tightly.
+    nm = ~mask
+    col_ok = nm.any(1, keepdim=True).expand_as(mask); row_ok = nm.any(2, keepdim=True).expand_as(mask)
+    ok = (col_ok & row_ok).flatten(1)
+    assert rel(got[ok], ref[ok]) < 2e-5
+    assert torch.isfinite(got).all()
 
 
 # ------------------------------------------------------------------ small fused ops
