@@ -1,0 +1,201 @@
+"""RefTR training-step benchmark on MI355X (BASELINE.json metric: images/sec of one full training step,
+RefCOCO-shaped batch, ResNet-50, 640x640, batch 8 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = the loop body of engine_vg.train_one_epoch (engine_vg.py:40-72): forward, criterion, backward,
+(N > 1: gradient all-reduce over RCCL), clip_grad_norm(0.1), AdamW, on one seeded synthetic batch that is
+already resident in HBM (images N(0,1), half the batch padded on the right quarter, sentences
+of 4..20 of L = 40 tokens, one box per image).  Random-init weights, dropout ON (train mode).  One process
+per GPU, weak scaling (8 images per GPU); value = whole-job images/s from the max-over-ranks wall time.
+
+Extra objects on the JSON line:
+  roofline      MFMA roofline of the dominant kernel family (the implicit-GEMM conv/linear kernels
+                rt_conv_gemm + rt_conv_wgrad): algorithmic 2*MAC FLOPs of their launches in one step divided by
+                the summed launch durations, measured with HIP events on the launch stream in an instrumented
+                pass of the same step right after the timed region; peak = 2.5 PFLOP/s dense bf16.
+  step_roofline the same ratio for the whole step (219.56 GFLOP/img from SURVEY.md §8d x img/s).
+  cpu_baseline  the CPU oracle (oracle/reftr_oracle.py, the restatement pinned against the reference) running
+                the same loop body on the host cores for a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GF_PER_IMG = 219.56          # fwd+bwd matmul+conv GFLOP per image, cfg2 (SURVEY.md §8d / BASELINE.md §4)
+PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_batch(B, H, W, L, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, H, W, generator=g)
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    for b in range(0, B, 2):                      # landscape images: right quarter is padding
+        wv = (W * 3) // 4
+        mask[b, :, wv:] = True
+        img[b, :, :, wv:] = 0
+    ids = torch.zeros(B, L, dtype=torch.long)
+    smask = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(4, 21, (1,), generator=g))
+        ids[b, :n] = torch.randint(1000, 30000, (n,), generator=g)
+        ids[b, 0] = 101; ids[b, n - 1] = 102
+        smask[b, :n] = 1
+    targets = []
+    for b in range(B):
+        u = torch.rand(4, generator=g)
+        box = torch.tensor([[0.3 + 0.4 * u[0], 0.3 + 0.4 * u[1], 0.1 + 0.4 * u[2], 0.1 + 0.4 * u[3]]])
+        targets.append({"boxes": box, "labels": torch.zeros(1, dtype=torch.long)})
+    samples = {"img": img, "img_mask": mask, "sentence": ids, "sentence_mask": smask}
+    return samples, targets
+
+
+def cpu_baseline(B, H, W, L, max_seconds=30.0):
+    """Times the oracle's train_step (fp32, dropout on, clip 0.1, AdamW) on the host cores."""
+    from oracle import reftr_oracle as O
+    from oracle.shapes import param_shapes
+    from oracle.weights import formula_state
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.Cfg()
+    P = formula_state(param_shapes(cfg))
+    samples, targets = synth_batch(B, H, W, L, "cpu", 1234)
+    state = {}
+    t0 = time.time()
+    O.train_step(P, samples, targets, cfg, state, 1, max_norm=0.1, train=True)       # warm-up
+    warm = time.time() - t0
+    times = []
+    step = 2
+    while sum(times) + warm < max_seconds and len(times) < 3:
+        t0 = time.time()
+        O.train_step(P, samples, targets, cfg, state, step, max_norm=0.1, train=True)
+        times.append(time.time() - t0)
+        step += 1
+    if not times:
+        times = [warm]
+    med = sorted(times)[len(times) // 2]
+    return {"value": B / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed step(s) after 1 warm-up of the same workload (B={B}, {H}x{W}, L={L}, fp32, dropout on)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists for the product)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+    dev = torch.device("cuda", local)
+
+    from reftr_amd import hip
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.models import layout as Lm
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.optim import FusedAdamW
+    from reftr_amd.parallel import DistributedDataParallel
+    from reftr_amd.util.misc import NestedTensor
+
+    B, S_, Lq = args.batch, args.size, 40
+    cfg = Lm.ModelConfig()
+    model = RefTR(cfg, device=dev, aux_loss=True)
+    wd = {"loss_giou": 1.0, "loss_bbox": 1.0}
+    wd.update({f"{k}_{i}": v for i in range(cfg.dec_layers - 1) for k, v in list(wd.items())})
+    crit = CriterionVGMultiPhrase(wd, ["boxes"])
+    # a non-degenerate head so the loss has gradients everywhere (the reference zero-inits the last bbox layer)
+    torch.manual_seed(1234)
+    model.store.P["bbox_embed.layers.2.weight"].normal_(0, 0.02)
+    model.mark_dirty()
+    opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    runner = DistributedDataParallel(model) if world > 1 else model
+    model.train()
+
+    samples, targets = synth_batch(B, S_, S_, Lq, dev, 1234 + rank)
+    s = {k: v.to(dev) for k, v in samples.items() if k not in ("img", "img_mask")}
+    s["img"] = NestedTensor(samples["img"].to(dev), samples["img_mask"].to(dev))
+    tg = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+
+    def step():
+        return train_step(runner, crit, s, tg, opt, None, max_norm=0.1)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_value = step()[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t)
+
+    ms_per_step = el / args.steps * 1e3
+    value = B * world * args.steps / el
+
+    roof = None
+    if rank == 0 and not args.no_kernel_roofline:
+        recs = []
+        hip.set_launch_timer(recs)
+        step()
+        torch.cuda.synchronize()
+        hip.set_launch_timer(None)
+        fl = sum(r["flops"] for r in recs)
+        tm = sum(r["start"].elapsed_time(r["end"]) for r in recs) * 1e-3
+        ach = fl / tm / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_gemm_kernel+conv_wgrad_kernel (rt_conv_gemm / rt_conv_wgrad)",
+                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
+                "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3}
+    out = {
+        "metric": "images/sec training step, RefCOCO R50 640x640 bs=8/GPU", "value": value, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"RefCOCO-shaped REC train step, ResNet-50 + BERT-base + VL transformer 6+6, "
+                               f"{S_}x{S_}, batch {B}/GPU, L=40, aux loss, dropout on, clip 0.1, AdamW (configs[1])",
+                   "global_batch": B * world, "parallelism": f"dp{world}"},
+        "loss": loss_value,
+    }
+    if rank == 0:
+        step_tf = value * GF_PER_IMG / 1e3
+        out["step_roofline"] = {"bound": "mfma", "achieved": step_tf, "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
+                                "frac": step_tf / (PEAK_BF16_TFLOPS * world), "gflop_per_img": GF_PER_IMG}
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, S_, S_, Lq)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -213,6 +213,27 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_TIMER = None
+
+
+def set_launch_timer(records):
+    """bench.py instrumentation: when `records` is a list, every rt_conv_gemm / rt_conv_wgrad launch is
+    bracketed by HIP events on the launch stream and appended as {kind, flops, start, end}."""
+    global _TIMER
+    _TIMER = records
+
+
+def _timed(kind, flops, fn):
+    if _TIMER is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _TIMER.append({"kind": kind, "flops": float(flops), "start": e0, "end": e1})
+    return r
+
+
 def _req(t, dtype, name):
     if t is None:
         return
@@ -256,7 +277,11 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
     if out_preact:
         op = torch.empty((M, N), dtype=torch.bfloat16, device=src.device)
         d.out_preact = _p(op)
-    _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm")
+    if transposed:     # algorithmic FLOPs of backward-data = those of the forward conv it differentiates
+        flops = 2.0 * B * SH * SW * SC * N * KH * KW
+    else:
+        flops = 2.0 * M * N * KH * KW * SC
+    _timed("conv_gemm", flops, lambda: _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm"))
     if out_preact:
         return ob, of, op
     return ob, of
@@ -276,7 +301,8 @@ def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0):
     _req(scale, torch.float32, "scale")
     assert dy.numel() == B * DH * DW * N and x.numel() == B * SH * SW * SC and dw.numel() == N * KH * KW * SC
     d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit)
-    _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad")
+    _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
+           lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"))
     return dw
 
 
