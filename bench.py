@@ -61,16 +61,17 @@ def synth_batch(B, H, W, L, device, seed):
     return samples, targets
 
 
-def cpu_baseline(B, H, W, L, max_seconds=30.0):
-    """Times the oracle's train_step (fp32, dropout on, clip 0.1, AdamW) on the host cores."""
+def cpu_baseline(B, H, W, L, max_seconds=25.0, sample_batch=2, threads=32):
+    """Times the oracle's train_step (fp32, dropout on, clip 0.1, AdamW) on the host cores, on a bounded sample:
+    `sample_batch` images of the same workload (per-image cost of this path is batch-independent on CPU)."""
     from oracle import reftr_oracle as O
     from oracle.shapes import param_shapes
     from oracle.weights import formula_state
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, threads)
     torch.set_num_threads(cores)
     cfg = O.Cfg()
     P = formula_state(param_shapes(cfg))
-    samples, targets = synth_batch(B, H, W, L, "cpu", 1234)
+    samples, targets = synth_batch(sample_batch, H, W, L, "cpu", 1234)
     state = {}
     t0 = time.time()
     O.train_step(P, samples, targets, cfg, state, 1, max_norm=0.1, train=True)       # warm-up
@@ -85,8 +86,9 @@ def cpu_baseline(B, H, W, L, max_seconds=30.0):
     if not times:
         times = [warm]
     med = sorted(times)[len(times) // 2]
-    return {"value": B / med, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} timed step(s) after 1 warm-up of the same workload (B={B}, {H}x{W}, L={L}, fp32, dropout on)"}
+    return {"value": sample_batch / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed step(s) after 1 warm-up on {sample_batch} images of the same workload "
+                      f"({H}x{W}, L={L}, fp32, dropout on, clip 0.1, AdamW), torch CPU threads = {cores}"}
 
 
 def main():

@@ -1,263 +1,333 @@
-// Masked multi-head attention forward / backward for the RefTR sequence lengths
-// (VL encoder S = L + HW/32^2 <= 768, dh = 32; BERT L <= 128, dh = 64; decoder n_q*n_ph queries).
+// Masked multi-head attention forward / backward on MFMA for the RefTR sequence lengths
+// (VL encoder S = L + HW/32^2, dh = 32; BERT L <= 128, dh = 64; decoder cross-attention n_q*n_ph x S).
 //
-// Work decomposition: a workgroup owns one (batch, head) and a 64-row tile of the "outer" axis; the whole
-// inner-axis operand pair (K,V for forward / dQ; Q,dO for dK/dV) is staged once in LDS as bf16 rows padded
-// by 16 B (conflict-free ds_read_b128 when lane j reads row j).  One 64-lane wave processes one outer row at
-// a time with the inner axis spread across lanes; softmax statistics are wave reductions and the
-// [64 lanes x dh] partial outputs are combined with a butterfly reduce-scatter (dh shuffles, no LDS).
-// The score matrix never touches HBM; backward recomputes probabilities from the saved log-sum-exp.
+// One workgroup (8 waves) owns one (batch, head) and 128 rows of the "outer" axis, 16 per wave; the whole
+// inner-axis operand pair of that head is staged once in LDS in its natural [row][dh] layout (row stride
+// padded by 32 B, conflict-free for both access patterns below).  The score matrix never leaves registers:
+//
+//   forward / dQ : S^T tile [16 keys x 16 queries] = mfma(K rows, Q^T)  ("swapped" product): a lane then holds,
+//     for ONE query (lane & 15), keys 4g..4g+3 of the tile (g = lane >> 4).  Two such tiles (32 keys) are exactly
+//     the B-operand fragment of the next MFMA  O^T[d][q] += V^T[d][keys] P^T[keys][q]  — no cross-lane traffic for
+//     P; V^T / K^T fragments come from the natural V / K rows through the gfx950 LDS transpose read
+//     (ds_read_b64_tr_b16), with the same key -> k-slot assignment on both operands.
+//     Softmax: two streaming passes over the keys (pass 1: running max / sum, pass 2: normalised P and PV), so
+//     any S fits without holding S scores in registers; row statistics are combined across the 4 lane groups
+//     with two shuffles.
+//   dK / dV      : the roles swap — a wave owns 16 keys, S tile [16 queries x 16 keys] = mfma(Q rows, K^T), and
+//     dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]  with dO^T / Q^T via transpose reads.
+//
+// Dropout acts on the probabilities with the shared counter hash (index ((b*H+h)*Sq + q)*Sk + key); a fully
+// masked row gives NaN like the reference's softmax over -inf.
 #include "rt_common.h"
 
 namespace {
 
-constexpr int TMAX = 12;   // inner axis <= 768
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-template <int DH>
-__device__ __forceinline__ void load_row_f32(const bf16_t* p, float (&r)[DH]) {
-#pragma unroll
-    for (int c = 0; c < DH / 8; ++c) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r[c * 8 + e] = (float)v[e];
-    }
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p1);
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
 }
 
-template <int DH>
-__device__ __forceinline__ float dot_lds(const unsigned char* row, const float (&q)[DH]) {
-    float s = 0.f;
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    bf16x8 o;
 #pragma unroll
-    for (int c = 0; c < DH / 8; ++c) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c * 16);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += q[c * 8 + e] * (float)v[e];
-    }
-    return s;
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    return o;
 }
 
-template <int DH>
-__device__ __forceinline__ void axpy_lds(const unsigned char* row, float a, float (&o)[DH]) {
-#pragma unroll
-    for (int c = 0; c < DH / 8; ++c) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c * 16);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[c * 8 + e] += a * (float)v[e];
-    }
-}
+template <int DH> struct Geo {
+    static constexpr int RS = DH * 2 + 32;     // LDS row stride (bytes)
+    static constexpr int KH = DH / 32;         // MFMA k-steps over the head dim
+    static constexpr int DT = DH / 16;         // 16-wide output tiles over the head dim
+};
 
-// Sum o[d] over the 64 lanes; afterwards lane L holds the total for d = (DH == 64 ? L : L >> 1) in o[0].
+// rows [0, rows) of a [*, ld] bf16 matrix (head slice) -> LDS rows of stride RS; rows [rows, rows_pad) zeroed
 template <int DH>
-__device__ __forceinline__ void butterfly_reduce(float (&o)[DH], int lane) {
-    int mask = 32;
-#pragma unroll
-    for (int h = DH / 2; h >= 1; h >>= 1) {
-        const bool up = (lane & mask) != 0;
-#pragma unroll
-        for (int i = 0; i < h; ++i) {
-            const float keep = up ? o[i + h] : o[i];
-            const float send = up ? o[i] : o[i + h];
-            o[i] = keep + __shfl_xor(send, mask, 64);
-        }
-        mask >>= 1;
-    }
-    if (DH == 32) o[0] += __shfl_xor(o[0], 1, 64);
-}
-
-template <int DH>
-__device__ __forceinline__ void stage_rows(unsigned char* dst, const bf16_t* src, int rows, int ld, int tid) {
-    constexpr int RS = DH * 2 + 16;
-    constexpr int CPR = DH / 8;
-    for (int c = tid; c < rows * CPR; c += 256) {
+__device__ __forceinline__ void stage_rows(unsigned char* dst, const bf16_t* src, int rows, int rows_pad, int ld, int tid, int nthreads) {
+    constexpr int RS = Geo<DH>::RS, CPR = DH / 8;
+    for (int c = tid; c < rows_pad * CPR; c += nthreads) {
         const int r = c / CPR, cc = c % CPR;
-        *reinterpret_cast<uint4*>(dst + r * RS + cc * 16) = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + cc * 8);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < rows) v = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + cc * 8);
+        *reinterpret_cast<uint4*>(dst + r * RS + cc * 16) = v;
     }
 }
 
+// fragment of a [rows][DH] global matrix used as MFMA B operand: lane (i, g) <- row (r0 + i), cols 32*kh + 8g..+7
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const rt_attn_desc p) {
-    constexpr int RS = DH * 2 + 16;
+__device__ __forceinline__ void load_bfrag(const bf16_t* base, int row, int nrows, int ld, int lg, bf16x8 (&f)[Geo<DH>::KH]) {
+#pragma unroll
+    for (int kh = 0; kh < Geo<DH>::KH; ++kh) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < nrows) v = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + kh * 32 + lg * 8);
+        f[kh] = *reinterpret_cast<bf16x8*>(&v);
+    }
+}
+
+// S tile = sum_kh mfma(A rows from LDS (row0 + li), B frag)
+template <int DH>
+__device__ __forceinline__ f32x4 tile_dot(const unsigned char* sA, int row0, int li, int lg, const bf16x8 (&bf)[Geo<DH>::KH]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < Geo<DH>::KH; ++kh) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sA + (row0 + li) * Geo<DH>::RS + kh * 64 + lg * 16);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[kh], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int DH>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const rt_attn_desc p) {
+    constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Skp = (p.Sk + 31) & ~31;
     unsigned char* sK = smem;
-    unsigned char* sV = smem + (size_t)p.Sk * RS;
+    unsigned char* sV = sK + (size_t)Skp * RS;
+    float* sBias = reinterpret_cast<float*>(sV + (size_t)Skp * RS);
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bf16_t* kb = (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH;
-    const bf16_t* vb = (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH;
-    stage_rows<DH>(sK, kb, p.Sk, p.ldk, threadIdx.x);
-    stage_rows<DH>(sV, vb, p.Sk, p.ldv, threadIdx.x);
+    const int li = lane & 15, lg = lane >> 4;
+    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 512);
+    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 512);
+    for (int j = threadIdx.x; j < Skp; j += 512)
+        sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
+
+    const int q = blockIdx.x * 128 + wave * 16 + li;          // this lane's query
+    if (blockIdx.x * 128 + wave * 16 >= p.Sq) return;
+    bf16x8 qf[Geo<DH>::KH];
+    load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
+    const int nblk = Skp >> 4;
+
+    // pass 1: running max / sum over this lane's keys (4 per 16-key tile)
+    float m = -INFINITY, l = 0.f;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const f32x4 acc = tile_dot<DH>(sK, blk * 16, li, lg, qf);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + blk * 16 + lg * 4);
+        float s[4], mx = m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[r] = acc[r] * p.scale + bias[r]; mx = fmaxf(mx, s[r]); }
+        const float ms = (mx == -INFINITY) ? 0.f : mx;
+        float add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) add += __expf(s[r] - ms);
+        l = l * __expf(m - ms) + add;
+        m = mx;
+    }
+    float M = fmaxf(m, __shfl_xor(m, 16, 64));
+    M = fmaxf(M, __shfl_xor(M, 32, 64));
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    l *= __expf(m - Ms);
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.f / l;                 // fully masked row: 0 * inf = NaN below, as the reference
+
+    // pass 2: normalised probabilities -> P^T fragments -> O^T += V^T P^T
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
-    const int nt = (p.Sk + 63) >> 6;
-    const uint8_t* kpm = p.kpm ? p.kpm + (size_t)b * p.Sk : nullptr;
-
-    for (int r = 0; r < 16; ++r) {
-        const int i = blockIdx.x * 64 + wave * 16 + r;
-        if (i >= p.Sq) break;
-        float q[DH];
-        load_row_f32<DH>((const bf16_t*)p.q + ((size_t)b * p.Sq + i) * p.ldq + h * DH, q);
-        float s[TMAX];
-        float m = -INFINITY;
+    const uint32_t drop_row = (uint32_t)(((size_t)bh * p.Sq + q) * p.Sk);
+    f32x4 o[DT];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            s[t] = -INFINITY;
-            if (t < nt) {
-                const int j = lane + (t << 6);
-                if (j < p.Sk && !(kpm && kpm[j])) s[t] = dot_lds<DH>(sK + (size_t)j * RS, q) * p.scale;
-                m = fmaxf(m, s[t]);
+    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tr_r = 4 * lg + (li >> 2), tr_c = (li & 3) * 8;
+    for (int c = 0; c < (Skp >> 5); ++c) {
+        float pv[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k0 = c * 32 + half * 16;
+            const f32x4 acc = tile_dot<DH>(sK, k0, li, lg, qf);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + k0 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = __expf(acc[r] * p.scale + bias[r] - Ms) * inv_l;
+                if (do_drop) pr = (rt_hash32(p.drop_seed, drop_row + (uint32_t)(k0 + lg * 4 + r)) >= thresh) ? pr * ks : 0.f;
+                pv[half * 4 + r] = pr;
             }
         }
-        m = rt_wave_max(m);
-        float l = 0.f;
+        const bf16x8 pf = pack8(pv);
+        const unsigned char* v0 = sV + (c * 32 + tr_r) * RS + tr_c;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < nt) { s[t] = __expf(s[t] - m); l += s[t]; }   // all-masked row: (-inf) - (-inf) = NaN, as the reference
-        l = rt_wave_sum(l);
-        const float inv_l = 1.f / l;
-        float o[DH];
-#pragma unroll
-        for (int d = 0; d < DH; ++d) o[d] = 0.f;
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            if (t < nt) {
-                const int j = lane + (t << 6);
-                if (j < p.Sk) {
-                    float pj = s[t] * inv_l;
-                    if (do_drop)
-                        pj = (rt_hash32(p.drop_seed, (uint32_t)(((size_t)bh * p.Sq + i) * p.Sk + j)) >= thresh) ? pj * ks : 0.f;
-                    axpy_lds<DH>(sV + (size_t)j * RS, pj, o);
-                }
-            }
+        for (int t = 0; t < DT; ++t) {
+            const bf16x8 vf = tr_pair(v0 + t * 32, v0 + 16 * RS + t * 32);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
         }
-        butterfly_reduce<DH>(o, lane);
-        bf16_t* orow = (bf16_t*)p.out + ((size_t)b * p.Sq + i) * p.ldo + h * DH;
-        if (DH == 64) orow[lane] = (bf16_t)o[0];
-        else if ((lane & 1) == 0) orow[lane >> 1] = (bf16_t)o[0];
-        if (lane == 0 && p.lse) p.lse[(size_t)bh * p.Sq + i] = m + __logf(l);
+    }
+    if (q < p.Sq) {
+        bf16_t* orow = (bf16_t*)p.out + ((size_t)b * p.Sq + q) * p.ldo + h * DH;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)o[t][r];
+            *reinterpret_cast<bf16x4*>(orow + t * 16 + lg * 4) = ov;
+        }
+        if (lg == 0 && p.lse) p.lse[(size_t)bh * p.Sq + q] = M + __logf(l);
     }
 }
 
-// dQ (+ delta = dO . O) : same traversal as forward
+// ------------------------------------------------------------------------------------------------ dQ (+ delta)
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const rt_attn_bwd_desc p) {
-    constexpr int RS = DH * 2 + 16;
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const rt_attn_bwd_desc p) {
+    constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Skp = (p.Sk + 31) & ~31;
     unsigned char* sK = smem;
-    unsigned char* sV = smem + (size_t)p.Sk * RS;
+    unsigned char* sV = sK + (size_t)Skp * RS;
+    float* sBias = reinterpret_cast<float*>(sV + (size_t)Skp * RS);
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, p.ldk, threadIdx.x);
-    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, p.ldv, threadIdx.x);
+    const int li = lane & 15, lg = lane >> 4;
+    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 512);
+    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 512);
+    for (int j = threadIdx.x; j < Skp; j += 512)
+        sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
+
+    const int q = blockIdx.x * 128 + wave * 16 + li;
+    if (blockIdx.x * 128 + wave * 16 >= p.Sq) return;
+    bf16x8 qf[KH], dof[KH], of[KH];
+    load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
+    load_bfrag<DH>((const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, q, p.Sq, p.ldo, lg, dof);
+    load_bfrag<DH>((const bf16_t*)p.out + (size_t)b * p.Sq * p.ldo + h * DH, q, p.Sq, p.ldo, lg, of);
+    float delta = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) delta += (float)dof[kh][e] * (float)of[kh][e];
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = (q < p.Sq) ? p.lse[(size_t)bh * p.Sq + q] : INFINITY;
+    if (lg == 0 && q < p.Sq) p.delta[(size_t)bh * p.Sq + q] = delta;
+
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
-    const int nt = (p.Sk + 63) >> 6;
-    const uint8_t* kpm = p.kpm ? p.kpm + (size_t)b * p.Sk : nullptr;
-
-    for (int r = 0; r < 16; ++r) {
-        const int i = blockIdx.x * 64 + wave * 16 + r;
-        if (i >= p.Sq) break;
-        float q[DH], dO[DH];
-        load_row_f32<DH>((const bf16_t*)p.q + ((size_t)b * p.Sq + i) * p.ldq + h * DH, q);
-        load_row_f32<DH>((const bf16_t*)p.dout + ((size_t)b * p.Sq + i) * p.ldo + h * DH, dO);
-        float delta = 0.f;
-        {
-            float O[DH];
-            load_row_f32<DH>((const bf16_t*)p.out + ((size_t)b * p.Sq + i) * p.ldo + h * DH, O);
+    const uint32_t drop_row = (uint32_t)(((size_t)bh * p.Sq + q) * p.Sk);
+    f32x4 dq[DT];
 #pragma unroll
-            for (int d = 0; d < DH; ++d) delta += dO[d] * O[d];
-        }
-        const float lse = p.lse[(size_t)bh * p.Sq + i];
-        if (lane == 0) p.delta[(size_t)bh * p.Sq + i] = delta;
-        float dq[DH];
+    for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tr_r = 4 * lg + (li >> 2), tr_c = (li & 3) * 8;
+    for (int c = 0; c < (Skp >> 5); ++c) {
+        float dsv[8];
 #pragma unroll
-        for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+        for (int half = 0; half < 2; ++half) {
+            const int k0 = c * 32 + half * 16;
+            const f32x4 s = tile_dot<DH>(sK, k0, li, lg, qf);
+            const f32x4 dp = tile_dot<DH>(sV, k0, li, lg, dof);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + k0 + lg * 4);
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            if (t < nt) {
-                const int j = lane + (t << 6);
-                if (j < p.Sk && !(kpm && kpm[j])) {
-                    const float sij = dot_lds<DH>(sK + (size_t)j * RS, q) * p.scale;
-                    const float pij = __expf(sij - lse);
-                    float dp = dot_lds<DH>(sV + (size_t)j * RS, dO);
-                    if (do_drop)
-                        dp = (rt_hash32(p.drop_seed, (uint32_t)(((size_t)bh * p.Sq + i) * p.Sk + j)) >= thresh) ? dp * ks : 0.f;
-                    const float ds = pij * (dp - delta) * p.scale;
-                    axpy_lds<DH>(sK + (size_t)j * RS, ds, dq);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float pr = __expf(s[r] * p.scale + bias[r] - lse);
+                float d = dp[r];
+                if (do_drop) d = (rt_hash32(p.drop_seed, drop_row + (uint32_t)(k0 + lg * 4 + r)) >= thresh) ? d * ks : 0.f;
+                dsv[half * 4 + r] = pr * (d - delta) * p.scale;
             }
         }
-        butterfly_reduce<DH>(dq, lane);
-        bf16_t* drow = (bf16_t*)p.dq + ((size_t)b * p.Sq + i) * p.lddq + h * DH;
-        if (DH == 64) drow[lane] = (bf16_t)dq[0];
-        else if ((lane & 1) == 0) drow[lane >> 1] = (bf16_t)dq[0];
+        const bf16x8 dsf = pack8(dsv);
+        const unsigned char* k0p = sK + (c * 32 + tr_r) * RS + tr_c;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const bf16x8 kf = tr_pair(k0p + t * 32, k0p + 16 * RS + t * 32);
+            dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[t], 0, 0, 0);
+        }
+    }
+    if (q < p.Sq) {
+        bf16_t* drow = (bf16_t*)p.dq + ((size_t)b * p.Sq + q) * p.lddq + h * DH;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[t][r];
+            *reinterpret_cast<bf16x4*>(drow + t * 16 + lg * 4) = ov;
+        }
     }
 }
 
-// dK, dV: outer axis = keys, inner axis = queries (Q and dO staged in LDS)
+// ------------------------------------------------------------------------------------------------ dK, dV
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const rt_attn_bwd_desc p) {
-    constexpr int RS = DH * 2 + 16;
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const rt_attn_bwd_desc p) {
+    constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Sqp = (p.Sq + 31) & ~31;
     unsigned char* sQ = smem;
-    unsigned char* sD = smem + (size_t)p.Sq * RS;
-    float* sL = reinterpret_cast<float*>(smem + 2 * (size_t)p.Sq * RS);
-    float* sDel = sL + p.Sq;
+    unsigned char* sD = sQ + (size_t)Sqp * RS;
+    float* sL = reinterpret_cast<float*>(sD + (size_t)Sqp * RS);
+    float* sDel = sL + Sqp;
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    stage_rows<DH>(sQ, (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, p.Sq, p.ldq, threadIdx.x);
-    stage_rows<DH>(sD, (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, p.Sq, p.ldo, threadIdx.x);
-    for (int i = threadIdx.x; i < p.Sq; i += 256) {
-        sL[i] = p.lse[(size_t)bh * p.Sq + i];
-        sDel[i] = p.delta[(size_t)bh * p.Sq + i];
+    const int li = lane & 15, lg = lane >> 4;
+    stage_rows<DH>(sQ, (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, p.Sq, Sqp, p.ldq, threadIdx.x, 512);
+    stage_rows<DH>(sD, (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, p.Sq, Sqp, p.ldo, threadIdx.x, 512);
+    for (int i = threadIdx.x; i < Sqp; i += 512) {
+        sL[i] = (i < p.Sq) ? p.lse[(size_t)bh * p.Sq + i] : INFINITY;       // padded query rows: p = exp(-inf) = 0
+        sDel[i] = (i < p.Sq) ? p.delta[(size_t)bh * p.Sq + i] : 0.f;
     }
     __syncthreads();
+
+    const int key = blockIdx.x * 128 + wave * 16 + li;         // this lane's key (MFMA column)
+    if (blockIdx.x * 128 + wave * 16 >= p.Sk) return;
+    bf16x8 kf[KH], vf[KH];
+    load_bfrag<DH>((const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, key, p.Sk, p.ldk, lg, kf);
+    load_bfrag<DH>((const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, key, p.Sk, p.ldv, lg, vf);
+    const float kbias = (key < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + key])) ? 0.f : -INFINITY;
+
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
-    const int nt = (p.Sq + 63) >> 6;
-    const uint8_t* kpm = p.kpm ? p.kpm + (size_t)b * p.Sk : nullptr;
-
-    for (int r = 0; r < 16; ++r) {
-        const int j = blockIdx.x * 64 + wave * 16 + r;
-        if (j >= p.Sk) break;
-        float dk[DH], dv[DH];
+    f32x4 dk[DT], dv[DT];
 #pragma unroll
-        for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-        const bool masked = kpm && kpm[j];
-        if (!masked) {
-            float kr[DH], vr[DH];
-            load_row_f32<DH>((const bf16_t*)p.k + ((size_t)b * p.Sk + j) * p.ldk + h * DH, kr);
-            load_row_f32<DH>((const bf16_t*)p.v + ((size_t)b * p.Sk + j) * p.ldv + h * DH, vr);
+    for (int t = 0; t < DT; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int tr_r = 4 * lg + (li >> 2), tr_c = (li & 3) * 8;
+    for (int c = 0; c < (Sqp >> 5); ++c) {
+        float pv[8], dsv[8];
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) {
-                if (t < nt) {
-                    const int i = lane + (t << 6);
-                    if (i < p.Sq) {
-                        const float sij = dot_lds<DH>(sQ + (size_t)i * RS, kr) * p.scale;
-                        const float pij = __expf(sij - sL[i]);
-                        float dp = dot_lds<DH>(sD + (size_t)i * RS, vr);
-                        float pd = pij;
-                        if (do_drop) {
-                            const bool keep = rt_hash32(p.drop_seed, (uint32_t)(((size_t)bh * p.Sq + i) * p.Sk + j)) >= thresh;
-                            dp = keep ? dp * ks : 0.f;
-                            pd = keep ? pij * ks : 0.f;
-                        }
-                        axpy_lds<DH>(sD + (size_t)i * RS, pd, dv);
-                        const float ds = pij * (dp - sDel[i]) * p.scale;
-                        axpy_lds<DH>(sQ + (size_t)i * RS, ds, dk);
-                    }
+        for (int half = 0; half < 2; ++half) {
+            const int q0 = c * 32 + half * 16;
+            const f32x4 s = tile_dot<DH>(sQ, q0, li, lg, kf);          // [query 4g+r][key li]
+            const f32x4 dp = tile_dot<DH>(sD, q0, li, lg, vf);
+            const f32x4 lse = *reinterpret_cast<const f32x4*>(sL + q0 + lg * 4);
+            const f32x4 del = *reinterpret_cast<const f32x4*>(sDel + q0 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = __expf(s[r] * p.scale + kbias - lse[r]);
+                float d = dp[r], pd = pr;
+                if (do_drop) {
+                    const int qq = q0 + lg * 4 + r;
+                    const bool keep = rt_hash32(p.drop_seed, (uint32_t)(((size_t)bh * p.Sq + qq) * p.Sk + key)) >= thresh;
+                    d = keep ? d * ks : 0.f; pd = keep ? pr * ks : 0.f;
                 }
+                pv[half * 4 + r] = pd;
+                dsv[half * 4 + r] = pr * (d - del[r]) * p.scale;
             }
         }
-        butterfly_reduce<DH>(dk, lane);
-        butterfly_reduce<DH>(dv, lane);
-        bf16_t* kro = (bf16_t*)p.dk + ((size_t)b * p.Sk + j) * p.lddk + h * DH;
-        bf16_t* vro = (bf16_t*)p.dv + ((size_t)b * p.Sk + j) * p.lddv + h * DH;
-        if (DH == 64) { kro[lane] = (bf16_t)dk[0]; vro[lane] = (bf16_t)dv[0]; }
-        else if ((lane & 1) == 0) { kro[lane >> 1] = (bf16_t)dk[0]; vro[lane >> 1] = (bf16_t)dv[0]; }
+        const bf16x8 pf = pack8(pv), dsf = pack8(dsv);
+        const unsigned char* d0 = sD + (c * 32 + tr_r) * RS + tr_c;
+        const unsigned char* q0p = sQ + (c * 32 + tr_r) * RS + tr_c;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const bf16x8 dof = tr_pair(d0 + t * 32, d0 + 16 * RS + t * 32);
+            dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[t], 0, 0, 0);
+            const bf16x8 qtf = tr_pair(q0p + t * 32, q0p + 16 * RS + t * 32);
+            dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[t], 0, 0, 0);
+        }
+    }
+    if (key < p.Sk) {
+        bf16_t* kro = (bf16_t*)p.dk + ((size_t)b * p.Sk + key) * p.lddk + h * DH;
+        bf16_t* vro = (bf16_t*)p.dv + ((size_t)b * p.Sk + key) * p.lddv + h * DH;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            bf16x4 a, c2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[t][r]; c2[r] = (bf16_t)dv[t][r]; }
+            *reinterpret_cast<bf16x4*>(kro + t * 16 + lg * 4) = a;
+            *reinterpret_cast<bf16x4*>(vro + t * 16 + lg * 4) = c2;
+        }
     }
 }
 
@@ -271,21 +341,26 @@ int set_smem(K kernel, size_t bytes) {
     return RT_OK;
 }
 
+size_t smem_bytes(int inner, int dh) {
+    const size_t ip = (size_t)((inner + 31) & ~31);
+    return 2 * ip * (dh * 2 + 32) + 2 * sizeof(float) * ip;
+}
+
 }  // namespace
 
 extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
     if (!d || !d->q || !d->k || !d->v || !d->out) return RT_ERR_BADARG;
-    if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sk > 64 * TMAX || d->Sq <= 0) return RT_ERR_UNSUPPORTED;
+    if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sq <= 0) return RT_ERR_UNSUPPORTED;
     if ((d->ldq | d->ldk | d->ldv | d->ldo) & 7) return RT_ERR_UNSUPPORTED;
-    const size_t smem = 2 * (size_t)d->Sk * (d->dh * 2 + 16);
-    const dim3 grid((d->Sq + 63) / 64, d->B * d->H);
+    const size_t smem = smem_bytes(d->Sk, d->dh);
+    const dim3 grid((d->Sq + 127) / 128, d->B * d->H);
     int rc;
     if (d->dh == 32) {
         if ((rc = set_smem(attn_fwd_kernel<32>, smem)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), smem, (hipStream_t)stream, *d);
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(512), smem, (hipStream_t)stream, *d);
     } else {
         if ((rc = set_smem(attn_fwd_kernel<64>, smem)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), smem, (hipStream_t)stream, *d);
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(512), smem, (hipStream_t)stream, *d);
     }
     RT_CHECK_LAUNCH();
     return RT_OK;
@@ -294,24 +369,22 @@ extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
 extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
     if (!d || !d->q || !d->k || !d->v || !d->out || !d->dout || !d->lse || !d->delta || !d->dq || !d->dk || !d->dv)
         return RT_ERR_BADARG;
-    if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sk > 64 * TMAX || d->Sq <= 0 || d->Sq > 64 * TMAX)
-        return RT_ERR_UNSUPPORTED;
+    if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sq <= 0) return RT_ERR_UNSUPPORTED;
     if ((d->ldq | d->ldk | d->ldv | d->ldo | d->lddq | d->lddk | d->lddv) & 7) return RT_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const size_t smem1 = 2 * (size_t)d->Sk * (d->dh * 2 + 16);
-    const size_t smem2 = 2 * (size_t)d->Sq * (d->dh * 2 + 16) + 2 * sizeof(float) * (size_t)d->Sq;
-    const dim3 g1((d->Sq + 63) / 64, d->B * d->H), g2((d->Sk + 63) / 64, d->B * d->H);
+    const size_t smem1 = smem_bytes(d->Sk, d->dh), smem2 = smem_bytes(d->Sq, d->dh);
+    const dim3 g1((d->Sq + 127) / 128, d->B * d->H), g2((d->Sk + 127) / 128, d->B * d->H);
     int rc;
     if (d->dh == 32) {
         if ((rc = set_smem(attn_bwd_dq_kernel<32>, smem1)) != RT_OK) return rc;
         if ((rc = set_smem(attn_bwd_dkv_kernel<32>, smem2)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, g1, dim3(256), smem1, s, *d);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, g2, dim3(256), smem2, s, *d);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, g1, dim3(512), smem1, s, *d);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, g2, dim3(512), smem2, s, *d);
     } else {
         if ((rc = set_smem(attn_bwd_dq_kernel<64>, smem1)) != RT_OK) return rc;
         if ((rc = set_smem(attn_bwd_dkv_kernel<64>, smem2)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, g1, dim3(256), smem1, s, *d);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, g2, dim3(256), smem2, s, *d);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, g1, dim3(512), smem1, s, *d);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, g2, dim3(512), smem2, s, *d);
     }
     RT_CHECK_LAUNCH();
     return RT_OK;

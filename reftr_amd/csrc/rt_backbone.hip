@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void mask_posenc_kernel(const rt_mask_posenc_d
         sy = min(sy, p.H - 1); sx = min(sx, p.W - 1);
         const unsigned char m = p.mask[((size_t)b * p.H + sy) * p.W + sx];
         sm_mask[i] = m;
-        p.kpm_out[(size_t)b * p.kpm_stride + p.kpm_off + i] = m;
+        if (blockIdx.y == 0) p.kpm_out[(size_t)b * p.kpm_stride + p.kpm_off + i] = m;
     }
     __syncthreads();
     for (int x = threadIdx.x; x < p.w; x += 256) {
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void mask_posenc_kernel(const rt_mask_posenc_d
     __syncthreads();
     const int npf = p.C / 2;
     const float scale = 6.283185307179586f, eps = 1e-6f;
-    for (int i = threadIdx.x; i < hw * p.C; i += 256) {
+    // the (pixel, channel) plane is split over gridDim.y workgroups (each recomputes the cheap cumulative sums)
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < hw * p.C; i += 256 * gridDim.y) {
         const int c = i % p.C, pix = i / p.C;
         const int y = pix / p.w, x = pix % p.w;
         float e;
@@ -260,7 +261,7 @@ extern "C" int rt_mask_posenc(const rt_mask_posenc_desc* d, rt_stream_t stream) 
     const int hw = d->h * d->w;
     const size_t smem = sizeof(float) * ((hw + 3) / 4 + 2 * (size_t)hw);
     if (smem > 64 * 1024) return RT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(mask_posenc_kernel, dim3(d->B), dim3(256), smem, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(mask_posenc_kernel, dim3(d->B, 16), dim3(256), smem, (hipStream_t)stream, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

@@ -202,21 +202,26 @@ __global__ __launch_bounds__(256) void small_dgrad_kernel(const float* __restric
 // dpos fp32 [B*S, E] (gradient w.r.t. the `pos` sequence, models/reftr.py:51-120):
 //   d lang_pos_embeddings[l] += sum_b dpos[b, l];  d token_type[0] += sum over language rows;
 //   d level_embed[0], d token_type[1] += sum over image rows.
-__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dpos, float* __restrict__ d_lang_pos,
-                                                       float* __restrict__ d_type, float* __restrict__ d_level,
-                                                       int B, int S, int L, int E) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= E) return;
-    float t0 = 0.f, t1 = 0.f;
-    for (int l = 0; l < L; ++l) {
+__global__ __launch_bounds__(256) void pos_grad_lang_kernel(const float* __restrict__ dpos, float* __restrict__ d_lang_pos,
+                                                            float* __restrict__ d_type, int B, int S, int L, int E) {
+    const int l = blockIdx.x;
+    for (int c = threadIdx.x; c < E; c += 256) {
         float a = 0.f;
         for (int b = 0; b < B; ++b) a += dpos[((size_t)b * S + l) * E + c];
         d_lang_pos[(size_t)l * E + c] += a;
-        t0 += a;
+        atomicAdd(d_type + c, a);
     }
-    for (int b = 0; b < B; ++b)
-        for (int r = L; r < S; ++r) t1 += dpos[((size_t)b * S + r) * E + c];
-    d_type[c] += t0; d_type[E + c] += t1; d_level[c] += t1;
+}
+__global__ __launch_bounds__(256) void pos_grad_img_kernel(const float* __restrict__ dpos, float* __restrict__ d_type,
+                                                           float* __restrict__ d_level, int B, int S, int L, int E) {
+    const int b = blockIdx.y;
+    const int r0 = L + blockIdx.x * 32, r1 = min(r0 + 32, S);
+    for (int c = threadIdx.x; c < E; c += 256) {
+        float a = 0.f;
+        for (int r = r0; r < r1; ++r) a += dpos[((size_t)b * S + r) * E + c];
+        atomicAdd(d_type + E + c, a);
+        atomicAdd(d_level + c, a);
+    }
 }
 
 }  // namespace
@@ -300,7 +305,8 @@ extern "C" int rt_small_dgrad(const float* dy, const float* w, const void* gate,
 extern "C" int rt_pos_grad(const float* dpos, float* d_lang_pos, float* d_type, float* d_level, int B, int S, int L, int E,
                            rt_stream_t stream) {
     if (!dpos || !d_lang_pos || !d_type || !d_level) return RT_ERR_BADARG;
-    hipLaunchKernelGGL(pos_grad_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpos, d_lang_pos, d_type, d_level, B, S, L, E);
+    if (L > 0) hipLaunchKernelGGL(pos_grad_lang_kernel, dim3(L), dim3(256), 0, (hipStream_t)stream, dpos, d_lang_pos, d_type, B, S, L, E);
+    if (S > L) hipLaunchKernelGGL(pos_grad_img_kernel, dim3((S - L + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, dpos, d_type, d_level, B, S, L, E);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
