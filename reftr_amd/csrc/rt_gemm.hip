@@ -23,6 +23,74 @@ struct GemmArgs {
     int M, K, sshift;
 };
 
+// epilogue of one lane's 4 consecutive output features of row m:
+// +bias -> [+res] -> act -> dropout -> [+res] -> *gate -> *gelu'(preact) -> *(1 - dtanh^2) -> store
+__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) {
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    const size_t o = (size_t)m * p.N + n;
+    if (p.out_preact) {
+        bf16x4 pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = (bf16_t)v[r];
+        *reinterpret_cast<bf16x4*>(p.out_preact + o) = pv;
+    }
+    if (p.res_first) {
+        if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
+        if (p.res_bf16) {
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        }
+    }
+    if (p.act == RT_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (p.act == RT_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rt_gelu(v[r]);
+    } else if (p.act == RT_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+    }
+    if (p.drop_p > 0.f) {
+        const uint32_t thresh = rt_drop_thresh(p.drop_p);
+        const float keep_scale = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            v[r] = (rt_hash32(p.drop_seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
+    }
+    if (!p.res_first) {
+        if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
+        if (p.res_bf16) {
+            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        }
+    }
+    if (p.gate) {
+        const bf16x4 gg = *reinterpret_cast<const bf16x4*>(p.gate + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((float)gg[r] > 0.f) ? v[r] * p.gate_scale : 0.f;
+    }
+    if (p.preact) {
+        const bf16x4 uu = *reinterpret_cast<const bf16x4*>(p.preact + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= rt_gelu_grad((float)uu[r]);
+    }
+    if (p.dtanh) {
+        const bf16x4 tt = *reinterpret_cast<const bf16x4*>(p.dtanh + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= (1.f - (float)tt[r] * (float)tt[r]);
+    }
+    if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
+    if (p.out_bf16) {
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
+        *reinterpret_cast<bf16x4*>(p.out_bf16 + o) = ov;
+    }
+}
+
 // MODE 0: dense rows (1x1, stride 1, pad 0: every Linear and most bottleneck convs)
 // MODE 1: forward conv gather       MODE 2: transposed (backward-data) gather
 template <int BM, int BN, int MODE>
@@ -170,83 +238,53 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
     }
     compute((nk - 1) & 1);
 
-    // ---- epilogue: +bias -> act -> dropout -> +res -> *gate -> *gelu'(preact) -> store ----
-    const bool do_drop = p.drop_p > 0.f;
-    const uint32_t thresh = rt_drop_thresh(p.drop_p);
-    const float keep_scale = do_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    // ---- epilogue (shared with the skinny kernel) ----
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
         const int n = n0 + wn * (BN / 2) + a * 16 + lg * 4;
         if (n >= p.N) continue;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
             const int m = m0 + wm * (BM / 2) + b * 16 + li;
             if (m >= p.M) continue;
-            f32x4 v = acc[a][b] + bv;
-            if (p.out_preact) {
-                bf16x4 pv;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pv[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(p.out_preact + (size_t)m * p.N + n) = pv;
-            }
-            const size_t o = (size_t)m * p.N + n;
-            if (p.res_first) {
-                if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
-                if (p.res_bf16) {
-                    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                }
-            }
-            if (p.act == RT_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            } else if (p.act == RT_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rt_gelu(v[r]);
-            } else if (p.act == RT_ACT_TANH) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-            }
-            if (do_drop) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = (rt_hash32(p.drop_seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
-            }
-            if (!p.res_first) {
-                if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
-                if (p.res_bf16) {
-                    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                }
-            }
-            if (p.gate) {
-                const bf16x4 gg = *reinterpret_cast<const bf16x4*>(p.gate + o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ((float)gg[r] > 0.f) ? v[r] * p.gate_scale : 0.f;
-            }
-            if (p.preact) {
-                const bf16x4 uu = *reinterpret_cast<const bf16x4*>(p.preact + o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= rt_gelu_grad((float)uu[r]);
-            }
-            if (p.dtanh) {
-                const bf16x4 tt = *reinterpret_cast<const bf16x4*>(p.dtanh + o);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= (1.f - (float)tt[r] * (float)tt[r]);
-            }
-            if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
-            if (p.out_bf16) {
-                bf16x4 ov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
-                *reinterpret_cast<bf16x4*>(p.out_bf16 + o) = ov;
-            }
+            epilogue4(p, m, n, acc[a][b]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny path (M <= 16 rows: the decoder / query-encoder / box-head Linears over B*n_q tokens).  No LDS tiles:
+// a workgroup owns 16 output features, its 4 waves split K four ways and stream both operands straight from
+// global memory into MFMA fragments (A = 16 weight rows, B = the <=16 token rows), then reduce through LDS.
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt,
+                                                          const GemmArgs p) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nrow = n0 + li;
+    const bool n_ok = nrow < p.N, m_ok = li < p.M;
+    const bf16_t* wp = wgt + (size_t)(n_ok ? nrow : 0) * p.K + lg * 8;
+    const bf16_t* xp = src + (size_t)(m_ok ? li : 0) * p.K + lg * 8;
+    const int ksteps = p.K >> 5;                       // 32-wide steps
+    const int per = (ksteps + 3) >> 2;
+    const int k_begin = wave * per, k_end = min(k_begin + per, ksteps);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll 4
+    for (int ks = k_begin; ks < k_end; ++ks) {
+        uint4 wv = *reinterpret_cast<const uint4*>(wp + ks * 32);
+        uint4 xv = *reinterpret_cast<const uint4*>(xp + ks * 32);
+        if (!n_ok) wv = z;
+        if (!m_ok) xv = z;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv), *reinterpret_cast<bf16x8*>(&xv), acc, 0, 0, 0);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    const int n = n0 + lg * 4;
+    if (n < p.N && li < p.M) epilogue4(p, li, n, acc);
 }
 
 template <int BM, int BN>
@@ -254,7 +292,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const size_t smem = 2 * (size_t)(BM + BN) * 128;
     const dim3 grid((unsigned)(mt * nt)), block(256);
-    const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0);
+    const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
     if (dense)
         hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, 0>), grid, block, smem, s, a.src, a.wgt, a);
     else if (!a.transposed)
@@ -287,6 +325,12 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.M = (int)M; a.K = d->KH * d->KW * d->SC; a.sshift = d->stride == 2 ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
 
+    const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
+    if (d->tile_hint == 0 && dense && a.M <= 16) {
+        hipLaunchKernelGGL(skinny_gemm_kernel, dim3((unsigned)((a.N + 15) / 16)), dim3(256), 0, s, a.src, a.wgt, a);
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
     int hint = d->tile_hint;
     if (hint == 0) {
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);

@@ -187,6 +187,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
     }
 }
 
+// M <= 16 rows (decoder-side Linears): plain outer-product accumulation, one thread per (n, 4 k's)
+__global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            float* __restrict__ dw, const float* __restrict__ scale,
+                                                            int M, int N, int K) {
+    const int k4 = K >> 2;
+    const size_t total = (size_t)N * k4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int kk = (int)(i % k4) * 4;
+        const int n = (int)(i / k4);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < M; ++m) {
+            const float g = (float)dy[(size_t)m * N + n];
+            const bf16x4 xv = *reinterpret_cast<const bf16x4*>(x + (size_t)m * K + kk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += g * (float)xv[r];
+        }
+        if (scale) a *= scale[n];
+        f32x4* o = reinterpret_cast<f32x4*>(dw + (size_t)n * K + kk);
+        *o = *o + a;
+    }
+}
+
 template <int BN, int BC>
 int launch_wgrad(WgradArgs a, int msplit, hipStream_t s) {
     const int nt = (a.N + BN - 1) / BN;
@@ -195,8 +217,9 @@ int launch_wgrad(WgradArgs a, int msplit, hipStream_t s) {
     const int total_chunks = (a.M + 31) / 32;
     const long long base_blocks = (long long)nt * a.c_tiles * taps;
     if (msplit <= 0) {
-        long long want = (1024 + base_blocks - 1) / base_blocks;   // aim for ~1024 workgroups
-        long long maxs = (total_chunks + 3) / 4;                   // at least 4 chunks per block
+        long long want = (512 + base_blocks - 1) / base_blocks;    // aim for ~512 workgroups ...
+        long long maxs = total_chunks / 16;                        // ... of >= 16 chunks (512 rows): each split costs a
+                                                                   // full tile of fp32 atomics
         if (maxs < 1) maxs = 1;
         if (want > maxs) want = maxs;
         if (want < 1) want = 1;
@@ -233,6 +256,13 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (M * d->N >= 0x7fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x7fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0;
     hipStream_t s = (hipStream_t)stream;
+    if (a.M <= 16 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && (a.SC & 3) == 0) {
+        const size_t total = (size_t)a.N * (a.SC >> 2);
+        int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(small_m_wgrad_kernel, dim3(blocks), dim3(256), 0, s, a.dy, a.x, a.dw, a.scale, a.M, a.N, a.SC);
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
     if (a.N >= 128 && a.SC >= 128) return launch_wgrad<128, 128>(a, d->msplit, s);
     if (a.N >= 128) return launch_wgrad<128, 64>(a, d->msplit, s);
     if (a.SC >= 128) return launch_wgrad<64, 128>(a, d->msplit, s);

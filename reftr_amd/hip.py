@@ -223,14 +223,14 @@ def set_launch_timer(records):
     _TIMER = records
 
 
-def _timed(kind, flops, fn):
+def _timed(kind, flops, fn, tag=None):
     if _TIMER is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    _TIMER.append({"kind": kind, "flops": float(flops), "start": e0, "end": e1})
+    _TIMER.append({"kind": kind, "flops": float(flops), "start": e0, "end": e1, "tag": tag})
     return r
 
 
@@ -281,7 +281,8 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
         flops = 2.0 * B * SH * SW * SC * N * KH * KW
     else:
         flops = 2.0 * M * N * KH * KW * SC
-    _timed("conv_gemm", flops, lambda: _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm"))
+    _timed("conv_gemm", flops, lambda: _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm"),
+           tag=("T" if transposed else "F",) + tuple(geom))
     if out_preact:
         return ob, of, op
     return ob, of
@@ -302,7 +303,7 @@ def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0):
     assert dy.numel() == B * DH * DW * N and x.numel() == B * SH * SW * SC and dw.numel() == N * KH * KW * SC
     d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit)
     _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
-           lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"))
+           lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"), tag=("W",) + tuple(geom))
     return dw
 
 

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (reftr_amd/parallel.py) — parameter broadcast from rank 0,
+chunked all-reduce of the flat gradient buffer, 1/world folded into the optimizer's grad_scale, num_boxes
+all-reduce of the criterion (models/criterion.py:176-180)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reftr_amd.models import layout as L
+        from reftr_amd.models.reftr_transformer import RefTR
+        from reftr_amd.parallel import DistributedDataParallel
+        cfg = L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=1))
+        m = RefTR(cfg, device="cpu")
+        m.reset_parameters(seed=100 + rank)                    # ranks start different ...
+        ddp = DistributedDataParallel(m, n_chunks=5)
+        ref = [torch.empty_like(m.store.flat_p) for _ in range(world)]
+        dist.all_gather(ref, m.store.flat_p)
+        same = all(torch.equal(ref[0], r) for r in ref)         # ... and are identical after the wrapper's broadcast
+        bounds = ddp.chunk_bounds()
+        covered = bounds[0][0] == 0 and bounds[-1][1] == m.store.flat_g.numel() and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+        g = torch.Generator().manual_seed(7 + rank)
+        local = torch.randn(m.store.flat_g.numel(), generator=g)
+        m.store.flat_g.copy_(local)
+        for hook in m._post_backward_hooks:
+            hook()
+        both = [torch.randn(m.store.flat_g.numel(), generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+        ok_sum = torch.allclose(m.store.flat_g, both[0] + both[1], atol=1e-6)
+        nb = torch.tensor([3.0 + rank])
+        dist.all_reduce(nb)
+        q.put((rank, same, covered, ok_sum, m._grad_scale, float(nb / world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, covered, ok_sum, gs, nb in res:
+        assert same and covered and ok_sum
+        assert gs == 0.5 and nb == 3.5

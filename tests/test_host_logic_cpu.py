@@ -1,0 +1,133 @@
+"""CPU: host-side logic of the product package — parameter layout / flat storage / state_dict contract,
+factory and optimizer bookkeeping, post-processing (exact vs golden), and the guarantee that the product path
+has NO CPU fallback and never touches oracle/."""
+import argparse
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reftr_oracle as O
+from oracle.shapes import param_shapes
+from oracle.weights import formula_state
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def small():
+    from reftr_amd.models import layout as L
+    return L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2)), \
+        O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2))
+
+
+def ref_args(**kw):
+    a = argparse.Namespace(hidden_dim=256, nheads=8, enc_layers=2, dec_layers=2, dim_feedforward=2048, dropout=0.1,
+                           num_feature_levels=1, max_lang_seq=128, position_embedding="sine", lr_backbone=1e-5, masks=False,
+                           backbone="resnet50", dilation=False, num_queries_per_phrase=1, aux_loss=True, ablation="none",
+                           freeze_bert=False, giou_loss_coef=1.0, bbox_loss_coef=1.0, device="cpu", no_decoder=False,
+                           bert_layers=2, lr=1e-4, weight_decay=1e-4)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_state_dict_contract_and_flat_views():
+    from reftr_amd.models.reftr_transformer import RefTR
+    cfg, ocfg = small()
+    m = RefTR(cfg, device="cpu")
+    shapes = param_shapes(ocfg)                       # independent restatement of the reference key table
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == shapes
+    trainable = sorted(n for n, p in m.named_parameters() if p.requires_grad)
+    assert trainable == sorted(k for k in shapes if O.is_trainable(k))       # backbone.py:87-89
+    P = formula_state(shapes)
+    m.load_state_dict(P, strict=True)
+    st = m.store
+    # conv weights are stored channels-last inside the flat buffer
+    k = "img_backbone.0.body.layer3.1.conv2.weight"
+    assert torch.equal(st.phys(k), P[k].permute(0, 2, 3, 1).reshape(256, 9, 256))
+    assert torch.equal(m.state_dict()[k], P[k]) and m.state_dict()[k].is_contiguous()
+    # BERT q/k/v are adjacent: the packed [3H, H] view is free
+    q = "lang_backbone.encoder.layer.1.attention.self.query.weight"
+    packed = st.packed(q, 3)
+    assert torch.equal(packed, torch.cat([P[q], P[q.replace("query", "key")], P[q.replace("query", "value")]]))
+    # gradients are views of ONE buffer; parameters keep their .grad across zero_grad
+    named = dict(m.named_parameters())
+    assert named[k].grad.data_ptr() == st.G[k].data_ptr()
+    assert st.flat_g.numel() == st.flat_p.numel() and st.flat_p.numel() % 4 == 0
+    # lr groups (main_vg.py:29-33) are three contiguous ranges
+    from reftr_amd.models import layout as L
+    r = st.group_range
+    assert r[L.GROUP_MAIN][0] == 0 and r[L.GROUP_MAIN][1] == r[L.GROUP_BACKBONE][0] and r[L.GROUP_BACKBONE][1] == r[L.GROUP_BERT][0]
+    for n, (b, off) in st.offset.items():
+        if b == "p":
+            lo, hi = r[L.lr_group(n)]
+            assert lo <= off < hi, n
+
+
+def test_build_reftr_factory_and_weight_dict():
+    from reftr_amd import build_reftr
+    model, criterion, post = build_reftr(ref_args())
+    assert set(post) == {"bbox"}
+    wd = criterion.weight_dict                       # models/reftr_transformer.py:320-329
+    assert set(wd) == {"loss_giou", "loss_bbox", "loss_giou_0", "loss_bbox_0", "loss_giou_enc", "loss_bbox_enc"}
+    with pytest.raises(NotImplementedError):
+        build_reftr(ref_args(masks=True))
+
+
+def test_no_cpu_fallback_exists():
+    from reftr_amd import build_reftr
+    from reftr_amd.util.misc import NestedTensor
+    model, criterion, _ = build_reftr(ref_args())
+    samples = {"img": NestedTensor(torch.zeros(1, 3, 64, 64), torch.zeros(1, 64, 64, dtype=torch.bool)),
+               "sentence": torch.tensor([[101, 2000, 102, 0]]), "sentence_mask": torch.tensor([[1, 1, 1, 0]])}
+    with pytest.raises(RuntimeError):                # device tensors required / library or GPU missing: loud, not silent
+        model(samples)
+
+
+def test_product_never_imports_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for d, _, files in os.walk(os.path.join(ROOT, "reftr_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert not pat.search(open(os.path.join(d, f)).read()), f
+    assert not pat.search(open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0])
+
+
+def test_postprocess_matches_reference_golden_exactly():
+    from reftr_amd.models.post_process import PostProcessVGMultiPhrase
+    g = np.load(os.path.join(GOLD, "postprocess.npz"))
+    res = PostProcessVGMultiPhrase()({"pred_boxes": torch.from_numpy(g["pred"]), "phrase_mask": torch.from_numpy(g["mask"])},
+                                     torch.from_numpy(g["sizes"]), scale_to_original_shape=True)
+    for i, r in enumerate(res):
+        assert torch.equal(r["boxes"], torch.from_numpy(g[f"boxes{i}"]))
+
+
+def test_nested_tensor_padding():
+    from reftr_amd.util.misc import nested_tensor_from_tensor_list
+    nt = nested_tensor_from_tensor_list([torch.ones(3, 4, 6), torch.ones(3, 5, 3)])
+    t, m = nt.decompose()
+    assert t.shape == (2, 3, 5, 6) and m.dtype == torch.bool
+    assert not m[0, :4, :6].any() and m[0, 4:].all() and m[1, :, 3:].all() and not m[1, :5, :3].any()
+    assert float(t[1, :, :, 3:].abs().sum()) == 0
+
+
+def test_optimizer_groups_follow_reference_param_groups():
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.optim import FusedAdamW
+    cfg, _ = small()
+    m = RefTR(cfg, device="cpu")
+    opt = FusedAdamW(m, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    lrs = [g["lr"] for g in opt.param_groups]
+    assert lrs == [1e-4, 1e-5, 1e-5]                 # main_vg.py:234-262 (BERT group also uses lr_backbone)
+    n = sum(p.numel() for g in opt.param_groups for p in g["params"])
+    assert n == sum(p.numel() for p in m.parameters() if p.requires_grad)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 2)  # engine_vg.py:67: stepped per iteration
+    opt.zero_grad()
+    assert float(m.store.flat_g.abs().sum()) == 0 and dict(m.named_parameters())["bbox_embed.layers.0.weight"].grad is not None
+    for _ in range(2):
+        sched.step()
+    assert abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12
