@@ -21,6 +21,7 @@ struct GemmArgs {
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed;
     int M, K, sshift;
+    unsigned src_bytes, wgt_bytes;
 };
 
 // epilogue of one lane's 4 consecutive output features of row m:
@@ -94,7 +95,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
 // MODE 0: dense rows (1x1, stride 1, pad 0: every Linear and most bottleneck convs)
 // MODE 1: forward conv gather       MODE 2: transposed (backward-data) gather
 template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict__ src,
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restrict__ src,
                                                         const bf16_t* __restrict__ wgt, const GemmArgs p) {
     constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 MFMA tiles per wave along m / n
     constexpr int AJ = BN / 32, BJ = BM / 32;      // 16-B staging chunks per thread
@@ -147,24 +148,33 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
         for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K >> 6;
-    // running K-tile position: k0 = kt*64 = ((kh*KW)+kw)*SC + c0
-    int c0 = 0, kw = 0, kh = 0;
+    // running K-tile position of the NEXT tile to be loaded: k0 = kt*64 = ((kh*KW)+kw)*SC + c0
+    int lk = 0, c0 = 0, kw = 0, kh = 0;
 
-    uint4 ra[AJ], rb[BJ];
+    // Two register stages (R0 / R1) + two LDS buffers: the global loads of tile kt+2 are issued while tile kt is
+    // being multiplied and tile kt+1 is still in flight, so a K tile's HBM/L2 latency is spread over two iterations.
+    uint4 ra0[AJ], rb0[BJ], ra1[AJ], rb1[BJ];
 
-    auto load_tiles = [&](int k0) __attribute__((always_inline)) {
+    // Operand tiles are fetched with buffer loads: an out-of-range byte offset (padding taps, ragged M / N rows)
+    // returns zeros from the hardware bounds check, so the loads are straight-line code — no exec-mask branches, and
+    // the compiler keeps counted vmcnt waits (tile kt+2 stays in flight while tile kt+1 is written to LDS).
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wgt), 0, p.wgt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(src), 0, p.src_bytes, 0x00020000);
+    constexpr int OOB = 0x7fffffff;
+    auto load_tiles = [&](uint4 (&ra)[AJ], uint4 (&rb)[BJ]) __attribute__((always_inline)) {
+        const int k0b = lk << 7;                                  // byte offset of the K tile inside a row
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const uint4 v = *reinterpret_cast<const uint4*>(wgt + (a_off[j] + (a_ok[j] ? k0 : 0)));
-            ra[j] = a_ok[j] ? v : make_uint4(0, 0, 0, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_ok[j] ? a_off[j] * 2 : OOB, k0b, 0);
+            ra[j] = make_uint4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            bool ok = b_ok[j];
-            int off;
             if (MODE == 0) {
-                off = b_off[j] + k0;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, b_ok[j] ? b_off[j] * 2 : OOB, k0b, 0);
+                rb[j] = make_uint4(v[0], v[1], v[2], v[3]);
             } else {
+                bool ok = b_ok[j];
                 int sy, sx;
                 if (MODE == 1) { sy = b_y[j] + kh; sx = b_x[j] + kw; }
                 else {
@@ -174,19 +184,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
                     sy = ny >> p.sshift; sx = nx >> p.sshift;
                 }
                 ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
-                off = b_off[j] + (sy * p.SW + sx) * p.SC + c0;
+                const int off = (b_off[j] + (sy * p.SW + sx) * p.SC) * 2;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, c0 * 2, 0);
+                rb[j] = make_uint4(v[0], v[1], v[2], v[3]);
             }
-            const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? off : 0));
-            rb[j] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+        // advance to the next K tile; past the end the last tile is simply re-loaded (never consumed), which keeps
+        // every load unconditional and the compiler's vmcnt bookkeeping exact
+        if (lk + 1 < nk) {
+            ++lk;
+            if (MODE != 0) {
+                c0 += 64;
+                if (c0 >= p.SC) { c0 = 0; ++kw; if (kw >= p.KW) { kw = 0; ++kh; } }
+            }
         }
     };
-    auto advance_k = [&]() __attribute__((always_inline)) {
-        if (MODE != 0) {
-            c0 += 64;
-            if (c0 >= p.SC) { c0 = 0; ++kw; if (kw >= p.KW) { kw = 0; ++kh; } }
-        }
-    };
-    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    auto store_tiles = [&](int buf, const uint4 (&ra)[AJ], const uint4 (&rb)[BJ]) __attribute__((always_inline)) {
         unsigned char* bA = smem + buf * BUF_BYTES;
         unsigned char* bB = bA + A_BYTES;
 #pragma unroll
@@ -225,18 +238,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const bf16_t* __restrict
         }
     };
 
-    load_tiles(0);
-    advance_k();
-    store_tiles(0);
+    load_tiles(ra0, rb0);                 // tile 0
+    load_tiles(ra1, rb1);                 // tile 1 (or tile 0 again when nk == 1)
+    store_tiles(0, ra0, rb0);
     __syncthreads();
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        load_tiles((kt + 1) << 6);      // next tile's global loads fly under this tile's MFMAs
-        advance_k();
-        compute(kt & 1);
-        store_tiles((kt & 1) ^ 1);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: LDS[0] = tile kt, R1 = tile kt+1 (in flight), R0 free
+        load_tiles(ra0, rb0);             // tile kt+2
+        compute(0);
+        store_tiles(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: LDS[1] = tile kt+1, R0 = tile kt+2 (in flight), R1 free
+        load_tiles(ra1, rb1);             // tile kt+3
+        compute(1);
+        store_tiles(0, ra0, rb0);
         __syncthreads();
     }
-    compute((nk - 1) & 1);
 
     // ---- epilogue (shared with the skinny kernel) ----
 #pragma unroll
@@ -321,8 +339,10 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     // 32-bit element offsets inside the kernel
-    if ((long long)d->B * d->SH * d->SW * d->SC >= 0x7fffffffLL || (long long)d->N * d->KH * d->KW * d->SC >= 0x7fffffffLL) return RT_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL || (long long)d->N * d->KH * d->KW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.K = d->KH * d->KW * d->SC; a.sshift = d->stride == 2 ? 1 : 0;
+    a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
+    a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;
 
     const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
