@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -113,7 +114,7 @@ def main():
     dev = torch.device("cuda", local)
 
     from reftr_amd import hip
-    from reftr_amd.engine_vg import train_step
+    from reftr_amd.engine_vg import CapturedTrainStep, train_step
     from reftr_amd.models import layout as Lm
     from reftr_amd.models.criterion import CriterionVGMultiPhrase
     from reftr_amd.models.reftr_transformer import RefTR
@@ -140,8 +141,22 @@ def main():
     s["img"] = NestedTensor(samples["img"].to(dev), samples["img_mask"].to(dev))
     tg = [{k: v.to(dev) for k, v in t.items()} for t in targets]
 
-    def step():
+    def eager_step():
         return train_step(runner, crit, s, tg, opt, None, max_norm=0.1)
+
+    mode = "eager"
+    step = eager_step
+    if not args.no_graph:
+        try:
+            cap = CapturedTrainStep(runner, crit, opt, 0.1, s, tg)
+
+            def step():
+                losses, _, gn = cap(s, tg)
+                return (losses.item(), None, None, gn)       # same host sync as the reference loop (engine_vg.py:53)
+            mode = "hipgraph"
+        except Exception as e:                               # capture unsupported in this environment: stay eager
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
 
     for _ in range(args.warmup):
         step()
@@ -167,7 +182,7 @@ def main():
     if rank == 0 and not args.no_kernel_roofline:
         recs = []
         hip.set_launch_timer(recs)
-        step()
+        eager_step()
         torch.cuda.synchronize()
         hip.set_launch_timer(None)
         fl = sum(r["flops"] for r in recs)
@@ -183,7 +198,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"RefCOCO-shaped REC train step, ResNet-50 + BERT-base + VL transformer 6+6, "
                                f"{S_}x{S_}, batch {B}/GPU, L=40, aux loss, dropout on, clip 0.1, AdamW (configs[1])",
-                   "global_batch": B * world, "parallelism": f"dp{world}"},
+                   "global_batch": B * world, "parallelism": f"dp{world}", "launch": mode},
         "loss": loss_value,
     }
     if rank == 0:

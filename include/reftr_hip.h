@@ -82,6 +82,7 @@ typedef struct rt_conv_gemm_desc {
     void*    out_preact;    /* bf16 [M, N] or NULL: value after +bias, BEFORE act (saved for GELU backward) */
     const void* dtanh;      /* bf16 [M, N] or NULL: out *= (1 - dtanh^2)  (backward of a tanh output, BERT pooler) */
     int32_t  res_first;     /* 1: add res_* BEFORE act (bottleneck tail relu(bn(conv) + identity)); 0: after dropout */
+    const uint32_t* seed_dev; /* optional DEVICE word: effective dropout seed = hash(*seed_dev, drop_seed) (hipGraph replay) */
 } rt_conv_gemm_desc;
 int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream);
 
@@ -135,6 +136,7 @@ typedef struct rt_layernorm_desc {
     float    drop_p;       /* dropout after act, index r*D + c */
     uint32_t drop_seed;
     int32_t grp_rows, grp_stride, grp_off;
+    const uint32_t* seed_dev;   /* optional, see rt_conv_gemm_desc */
 } rt_layernorm_desc;
 int rt_layernorm_fwd(const rt_layernorm_desc* d, rt_stream_t stream);
 
@@ -155,6 +157,7 @@ typedef struct rt_layernorm_bwd_desc {
     float    drop_p;  uint32_t drop_seed;    /* the LN's own post-act dropout */
     float    drop2_p; uint32_t drop2_seed;   /* dropout of the producing sub-layer (index r*D + c) */
     int32_t grp_rows, grp_stride, grp_off;
+    const uint32_t* seed_dev;   /* optional, applies to both dropout seeds */
 } rt_layernorm_bwd_desc;
 int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stream);
 
@@ -206,6 +209,7 @@ typedef struct rt_attn_desc {
     int32_t ldq, ldk, ldv, ldo;
     float    scale;
     float    drop_p; uint32_t drop_seed;
+    const uint32_t* seed_dev;   /* optional, see rt_conv_gemm_desc */
 } rt_attn_desc;
 int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream);
 
@@ -219,6 +223,7 @@ typedef struct rt_attn_bwd_desc {
     int32_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
     float    scale;
     float    drop_p; uint32_t drop_seed;
+    const uint32_t* seed_dev;
 } rt_attn_bwd_desc;
 int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream);
 
@@ -342,8 +347,11 @@ typedef struct rt_adamw_desc {
     int32_t step, n_ranges;
     int64_t range_begin[8], range_end[8];
     float   range_lr[8], range_wd[8];
+    const int32_t* step_dev;  /* optional DEVICE word overriding `step` (the optimizer step counter under hipGraph replay) */
 } rt_adamw_desc;
 int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream);
+/* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */
+int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream);
 
 #ifdef __cplusplus
 }

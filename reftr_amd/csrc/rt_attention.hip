@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const rt_attn_desc p) {
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
     const uint32_t drop_row = (uint32_t)(((size_t)bh * p.Sq + q) * p.Sk);
     f32x4 o[DT];
 #pragma unroll
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const rt_attn_desc p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pr = __expf(acc[r] * p.scale + bias[r] - Ms) * inv_l;
-                if (do_drop) pr = (rt_hash32(p.drop_seed, drop_row + (uint32_t)(k0 + lg * 4 + r)) >= thresh) ? pr * ks : 0.f;
+                if (do_drop) pr = (rt_hash32(dseed, drop_row + (uint32_t)(k0 + lg * 4 + r)) >= thresh) ? pr * ks : 0.f;
                 pv[half * 4 + r] = pr;
             }
         }
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const rt_attn_bwd_desc
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
     const uint32_t drop_row = (uint32_t)(((size_t)bh * p.Sq + q) * p.Sk);
     f32x4 dq[DT];
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const rt_attn_bwd_desc
             for (int r = 0; r < 4; ++r) {
                 const float pr = __expf(s[r] * p.scale + bias[r] - lse);
                 float d = dp[r];
-                if (do_drop) d = (rt_hash32(p.drop_seed, drop_row + (uint32_t)(k0 + lg * 4 + r)) >= thresh) ? d * ks : 0.f;
+                if (do_drop) d = (rt_hash32(dseed, drop_row + (uint32_t)(k0 + lg * 4 + r)) >= thresh) ? d * ks : 0.f;
                 dsv[half * 4 + r] = pr * (d - delta) * p.scale;
             }
         }
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const rt_attn_bwd_des
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
     f32x4 dk[DT], dv[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const rt_attn_bwd_des
                 float d = dp[r], pd = pr;
                 if (do_drop) {
                     const int qq = q0 + lg * 4 + r;
-                    const bool keep = rt_hash32(p.drop_seed, (uint32_t)(((size_t)bh * p.Sq + qq) * p.Sk + key)) >= thresh;
+                    const bool keep = rt_hash32(dseed, (uint32_t)(((size_t)bh * p.Sq + qq) * p.Sk + key)) >= thresh;
                     d = keep ? d * ks : 0.f; pd = keep ? pr * ks : 0.f;
                 }
                 pv[half * 4 + r] = pd;
@@ -331,13 +334,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const rt_attn_bwd_des
     }
 }
 
+// Opt a kernel into the full 160 KiB of dynamic LDS once per kernel (not per launch: keeps launches capturable in a
+// hipGraph).  Keyed by the function pointer (kernels of equal signature share a C++ type).
 template <typename K>
 int set_smem(K kernel, size_t bytes) {
     if (bytes > 160 * 1024) return RT_ERR_UNSUPPORTED;
-    if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return (int)e;
-    }
+    static const void* seen[16];
+    static int nseen = 0;
+    const void* fp = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < nseen; ++i) if (seen[i] == fp) return RT_OK;
+    hipError_t e = hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    if (nseen < 16) seen[nseen++] = fp;
     return RT_OK;
 }
 

@@ -28,6 +28,10 @@ __device__ __forceinline__ uint32_t rt_hash32(uint32_t seed, uint32_t idx) {
     x ^= x >> 16;
     return x;
 }
+// effective seed of a dropout site when the step seed lives in device memory (captured graphs)
+__device__ __forceinline__ uint32_t rt_site_seed(const uint32_t* seed_dev, uint32_t site) {
+    return seed_dev ? rt_hash32(*seed_dev, site) : site;
+}
 __device__ __forceinline__ uint32_t rt_drop_thresh(float p) {
     return (uint32_t)((double)p * 4294967296.0);
 }

@@ -22,6 +22,7 @@ struct GemmArgs {
     float gate_scale, drop_p; uint32_t drop_seed;
     int M, K, sshift;
     unsigned src_bytes, wgt_bytes;
+    const uint32_t* seed_dev;
 };
 
 // epilogue of one lane's 4 consecutive output features of row m:
@@ -56,9 +57,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
     if (p.drop_p > 0.f) {
         const uint32_t thresh = rt_drop_thresh(p.drop_p);
         const float keep_scale = 1.0f / (1.0f - p.drop_p);
+        const uint32_t seed = rt_site_seed(p.seed_dev, p.drop_seed);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            v[r] = (rt_hash32(p.drop_seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
+            v[r] = (rt_hash32(seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
     }
     if (!p.res_first) {
         if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
@@ -335,7 +337,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.gate = (const bf16_t*)d->gate; a.preact = (const bf16_t*)d->preact; a.dtanh = (const bf16_t*)d->dtanh;
     a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed;
-    a.act = d->act; a.res_first = d->res_first; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
+    a.act = d->act; a.res_first = d->res_first; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.seed_dev = d->seed_dev;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     // 32-bit element offsets inside the kernel
@@ -367,7 +369,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     }
 }
 
-extern "C" int rt_abi_version(void) { return 5; }
+extern "C" int rt_abi_version(void) { return 6; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const rt_layernorm_d
         if (i < nper && c < D) {
             float y = (v[i] - mean) * rstd * p.gamma[c] + p.beta[c];
             if (p.act == RT_ACT_RELU) y = fmaxf(y, 0.f);
-            if (do_drop) y = (rt_hash32(p.drop_seed, (uint32_t)(row * D + c)) >= thresh) ? y * ks : 0.f;
+            if (do_drop) y = (rt_hash32(rt_site_seed(p.seed_dev, p.drop_seed), (uint32_t)(row * D + c)) >= thresh) ? y * ks : 0.f;
             const size_t o = (size_t)orow * D + c;
             if (p.y_f32) p.y_f32[o] = y;
             if (yb) yb[o] = (bf16_t)y;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const rt_layernorm_b
                 if (p.dy2) d += p.dy2[o];
                 xh[i] = (xr[c] - mean) * rstd;
                 const float gam = p.gamma[c];
-                if (do_drop) d = (rt_hash32(p.drop_seed, (uint32_t)(row * D + c)) >= thresh) ? d * ks : 0.f;
+                if (do_drop) d = (rt_hash32(rt_site_seed(p.seed_dev, p.drop_seed), (uint32_t)(row * D + c)) >= thresh) ? d * ks : 0.f;
                 if (p.act == RT_ACT_RELU) { if (xh[i] * gam + p.beta[c] <= 0.f) d = 0.f; }
                 dg[i] += d * xh[i]; db[i] += d;
                 g[i] = d * gam;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const rt_layernorm_b
                 if (p.dx_f32) p.dx_f32[o] = dx;
                 if (dxb) {
                     float d2 = dx;
-                    if (do_drop2) d2 = (rt_hash32(p.drop2_seed, (uint32_t)o) >= thresh2) ? dx * ks2 : 0.f;
+                    if (do_drop2) d2 = (rt_hash32(rt_site_seed(p.seed_dev, p.drop2_seed), (uint32_t)o) >= thresh2) ? dx * ks2 : 0.f;
                     dxb[o] = (bf16_t)d2;
                 }
             }

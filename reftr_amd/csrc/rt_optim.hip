@@ -26,8 +26,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p) {
     if (p.max_norm > 0.f) coef = fminf(1.f, p.max_norm / (total + 1e-6f));
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.gnorm_out) p.gnorm_out[0] = total;
     const float gs = p.grad_scale * coef;
-    const float bc1 = 1.f - powf(p.beta1, (float)p.step);
-    const float bc2 = 1.f - powf(p.beta2, (float)p.step);
+    const int step = p.step_dev ? p.step_dev[0] : p.step;
+    const float bc1 = 1.f - powf(p.beta1, (float)step);
+    const float bc2 = 1.f - powf(p.beta2, (float)step);
     const float inv_sqrt_bc2 = rsqrtf(bc2);
     const size_t n4 = p.n >> 2;
     float4* P4 = reinterpret_cast<float4*>(p.p);
@@ -55,7 +56,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p) {
     }
 }
 
+__global__ void counter_add_kernel(int32_t* c, int32_t inc) { c[0] += inc; }
+
 }  // namespace
+
+extern "C" int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream) {
+    if (!ctr) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
 
 extern "C" int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stream) {
     if (!g || !out || n <= 0) return RT_ERR_BADARG;
@@ -69,7 +79,7 @@ extern "C" int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stre
 }
 
 extern "C" int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream) {
-    if (!d || !d->p || !d->g || !d->m || !d->v || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8 || d->step < 1)
+    if (!d || !d->p || !d->g || !d->m || !d->v || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8 || (d->step < 1 && !d->step_dev))
         return RT_ERR_BADARG;
     for (int r = 0; r < d->n_ranges; ++r) if ((d->range_begin[r] & 3) || (d->range_end[r] & 3)) return RT_ERR_BADARG;
     int blocks = (int)(((size_t)d->n / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;

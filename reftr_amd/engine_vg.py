@@ -91,6 +91,107 @@ def train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None,
     return loss_value, scaled, unscaled, grad_total_norm
 
 
+def _clone_batch(samples, targets):
+    def c(v):
+        if isinstance(v, utils.NestedTensor):
+            return utils.NestedTensor(v.tensors.clone(), v.mask.clone())
+        return v.clone() if torch.is_tensor(v) else v
+    return {k: c(v) for k, v in samples.items()}, [{k: c(v) for k, v in t.items()} for t in targets]
+
+
+def _copy_batch(dst_s, dst_t, samples, targets):
+    for k, v in samples.items():
+        if isinstance(v, utils.NestedTensor):
+            dst_s[k].tensors.copy_(v.tensors, non_blocking=True); dst_s[k].mask.copy_(v.mask, non_blocking=True)
+        elif torch.is_tensor(v):
+            dst_s[k].copy_(v, non_blocking=True)
+    for d, t in zip(dst_t, targets):
+        for k, v in t.items():
+            if torch.is_tensor(v):
+                d[k].copy_(v, non_blocking=True)
+
+
+class CapturedTrainStep:
+    """The loop body (engine_vg.py:40-72) captured into HIP graphs for one input shape.
+
+    A step is ~1500 kernel launches; replaying them from a hipGraph removes the per-launch host cost.  Everything
+    that changes from step to step lives in device memory (dropout step-seed word, optimizer step counter, the
+    input batch copied into static buffers), so replays are real training steps.  With world_size > 1 the body is
+    split in two graphs around the (eager) gradient all-reduce.  Learning-rate changes re-capture the optimizer
+    part (`refresh_lr()`), shapes other than the captured one must use `train_step`.
+    """
+
+    def __init__(self, model, criterion, optimizer, max_norm, samples, targets, warmup=2):
+        self.model, self.criterion, self.optimizer, self.max_norm = model, criterion, optimizer, max_norm
+        self.inner = getattr(model, "module", model)
+        self.ddp = model if model is not self.inner else None
+        self.s, self.t = _clone_batch(samples, targets)
+        self.key = self.shape_key(samples, targets)
+        self._lrs = [g["lr"] for g in optimizer.param_groups]
+        hooks, self.inner._post_backward_hooks = self.inner._post_backward_hooks, []     # collectives stay outside graphs
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._fwd_bwd(); self._sync_grads(hooks); self._opt()
+            torch.cuda.current_stream().wait_stream(side)
+            self.g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb):
+                self.out = self._fwd_bwd()
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+                self._opt()
+        finally:
+            self.inner._post_backward_hooks = hooks
+        self._hooks = hooks
+
+    @staticmethod
+    def shape_key(samples, targets):
+        k = []
+        for n, v in sorted(samples.items()):
+            k.append((n, tuple(v.tensors.shape) if isinstance(v, utils.NestedTensor) else tuple(v.shape)))
+        return tuple(k) + tuple(int(t["boxes"].shape[0]) for t in targets)
+
+    def _fwd_bwd(self):
+        outputs = self.model(self.s)
+        loss_dict = self.criterion(outputs, self.t)
+        wd = self.criterion.weight_dict
+        losses = sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
+        self.optimizer.zero_grad()
+        losses.backward()
+        return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}
+
+    @staticmethod
+    def _sync_grads(hooks):
+        for h in hooks:
+            h()
+
+    def _opt(self):
+        self.grad_norm = self.optimizer.clip_grad_norm_(self.max_norm)
+        self.optimizer.step()
+
+    def __call__(self, samples, targets):
+        assert self.shape_key(samples, targets) == self.key, "captured for another input shape; use train_step"
+        if [g["lr"] for g in self.optimizer.param_groups] != self._lrs:
+            self.refresh_lr()
+        _copy_batch(self.s, self.t, samples, targets)
+        self.g_fb.replay()
+        self._sync_grads(self._hooks)
+        self.g_opt.replay()
+        self.optimizer.step_count += 1
+        self.inner.mark_dirty()          # eager forwards after a replay must rebuild the bf16 operands
+        return self.out[0], self.out[1], self.grad_norm
+
+    def refresh_lr(self):
+        self._lrs = [g["lr"] for g in self.optimizer.param_groups]
+        self.g_opt = torch.cuda.CUDAGraph()
+        sc = self.optimizer.step_count
+        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+            self._opt()
+        self.optimizer.step_count = sc
+
+
 def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, device, epoch, max_norm=0):
     model.train()
     criterion.train()

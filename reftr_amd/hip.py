@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -28,7 +28,7 @@ class ConvGemmDesc(Structure):
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
         ("transposed", c_int32), ("act", c_int32),
         ("gate_scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32), ("tile_hint", c_int32),
-        ("out_preact", c_void_p), ("dtanh", c_void_p), ("res_first", c_int32),
+        ("out_preact", c_void_p), ("dtanh", c_void_p), ("res_first", c_int32), ("seed_dev", c_void_p),
     ]
 
 
@@ -48,7 +48,7 @@ class LayerNormDesc(Structure):
         ("pos", c_void_p), ("ypos_bf16", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
         ("M", c_int32), ("D", c_int32), ("eps", c_float), ("act", c_int32),
         ("drop_p", c_float), ("drop_seed", c_uint32),
-        ("grp_rows", c_int32), ("grp_stride", c_int32), ("grp_off", c_int32),
+        ("grp_rows", c_int32), ("grp_stride", c_int32), ("grp_off", c_int32), ("seed_dev", c_void_p),
     ]
 
 
@@ -59,7 +59,7 @@ class LayerNormBwdDesc(Structure):
         ("dgamma", c_void_p), ("dbeta", c_void_p),
         ("M", c_int32), ("D", c_int32), ("act", c_int32),
         ("drop_p", c_float), ("drop_seed", c_uint32), ("drop2_p", c_float), ("drop2_seed", c_uint32),
-        ("grp_rows", c_int32), ("grp_stride", c_int32), ("grp_off", c_int32),
+        ("grp_rows", c_int32), ("grp_stride", c_int32), ("grp_off", c_int32), ("seed_dev", c_void_p),
     ]
 
 
@@ -86,7 +86,7 @@ class AttnDesc(Structure):
         ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p), ("kpm", c_void_p),
         ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Sk", c_int32), ("dh", c_int32),
         ("ldq", c_int32), ("ldk", c_int32), ("ldv", c_int32), ("ldo", c_int32),
-        ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32),
+        ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32), ("seed_dev", c_void_p),
     ]
 
 
@@ -97,7 +97,7 @@ class AttnBwdDesc(Structure):
         ("B", c_int32), ("H", c_int32), ("Sq", c_int32), ("Sk", c_int32), ("dh", c_int32),
         ("ldq", c_int32), ("ldk", c_int32), ("ldv", c_int32), ("ldo", c_int32),
         ("lddq", c_int32), ("lddk", c_int32), ("lddv", c_int32),
-        ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32),
+        ("scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32), ("seed_dev", c_void_p),
     ]
 
 
@@ -135,6 +135,7 @@ class AdamWDesc(Structure):
         ("grad_scale", c_float), ("max_norm", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
         ("step", c_int32), ("n_ranges", c_int32),
         ("range_begin", c_int64 * 8), ("range_end", c_int64 * 8), ("range_lr", c_float * 8), ("range_wd", c_float * 8),
+        ("step_dev", c_void_p),
     ]
 
 
@@ -170,6 +171,7 @@ _SIGNATURES = {
     "rt_pos_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
+    "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
 }
 
 _lib = None
@@ -214,6 +216,18 @@ def _stream():
 
 
 _TIMER = None
+_SEED_DEV = None
+
+
+def set_seed_dev(t):
+    """Device uint32/int32 word mixed into every dropout seed (lets a captured hipGraph draw fresh masks per replay)."""
+    global _SEED_DEV
+    _SEED_DEV = t
+
+
+def _seedp(drop_p):
+    return _p(_SEED_DEV) if (drop_p > 0 and _SEED_DEV is not None) else None
+
 
 
 def set_launch_timer(records):
@@ -272,7 +286,7 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
     assert (ob is None or ob.numel() == M * N) and (of is None or of.numel() == M * N)
     d = ConvGemmDesc(_p(src), _p(wgt), _p(ob), _p(of), _p(bias), _p(res_f32), _p(res_bf16), _p(gate),
                      _p(preact), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad,
-                     1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint, None, _p(dtanh), 1 if res_first else 0)
+                     1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint, None, _p(dtanh), 1 if res_first else 0, _seedp(drop_p))
     op = None
     if out_preact:
         op = torch.empty((M, N), dtype=torch.bfloat16, device=src.device)
@@ -337,7 +351,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, *, act=ACT_NONE, drop_p=0.0, drop_se
     mean = _new((M,), torch.float32, x) if save_stats else None
     rstd = _new((M,), torch.float32, x) if save_stats else None
     d = LayerNormDesc(_p(x), _p(gamma), _p(beta), _p(y_f32), _p(y_bf16), _p(pos), _p(ypos_bf16), _p(mean), _p(rstd),
-                      M, D, eps, act, drop_p, drop_seed & 0xFFFFFFFF, *rowmap)
+                      M, D, eps, act, drop_p, drop_seed & 0xFFFFFFFF, *rowmap, _seedp(drop_p))
     _check(lib().rt_layernorm_fwd(ctypes.byref(d), _stream()), "rt_layernorm_fwd")
     return y_f32, y_bf16, ypos_bf16, mean, rstd
 
@@ -351,7 +365,7 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy2=None, ac
     dx_bf16 = _new((M, D), torch.bfloat16, x) if want_bf16 else None
     d = LayerNormBwdDesc(_p(dy), _p(dy2), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx_f32), _p(dx_bf16),
                          _p(dgamma), _p(dbeta), M, D, act, drop_p, drop_seed & 0xFFFFFFFF, drop2_p,
-                         drop2_seed & 0xFFFFFFFF, *rowmap)
+                         drop2_seed & 0xFFFFFFFF, *rowmap, _seedp(max(drop_p, drop2_p)))
     _check(lib().rt_layernorm_bwd(ctypes.byref(d), _stream()), "rt_layernorm_bwd")
     return dx_f32, dx_bf16
 
@@ -397,7 +411,7 @@ def attn_fwd(q, k, v, kpm, *, B, H, Sq, Sk, dh, scale, drop_p=0.0, drop_seed=0, 
         out = _new((B * Sq, H * dh), torch.bfloat16, q)
     lse = _new((B, H, Sq), torch.float32, q)
     d = AttnDesc(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(kpm), B, H, Sq, Sk, dh, _ld(q), _ld(k), _ld(v), _ld(out),
-                 scale, drop_p, drop_seed & 0xFFFFFFFF)
+                 scale, drop_p, drop_seed & 0xFFFFFFFF, _seedp(drop_p))
     _check(lib().rt_attn_fwd(ctypes.byref(d), _stream()), "rt_attn_fwd")
     return out, lse
 
@@ -414,7 +428,7 @@ def attn_bwd(q, k, v, out, dout, lse, kpm, *, B, H, Sq, Sk, dh, scale, drop_p=0.
     delta = _new((B, H, Sq), torch.float32, q)
     d = AttnBwdDesc(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(delta), _p(kpm), _p(dq), _p(dk), _p(dv),
                     B, H, Sq, Sk, dh, _ld(q), _ld(k), _ld(v), _ld(out), _ld(dq), _ld(dk), _ld(dv),
-                    scale, drop_p, drop_seed & 0xFFFFFFFF)
+                    scale, drop_p, drop_seed & 0xFFFFFFFF, _seedp(drop_p))
     assert _ld(dout) == _ld(out)
     _check(lib().rt_attn_bwd(ctypes.byref(d), _stream()), "rt_attn_bwd")
     return dq, dk, dv
@@ -562,13 +576,14 @@ def sqnorm(g, out):
 
 
 def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_scale=1.0, max_norm=0.0,
-               beta1=0.9, beta2=0.999, eps=1e-8):
+               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None):
     """ranges = [(begin, end, lr, wd), ...] element ranges of the flat buffers (multiples of 4)."""
     d = AdamWDesc()
     d.p, d.g, d.m, d.v, d.n = _p(p), _p(g), _p(m), _p(v), p.numel()
     d.gnorm_sq, d.gnorm_out = _p(gnorm_sq), _p(gnorm_out)
     d.grad_scale, d.max_norm, d.beta1, d.beta2, d.eps = grad_scale, max_norm, beta1, beta2, eps
     d.step, d.n_ranges = step, len(ranges)
+    d.step_dev = _p(step_dev)
     for i, (b, e, lr, wd) in enumerate(ranges):
         d.range_begin[i], d.range_end[i], d.range_lr[i], d.range_wd[i] = b, e, lr, wd
     _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")
@@ -586,3 +601,7 @@ def small_dgrad(dy_f32, w_f32, gate=None):
 def pos_grad(dpos, d_lang_pos, d_type, d_level, B, S, L):
     E = dpos.shape[1]
     _check(lib().rt_pos_grad(_p(dpos), _p(d_lang_pos), _p(d_type), _p(d_level), B, S, L, E, _stream()), "rt_pos_grad")
+
+
+def counter_add(ctr, inc=1):
+    _check(lib().rt_counter_add(_p(ctr), inc, _stream()), "rt_counter_add")

@@ -34,6 +34,7 @@ class CriterionVGMultiPhrase(nn.Module):
         self.weight_dict = weight_dict
         self.losses = losses
         self._off_cache = {}
+        self._nb_cache = {}
 
     def _targets(self, targets, device):
         lens = tuple(int(t["boxes"].shape[0]) for t in targets)
@@ -55,10 +56,15 @@ class CriterionVGMultiPhrase(nn.Module):
         device = logits.device
         # criterion.py:176-180: number of target boxes averaged over ranks, clamp >= 1 (in the kernel); kept on
         # the device so no host sync is needed
-        num_boxes = torch.tensor([float(sum(len(t["labels"]) for t in targets))], dtype=torch.float32, device=device)
+        nb = float(sum(len(t["labels"]) for t in targets))
         if is_dist_avail_and_initialized():
+            num_boxes = torch.tensor([nb], dtype=torch.float32, device=device)
             torch.distributed.all_reduce(num_boxes)
             num_boxes = num_boxes / get_world_size()
+        else:
+            if nb not in self._nb_cache:           # cached device scalar: no H2D copy in the steady state / under capture
+                self._nb_cache[nb] = torch.tensor([nb], dtype=torch.float32, device=device)
+            num_boxes = self._nb_cache[nb]
         boxes, off = self._targets(targets, device)
         valid = outputs["phrase_mask"].to(torch.uint8).contiguous()
         losses = _BoxLossFunction.apply(logits, valid, boxes, off, num_boxes)     # [NL, 2]

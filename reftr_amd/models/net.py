@@ -103,15 +103,16 @@ class Net:
             l.refresh()
 
     # ------------------------------------------------------------------ helpers
-    def begin_step(self, training, seed):
-        self.training, self._seed_base, self._site = training, int(seed) & 0x7FFFFFFF, 0
+    def begin_step(self, training):
+        self.training, self._site = training, 0
 
     def _drop(self, p):
-        """(p, seed) of the next dropout site; p = 0 in eval mode."""
+        """(p, site id) of the next dropout site; p = 0 in eval mode.  The site id is mixed on the device with the
+        model's step-seed word (hip.set_seed_dev), so a captured graph draws fresh masks at every replay."""
         self._site += 1
         if not self.training or p <= 0:
             return 0.0, 0
-        return float(p), (self._seed_base * 2654435761 + self._site * 40503) & 0xFFFFFFFF
+        return float(p), (self._site * 40503 + 977) & 0xFFFFFFFF
 
     def lin_fwd(self, key, x, **kw):
         l = self.lins[key]

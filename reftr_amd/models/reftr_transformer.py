@@ -45,6 +45,7 @@ class RefTR(nn.Module):
         self.body = ResNetBody(self.store, cfg)
         self.net = Net(self.store, cfg)
         self._anchor = torch.zeros((), device=device, requires_grad=True)
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)   # dropout step-seed (advanced on device)
         self._operands_dirty = True       # bf16 operands must be rebuilt (after init / load / optimizer step)
         self._full_refresh = True
         self._step = 0
@@ -130,6 +131,7 @@ class RefTR(nn.Module):
             self.body = ResNetBody(self.store, self.cfg)
             self.net = Net(self.store, self.cfg)
             self._anchor = torch.zeros((), device=probe.device, requires_grad=True)
+            self.seed_dev = self.seed_dev.to(probe.device)
             self.mark_dirty(full=True)
         return self
 
@@ -163,7 +165,10 @@ class RefTR(nn.Module):
         mask_u8 = mask.to(dev).to(torch.uint8).contiguous()
         B = x.shape[0]
         self._step += 1
-        net.begin_step(self.training, self._step * 7919 + 13)
+        net.begin_step(self.training)
+        H.set_seed_dev(self.seed_dev)
+        if self.training:
+            H.counter_add(self.seed_dev, 1)
 
         feats, bb_saved = self.body.forward(x)
         c5, (_, h, w) = feats[-1]
@@ -263,6 +268,7 @@ class RefTR(nn.Module):
             memp16=memp16, mem32=mem32, cls16=cls16, lang16=lang16, kq=kq, qs=qs, vs=vs, qw=qw, c16=c16, co=co,
             cst=(cm, cr), fq_ctx=fq_ctx, dec=dec, hs_stats=hs_stats, t3s=t3s, hs16=hs16, y1=y1, y2=y2, pooled16=pooled16,
             phrase_mask=(qmask == 0).view(B, T), memory=mem32)
+        H.set_seed_dev(None)
         return logits.view(NL, B, Pn, cfg.n_q, 4)
 
     # ------------------------------------------------------------------ backward
@@ -270,6 +276,7 @@ class RefTR(nn.Module):
         cfg, net, st, sv = self.cfg, self.net, self.store, self._saved
         E = cfg.hidden
         dev = st.device
+        H.set_seed_dev(self.seed_dev)
         B, S, Lq, HW, Pn, N, T, NL = (sv[k] for k in ("B", "S", "Lq", "HW", "Pn", "N", "T", "NL"))
         vt, qe = "vl_transformer.", "query_encoder."
         M = B * S
@@ -354,6 +361,7 @@ class RefTR(nn.Module):
         else:
             net.bert_bwd(sv["bctx"], d_seq, None)
             net.bert_bwd(sv["pctx"], None, dpool)
+        H.set_seed_dev(None)
         for hook in self._post_backward_hooks:
             hook()
 

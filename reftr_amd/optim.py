@@ -29,6 +29,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)    # device-resident step counter (graph replay)
         self._max_norm = 0.0
         self._have_sq = False
 
@@ -47,6 +48,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         st = self.model.store
         self.step_count += 1
+        H.counter_add(self.step_dev, 1)
         if not self._have_sq:
             H.sqnorm(st.flat_g, self.sq)
         ranges = []
@@ -57,7 +59,7 @@ class FusedAdamW(torch.optim.Optimizer):
         b1, b2 = self.defaults["betas"]
         H.adamw_flat(st.flat_p, st.flat_g, self.m, self.v, step=self.step_count, ranges=ranges, gnorm_sq=self.sq,
                      gnorm_out=self.grad_norm, grad_scale=getattr(self.model, "_grad_scale", 1.0),
-                     max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"])
+                     max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"], step_dev=self.step_dev)
         self._have_sq = False
         self.model.mark_dirty()
 
@@ -67,6 +69,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count = int(sd["step"])
+        self.step_dev.fill_(self.step_count)
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
 
