@@ -164,8 +164,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    trace = []
     for _ in range(args.steps):
         loss_value = step()[0]
+        trace.append(loss_value)
+    if os.environ.get("BENCH_TRACE") and rank == 0:
+        print("[bench] losses:", " ".join("%.4g" % v for v in trace), file=sys.stderr)
+        print("[bench] step_dev", int(opt.step_dev), "seed_dev", int(model.seed_dev), "gnorm", float(opt.grad_norm),
+              "|p|", float(model.store.flat_p.norm()), "|g|", float(model.store.flat_g.norm()), "dirty", model._operands_dirty, file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -175,6 +181,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
 
+    import math
+    assert math.isfinite(loss_value) and abs(loss_value) < 1e3, f"training step produced a non-finite / absurd loss ({loss_value})"
     ms_per_step = el / args.steps * 1e3
     value = B * world * args.steps / el
 

@@ -105,6 +105,7 @@ typedef struct rt_conv_wgrad_desc {
     int32_t DH, DW, N;
     int32_t KH, KW, stride, pad;
     int32_t msplit;
+    float*  dbias;        /* optional [N]: dbias[n] += sum_m dy[m, n] (fused bias gradient; no scale applied) */
 } rt_conv_wgrad_desc;
 int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
 
@@ -245,6 +246,10 @@ int rt_stem_conv(const void* xp, const void* w, const float* bias, void* out,
                  int B, int Hp, int Wp, int Ho, int Wo, rt_stream_t stream);
 int rt_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, rt_stream_t stream);
 int rt_weight_prep(const float* src, const float* scale, void* dst, void* dst_t, int N, int T, int C, rt_stream_t stream);
+/* rt_weight_prep_batched — every per-step operand refresh in ONE launch.  table: DEVICE int64 [njobs][8] =
+ * {src, scale|0, dst|0, dst_t|0, N, T, C, first_tile}; a job's tiles are 32(n) x 32(c) per tap, tiles numbered
+ * consecutively over jobs (total_tiles = sum).  Both outputs are written coalesced (LDS tile transpose). */
+int rt_weight_prep_batched(const int64_t* table, int njobs, int total_tiles, rt_stream_t stream);
 int rt_stem_weight_prep(const float* src, const float* scale, void* dst, rt_stream_t stream);
 int rt_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps,
                float* scale, float* shift, int n, rt_stream_t stream);

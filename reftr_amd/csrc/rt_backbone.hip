@@ -131,6 +131,45 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
     }
 }
 
+// One launch for all per-step operand refreshes: job table in device memory, 32(n) x 32(c) tiles per tap; the
+// transposed copy goes through a padded LDS tile so both global writes are coalesced.
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const int64_t* __restrict__ table, int njobs) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = njobs - 1;                       // last job whose first_tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 7] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* j = table + lo * 8;
+    const float* src = reinterpret_cast<const float*>(j[0]);
+    const float* scale = reinterpret_cast<const float*>(j[1]);
+    bf16_t* dst = reinterpret_cast<bf16_t*>(j[2]);
+    bf16_t* dst_t = reinterpret_cast<bf16_t*>(j[3]);
+    const int N = (int)j[4], T = (int)j[5], C = (int)j[6];
+    const int local = blockIdx.x - (int)j[7];
+    const int ct = (C + 31) >> 5, nt = (N + 31) >> 5;
+    const int tc = local % ct, tn = (local / ct) % nt, tap = local / (ct * nt);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = tn * 32 + ty + r * 8, c = tc * 32 + tx;
+        float v = 0.f;
+        if (n < N && c < C) {
+            v = src[((size_t)n * T + tap) * C + c];
+            if (scale) v *= scale[n];
+            if (dst) dst[((size_t)n * T + tap) * C + c] = (bf16_t)v;
+        }
+        tile[ty + r * 8][tx] = v;
+    }
+    if (!dst_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = tc * 32 + ty + r * 8, n = tn * 32 + tx;
+        if (n < N && c < C) dst_t[((size_t)c * T + tap) * N + n] = (bf16_t)tile[tx][ty + r * 8];
+    }
+}
+
 // stem: src fp32 [64][7][7][3] (channels_last view of [64,3,7,7]) -> bf16 [64][7][8][4], zero padded
 __global__ __launch_bounds__(256) void stem_weight_prep_kernel(const float* __restrict__ src, const float* __restrict__ scale,
                                                                bf16_t* __restrict__ dst) {
@@ -236,6 +275,13 @@ extern "C" int rt_weight_prep(const float* src, const float* scale, void* dst, v
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        src, scale, (bf16_t*)dst, (bf16_t*)dst_t, N, T, C);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_weight_prep_batched(const int64_t* table, int njobs, int total_tiles, rt_stream_t stream) {
+    if (!table || njobs <= 0 || total_tiles <= 0) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(weight_prep_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table, njobs);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

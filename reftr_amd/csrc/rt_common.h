@@ -68,4 +68,16 @@ __device__ __forceinline__ float rt_block_sum(float v, float* sm) {
     return r;
 }
 
+// Small fp32 workspaces are cleared with a KERNEL, not hipMemsetAsync: inside a captured hipGraph (ROCm 7.2) memset
+// nodes were observed to race with the kernel nodes that follow them (intermittent garbage statistics / losses),
+// while kernel -> kernel ordering on the captured stream is reliable.
+static __global__ void rt_zero_f32_kernel(float* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+static inline hipError_t rt_zero_f32(float* p, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(rt_zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, (int)n);
+    return hipGetLastError();
+}
+
 #define RT_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

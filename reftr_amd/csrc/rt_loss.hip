@@ -89,9 +89,9 @@ extern "C" int rt_box_loss(const rt_box_loss_desc* d, rt_stream_t stream) {
     if (!d || !d->logits || !d->valid || !d->targets || !d->tgt_off || !d->num_boxes || !d->losses || !d->total)
         return RT_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d->losses, 0, sizeof(float) * 2 * (size_t)d->NL, s);
+    hipError_t e = rt_zero_f32(d->losses, 2 * (size_t)d->NL, s);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(d->total, 0, sizeof(float), s);
+    e = rt_zero_f32(d->total, 1, s);
     if (e != hipSuccess) return (int)e;
     const int total = d->NL * d->B * d->P * d->K;
     hipLaunchKernelGGL(box_loss_kernel, dim3((total + 255) / 256), dim3(256), 0, s, *d);

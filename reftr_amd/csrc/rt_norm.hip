@@ -256,7 +256,7 @@ extern "C" int rt_groupnorm_fwd(const rt_groupnorm_desc* d, rt_stream_t stream) 
     if (d->C <= 0 || d->C > 256 || d->G <= 0 || (d->C % d->G) || (d->C / d->G) > 64 || ((d->C / d->G) & (d->C / d->G - 1)))
         return RT_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d->stats, 0, sizeof(float) * 2 * (size_t)d->B * d->G, s);
+    hipError_t e = rt_zero_f32(d->stats, 2 * (size_t)d->B * d->G, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(gn_stats_kernel, dim3((d->HW + 63) / 64, d->B), dim3(256), 0, s, d->x, d->stats, d->HW, d->C, d->G);
     RT_CHECK_LAUNCH();
@@ -271,7 +271,7 @@ extern "C" int rt_groupnorm_bwd(const rt_groupnorm_bwd_desc* d, rt_stream_t stre
     if (!d || !d->x || !d->dy || !d->gamma || !d->stats || !d->bstats) return RT_ERR_BADARG;
     if (d->C <= 0 || d->C > 256 || d->G <= 0 || (d->C % d->G) || (d->C / d->G) > 64) return RT_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d->bstats, 0, sizeof(float) * 2 * (size_t)d->B * d->G, s);
+    hipError_t e = rt_zero_f32(d->bstats, 2 * (size_t)d->B * d->G, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((d->HW + 63) / 64, d->B), dim3(256), 0, s, *d);
     RT_CHECK_LAUNCH();

@@ -70,7 +70,7 @@ extern "C" int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream) {
 extern "C" int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stream) {
     if (!g || !out || n <= 0) return RT_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+    hipError_t e = rt_zero_f32(out, 1, s);
     if (e != hipSuccess) return (int)e;
     int blocks = (int)(((size_t)n / 4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, s, g, (size_t)n, out);

@@ -16,7 +16,7 @@
 namespace {
 
 struct WgradArgs {
-    const bf16_t* dy; const bf16_t* x; float* dw; const float* scale;
+    const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
     int M, chunks_per_block, c_tiles;
 };
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
         for (int b = 0; b < TC; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[AJ], rb[BJ];
+    const bool do_bias = p.dbias && tile_c == 0 && tap == 0;
+    float bsum = 0.f;
 
     auto load_tiles = [&](int ch) __attribute__((always_inline)) {
         const int mbase = ch << 5;
@@ -152,6 +154,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
 #pragma unroll
             for (int b = 0; b < TC; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        if (do_bias) {      // fused bias gradient: column sums of the dy tile that is already in LDS
+            constexpr int TPC = 256 / BN;            // threads per column
+            constexpr int RPT = 32 / TPC;            // rows per thread
+            const int col = t % BN, r0 = (t / BN) * RPT;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+                bsum += (float)*reinterpret_cast<const bf16_t*>(bA + (r0 + r) * SA + col * 2);
+        }
     };
 
     load_tiles(chunk_begin);
@@ -167,6 +177,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
     }
     compute(cur);
 
+    if (do_bias) {
+        const int n = n0 + t % BN;
+        if (n < p.N) atomicAdd(p.dbias + n, bsum);
+    }
     const int taps = p.KH * p.KW;
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
@@ -190,15 +204,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
 // M <= 16 rows (decoder-side Linears): plain outer-product accumulation, one thread per (n, 4 k's)
 __global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             float* __restrict__ dw, const float* __restrict__ scale,
-                                                            int M, int N, int K) {
+                                                            float* __restrict__ dbias, int M, int N, int K) {
     const int k4 = K >> 2;
     const size_t total = (size_t)N * k4;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int kk = (int)(i % k4) * 4;
         const int n = (int)(i / k4);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        float gs = 0.f;
         for (int m = 0; m < M; ++m) {
             const float g = (float)dy[(size_t)m * N + n];
+            gs += g;
             const bf16x4 xv = *reinterpret_cast<const bf16x4*>(x + (size_t)m * K + kk);
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] += g * (float)xv[r];
@@ -206,6 +222,7 @@ __global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __rest
         if (scale) a *= scale[n];
         f32x4* o = reinterpret_cast<f32x4*>(dw + (size_t)n * K + kk);
         *o = *o + a;
+        if (dbias && kk == 0) dbias[n] += gs;
     }
 }
 
@@ -248,7 +265,7 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (d->SC <= 0 || (d->SC & 15) || (d->N & 3) || d->N <= 0) return RT_ERR_UNSUPPORTED;
     if (d->KH <= 0 || d->KW <= 0 || d->B <= 0 || d->DH <= 0 || d->DW <= 0 || d->stride <= 0) return RT_ERR_BADARG;
     WgradArgs a;
-    a.dy = (const bf16_t*)d->dy; a.x = (const bf16_t*)d->x; a.dw = d->dw; a.scale = d->scale;
+    a.dy = (const bf16_t*)d->dy; a.x = (const bf16_t*)d->x; a.dw = d->dw; a.scale = d->scale; a.dbias = d->dbias;
     a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     const long long M = (long long)d->B * d->DH * d->DW;
@@ -259,7 +276,7 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (a.M <= 16 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && (a.SC & 3) == 0) {
         const size_t total = (size_t)a.N * (a.SC >> 2);
         int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(small_m_wgrad_kernel, dim3(blocks), dim3(256), 0, s, a.dy, a.x, a.dw, a.scale, a.M, a.N, a.SC);
+        hipLaunchKernelGGL(small_m_wgrad_kernel, dim3(blocks), dim3(256), 0, s, a.dy, a.x, a.dw, a.scale, a.dbias, a.M, a.N, a.SC);
         RT_CHECK_LAUNCH();
         return RT_OK;
     }

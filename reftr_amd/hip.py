@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -38,7 +38,7 @@ class ConvWgradDesc(Structure):
         ("B", c_int32), ("SH", c_int32), ("SW", c_int32), ("SC", c_int32),
         ("DH", c_int32), ("DW", c_int32), ("N", c_int32),
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
-        ("msplit", c_int32),
+        ("msplit", c_int32), ("dbias", c_void_p),
     ]
 
 
@@ -156,6 +156,7 @@ _SIGNATURES = {
     "rt_stem_conv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_weight_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rt_weight_prep_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rt_stem_weight_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "rt_bn_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_mask_posenc": (c_int, [POINTER(MaskPosencDesc), c_void_p]),
@@ -309,13 +310,14 @@ def linear(x, w, bias=None, **kw):
     return conv_gemm(x, w, geom=(M, 1, 1, K, 1, 1, N, 1, 1, 1, 0), bias=bias, **kw)
 
 
-def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0):
+def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None):
     """dw[N,KH,KW,SC] (fp32, accumulated) += scale[n] * sum_m dy[m,n] * gather(x)[m,(kh,kw,c)]."""
     B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw")
     _req(scale, torch.float32, "scale")
     assert dy.numel() == B * DH * DW * N and x.numel() == B * SH * SW * SC and dw.numel() == N * KH * KW * SC
-    d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit)
+    _req(dbias, torch.float32, "dbias")
+    d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit, _p(dbias))
     _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
            lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"), tag=("W",) + tuple(geom))
     return dw
@@ -605,3 +607,25 @@ def pos_grad(dpos, d_lang_pos, d_type, d_level, B, S, L):
 
 def counter_add(ctr, inc=1):
     _check(lib().rt_counter_add(_p(ctr), inc, _stream()), "rt_counter_add")
+
+
+class WeightPrepBatch:
+    """All per-step operand refreshes as ONE launch: jobs are (src fp32 [N,T,C], scale|None, dst|None, dst_t|None)."""
+
+    def __init__(self, device):
+        self.jobs, self.device, self.table, self.tiles = [], device, None, 0
+        self._keep = []
+
+    def add(self, src, N, T, C, scale=None, dst=None, dst_t=None):
+        assert src.is_contiguous() and src.numel() == N * T * C
+        self.jobs.append([_p(src), _p(scale) or 0, _p(dst) or 0, _p(dst_t) or 0, N, T, C, self.tiles])
+        self.tiles += ((N + 31) // 32) * ((C + 31) // 32) * T
+        self._keep.append((src, scale, dst, dst_t))
+        self.table = None
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self.table is None:
+            self.table = torch.tensor(self.jobs, dtype=torch.int64).to(self.device)
+        _check(lib().rt_weight_prep_batched(_p(self.table), len(self.jobs), self.tiles, _stream()), "rt_weight_prep_batched")

@@ -72,15 +72,23 @@ class ResNetBody:
             self.W["stem"] = torch.empty(64, 7, 8, 4, dtype=torch.bfloat16, device=dev)
             H.stem_weight_prep(st.phys(self.PFX + "conv1.weight"), self.bn[self.PFX + "bn1."][0], self.W["stem"])
         for c in self.all_convs:
-            if not (full or c.trainable):
-                continue
             T = c.k * c.k
             if c.name not in self.W:
                 self.W[c.name] = torch.empty(c.cout, T, c.cin, dtype=torch.bfloat16, device=dev)
                 if c.trainable:
                     self.W[c.name + ".t"] = torch.empty(c.cin, T, c.cout, dtype=torch.bfloat16, device=dev)
-            H.weight_prep(st.phys(c.name), c.cout, T, c.cin, scale=self.bn[c.bn][0], dst=self.W[c.name],
-                          dst_t=self.W.get(c.name + ".t"))
+        if full:       # the BN scale tensors were re-created: rebuild both job tables
+            self._prep_all = H.WeightPrepBatch(dev)
+            self._prep_train = H.WeightPrepBatch(dev)
+            for c in self.all_convs:
+                args = (st.phys(c.name), c.cout, c.k * c.k, c.cin)
+                kw = dict(scale=self.bn[c.bn][0], dst=self.W[c.name], dst_t=self.W.get(c.name + ".t"))
+                self._prep_all.add(*args, **kw)
+                if c.trainable:
+                    self._prep_train.add(*args, **kw)
+            self._prep_all.run()
+        else:
+            self._prep_train.run()
 
     # ------------------------------------------------------------------ forward
     def _conv(self, x, shp, c, relu, res=None):

@@ -99,8 +99,11 @@ class Net:
         self._lin(p + "out_proj.", p + "out_proj.weight", p + "out_proj.bias")
 
     def refresh(self):
-        for l in self.lins.values():
-            l.refresh()
+        if getattr(self, "_prep", None) is None:
+            self._prep = H.WeightPrepBatch(self.store.device)
+            for l in self.lins.values():
+                self._prep.add(l.w32, l.N, 1, l.K, dst=l.W, dst_t=l.WT)
+        self._prep.run()
 
     # ------------------------------------------------------------------ helpers
     def begin_step(self, training):
@@ -121,8 +124,7 @@ class Net:
     def lin_bwd(self, key, dy, x, need_dx=True, **kw):
         """weight + bias gradient of a Linear (accumulated) and, if asked, its input gradient."""
         l = self.lins[key]
-        H.linear_wgrad(dy, x, l.gw)
-        H.colsum(dy, l.gb)
+        H.linear_wgrad(dy, x, l.gw, dbias=l.gb)
         if need_dx:
             return H.linear(dy, l.WT, **kw)
         return None

@@ -145,3 +145,31 @@ def test_errors_are_loud(hip):
         hip.linear(x, w)
     with pytest.raises(RuntimeError):
         hip.linear(x.cpu(), w.cpu())
+
+
+@pytest.mark.parametrize("M,K,N", [(200, 256, 256), (3520, 256, 2048), (8, 256, 256), (320, 768, 64)])
+def test_wgrad_fused_bias_grad(hip, M, K, N):
+    g = torch.Generator().manual_seed(M + 3 * N)
+    x = bf(torch.randn(M, K, generator=g)); dy = bf(torch.randn(M, N, generator=g))
+    dw = torch.zeros(N, K, device="cuda"); db = torch.ones(N, device="cuda")
+    hip.linear_wgrad(dy.cuda(), x.cuda(), dw, dbias=db)
+    assert rel(dw, dy.float().T @ x.float()) < TOL_F32
+    assert rel(db, 1 + dy.float().sum(0)) < 1e-5
+
+
+def test_weight_prep_batched(hip):
+    g = torch.Generator().manual_seed(12)
+    jobs = [(24, 9, 16, True), (100, 1, 70, False), (4, 1, 256, False), (33, 4, 33, True)]
+    batch = hip.WeightPrepBatch("cuda")
+    keep = []
+    for N, T, C, scaled in jobs:
+        src = torch.randn(N, T, C, generator=g)
+        sc = (torch.rand(N, generator=g) + 0.5) if scaled else None
+        dst = torch.zeros(N, T, C, dtype=torch.bfloat16, device="cuda"); dst_t = torch.zeros(C, T, N, dtype=torch.bfloat16, device="cuda")
+        sc_c = sc.cuda() if scaled else None
+        batch.add(src.cuda(), N, T, C, scale=sc_c, dst=dst, dst_t=dst_t)
+        keep.append((src, sc, dst, dst_t))
+    batch.run()
+    for src, sc, dst, dst_t in keep:
+        ref = (src * sc.view(-1, 1, 1) if sc is not None else src).bfloat16()
+        assert torch.equal(dst.cpu(), ref) and torch.equal(dst_t.cpu(), ref.permute(2, 1, 0).contiguous())
