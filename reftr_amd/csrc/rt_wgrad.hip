@@ -19,6 +19,7 @@ struct WgradArgs {
     const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
     int M, chunks_per_block, c_tiles;
+    unsigned dy_bytes, x_bytes;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off0, int off1) {
@@ -32,7 +33,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off0, i
 
 // SIMPLE: 1x1 / stride 1 / pad 0 (x row = m).  NVEC: N % 8 == 0 (16-B dy loads).
 template <int BN, int BC, bool SIMPLE, bool NVEC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restrict__ dyp,
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t* __restrict__ dyp,
                                                          const bf16_t* __restrict__ xp, const WgradArgs p) {
     constexpr int TN = BN / 32, TC = BC / 32;       // MFMA tiles per wave (waves 2(n) x 2(c))
     constexpr int SA = BN * 2 + 32, SB = BC * 2 + 32;   // LDS row strides (bytes)
@@ -83,19 +84,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
 #pragma unroll
         for (int b = 0; b < TC; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[AJ], rb[BJ];
     const bool do_bias = p.dbias && tile_c == 0 && tap == 0;
     float bsum = 0.f;
 
-    auto load_tiles = [&](int ch) __attribute__((always_inline)) {
-        const int mbase = ch << 5;
+    // Two register stages + two LDS buffers, operands fetched with bounds-checked buffer loads (out-of-range offset
+    // -> zeros): chunk ch+2 is requested while chunk ch is multiplied and chunk ch+1 is still in flight.
+    uint4 ra0[AJ], rb0[BJ], ra1[AJ], rb1[BJ];
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dyp), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xp), 0, p.x_bytes, 0x00020000);
+    constexpr int OOB = 0x7fffffff;
+    int lc = chunk_begin;             // next chunk to load (the gather state gb/gy/gx belongs to it)
+
+    auto load_tiles = [&](uint4 (&ra)[AJ], uint4 (&rb)[BJ]) __attribute__((always_inline)) {
+        const int mbase = lc << 5;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int m = mbase + a_row + A_RSTEP * j;
             const bool ok = a_nok && m < p.M;
             if (NVEC) {
-                const uint4 v = *reinterpret_cast<const uint4*>(dyp + (ok ? m * p.N + a_n : 0));
-                ra[j] = ok ? v : make_uint4(0, 0, 0, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, ok ? (m * p.N + a_n) * 2 : OOB, 0, 0);
+                ra[j] = make_uint4(v[0], v[1], v[2], v[3]);
             } else {   // ragged N (e.g. the 4-wide box head): element loads, zero fill
                 union { uint4 q; unsigned short e[8]; } u; u.q = make_uint4(0, 0, 0, 0);
                 const unsigned short* d16 = reinterpret_cast<const unsigned short*>(dyp);
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
                 ra[j] = u.q;
             }
         }
+        const bool last = (lc + 1 >= chunk_end);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int m = mbase + b_row + B_RSTEP * j;
@@ -115,14 +124,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
                 const int sy = gy[j] * p.stride - p.pad + kh, sx = gx[j] * p.stride - p.pad + kw;
                 ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
                 pix = (gb[j] * p.SH + sy) * p.SW + sx;
-                gx[j] += 32;
-                while (gx[j] >= p.DW) { gx[j] -= p.DW; if (++gy[j] >= p.DH) { gy[j] = 0; ++gb[j]; } }
+                if (!last) {
+                    gx[j] += 32;
+                    while (gx[j] >= p.DW) { gx[j] -= p.DW; if (++gy[j] >= p.DH) { gy[j] = 0; ++gb[j]; } }
+                }
             }
-            const uint4 v = *reinterpret_cast<const uint4*>(xp + (ok ? pix * p.SC + b_c : 0));
-            rb[j] = ok ? v : make_uint4(0, 0, 0, 0);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (pix * p.SC + b_c) * 2 : OOB, 0, 0);
+            rb[j] = make_uint4(v[0], v[1], v[2], v[3]);
         }
+        if (!last) ++lc;              // past the end the last chunk is re-loaded (never consumed)
     };
-    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    auto store_tiles = [&](int buf, const uint4 (&ra)[AJ], const uint4 (&rb)[BJ]) __attribute__((always_inline)) {
         unsigned char* bA = smem + buf * BUF_BYTES;
         unsigned char* bB = bA + A_BYTES;
 #pragma unroll
@@ -164,18 +176,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const bf16_t* __restric
         }
     };
 
-    load_tiles(chunk_begin);
-    store_tiles(0);
+    const int nch = chunk_end - chunk_begin;
+    load_tiles(ra0, rb0);
+    load_tiles(ra1, rb1);
+    store_tiles(0, ra0, rb0);
     __syncthreads();
-    int cur = 0;
-    for (int ch = chunk_begin; ch < chunk_end - 1; ++ch) {
-        load_tiles(ch + 1);
-        compute(cur);
-        store_tiles(cur ^ 1);
+    for (int c = 0; c < nch; c += 2) {
+        load_tiles(ra0, rb0);             // chunk c+2
+        compute(0);
+        store_tiles(1, ra1, rb1);
         __syncthreads();
-        cur ^= 1;
+        if (c + 1 >= nch) break;
+        load_tiles(ra1, rb1);             // chunk c+3
+        compute(1);
+        store_tiles(0, ra0, rb0);
+        __syncthreads();
     }
-    compute(cur);
 
     if (do_bias) {
         const int n = n0 + t % BN;
@@ -270,8 +286,10 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
-    if (M * d->N >= 0x7fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x7fffffffLL) return RT_ERR_UNSUPPORTED;
+    if (M * d->N >= 0x3fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0;
+    a.dy_bytes = (unsigned)(M * d->N * 2);
+    a.x_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;
     if (a.M <= 16 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && (a.SC & 3) == 0) {
         const size_t total = (size_t)a.N * (a.SC >> 2);
