@@ -11,6 +11,7 @@
 // zero) -> XOR-swizzled LDS (slot ^= row&7, conflict-free for ds_read_b128 fragment reads), LDS double
 // buffered with ONE barrier per K tile; next tile's global loads are in flight under the MFMAs.
 #include "rt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -357,7 +358,9 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     if (hint == 0) {
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-        if (a.N > 64 && t128 >= 384) hint = 1;
+        static const int smallk = getenv("REFTR_SMALLK") ? atoi(getenv("REFTR_SMALLK")) : 256;   // A/B on the real step: -0.75 ms
+        if (a.K <= smallk) hint = 3;     // K <= 128: pure streaming, many small workgroups per CU
+        else if (a.N > 64 && t128 >= 384) hint = 1;
         else if (t12864 >= 256) hint = 2;
         else hint = 3;
     }

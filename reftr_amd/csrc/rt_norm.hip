@@ -2,6 +2,7 @@
 // One 64-lane wave owns one token row (D <= 1024); the epilogue emits everything the next GEMM needs
 // (fp32 residual stream, bf16 operand copy, bf16 copy of y + pos) so no separate cast/add kernels run.
 #include "rt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -244,8 +245,12 @@ extern "C" int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stre
     if (!d || !d->dy || !d->x || !d->gamma || !d->mean || !d->rstd) return RT_ERR_BADARG;
     if (d->D <= 0 || d->D > 64 * LN_MAX_PER_LANE || d->M <= 0) return RT_ERR_UNSUPPORTED;
     if (d->act == RT_ACT_RELU && !d->beta) return RT_ERR_BADARG;
+    // few, fat workgroups: every block ends with D atomics per parameter vector, so contention (not bandwidth)
+    // is what scales with the block count
+    static const int lnb = getenv("REFTR_LNB") ? atoi(getenv("REFTR_LNB")) : 512;
     int blocks = (d->M + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    if (blocks > lnb) blocks = lnb;
+    if (!d->dgamma && !d->dbeta) { blocks = (d->M + 3) / 4; if (blocks > 1024) blocks = 1024; }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;

@@ -629,3 +629,50 @@ class WeightPrepBatch:
         if self.table is None:
             self.table = torch.tensor(self.jobs, dtype=torch.int64).to(self.device)
         _check(lib().rt_weight_prep_batched(_p(self.table), len(self.jobs), self.tiles, _stream()), "rt_weight_prep_batched")
+
+
+class SideStream:
+    """A second HIP stream for work that is off the critical path (the BERT branch, queued weight gradients).
+    `run` forks it from the current stream (event edge) -- or, with defer=True, only queues the closure until
+    `flush` forks ONCE and launches the whole queue (per-launch fork edges cost more than they give inside a
+    hipGraph); `join` makes the current stream wait for it.  Tensors the side work reads are kept referenced until
+    the join so the caching allocator cannot hand their memory out early.  Under hipGraph capture the fork / join
+    events become graph edges and the branches replay concurrently."""
+
+    def __init__(self, enabled=True, defer=False):
+        self.enabled = enabled and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream() if self.enabled else None
+        self.defer = defer
+        self.jobs = []
+        self.keep = []
+        self.dirty = False
+
+    def run(self, fn, *keep):
+        if not self.enabled:
+            return fn()
+        self.keep.extend(keep)
+        if self.defer:
+            self.jobs.append(fn)
+            return None
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            r = fn()
+        self.dirty = True
+        return r
+
+    def flush(self):
+        if not self.enabled or not self.jobs:
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for fn in self.jobs:
+                fn()
+        self.jobs = []
+        self.dirty = True
+
+    def join(self):
+        self.flush()
+        if self.enabled and self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+        self.dirty = False

@@ -51,6 +51,7 @@ class ResNetBody:
                 stage.append(b)
                 inpl = planes * 4
             self.blocks.append(stage)
+        self.wg = H.SideStream(False)     # conv weight gradients stay inline (they fill the chip on their own)
         self.W = {}      # bf16 operands: name -> [N][T][C]; name + '.t' -> [C][T][N]
         self.bn = {}     # bn prefix -> (scale, shift) fp32
         self.all_convs = [c for st in self.blocks for b in st for c in (b.conv1, b.conv2, b.conv3, b.down) if c is not None]
@@ -128,7 +129,8 @@ class ResNetBody:
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, g, x, c, geom):
-        H.conv_wgrad(g, x, self.store.phys(c.name, grad=True), geom=geom, scale=self.bn[c.bn][0])
+        dw, sc = self.store.phys(c.name, grad=True), self.bn[c.bn][0]
+        self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc), g, x)
 
     def _dgrad(self, g, c, geom, res=None, gate=None):
         B, SH, SW, SC, DH, DW, N, KH, KW, s, p = geom

@@ -41,6 +41,11 @@ class Net:
         self.training = True
         self._seed_base = 0x1234567
         self._site = 0
+        import os
+        # bit 0: BERT branch on its own stream; bit 1: weight-gradient launches on their own stream
+        on = int(os.environ.get("REFTR_STREAMS", "1")) if str(store.device).startswith("cuda") else 0
+        self.wg = H.SideStream(bool(on & 2), defer=True)
+        self.side = H.SideStream(bool(on & 1))
         self._build_lins()
 
     # ------------------------------------------------------------------ operand bank
@@ -124,7 +129,7 @@ class Net:
     def lin_bwd(self, key, dy, x, need_dx=True, **kw):
         """weight + bias gradient of a Linear (accumulated) and, if asked, its input gradient."""
         l = self.lins[key]
-        H.linear_wgrad(dy, x, l.gw, dbias=l.gb)
+        self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb), dy, x)
         if need_dx:
             return H.linear(dy, l.WT, **kw)
         return None

@@ -170,12 +170,14 @@ class RefTR(nn.Module):
         if self.training:
             H.counter_add(self.seed_dev, 1)
 
-        feats, bb_saved = self.body.forward(x)
-        c5, (_, h, w) = feats[-1]
-        HW = h * w
         ids = samples["sentence"].to(dev).contiguous()
         smask_u8 = samples["sentence_mask"].to(dev).to(torch.uint8).contiguous()
         Lq = ids.shape[1]
+        # language branch (BERT) on the side stream, concurrently with the ResNet branch below
+        seq16, pooled16, bctx = net.side.run(lambda: net.bert_fwd(ids, smask_u8), ids, smask_u8)
+        feats, bb_saved = self.body.forward(x)
+        c5, (_, h, w) = feats[-1]
+        HW = h * w
         assert Lq <= cfg.max_lang_seq                                       # models/reftr.py:81
         S = Lq + HW
         M = B * S
@@ -194,7 +196,7 @@ class RefTR(nn.Module):
                    b_map=(-1, 0, 1), out_f32=addv)
         H.mask_posenc(mask_u8, h, w, E, addv, kpm, Lq, pos, S, Lq)
 
-        seq16, pooled16, bctx = net.bert_fwd(ids, smask_u8)
+        net.side.join()
         _, ms_ctx = net.mlp_fwd(seq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos, rowmap=(Lq, S, 0))
         _, ip = net.lin_fwd("input_proj.0.0.", c5, out_bf16=False, out_f32=True)
         gn_stats = H.groupnorm_fwd(ip.view(B, HW, E), st.P["input_proj.0.1.weight"], st.P["input_proj.0.1.bias"], 32, 1e-5,
@@ -350,17 +352,23 @@ class RefTR(nn.Module):
         _, dip16 = H.groupnorm_bwd(dxa, sv["ip"].view(B, HW, E), st.P["input_proj.0.1.weight"], sv["gn_stats"],
                                    st.G["input_proj.0.1.weight"], st.G["input_proj.0.1.bias"], 32, 1e-5, dy2=dxb,
                                    rows_per_img=S, row_off=Lq)
+        # ---- BERT backward (sentence pass; phrase pass for multi-phrase inputs) on the side stream, concurrently
+        # with the input_proj / ResNet backward below
+        def _bert_bwd():
+            if sv["pctx"] is None:
+                net.bert_bwd(sv["bctx"], d_seq, dpool)
+            else:
+                net.bert_bwd(sv["bctx"], d_seq, None)
+                net.bert_bwd(sv["pctx"], None, dpool)
+            net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
+        net.wg.flush()               # transformer weight gradients queued so far -> their own stream, from here
+        net.side.run(_bert_bwd, d_seq, dpool)
         g_c5, _ = net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], gate=sv["c5"])
         if getattr(self, "_debug", False):
             self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=g_c5.clone())
         self.body.backward(sv["bb_saved"], g_c5)
-
-        # ---- BERT (sentence pass; phrase pass for multi-phrase inputs)
-        if sv["pctx"] is None:
-            net.bert_bwd(sv["bctx"], d_seq, dpool)
-        else:
-            net.bert_bwd(sv["bctx"], d_seq, None)
-            net.bert_bwd(sv["pctx"], None, dpool)
+        net.side.join()
+        net.wg.join()
         H.set_seed_dev(None)
         for hook in self._post_backward_hooks:
             hook()
