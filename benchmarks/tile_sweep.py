@@ -1,13 +1,16 @@
-"""Tile-shape sweep of rt_conv_gemm on the ResNet 1x1 / low-K shapes (which tile config streams best)."""
+"""Tile / staging sweep of rt_conv_gemm on the step's shapes: register-staged tiles (hints 1-3) against the LDS-DMA
+variants (hints 11-33), timed as 20 back-to-back launches inside one hipGraph."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reftr_amd import hip
+HINTS = [1, 2, 3, 11, 12, 13, 21, 22, 31, 32, 33]
 SHAPES = [("l1 64->256 @160", 204800, 64, 256), ("l1 256->64 @160", 204800, 256, 64), ("l1 64->64", 204800, 64, 64),
           ("l2 256->128 @160", 204800, 256, 128), ("l2 128->512 @80", 51200, 128, 512), ("l2 512->128 @80", 51200, 512, 128),
           ("l3 256->1024 @40", 12800, 256, 1024), ("l3 1024->256 @40", 12800, 1024, 256), ("l3 512->256 @80", 51200, 512, 256),
           ("l4 512->2048 @20", 3200, 512, 2048), ("l4 2048->512 @20", 3200, 2048, 512), ("l4 1024->512 @40", 12800, 1024, 512),
           ("enc 256->256", 3520, 256, 256), ("enc 256->2048", 3520, 256, 2048), ("enc 2048->256", 3520, 2048, 256),
-          ("bert 768->768", 320, 768, 768), ("bert 768->3072", 320, 768, 3072), ("bert 3072->768", 320, 3072, 768)]
+          ("bert 768->768", 320, 768, 768), ("bert 768->3072", 320, 768, 3072), ("bert 3072->768", 320, 3072, 768),
+          ("big 4096^3", 4096, 4096, 4096)]
 def graph_time(fn, iters=20):
     fn(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -21,30 +24,33 @@ def graph_time(fn, iters=20):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-CONVS = [("l1 3x3 64 @160", 8, 160, 64, 64, 1), ("l2 3x3 128 @80", 8, 80, 128, 128, 1), ("l2 3x3s2 128 @160", 8, 160, 128, 128, 2),
-         ("l3 3x3 256 @40", 8, 40, 256, 256, 1), ("l4 3x3 512 @20", 8, 20, 512, 512, 1), ("l4 3x3s2 512 @40", 8, 40, 512, 512, 2)]
+if __name__ != "__main__":
+    CONVS = SHAPES = []
+else:
+  CONVS = [("l1 3x3 64 @160", 8, 160, 64, 64, 1), ("l2 3x3 128 @80", 8, 80, 128, 128, 1), ("l2 3x3s2 128 @160", 8, 160, 128, 128, 2),
+           ("l3 3x3 256 @40", 8, 40, 256, 256, 1), ("l4 3x3 512 @20", 8, 20, 512, 512, 1), ("l4 3x3s2 512 @40", 8, 40, 512, 512, 2)]
+if __name__ == "__main__": print("hints: " + " ".join("%6d" % h for h in HINTS))
 for name, B, Hh, ci, co, st in CONVS:
     ho = (Hh + 2 - 3) // st + 1
     x = torch.randn(B, Hh, Hh, ci, device="cuda").bfloat16(); w = (torch.randn(co, 3, 3, ci, device="cuda") / (9 * ci) ** 0.5).bfloat16()
     wt = (torch.randn(ci, 3, 3, co, device="cuda") / (9 * ci) ** 0.5).bfloat16(); dy = torch.randn(B, ho, ho, co, device="cuda").bfloat16()
     geom = (B, Hh, Hh, ci, ho, ho, co, 3, 3, st, 1); geom_t = (B, ho, ho, co, Hh, Hh, ci, 3, 3, st, 1)
     rf, rd = [], []
-    for hint in (1, 2, 3):
+    for hint in HINTS:
         rf.append(graph_time(lambda: hip.conv_gemm(x, w, geom=geom, act=hip.ACT_RELU, tile_hint=hint)))
         rd.append(graph_time(lambda: hip.conv_gemm(dy, wt, geom=geom_t, transposed=True, tile_hint=hint)))
     fl = 2.0 * B * ho * ho * co * ci * 9
-    print("%-20s fwd 128x128 %6.1f 128x64 %6.1f 64x64 %6.1f (%5.0f TF) | dgrad %6.1f %6.1f %6.1f (%5.0f TF)" % (
-        name, rf[0], rf[1], rf[2], fl / min(rf) / 1e6, rd[0], rd[1], rd[2], fl / min(rd) / 1e6), flush=True)
-for name, M, K, N in SHAPES[:0]:
+    print("%-20s fwd   " % name + " ".join("%6.1f" % v for v in rf) + "  best %d (%4.0f TF)" % (HINTS[rf.index(min(rf))], fl / min(rf) / 1e6), flush=True)
+    print("%-20s dgrad " % name + " ".join("%6.1f" % v for v in rd) + "  best %d (%4.0f TF)" % (HINTS[rd.index(min(rd))], fl / min(rd) / 1e6), flush=True)
+for name, M, K, N in SHAPES:
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     res = torch.randn(M, N, device="cuda").bfloat16()
     ob = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     row = []
-    for hint in (1, 2, 3):
-        t = graph_time(lambda: hip.linear(x, w, act=hip.ACT_RELU, res_bf16=res, res_first=True, out_bf16=ob, tile_hint=hint))
-        row.append(t)
+    for hint in HINTS:
+        row.append(graph_time(lambda: hip.linear(x, w, act=hip.ACT_RELU, res_bf16=res, res_first=True, out_bf16=ob, tile_hint=hint)))
     gb = (M * K + N * K + 2 * M * N) * 2 / 1e9
     fl = 2.0 * M * N * K
     best = min(row)
-    print("%-20s M=%6d K=%4d N=%4d | 128x128 %7.1f us | 128x64 %7.1f us | 64x64 %7.1f us | best %6.1f TF %5.2f TB/s" % (
-        name, M, K, N, row[0], row[1], row[2], fl / best / 1e6, gb / best * 1e-3 * 1e3), flush=True)
+    print("%-20s       " % name + " ".join("%6.1f" % v for v in row) + "  best %d (%4.0f TF, %4.2f TB/s)" % (
+        HINTS[row.index(best)], fl / best / 1e6, gb / best * 1e3), flush=True)

@@ -106,6 +106,10 @@ typedef struct rt_conv_wgrad_desc {
     int32_t KH, KW, stride, pad;
     int32_t msplit;
     float*  dbias;        /* optional [N]: dbias[n] += sum_m dy[m, n] (fused bias gradient; no scale applied) */
+    int32_t variant;      /* 0 = library's choice; >0 pins a kernel variant (tuning / tests, see rt_wgrad.hip) */
+    float*  workspace;    /* optional scratch for the split-M partial tiles (plain stores + one reduction pass instead of
+                             fp32 atomics); must not be shared by launches on concurrent streams.  NULL: atomics */
+    int64_t workspace_bytes;
 } rt_conv_wgrad_desc;
 int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
 

@@ -274,6 +274,174 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-DMA variant: operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), never through VGPRs, so
+// the ds_write half of the LDS pipe (~80 B/clk/CU, as expensive as the MFMAs of a 128x128x64 tile) disappears and
+// NS tiles can be in flight without holding staging registers.  The DMA writes lane l of a wave instruction to
+// LDS base + 16*l (lane-linear), so the XOR swizzle is applied on the SOURCE side: lane l (row l>>3 of an 8-row
+// group, slot l&7) fetches K chunk (l&7)^(l>>3) of its row.  Out-of-range offsets make the DMA write zeros.
+// Completion is tracked with explicit counted vmcnt waits (the compiler cannot tell which stage a ds_read aliases).
+template <int N> __device__ __forceinline__ void rt_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ i32x4 rt_make_rsrc(const void* ptr, unsigned bytes) {
+    const uint64_t a = (uint64_t)ptr;
+    return i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)bytes, 0x00020000};   // stride 0, raw buffer
+}
+// One 16-B-per-lane global -> LDS DMA: lane l lands at LDS byte address lds_base + 16*l (lds_base wave-uniform).
+// Issued as inline asm so that the compiler's waitcnt pass does not turn every later ds_read into vmcnt(0).
+__device__ __forceinline__ void rt_dma16(const i32x4 rsrc, unsigned lds_base, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory", "m0");
+}
+
+template <int BM, int BN, int MODE, int NS, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* __restrict__ src,
+                                                                  const bf16_t* __restrict__ wgt, const GemmArgs p) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int AJ = BN / 32, BJ = BM / 32;
+    constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int LPT = AJ + BJ;                   // DMA instructions per thread per K tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+    const int n0 = tile_n * BN, m0 = tile_m * BM;
+
+    const int srow = t >> 3;
+    const int chunk = (t & 7) ^ (srow & 7);        // source-side swizzle
+    constexpr int OOB = 0x7fffffff;
+
+    int a_off[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int n = n0 + srow + 32 * j;
+        a_off[j] = n < p.N ? (n * p.K + chunk * 8) * 2 : OOB;
+    }
+    int b_off[BJ], b_y[BJ], b_x[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int m = m0 + srow + 32 * j;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        if (MODE == 0) {
+            b_off[j] = ok ? (mm * p.SC + chunk * 8) * 2 : OOB; b_y[j] = 0; b_x[j] = 0;
+        } else {
+            const int dx = mm % p.DW;
+            const int tmp = mm / p.DW;
+            const int dy = tmp % p.DH;
+            const int b = tmp / p.DH;
+            if (MODE == 1) { b_y[j] = dy * p.stride - p.pad; b_x[j] = dx * p.stride - p.pad; }
+            else           { b_y[j] = dy + p.pad;            b_x[j] = dx + p.pad; }
+            if (!ok) b_y[j] = -(1 << 28);           // every tap of a ragged row fails the bounds test
+            b_off[j] = b * p.SH * p.SW * p.SC + chunk * 8;
+        }
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K >> 6;
+    int lk = 0, c0 = 0, kw = 0, kh = 0;
+    const i32x4 rs_w = rt_make_rsrc(wgt, p.wgt_bytes), rs_x = rt_make_rsrc(src, p.src_bytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+
+    auto issue_tile = [&](int buf) __attribute__((always_inline)) {
+        const unsigned bA = lds0 + buf * BUF_BYTES;      // this wave's 8-row group of each 32-row slab
+        const unsigned bB = bA + A_BYTES;
+        const int k0b = lk << 7;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) rt_dma16(rs_w, bA + j * 4096, a_off[j], k0b);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            if (MODE == 0) {
+                rt_dma16(rs_x, bB + j * 4096, b_off[j], k0b);
+            } else {
+                bool ok;
+                int sy, sx;
+                if (MODE == 1) { sy = b_y[j] + kh; sx = b_x[j] + kw; ok = true; }
+                else {
+                    const int ny = b_y[j] - kh, nx = b_x[j] - kw;
+                    const int msk = p.stride - 1;
+                    ok = ((ny | nx) >= 0) && (((ny | nx) & msk) == 0);
+                    sy = ny >> p.sshift; sx = nx >> p.sshift;
+                }
+                ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
+                const int off = (b_off[j] + (sy * p.SW + sx) * p.SC) * 2;
+                rt_dma16(rs_x, bB + j * 4096, ok ? off : OOB, c0 * 2);
+            }
+        }
+        if (lk + 1 < nk) {
+            ++lk;
+            if (MODE != 0) {
+                c0 += 64;
+                if (c0 >= p.SC) { c0 = 0; ++kw; if (kw >= p.KW) { kw = 0; ++kh; } }
+            }
+        }
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* bA = smem + buf * BUF_BYTES;
+        const unsigned char* bB = bA + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TN], bfr[TM];
+            const int slot = ((kk * 4 + lg) ^ (li & 7)) << 4;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int row = wn * (BN / 2) + a * 16 + li;
+                af[a] = *reinterpret_cast<const bf16x8*>(bA + row * 128 + slot);
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int row = wm * (BM / 2) + b * 16 + li;
+                bfr[b] = *reinterpret_cast<const bf16x8*>(bB + row * 128 + slot);
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    // prologue: tiles 0 .. NS-2 in flight (past the end the last tile is re-fetched into a free stage)
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_tile(s);
+    int cbuf = 0, lbuf = NS - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        rt_wait_vmcnt<(NS - 2) * LPT>();           // tile kt has landed (this thread's part)
+        __syncthreads();                           // ... everyone's part; and stage lbuf (tile kt-1) is no longer read
+        issue_tile(lbuf);                          // tile kt+NS-1
+        compute(cbuf);
+        cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+        lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+    }
+    rt_wait_vmcnt<0>();                            // drain the over-fetched tail before the workgroup's LDS is released
+
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        const int n = n0 + wn * (BN / 2) + a * 16 + lg * 4;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = m0 + wm * (BM / 2) + b * 16 + li;
+            if (m >= p.M) continue;
+            epilogue4(p, m, n, acc[a][b]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny path (M <= 16 rows: the decoder / query-encoder / box-head Linears over B*n_q tokens).  No LDS tiles:
 // a workgroup owns 16 output features, its 4 waves split K four ways and stream both operands straight from
 // global memory into MFMA fragments (A = 16 weight rows, B = the <=16 token rows), then reduce through LDS.
@@ -324,6 +492,29 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     return RT_OK;
 }
 
+template <int BM, int BN, int NS, int MINB>
+int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    const size_t smem = (size_t)NS * (BM + BN) * 128;
+    const dim3 grid((unsigned)(mt * nt)), block(256);
+    const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
+    auto set_smem = [&](const void* f) {
+        if (smem > 65536) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    };
+    if (dense) {
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 0, NS, MINB>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 0, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
+    } else if (!a.transposed) {
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 1, NS, MINB>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
+    } else {
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 2, NS, MINB>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
+    }
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
@@ -356,23 +547,40 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     }
     int hint = d->tile_hint;
     if (hint == 0) {
+        // Tile choice from the in-step sweeps (benchmarks/tile_sweep.py, profiles/r01e_tile_sweep.txt): small K streams
+        // best through many 64x64 workgroups; 128x128 needs >= 1.5 waves of tiles over the 256 CUs to pay off.
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-        static const int smallk = getenv("REFTR_SMALLK") ? atoi(getenv("REFTR_SMALLK")) : 256;   // A/B on the real step: -0.75 ms
-        if (a.K <= smallk) hint = 3;     // K <= 128: pure streaming, many small workgroups per CU
+        static const int smallk = getenv("REFTR_SMALLK") ? atoi(getenv("REFTR_SMALLK")) : 256;
+        static const int dma = getenv("REFTR_DMA") ? atoi(getenv("REFTR_DMA")) : 1;
+        if (a.K <= smallk) hint = 3;
         else if (a.N > 64 && t128 >= 384) hint = 1;
         else if (t12864 >= 256) hint = 2;
         else hint = 3;
+        if (dma) {          // LDS-DMA staging; deeper stages once K is long enough to fill them
+            if (hint == 1) hint = 11;
+            else if (hint == 2) hint = a.K >= 1024 ? 22 : 21;
+            else hint = a.K >= 1024 ? 33 : 31;
+        }
     }
     switch (hint) {
         case 1: return launch_gemm<128, 128>(a, s);
         case 2: return launch_gemm<128, 64>(a, s);
         case 3: return launch_gemm<64, 64>(a, s);
+        // LDS-DMA variants (tile, stages, min workgroups / CU)
+        case 11: return launch_gemm_dma<128, 128, 2, 2>(a, s);
+        case 12: return launch_gemm_dma<128, 128, 3, 2>(a, s);
+        case 13: return launch_gemm_dma<128, 128, 4, 2>(a, s);
+        case 21: return launch_gemm_dma<128, 64, 2, 2>(a, s);
+        case 22: return launch_gemm_dma<128, 64, 3, 2>(a, s);
+        case 31: return launch_gemm_dma<64, 64, 2, 4>(a, s);
+        case 32: return launch_gemm_dma<64, 64, 4, 2>(a, s);
+        case 33: return launch_gemm_dma<64, 64, 3, 3>(a, s);
         default: return RT_ERR_BADARG;
     }
 }
 
-extern "C" int rt_abi_version(void) { return 7; }
+extern "C" int rt_abi_version(void) { return 9; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

@@ -12,6 +12,7 @@
 // The m axis is split across blockIdx.y; partial tiles are accumulated with fp32 global atomics into the
 // (pre-zeroed) flat gradient buffer.
 #include "rt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -19,6 +20,7 @@ struct WgradArgs {
     const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
     int M, chunks_per_block, c_tiles;
+    float* part; int out_elems;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
     unsigned dy_bytes, x_bytes;
 };
 
@@ -217,6 +219,245 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (N % 8 == 0): both operand tiles go global -> LDS with buffer_load_dwordx4 ... lds, CR reduction
+// rows per stage, NS stages.  The DMA lands lane l of a wave instruction at LDS base + 16*l, so rows are unpadded
+// (row bytes = 2*BN / 2*BC) and the bank spreading the transpose read needs comes from a source-side XOR of the
+// 16-B slot index with a function of the row: 8 consecutive rows put their 32-B fragments on 8 distinct bank groups.
+// SIMPLE operands are addressed through a buffer descriptor that is re-based per chunk with scalar arithmetic (base +=
+// chunk bytes, num_records -= chunk bytes): the per-lane offsets are loop-invariant and the ragged tail rows fall off
+// the end of the descriptor, i.e. read as zeros.
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef __attribute__((ext_vector_type(4))) int wg_i32x4;
+__device__ __forceinline__ wg_i32x4 wg_make_rsrc(const void* ptr, unsigned bytes) {
+    const uint64_t a = (uint64_t)ptr;
+    return wg_i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void wg_dma16(const wg_i32x4 rsrc, unsigned lds_base, int voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 ::"s"(lds_base), "v"(voff), "s"(rsrc)
+                 : "memory", "m0");
+}
+template <int RB> __device__ __forceinline__ int wg_swz(int row) {      // XOR applied to the 16-B slot index
+    return RB >= 256 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
+}
+
+template <int BN, int BC, bool SIMPLE, int CR, int NS, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t* __restrict__ dyp,
+                                                                   const bf16_t* __restrict__ xp, const WgradArgs p) {
+    constexpr int TN = BN / 32, TC = BC / 32;
+    constexpr int RBA = BN * 2, RBB = BC * 2;            // LDS row bytes
+    constexpr int SPRA = BN / 8, SPRB = BC / 8;          // 16-B slots per row
+    constexpr int A_BYTES = CR * RBA, B_BYTES = CR * RBB, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int AJ = CR * SPRA / 256, BJ = CR * SPRB / 256;
+    constexpr int RPIA = 64 / SPRA, RPIB = 64 / SPRB;    // rows covered by one wave instruction
+    constexpr int KS = CR / 32;
+    constexpr int LPT = AJ + BJ;
+    constexpr int OOB = 0x7fffffff;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wn = wave & 1, wc = wave >> 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % n_tiles;
+    const int rest = blockIdx.x / n_tiles;
+    const int tile_c = rest % p.c_tiles;
+    const int tap = rest / p.c_tiles;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int n0 = tile_n * BN, c0 = tile_c * BC;
+
+    const int total_chunks = (p.M + CR - 1) / CR;
+    const int chunk_begin = blockIdx.y * p.chunks_per_block;
+    int chunk_end = chunk_begin + p.chunks_per_block;
+    if (chunk_end > total_chunks) chunk_end = total_chunks;
+    if (chunk_begin >= chunk_end) return;
+
+    // loop-invariant per-lane source offsets (relative to the chunk's first row)
+    int voff_a[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int r = (j * 4 + wave) * RPIA + lane / SPRA;
+        const int sl = (lane % SPRA) ^ wg_swz<RBA>(r);
+        const int n = n0 + sl * 8;
+        voff_a[j] = n < p.N ? (r * p.N + n) * 2 : OOB;
+    }
+    int voff_b[BJ], b_r[BJ], gb[BJ], gy[BJ], gx[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int r = (j * 4 + wave) * RPIB + lane / SPRB;
+        const int sl = (lane % SPRB) ^ wg_swz<RBB>(r);
+        const int c = c0 + sl * 8;
+        b_r[j] = r;
+        if (SIMPLE) { voff_b[j] = c < p.SC ? (r * p.SC + c) * 2 : OOB; gb[j] = gy[j] = gx[j] = 0; }
+        else {
+            voff_b[j] = c < p.SC ? c * 2 : OOB;
+            const int m = chunk_begin * CR + r;
+            gx[j] = m % p.DW; const int tmp = m / p.DW; gy[j] = tmp % p.DH; gb[j] = tmp / p.DH;
+        }
+    }
+
+    f32x4 acc[TN][TC];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TC; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool do_bias = p.dbias && tile_c == 0 && tap == 0;
+    float bsum = 0.f;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    const wg_i32x4 rs_x_abs = wg_make_rsrc(xp, p.x_bytes);
+    int lc = chunk_begin;
+
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const unsigned bA = lds0 + stage * BUF_BYTES, bB = bA + A_BYTES;
+        const unsigned aoff = (unsigned)lc * (unsigned)(CR * 2) * (unsigned)p.N;
+        const wg_i32x4 rs_dy = wg_make_rsrc(reinterpret_cast<const unsigned char*>(dyp) + aoff, p.dy_bytes - aoff);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) wg_dma16(rs_dy, bA + j * 4096, voff_a[j]);
+        const bool last = (lc + 1 >= chunk_end);
+        if (SIMPLE) {
+            const unsigned xoff = (unsigned)lc * (unsigned)(CR * 2) * (unsigned)p.SC;
+            const wg_i32x4 rs_x = wg_make_rsrc(reinterpret_cast<const unsigned char*>(xp) + xoff, p.x_bytes - xoff);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) wg_dma16(rs_x, bB + j * 4096, voff_b[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const int m = lc * CR + b_r[j];
+                const int sy = gy[j] * p.stride - p.pad + kh, sx = gx[j] * p.stride - p.pad + kw;
+                const bool ok = m < p.M && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW && voff_b[j] != OOB;
+                const int pix = (gb[j] * p.SH + sy) * p.SW + sx;
+                wg_dma16(rs_x_abs, bB + j * 4096, ok ? pix * p.SC * 2 + voff_b[j] : OOB);
+                if (!last) {
+                    gx[j] += CR;
+                    while (gx[j] >= p.DW) { gx[j] -= p.DW; if (++gy[j] >= p.DH) { gy[j] = 0; ++gb[j]; } }
+                }
+            }
+        }
+        if (!last) ++lc;
+    };
+
+    // transpose-read addresses: lane reads row tr_row0 (+16) of a 16-channel column block, 8 B at (li&3)*8
+    const int tr_row0 = 4 * lg + (li >> 2);
+    const int tr_col = (li & 3) * 8;
+    int addr_a[TN], addr_b[TC];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        const int colb = (wn * (BN / 2) + a * 16) * 2 + tr_col;
+        addr_a[a] = tr_row0 * RBA + ((((colb >> 4) ^ wg_swz<RBA>(tr_row0)) << 4) | (colb & 15));
+    }
+#pragma unroll
+    for (int b = 0; b < TC; ++b) {
+        const int colb = (wc * (BC / 2) + b * 16) * 2 + tr_col;
+        addr_b[b] = tr_row0 * RBB + ((((colb >> 4) ^ wg_swz<RBB>(tr_row0)) << 4) | (colb & 15));
+    }
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const unsigned char* bA = smem + stage * BUF_BYTES;
+        const unsigned char* bB = bA + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            bf16x8 af[TN], bfr[TC];
+#pragma unroll
+            for (int a = 0; a < TN; ++a) af[a] = tr_frag(bA, addr_a[a] + kk * 32 * RBA, addr_a[a] + (kk * 32 + 16) * RBA);
+#pragma unroll
+            for (int b = 0; b < TC; ++b) bfr[b] = tr_frag(bB, addr_b[b] + kk * 32 * RBB, addr_b[b] + (kk * 32 + 16) * RBB);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TC; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+        if (do_bias) {      // fused bias gradient: column sums of the dy tile that is already in LDS
+            constexpr int TPC = 256 / BN, RPT = CR / TPC;
+            const int col = t % BN, r0 = (t / BN) * RPT;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int row = r0 + r;
+                bsum += (float)*reinterpret_cast<const bf16_t*>(bA + row * RBA + ((((col >> 3) ^ wg_swz<RBA>(row)) << 4) | ((col & 7) * 2)));
+            }
+        }
+    };
+
+    const int nch = chunk_end - chunk_begin;
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
+    int cbuf = 0, lbuf = NS - 1;
+    for (int c = 0; c < nch; ++c) {
+        wg_wait_vmcnt<(NS - 2) * LPT>();
+        __syncthreads();
+        issue(lbuf);
+        compute(cbuf);
+        cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+        lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+    }
+    wg_wait_vmcnt<0>();
+
+    if (do_bias) {
+        const int n = n0 + t % BN;
+        if (n < p.N) atomicAdd(p.dbias + n, bsum);
+    }
+    const int taps = p.KH * p.KW;
+    // Partial tile -> (a) split workspace with plain stores (reduced by wgrad_reduce_kernel) or (b) fp32 atomics.
+    // fp32 atomics run at ~0.3 T elements/s chip-wide (one element per L2 channel clock,
+    // benchmarks/probes/atomic_probe.hip), 4-5x below plain stores, so they are kept for the unsplit case only (where a
+    // dependent load-add-store chain per lane would be slower than fire-and-forget atomics).
+    const int mode = p.part ? 0 : 2;
+    float* const dst = p.part ? p.part + (size_t)blockIdx.y * p.out_elems : p.dw;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        const int nb = n0 + wn * (BN / 2) + a * 16 + lg * 4;
+#pragma unroll
+        for (int b = 0; b < TC; ++b) {
+            const int c = c0 + wc * (BC / 2) + b * 16 + li;
+            if (c >= p.SC) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + r;
+                if (n >= p.N) continue;
+                float v = acc[a][b][r];
+                float* o = dst + ((size_t)n * taps + tap) * p.SC + c;
+                if (mode == 0) { *o = v; continue; }
+                if (p.scale) v *= p.scale[n];
+                atomicAdd(o, v);
+            }
+        }
+    }
+}
+
+// dw[i] += scale[i / row_elems] * sum_s part[s][i].  A workgroup owns 64 float4 columns; its 4 thread rows take the
+// splits round-robin (4 independent loads in flight each) and meet in LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           const float* __restrict__ scale, int out_elems, int row_elems, int nsplit) {
+    __shared__ f32x4 red[3][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = (blockIdx.x * 64 + tx) * 4;
+    const bool ok = i < out_elems;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        int sidx = ty;
+        for (; sidx + 12 < nsplit; sidx += 16) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(part + (size_t)sidx * out_elems + i);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(part + (size_t)(sidx + 4) * out_elems + i);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(part + (size_t)(sidx + 8) * out_elems + i);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(part + (size_t)(sidx + 12) * out_elems + i);
+            a += (v0 + v1) + (v2 + v3);
+        }
+        for (; sidx < nsplit; sidx += 4) a += *reinterpret_cast<const f32x4*>(part + (size_t)sidx * out_elems + i);
+    }
+    if (ty) red[ty - 1][tx] = a;
+    __syncthreads();
+    if (ty || !ok) return;
+    a += red[0][tx] + red[1][tx] + red[2][tx];
+    if (scale) a *= scale[i / row_elems];
+    f32x4* o = reinterpret_cast<f32x4*>(dw + i);
+    *o = *o + a;
+}
+
 // M <= 16 rows (decoder-side Linears): plain outer-product accumulation, one thread per (n, 4 k's)
 __global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             float* __restrict__ dw, const float* __restrict__ scale,
@@ -274,6 +515,57 @@ int launch_wgrad(WgradArgs a, int msplit, hipStream_t s) {
     return RT_OK;
 }
 
+template <int BN, int BC, int CR, int NS, int MINB>
+int launch_wgrad_dma(WgradArgs a, int msplit, float* ws, long long ws_bytes, hipStream_t s) {
+    const bool auto_split = msplit <= 0;
+    const int nt = (a.N + BN - 1) / BN;
+    a.c_tiles = (a.SC + BC - 1) / BC;
+    const int taps = a.KH * a.KW;
+    const int total_chunks = (a.M + CR - 1) / CR;
+    const long long base_blocks = (long long)nt * a.c_tiles * taps;
+    if (msplit <= 0) {
+        static const int target = getenv("REFTR_WG_TARGET") ? atoi(getenv("REFTR_WG_TARGET")) : 512;
+        // each split costs one more partial tile through the workspace: small outputs take >= 256-row splits, larger
+        // ones >= 512 (benchmarks/wgrad_probe.py)
+        static const int minrows_env = getenv("REFTR_WG_MINROWS") ? atoi(getenv("REFTR_WG_MINROWS")) : 0;
+        const int minrows = minrows_env ? minrows_env : ((long long)a.N * taps * a.SC * 4 <= (512 << 10) ? 256 : 512);
+        long long want = (target + base_blocks - 1) / base_blocks;
+        long long maxs = (long long)total_chunks * CR / minrows;
+        if (maxs < 1) maxs = 1;
+        if (want > maxs) want = maxs;
+        if (want < 1) want = 1;
+        msplit = (int)want;
+    }
+    if (msplit > total_chunks) msplit = total_chunks;
+    if (msplit < 1) msplit = 1;
+    const long long out_elems = (long long)a.N * taps * a.SC;
+    if (auto_split && ws && msplit > 1) {           // keep the partials inside the caller's workspace
+        const long long fit = ws_bytes / (out_elems * 4);
+        if (fit < msplit) msplit = fit >= 2 ? (int)fit : msplit;
+    }
+    a.chunks_per_block = (total_chunks + msplit - 1) / msplit;
+    const int gy = (total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
+    const bool use_ws = ws && gy > 1 && (long long)gy * out_elems * 4 <= ws_bytes && (out_elems & 3) == 0;
+    a.part = use_ws ? ws : nullptr; a.out_elems = (int)out_elems;
+    constexpr size_t smem = (size_t)NS * CR * (BN * 2 + BC * 2);
+    const dim3 grid((unsigned)base_blocks, (unsigned)gy), block(256);
+    const bool simple = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0);
+    if (simple) {
+        if (smem > 65536) (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BN, BC, true, CR, NS, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<BN, BC, true, CR, NS, MINB>), grid, block, smem, s, a.dy, a.x, a);
+    } else {
+        if (smem > 65536) (void)hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<BN, BC, false, CR, NS, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<BN, BC, false, CR, NS, MINB>), grid, block, smem, s, a.dy, a.x, a);
+    }
+    RT_CHECK_LAUNCH();
+    if (use_ws) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((out_elems / 4 + 63) / 64)), dim3(256), 0, s, ws, a.dw, a.scale,
+                           (int)out_elems, taps * a.SC, gy);
+        RT_CHECK_LAUNCH();
+    }
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
@@ -287,7 +579,7 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     if (M * d->N >= 0x3fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
-    a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0;
+    a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0; a.part = nullptr; a.out_elems = 0;
     a.dy_bytes = (unsigned)(M * d->N * 2);
     a.x_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;
@@ -297,6 +589,26 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
         hipLaunchKernelGGL(small_m_wgrad_kernel, dim3(blocks), dim3(256), 0, s, a.dy, a.x, a.dw, a.scale, a.dbias, a.M, a.N, a.SC);
         RT_CHECK_LAUNCH();
         return RT_OK;
+    }
+    // variant: 0 = LDS-DMA kernels (default), 9 = register-staged kernel, 1..5 = pinned 128x128 DMA staging shapes
+    static const int wgv_env = getenv("REFTR_WGV") ? atoi(getenv("REFTR_WGV")) : 0;
+    const int wgv = d->variant > 0 ? d->variant : wgv_env;
+    float* ws = d->workspace; long long wsb = d->workspace ? d->workspace_bytes : 0;
+    static const int no_ws = getenv("REFTR_WG_NOWS") ? atoi(getenv("REFTR_WG_NOWS")) : 0;
+    if (no_ws) { ws = nullptr; wsb = 0; }
+    if (wgv != 9 && (a.N & 7) == 0) {
+        if (a.N >= 128 && a.SC >= 128) {
+            switch (wgv) {
+                case 1: return launch_wgrad_dma<128, 128, 64, 2, 2>(a, d->msplit, ws, wsb, s);
+                case 2: return launch_wgrad_dma<128, 128, 32, 4, 2>(a, d->msplit, ws, wsb, s);
+                case 3: return launch_wgrad_dma<128, 128, 64, 3, 2>(a, d->msplit, ws, wsb, s);
+                case 5: return launch_wgrad_dma<128, 128, 64, 4, 2>(a, d->msplit, ws, wsb, s);
+                default: return launch_wgrad_dma<128, 128, 32, 3, 2>(a, d->msplit, ws, wsb, s);
+            }
+        }
+        if (a.N >= 128) return launch_wgrad_dma<128, 64, 64, 3, 2>(a, d->msplit, ws, wsb, s);
+        if (a.SC >= 128) return launch_wgrad_dma<64, 128, 64, 3, 2>(a, d->msplit, ws, wsb, s);
+        return launch_wgrad_dma<64, 64, 64, 4, 2>(a, d->msplit, ws, wsb, s);
     }
     if (a.N >= 128 && a.SC >= 128) return launch_wgrad<128, 128>(a, d->msplit, s);
     if (a.N >= 128) return launch_wgrad<128, 64>(a, d->msplit, s);

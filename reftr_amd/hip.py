@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 9
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -38,7 +38,8 @@ class ConvWgradDesc(Structure):
         ("B", c_int32), ("SH", c_int32), ("SW", c_int32), ("SC", c_int32),
         ("DH", c_int32), ("DW", c_int32), ("N", c_int32),
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
-        ("msplit", c_int32), ("dbias", c_void_p),
+        ("msplit", c_int32), ("dbias", c_void_p), ("variant", c_int32),
+        ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -310,14 +311,30 @@ def linear(x, w, bias=None, **kw):
     return conv_gemm(x, w, geom=(M, 1, 1, K, 1, 1, N, 1, 1, 1, 0), bias=bias, **kw)
 
 
-def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None):
+_WGRAD_WS = {}
+WGRAD_WS_BYTES = 64 << 20
+
+
+def _wgrad_workspace(dev):
+    """Per-(device, stream) scratch for rt_conv_wgrad's split partials: launches on concurrent streams must not
+    share it, launches on one stream reuse it in order."""
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(WGRAD_WS_BYTES // 4, dtype=torch.float32, device=dev)
+    return ws
+
+
+def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, workspace=True):
     """dw[N,KH,KW,SC] (fp32, accumulated) += scale[n] * sum_m dy[m,n] * gather(x)[m,(kh,kw,c)]."""
     B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw")
     _req(scale, torch.float32, "scale")
     assert dy.numel() == B * DH * DW * N and x.numel() == B * SH * SW * SC and dw.numel() == N * KH * KW * SC
     _req(dbias, torch.float32, "dbias")
-    d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit, _p(dbias))
+    ws = _wgrad_workspace(dy.device) if workspace else None
+    d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit, _p(dbias), variant,
+                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0)
     _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
            lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"), tag=("W",) + tuple(geom))
     return dw

@@ -41,6 +41,9 @@ def hash_keep(seed, idx, p):
     (200, 256, 256, 0), (200, 256, 256, 1), (200, 256, 256, 2), (200, 256, 256, 3),
     (3520, 256, 2048, 0), (3520, 2048, 256, 0), (320, 768, 3072, 0), (8, 256, 256, 0),
     (48, 256, 4, 0), (129, 64, 68, 0),
+    # LDS-DMA variants (tile / stages): ragged M and N, K of one tile and of many
+    (200, 256, 256, 11), (200, 256, 256, 12), (200, 256, 256, 13), (333, 64, 68, 21), (333, 192, 68, 22),
+    (129, 64, 68, 31), (3520, 2048, 256, 32), (320, 768, 3072, 33), (3520, 256, 2048, 13),
 ])
 def test_linear_fwd(hip, M, K, N, hint):
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -94,6 +97,29 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33])
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", [CONV_CASES[1], CONV_CASES[4], CONV_CASES[2]])
+def test_conv_dma_variants(hip, hint, B, H, W, Ci, Co, k, s, p):
+    """The LDS-DMA tile variants against torch fp32: forward gather and transposed (backward-data) gather."""
+    g = torch.Generator().manual_seed(hint * 1000 + H)
+    x = bf(torch.randn(B, Ci, H, W, generator=g)).float().requires_grad_(True)
+    w = bf(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).float().requires_grad_(True)
+    bias = torch.randn(Co, generator=g)
+    y = F.conv2d(x, w, bias, stride=s, padding=p)
+    Ho, Wo = y.shape[-2:]
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy.float())
+    x_nhwc = nhwc(x.detach()).bfloat16().cuda()
+    w_k = w.detach().permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    _, of = hip.conv_gemm(x_nhwc, w_k, geom=(B, H, W, Ci, Ho, Wo, Co, k, k, s, p), bias=bias.cuda(), out_bf16=False,
+                          out_f32=True, tile_hint=hint)
+    assert rel(of, nhwc(y.detach()).reshape(-1, Co)) < TOL_F32
+    w_t = w.detach().permute(1, 2, 3, 0).contiguous().bfloat16().cuda()
+    _, dxf = hip.conv_gemm(nhwc(dy).cuda(), w_t, geom=(B, Ho, Wo, Co, H, W, Ci, k, k, s, p), transposed=True,
+                           out_bf16=False, out_f32=True, tile_hint=hint)
+    assert rel(dxf, nhwc(x.grad).reshape(-1, Ci)) < TOL_F32
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(hip, B, H, W, Ci, Co, k, s, p):
     g = torch.Generator().manual_seed(B * 100 + H + Ci)
@@ -136,6 +162,42 @@ def test_linear_wgrad(hip, M, K, N):
     dw = torch.zeros(N, K, device="cuda")
     hip.linear_wgrad(dy.cuda(), x.cuda(), dw)
     assert rel(dw, dy.float().T @ x.float()) < TOL_F32
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 9])
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", [(2, 20, 24, 128, 128, 3, 2, 1), (3, 9, 9, 64, 64, 3, 1, 1), (2, 20, 20, 256, 512, 1, 2, 0),
+                                               (1, 13, 17, 64, 128, 3, 2, 1), (2, 10, 14, 512, 128, 1, 1, 0), (3, 21, 19, 128, 64, 3, 1, 1)])
+def test_conv_wgrad_dma_variants(hip, variant, B, H, W, Ci, Co, k, s, p):
+    g = torch.Generator().manual_seed(variant * 100 + H)
+    x = bf(torch.randn(B, Ci, H, W, generator=g)).float()
+    w = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=s, padding=p)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy.float())
+    Ho, Wo = y.shape[-2:]
+    scale = torch.rand(Co, generator=g) + 0.5
+    dw = torch.zeros(Co, k, k, Ci, device="cuda"); db = torch.zeros(Co, device="cuda")
+    geom = (B, H, W, Ci, Ho, Wo, Co, k, k, s, p)
+    ref_dw = w.grad.permute(0, 2, 3, 1) * scale.view(-1, 1, 1, 1)
+    # split partials through the workspace (plain stores + reduction pass), sole-writer read-modify-write (msplit 1),
+    # and fp32 atomics (no workspace) must all accumulate the same gradient
+    for msplit, ws in ((0, True), (1, True), (3, True), (3, False), (0, False)):
+        dw.fill_(1.0); db.zero_()
+        hip.conv_wgrad(nhwc(dy).cuda(), nhwc(x).bfloat16().cuda(), dw, geom=geom, scale=scale.cuda(), dbias=db, msplit=msplit,
+                       variant=variant, workspace=ws)
+        assert rel(dw - 1.0, ref_dw) < 5 * TOL_F32, (msplit, ws)
+        assert rel(db, dy.float().sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 9])
+@pytest.mark.parametrize("M,K,N", [(200, 256, 256), (3520, 256, 2048), (3520, 2048, 256), (320, 768, 768), (77, 64, 72), (1000, 128, 64)])
+def test_linear_wgrad_dma_variants(hip, variant, M, K, N):
+    g = torch.Generator().manual_seed(M + N + variant)
+    x = bf(torch.randn(M, K, generator=g)); dy = bf(torch.randn(M, N, generator=g))
+    dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    hip.linear_wgrad(dy.cuda(), x.cuda(), dw, dbias=db, variant=variant)
+    assert rel(dw, dy.float().T @ x.float()) < TOL_F32
+    assert rel(db, dy.float().sum(0)) < 1e-5
 
 
 def test_errors_are_loud(hip):
