@@ -315,6 +315,18 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
     const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
     const int n0 = tile_n * BN, m0 = tile_m * BM;
 
+    // MODE 3 (stride-2 backward-data): blockIdx.y is the output parity class (y&1, x&1).  Only taps with
+    // kh = (y+pad) mod 2, kw = (x+pad) mod 2 reach a source pixel, so a class walks 1/4 of the taps on average
+    // instead of multiplying zeros for the other 3/4; its rows are the class's pixels in (b, y/2, x/2) order.
+    int cy = 0, cx = 0, ny = p.DH, nx = p.DW, kh0 = 0, kw0 = 0, Mloc = p.M;
+    if (MODE == 3) {
+        cy = blockIdx.y >> 1; cx = blockIdx.y & 1;
+        ny = (p.DH - cy + 1) >> 1; nx = (p.DW - cx + 1) >> 1;
+        Mloc = p.B * ny * nx;
+        kh0 = (cy + p.pad) & 1; kw0 = (cx + p.pad) & 1;
+        if (m0 >= Mloc) return;
+    }
+
     const int srow = t >> 3;
     const int chunk = (t & 7) ^ (srow & 7);        // source-side swizzle
     constexpr int OOB = 0x7fffffff;
@@ -329,15 +341,16 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int m = m0 + srow + 32 * j;
-        const bool ok = m < p.M;
+        const bool ok = m < Mloc;
         const int mm = ok ? m : 0;
         if (MODE == 0) {
             b_off[j] = ok ? (mm * p.SC + chunk * 8) * 2 : OOB; b_y[j] = 0; b_x[j] = 0;
         } else {
-            const int dx = mm % p.DW;
-            const int tmp = mm / p.DW;
-            const int dy = tmp % p.DH;
-            const int b = tmp / p.DH;
+            int dx = mm % nx;
+            const int tmp = mm / nx;
+            int dy = tmp % ny;
+            const int b = tmp / ny;
+            if (MODE == 3) { dy = 2 * dy + cy; dx = 2 * dx + cx; }
             if (MODE == 1) { b_y[j] = dy * p.stride - p.pad; b_x[j] = dx * p.stride - p.pad; }
             else           { b_y[j] = dy + p.pad;            b_x[j] = dx + p.pad; }
             if (!ok) b_y[j] = -(1 << 28);           // every tap of a ragged row fails the bounds test
@@ -351,15 +364,19 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K >> 6;
-    int lk = 0, c0 = 0, kw = 0, kh = 0;
+    int nk = p.K >> 6;
+    if (MODE == 3) {
+        const int nkh = kh0 < p.KH ? (p.KH - kh0 + 1) >> 1 : 0, nkw = kw0 < p.KW ? (p.KW - kw0 + 1) >> 1 : 0;
+        nk = nkh * nkw * (p.SC >> 6);
+    }
+    int lk = 0, c0 = 0, kw = kw0, kh = kh0;
     const i32x4 rs_w = rt_make_rsrc(wgt, p.wgt_bytes), rs_x = rt_make_rsrc(src, p.src_bytes);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
 
     auto issue_tile = [&](int buf) __attribute__((always_inline)) {
         const unsigned bA = lds0 + buf * BUF_BYTES;      // this wave's 8-row group of each 32-row slab
         const unsigned bB = bA + A_BYTES;
-        const int k0b = lk << 7;
+        const int k0b = MODE == 3 ? ((kh * p.KW + kw) * p.SC + c0) * 2 : lk << 7;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) rt_dma16(rs_w, bA + j * 4096, a_off[j], k0b);
 #pragma unroll
@@ -370,7 +387,11 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
                 bool ok;
                 int sy, sx;
                 if (MODE == 1) { sy = b_y[j] + kh; sx = b_x[j] + kw; ok = true; }
-                else {
+                else if (MODE == 3) {
+                    const int ny_ = b_y[j] - kh, nx_ = b_x[j] - kw;      // even by construction of the class
+                    ok = (ny_ | nx_) >= 0;
+                    sy = ny_ >> 1; sx = nx_ >> 1;
+                } else {
                     const int ny = b_y[j] - kh, nx = b_x[j] - kw;
                     const int msk = p.stride - 1;
                     ok = ((ny | nx) >= 0) && (((ny | nx) & msk) == 0);
@@ -383,7 +404,10 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
         }
         if (lk + 1 < nk) {
             ++lk;
-            if (MODE != 0) {
+            if (MODE == 3) {
+                c0 += 64;
+                if (c0 >= p.SC) { c0 = 0; kw += 2; if (kw >= p.KW) { kw = kw0; kh += 2; } }
+            } else if (MODE != 0) {
                 c0 += 64;
                 if (c0 >= p.SC) { c0 = 0; ++kw; if (kw >= p.KW) { kw = 0; ++kh; } }
             }
@@ -434,8 +458,12 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
         if (n >= p.N) continue;
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
-            const int m = m0 + wm * (BM / 2) + b * 16 + li;
-            if (m >= p.M) continue;
+            int m = m0 + wm * (BM / 2) + b * 16 + li;
+            if (m >= Mloc) continue;
+            if (MODE == 3) {            // class-local row -> pixel row of the NHWC output
+                const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
+                m = (bb * p.DH + 2 * yy + cy) * p.DW + 2 * xx + cx;
+            }
             epilogue4(p, m, n, acc[a][b]);
         }
     }
@@ -498,6 +526,7 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
     const size_t smem = (size_t)NS * (BM + BN) * 128;
     const dim3 grid((unsigned)(mt * nt)), block(256);
     const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
+    static const int par_env = getenv("REFTR_S2PARITY") ? atoi(getenv("REFTR_S2PARITY")) : 1;
     auto set_smem = [&](const void* f) {
         if (smem > 65536) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     };
@@ -507,6 +536,11 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
     } else if (!a.transposed) {
         set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 1, NS, MINB>);
         hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
+    } else if (a.stride == 2 && par_env) {
+        const int m_cls = a.B * ((a.DH + 1) / 2) * ((a.DW + 1) / 2);           // largest parity class
+        const dim3 grid3((unsigned)(((m_cls + BM - 1) / BM) * nt), 4);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 3, NS, MINB>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 3, NS, MINB>), grid3, block, smem, s, a.src, a.wgt, a);
     } else {
         set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 2, NS, MINB>);
         hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
