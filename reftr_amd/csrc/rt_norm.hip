@@ -132,6 +132,148 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const rt_layernorm_b
     }
 }
 
+// ---------------- vectorised variants for D = 256 * V (V = 1: transformer width, V = 3: BERT width) ----------------
+// Same arithmetic as the kernels above; lane l owns channels 4*(64*i + l) .. +3 of float4 group i, so every tensor row
+// is moved with 16-byte accesses (8-byte for bf16) instead of four strided dword accesses per group.
+template <int V>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const rt_layernorm_desc p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    constexpr int D = 256 * V;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (size_t)row * D);
+    f32x4 v[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { v[i] = xr[i * 64 + lane]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    const float mean = rt_wave_sum(s) * (1.f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+    const float rstd = rsqrtf(rt_wave_sum(ss) * (1.f / D) + p.eps);
+    if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
+    const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t seed = do_drop ? rt_site_seed(p.seed_dev, p.drop_seed) : 0u;
+    bf16_t* yb = (bf16_t*)p.y_bf16;
+    bf16_t* ypb = (bf16_t*)p.ypos_bf16;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const f32x4 gam = *reinterpret_cast<const f32x4*>(p.gamma + c), bet = *reinterpret_cast<const f32x4*>(p.beta + c);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = (v[i][e] - mean) * rstd * gam[e] + bet[e];
+            if (p.act == RT_ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+            if (do_drop) y[e] = (rt_hash32(seed, (uint32_t)(row * D + c + e)) >= thresh) ? y[e] * ks : 0.f;
+        }
+        const size_t o = (size_t)orow * D + c;
+        if (p.y_f32) *reinterpret_cast<f32x4*>(p.y_f32 + o) = y;
+        if (yb) {
+            bf16x4 b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = (bf16_t)y[e];
+            *reinterpret_cast<bf16x4*>(yb + o) = b;
+        }
+        if (ypb) {
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + o);
+            bf16x4 b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = (bf16_t)(y[e] + ps[e]);
+            *reinterpret_cast<bf16x4*>(ypb + o) = b;
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const rt_layernorm_bwd_desc p) {
+    constexpr int D = 256 * V;
+    __shared__ float sm_g[4][D];
+    __shared__ float sm_b[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[V], db[V], gam[V], bet[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = dg[i];
+        gam[i] = *reinterpret_cast<const f32x4*>(p.gamma + (i * 64 + lane) * 4);
+        bet[i] = p.beta ? *reinterpret_cast<const f32x4*>(p.beta + (i * 64 + lane) * 4) : dg[i];
+    }
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const bool do_drop2 = p.drop2_p > 0.f;
+    const uint32_t thresh2 = rt_drop_thresh(p.drop2_p);
+    const float ks2 = do_drop2 ? 1.f / (1.f - p.drop2_p) : 1.f;
+    const uint32_t seed = do_drop ? rt_site_seed(p.seed_dev, p.drop_seed) : 0u;
+    const uint32_t seed2 = do_drop2 ? rt_site_seed(p.seed_dev, p.drop2_seed) : 0u;
+    bf16_t* dxb = (bf16_t*)p.dx_bf16;
+
+    for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
+        const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (size_t)row * D);
+        const f32x4* dyr = reinterpret_cast<const f32x4*>(p.dy + (size_t)orow * D);
+        const f32x4* dy2r = p.dy2 ? reinterpret_cast<const f32x4*>(p.dy2 + (size_t)orow * D) : nullptr;
+        f32x4 xh[V], g[V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            f32x4 d = dyr[i * 64 + lane];
+            if (dy2r) d += dy2r[i * 64 + lane];
+            const f32x4 xv = xr[i * 64 + lane];
+            const int c = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (xv[e] - mean) * rstd;
+                float de = d[e];
+                if (do_drop) de = (rt_hash32(seed, (uint32_t)(row * D + c + e)) >= thresh) ? de * ks : 0.f;
+                if (p.act == RT_ACT_RELU) { if (xh[i][e] * gam[i][e] + bet[i][e] <= 0.f) de = 0.f; }
+                dg[i][e] += de * xh[i][e]; db[i][e] += de;
+                g[i][e] = de * gam[i][e];
+                s1 += g[i][e]; s2 += g[i][e] * xh[i][e];
+            }
+        }
+        s1 = rt_wave_sum(s1) * (1.f / D); s2 = rt_wave_sum(s2) * (1.f / D);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const size_t o = (size_t)row * D + c;
+            f32x4 dx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+            if (p.dx_f32) *reinterpret_cast<f32x4*>(p.dx_f32 + o) = dx;
+            if (dxb) {
+                bf16x4 b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d2 = dx[e];
+                    if (do_drop2) d2 = (rt_hash32(seed2, (uint32_t)(o + e)) >= thresh2) ? d2 * ks2 : 0.f;
+                    b[e] = (bf16_t)d2;
+                }
+                *reinterpret_cast<bf16x4*>(dxb + o) = b;
+            }
+        }
+    }
+    if (!p.dgamma && !p.dbeta) return;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        *reinterpret_cast<f32x4*>(&sm_g[wave][(i * 64 + lane) * 4]) = dg[i];
+        *reinterpret_cast<f32x4*>(&sm_b[wave][(i * 64 + lane) * 4]) = db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float a = sm_g[0][c] + sm_g[1][c] + sm_g[2][c] + sm_g[3][c];
+        const float b = sm_b[0][c] + sm_b[1][c] + sm_b[2][c] + sm_b[3][c];
+        if (p.dgamma) atomicAdd(p.dgamma + c, a);
+        if (p.dbeta) atomicAdd(p.dbeta + c, b);
+    }
+}
+
 // ---------------- GroupNorm over token-major images x[b][p][c], groups of C/G channels ----------------
 // stats[b][g] = {sum, sumsq}; a block covers (b, 64-pixel chunk) with one thread per channel.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
@@ -236,7 +378,11 @@ extern "C" int rt_layernorm_fwd(const rt_layernorm_desc* d, rt_stream_t stream) 
     if (!d || !d->x || !d->gamma || !d->beta) return RT_ERR_BADARG;
     if (d->D <= 0 || d->D > 64 * LN_MAX_PER_LANE || d->M <= 0) return RT_ERR_UNSUPPORTED;
     if (d->ypos_bf16 && !d->pos) return RT_ERR_BADARG;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((d->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
+    static const int vec = getenv("REFTR_LNVEC") ? atoi(getenv("REFTR_LNVEC")) : 1;
+    const dim3 grid((d->M + 3) / 4);
+    if (vec && d->D == 256)      hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    else if (vec && d->D == 768) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    else                         hipLaunchKernelGGL(layernorm_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
@@ -251,7 +397,10 @@ extern "C" int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stre
     int blocks = (d->M + 3) / 4;
     if (blocks > lnb) blocks = lnb;
     if (!d->dgamma && !d->dbeta) { blocks = (d->M + 3) / 4; if (blocks > 1024) blocks = 1024; }
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    static const int vec = getenv("REFTR_LNVEC") ? atoi(getenv("REFTR_LNVEC")) : 1;
+    if (vec && d->D == 256)      hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    else if (vec && d->D == 768) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    else                         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
