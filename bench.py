@@ -108,8 +108,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists for the product)"
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = os.environ.get("REFTR_DDP_FORCE") == "1"        # one-GPU exercise of the data-parallel schedule
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
     dev = torch.device("cuda", local)
 
@@ -133,7 +135,7 @@ def main():
     model.store.P["bbox_embed.layers.2.weight"].normal_(0, 0.02)
     model.mark_dirty()
     opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
-    runner = DistributedDataParallel(model) if world > 1 else model
+    runner = DistributedDataParallel(model) if (world > 1 or force_dist) else model
     model.train()
 
     samples, targets = synth_batch(B, S_, S_, Lq, dev, 1234 + rank)
@@ -187,7 +189,7 @@ def main():
     value = B * world * args.steps / el
 
     roof = None
-    if rank == 0 and not args.no_kernel_roofline:
+    if rank == 0 and world == 1 and not force_dist and not args.no_kernel_roofline:   # (collectives need every rank)
         recs = []
         hip.set_launch_timer(recs)
         eager_step()
@@ -206,7 +208,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"RefCOCO-shaped REC train step, ResNet-50 + BERT-base + VL transformer 6+6, "
                                f"{S_}x{S_}, batch {B}/GPU, L=40, aux loss, dropout on, clip 0.1, AdamW (configs[1])",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "launch": mode},
+                   "global_batch": B * world, "parallelism": f"dp{world}", "launch": mode + ("+dp-overlap" if (world > 1 or force_dist) else "")},
         "loss": loss_value,
     }
     if rank == 0:

@@ -111,40 +111,78 @@ def _copy_batch(dst_s, dst_t, samples, targets):
                 d[k].copy_(v, non_blocking=True)
 
 
+# Stream capture is made thread-local: torch.distributed's RCCL watchdog thread polls hipEventQuery on its own schedule,
+# which a process-global capture would turn into hipErrorStreamCaptureUnsupported (and an abort) at world_size > 1.
+_CAPTURE_MODE = "thread_local"
+
+
 class CapturedTrainStep:
     """The loop body (engine_vg.py:40-72) captured into HIP graphs for one input shape.
 
     A step is ~1500 kernel launches; replaying them from a hipGraph removes the per-launch host cost.  Everything
     that changes from step to step lives in device memory (dropout step-seed word, optimizer step counter, the
     input batch copied into static buffers), so replays are real training steps.  With world_size > 1 the body is
-    split in two graphs around the (eager) gradient all-reduce.  Learning-rate changes re-capture the optimizer
+    three graphs (forward + backward phase 1 | ResNet backward | clip + AdamW) around the two eager, asynchronous
+    gradient exchanges of reftr_amd.parallel.DistributedDataParallel.  Learning-rate changes re-capture the optimizer
     part (`refresh_lr()`), shapes other than the captured one must use `train_step`.
     """
 
-    def __init__(self, model, criterion, optimizer, max_norm, samples, targets, warmup=2):
+    def __init__(self, model, criterion, optimizer, max_norm, samples, targets, warmup=2, force_two_phase=False):
         self.model, self.criterion, self.optimizer, self.max_norm = model, criterion, optimizer, max_norm
         self.inner = getattr(model, "module", model)
         self.ddp = model if model is not self.inner else None
         self.s, self.t = _clone_batch(samples, targets)
         self.key = self.shape_key(samples, targets)
         self._lrs = [g["lr"] for g in optimizer.param_groups]
-        hooks, self.inner._post_backward_hooks = self.inner._post_backward_hooks, []     # collectives stay outside graphs
+        inner = self.inner
+        warmup = max(warmup, 2)          # the second step is the first one with the steady-state operand refresh
+        # criterion.py:176-180 averages the box count over ranks: that collective runs eagerly before every replay and
+        # the graph reads its result from a static device scalar
+        self.nb = None
+        if utils.is_dist_avail_and_initialized():
+            self.nb = torch.zeros(1, dtype=torch.float32, device=self.s["sentence"].device)
+            self._refresh_num_boxes(targets)
+            criterion.num_boxes_static = self.nb
+        # collectives stay outside the graphs: the engine calls the hooks between replays
+        self._mid, inner._mid_backward_hooks = inner._mid_backward_hooks, []
+        self._post, inner._post_backward_hooks = inner._post_backward_hooks, []
+        # data parallel: backward is captured in two graphs (everything but the ResNet | the ResNet) so that the first
+        # gradient exchange runs under the second graph
+        self.two_phase = bool(self._mid) or force_two_phase
+        inner._defer_phase2 = self.two_phase
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    self._fwd_bwd(); self._sync_grads(hooks); self._opt()
+                    self._fwd_bwd(); self._run(self._mid)
+                    if self.two_phase:
+                        inner.finish_backward()
+                    self._run(self._post); self._opt()
             torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()     # no collective in flight while capturing (see _CAPTURE_MODE)
             self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode=_CAPTURE_MODE):
                 self.out = self._fwd_bwd()
+            self.g_bb = None
+            if self.two_phase:
+                self.g_bb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_bb, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
+                    inner.finish_backward()
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+            with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._opt()
         finally:
-            self.inner._post_backward_hooks = hooks
-        self._hooks = hooks
+            inner._mid_backward_hooks, inner._post_backward_hooks = self._mid, self._post
+            inner._defer_phase2 = False
+            criterion.num_boxes_static = None
+
+    def _refresh_num_boxes(self, targets):
+        if self.nb is None:
+            return
+        self.nb.fill_(float(sum(len(t["labels"]) for t in targets)))
+        torch.distributed.all_reduce(self.nb)
+        self.nb.div_(utils.get_world_size())
 
     @staticmethod
     def shape_key(samples, targets):
@@ -163,7 +201,7 @@ class CapturedTrainStep:
         return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}
 
     @staticmethod
-    def _sync_grads(hooks):
+    def _run(hooks):
         for h in hooks:
             h()
 
@@ -176,8 +214,12 @@ class CapturedTrainStep:
         if [g["lr"] for g in self.optimizer.param_groups] != self._lrs:
             self.refresh_lr()
         _copy_batch(self.s, self.t, samples, targets)
+        self._refresh_num_boxes(targets)
         self.g_fb.replay()
-        self._sync_grads(self._hooks)
+        self._run(self._mid)
+        if self.g_bb is not None:
+            self.g_bb.replay()
+        self._run(self._post)
         self.g_opt.replay()
         self.optimizer.step_count += 1
         self.inner.mark_dirty()          # eager forwards after a replay must rebuild the bf16 operands
@@ -187,7 +229,7 @@ class CapturedTrainStep:
         self._lrs = [g["lr"] for g in self.optimizer.param_groups]
         self.g_opt = torch.cuda.CUDAGraph()
         sc = self.optimizer.step_count
-        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
             self._opt()
         self.optimizer.step_count = sc
 

@@ -35,6 +35,7 @@ class CriterionVGMultiPhrase(nn.Module):
         self.losses = losses
         self._off_cache = {}
         self._nb_cache = {}
+        self.num_boxes_static = None      # CapturedTrainStep: device scalar it refreshes (all-reduced) before every replay
 
     def _targets(self, targets, device):
         lens = tuple(int(t["boxes"].shape[0]) for t in targets)
@@ -57,7 +58,9 @@ class CriterionVGMultiPhrase(nn.Module):
         # criterion.py:176-180: number of target boxes averaged over ranks, clamp >= 1 (in the kernel); kept on
         # the device so no host sync is needed
         nb = float(sum(len(t["labels"]) for t in targets))
-        if is_dist_avail_and_initialized():
+        if self.num_boxes_static is not None:
+            num_boxes = self.num_boxes_static
+        elif is_dist_avail_and_initialized():
             num_boxes = torch.tensor([nb], dtype=torch.float32, device=device)
             torch.distributed.all_reduce(num_boxes)
             num_boxes = num_boxes / get_world_size()

@@ -50,7 +50,10 @@ class RefTR(nn.Module):
         self._full_refresh = True
         self._step = 0
         self._saved = None
+        self._mid_backward_hooks = []     # after phase 1 of backward (everything but the ResNet): early DP exchange
         self._post_backward_hooks = []
+        self._defer_phase2 = False        # engine-driven: stop after phase 1, `finish_backward()` runs the ResNet part
+        self._pending = None
         self.reset_parameters()
 
     # ------------------------------------------------------------------ init / state
@@ -352,8 +355,9 @@ class RefTR(nn.Module):
         _, dip16 = H.groupnorm_bwd(dxa, sv["ip"].view(B, HW, E), st.P["input_proj.0.1.weight"], sv["gn_stats"],
                                    st.G["input_proj.0.1.weight"], st.G["input_proj.0.1.bias"], 32, 1e-5, dy2=dxb,
                                    rows_per_img=S, row_off=Lq)
-        # ---- BERT backward (sentence pass; phrase pass for multi-phrase inputs) on the side stream, concurrently
-        # with the input_proj / ResNet backward below
+        # ---- BERT backward (sentence pass; phrase pass for multi-phrase inputs).  Single GPU: on the side stream,
+        # concurrently with the ResNet backward.  Data parallel: on the main stream BEFORE the ResNet backward, so that
+        # phase 1 ends with every non-ResNet gradient final and their all-reduce (>80 % of the bytes) runs under phase 2.
         def _bert_bwd():
             if sv["pctx"] is None:
                 net.bert_bwd(sv["bctx"], d_seq, dpool)
@@ -362,13 +366,30 @@ class RefTR(nn.Module):
                 net.bert_bwd(sv["pctx"], None, dpool)
             net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
         net.wg.flush()               # transformer weight gradients queued so far -> their own stream, from here
-        net.side.run(_bert_bwd, d_seq, dpool)
+        two_phase = self._defer_phase2 or bool(self._mid_backward_hooks)
+        if two_phase:
+            _bert_bwd()
+        else:
+            net.side.run(_bert_bwd, d_seq, dpool)
         g_c5, _ = net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], gate=sv["c5"])
         if getattr(self, "_debug", False):
             self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=g_c5.clone())
-        self.body.backward(sv["bb_saved"], g_c5)
-        net.side.join()
-        net.wg.join()
+        self._pending = (sv["bb_saved"], g_c5)
+        if two_phase:
+            net.wg.join()
+            for hook in self._mid_backward_hooks:
+                hook()
+            if self._defer_phase2:
+                return
+        self.finish_backward()
+
+    def finish_backward(self):
+        """Phase 2 of backward: the ResNet body (its gradients are the last to become final)."""
+        bb_saved, g_c5 = self._pending
+        self._pending = None
+        self.body.backward(bb_saved, g_c5)
+        self.net.side.join()
+        self.net.wg.join()
         H.set_seed_dev(None)
         for hook in self._post_backward_hooks:
             hook()

@@ -34,7 +34,15 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(7 + rank)
         local = torch.randn(m.store.flat_g.numel(), generator=g)
         m.store.flat_g.copy_(local)
-        for hook in m._post_backward_hooks:
+        early, late = ddp.phase_bounds()                         # early = main + BERT groups, late = ResNet group
+        spans = sorted(early + late)
+        covered = covered and spans[0][0] == 0 and spans[-1][1] == m.store.flat_g.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        from reftr_amd.models import layout as Lm
+        bb = m.store.group_range[Lm.GROUP_BACKBONE]
+        covered = covered and late[0][0] == bb[0] and late[-1][1] == bb[1]
+        for hook in m._mid_backward_hooks:                       # phase 1 done -> early exchange in flight
+            hook()
+        for hook in m._post_backward_hooks:                      # phase 2 done -> late exchange + wait for everything
             hook()
         both = [torch.randn(m.store.flat_g.numel(), generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
         ok_sum = torch.allclose(m.store.flat_g, both[0] + both[1], atol=1e-6)

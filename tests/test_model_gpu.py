@@ -147,6 +147,44 @@ def test_three_training_steps(hip):
     assert 1e-6 < float(d.mean()) < 5e-5
 
 
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_captured_step_matches_eager(hip, two_phase):
+    """CapturedTrainStep (hipGraph replay; two_phase = the data-parallel schedule with backward split in
+    [everything but the ResNet | the ResNet]) must walk the same trajectory as the eager loop body: same kernels, so
+    only atomics-order noise separates them."""
+    from reftr_amd.engine_vg import CapturedTrainStep, train_step
+    from reftr_amd.optim import FusedAdamW
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    runs = []
+    for mode in ("eager", "graph"):
+        model, crit, P, ocfg = build(small=True)
+        model.eval()
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        if mode == "graph":
+            p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
+            cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg, warmup=1, force_two_phase=two_phase)
+            assert (cap.g_bb is not None) == two_phase
+            # capture warm-up steps moved the weights: restore the initial state before comparing trajectories
+            model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
+            model.mark_dirty(full=True)
+        losses, norms = [], []
+        for it in range(3):
+            if mode == "eager":
+                lv, _, _, gn = train_step(model, crit, s, tg, opt, None, max_norm=0.1)
+            else:
+                l, _, gn = cap(s, tg)
+                lv = float(l)
+            losses.append(lv); norms.append(float(gn))
+        runs.append((losses, norms, model.store.flat_p.clone()))
+    (l0, n0, p_e), (l1, n1, p_g) = runs
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < 2e-3 * abs(a), (l0, l1)
+    for a, b in zip(n0, n1):
+        assert abs(a - b) < 2e-2 * abs(a), (n0, n1)
+    assert rel(p_g, p_e) < 1e-5
+
+
 def test_dropout_train_mode_runs_and_is_reproducible(hip):
     model, crit, P, ocfg = build(small=True)
     model.train()
