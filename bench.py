@@ -191,10 +191,22 @@ def main():
     roof = None
     if rank == 0 and world == 1 and not force_dist and not args.no_kernel_roofline:   # (collectives need every rank)
         recs = []
-        hip.set_launch_timer(recs)
-        eager_step()
+        # HIP events bracket every rt_conv_gemm / rt_conv_wgrad launch on the launch stream.  The stream is first blocked
+        # by a spin kernel while the host enqueues the whole step (no host sync inside), so the kernels then run back to
+        # back as they do under graph replay and the event pairs measure kernel time, not host launch gaps.
+        side_was = model.net.side.enabled
+        model.net.side.enabled = False          # one stream for this pass: per-launch durations must be additive
+        if mode == "hipgraph":
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(2.4e9 * 0.12))
+            hip.set_launch_timer(recs)
+            cap._fwd_bwd(); cap._opt()
+        else:
+            hip.set_launch_timer(recs)
+            eager_step()
         torch.cuda.synchronize()
         hip.set_launch_timer(None)
+        model.net.side.enabled = side_was
         fl = sum(r["flops"] for r in recs)
         tm = sum(r["start"].elapsed_time(r["end"]) for r in recs) * 1e-3
         ach = fl / tm / 1e12
@@ -202,6 +214,15 @@ def main():
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                 "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
                 "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3}
+    if roof is not None:
+        # HBM bytes per launch from the PMC passes of this same command (benchmarks/pmc_passes.sh -> tools/pmc_traffic.py;
+        # FETCH_SIZE and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected inside the timed process)
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic.json")
+        if os.path.exists(pmc) and B == 8 and S_ == 640:
+            t = json.load(open(pmc))["gemm_family"]
+            roof["traffic"] = t["hbm_bytes_per_step"] / max(len(recs), 1)
+            roof["traffic_unit"] = "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01e_pmc_traffic.json)"
+            roof["algorithmic_bytes_per_launch"] = sum(r["bytes"] for r in recs) / max(len(recs), 1)
     out = {
         "metric": "images/sec training step, RefCOCO R50 640x640 bs=8/GPU", "value": value, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

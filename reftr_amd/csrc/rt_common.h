@@ -80,4 +80,14 @@ static inline hipError_t rt_zero_f32(float* p, size_t n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// XCD-aware workgroup -> work-item map.  Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has
+// its own L2: with the identity map, neighbouring tiles (which share operand rows) land on 8 different L2s and every
+// shared row is fetched over the fabric up to 8 times.  This map gives XCD x the contiguous range of items
+// [x*n/8, (x+1)*n/8), so tiles that share rows share an L2.  `xcd_on` = 0 keeps the identity map (A/B switch).
+__device__ __forceinline__ int rt_xcd_remap(int b, int n, int xcd_on) {
+    if (!xcd_on || n < 16) return b;
+    const int xcd = b & 7, idx = b >> 3, per = n >> 3, rem = n & 7;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
 #define RT_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

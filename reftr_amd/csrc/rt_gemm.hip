@@ -21,7 +21,7 @@ struct GemmArgs {
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed;
-    int M, K, sshift;
+    int M, K, sshift, xcd;
     unsigned src_bytes, wgt_bytes;
     const uint32_t* seed_dev;
 };
@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
     const int li = lane & 15, lg = lane >> 4;
 
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int tile_n = blockIdx.x % n_tiles, tile_m = blockIdx.x / n_tiles;
+    const int bid = rt_xcd_remap(blockIdx.x, gridDim.x, p.xcd);
+    const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
     const int n0 = tile_n * BN, m0 = tile_m * BM;
 
     // MODE 3 (stride-2 backward-data): blockIdx.y is the output parity class (y&1, x&1).  Only taps with
@@ -569,6 +570,8 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     // 32-bit element offsets inside the kernel
     if ((long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL || (long long)d->N * d->KH * d->KW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.K = d->KH * d->KW * d->SC; a.sshift = d->stride == 2 ? 1 : 0;
+    static const int xcd_env = getenv("REFTR_XCD") ? atoi(getenv("REFTR_XCD")) : 1;
+    a.xcd = xcd_env;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;

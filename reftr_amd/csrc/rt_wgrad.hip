@@ -20,7 +20,7 @@ struct WgradArgs {
     const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
     int M, chunks_per_block, c_tiles;
-    float* part; int out_elems;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
+    float* part; int out_elems; int xcd;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
     unsigned dy_bytes, x_bytes;
 };
 
@@ -263,15 +263,19 @@ __global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t*
     const int li = lane & 15, lg = lane >> 4;
 
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int tile_n = blockIdx.x % n_tiles;
-    const int rest = blockIdx.x / n_tiles;
+    // linear workgroup id -> (tile, split) with every split's tiles on one XCD (they read the same dy / x rows)
+    const int lin = rt_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, p.xcd);
+    const int by = __builtin_amdgcn_readfirstlane(lin / (int)gridDim.x);      // (integer division goes through VALU)
+    const int bx = __builtin_amdgcn_readfirstlane(lin - by * (int)gridDim.x);
+    const int tile_n = bx % n_tiles;
+    const int rest = bx / n_tiles;
     const int tile_c = rest % p.c_tiles;
     const int tap = rest / p.c_tiles;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
     const int n0 = tile_n * BN, c0 = tile_c * BC;
 
     const int total_chunks = (p.M + CR - 1) / CR;
-    const int chunk_begin = blockIdx.y * p.chunks_per_block;
+    const int chunk_begin = by * p.chunks_per_block;
     int chunk_end = chunk_begin + p.chunks_per_block;
     if (chunk_end > total_chunks) chunk_end = total_chunks;
     if (chunk_begin >= chunk_end) return;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t*
     // benchmarks/probes/atomic_probe.hip), 4-5x below plain stores, so they are kept for the unsplit case only (where a
     // dependent load-add-store chain per lane would be slower than fire-and-forget atomics).
     const int mode = p.part ? 0 : 2;
-    float* const dst = p.part ? p.part + (size_t)blockIdx.y * p.out_elems : p.dw;
+    float* const dst = p.part ? p.part + (size_t)by * p.out_elems : p.dw;
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
         const int nb = n0 + wn * (BN / 2) + a * 16 + lg * 4;
@@ -580,6 +584,8 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     if (M * d->N >= 0x3fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0; a.part = nullptr; a.out_elems = 0;
+    static const int xcd_env = getenv("REFTR_XCD") ? atoi(getenv("REFTR_XCD")) : 1;
+    a.xcd = xcd_env;
     a.dy_bytes = (unsigned)(M * d->N * 2);
     a.x_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;

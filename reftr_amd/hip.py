@@ -239,6 +239,16 @@ def set_launch_timer(records):
     _TIMER = records
 
 
+def _algo_bytes(tag):
+    """Compulsory HBM bytes of one GEMM-family launch: each operand read once (bf16), the result written once
+    (bf16 activations / fp32 weight gradients)."""
+    kind, B, SH, SW, SC, DH, DW, N, KH, KW = tag[:10]
+    M = B * DH * DW
+    if kind == "W":
+        return 2.0 * (M * N + B * SH * SW * SC) + 4.0 * N * KH * KW * SC
+    return 2.0 * (B * SH * SW * SC + N * KH * KW * SC + M * N)
+
+
 def _timed(kind, flops, fn, tag=None):
     if _TIMER is None:
         return fn()
@@ -246,7 +256,8 @@ def _timed(kind, flops, fn, tag=None):
     e0.record()
     r = fn()
     e1.record()
-    _TIMER.append({"kind": kind, "flops": float(flops), "start": e0, "end": e1, "tag": tag})
+    _TIMER.append({"kind": kind, "flops": float(flops), "start": e0, "end": e1, "tag": tag,
+                   "bytes": _algo_bytes(tag) if tag is not None else 0.0})
     return r
 
 

@@ -1,0 +1,56 @@
+"""HBM traffic of the GEMM-family kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes: the two do not fit one pass).
+
+    python tools/pmc_traffic.py <fetch.db> <write.db> --steps 5 [--json profiles/rNN_pmc_traffic.json]
+
+Units / corrections (same guide, "HBM [CDNA4]"): both counters are kilobytes; on gfx950 FETCH_SIZE reports half of the
+bytes of wide coalesced reads (128-B requests tallied at 64 B), so fetch bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE
+calibrates 1:1 on this run's own 607 MB gradient-buffer fill (592832 KB reported)."""
+import argparse, json, re, sqlite3
+
+FAMILY = re.compile(r"conv_gemm|conv_wgrad|wgrad_reduce|skinny_gemm|small_m_wgrad")
+
+
+def per_kernel(dbpath):
+    db = sqlite3.connect(dbpath)
+    out = {}
+    for name, val in db.execute("select kernel_name, value from counters_collection"):
+        a = out.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += float(val)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_db"); ap.add_argument("write_db")
+    ap.add_argument("--steps", type=int, required=True, help="training steps the profiled command ran (warm-up included)")
+    ap.add_argument("--json", default="")
+    a = ap.parse_args()
+    f, w = per_kernel(a.fetch_db), per_kernel(a.write_db)
+    rows, fam = [], dict(launches=0, fetch=0.0, write=0.0)
+    for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, [0, 0])[1] + w.get(k, [0, 0])[1])):
+        n = f.get(k, w.get(k))[0]
+        fb, wb = 2.0 * f.get(k, [0, 0.0])[1] * 1024, w.get(k, [0, 0.0])[1] * 1024
+        rows.append((k, n, fb, wb))
+        if FAMILY.search(k):
+            fam["launches"] += n; fam["fetch"] += fb; fam["write"] += wb
+    print("%-90s %7s %12s %12s" % ("kernel", "calls", "fetch MB/call", "write MB/call"))
+    for k, n, fb, wb in rows[:25]:
+        print("%-90s %7d %12.2f %12.2f" % (k[:90], n, fb / n / 1e6, wb / n / 1e6))
+    tot_f, tot_w = sum(r[2] for r in rows), sum(r[3] for r in rows)
+    res = {
+        "steps": a.steps,
+        "gemm_family": {"launches_per_step": fam["launches"] / a.steps,
+                        "hbm_bytes_per_step": (fam["fetch"] + fam["write"]) / a.steps,
+                        "hbm_bytes_per_launch": (fam["fetch"] + fam["write"]) / max(1, fam["launches"]),
+                        "fetch_bytes_per_step": fam["fetch"] / a.steps, "write_bytes_per_step": fam["write"] / a.steps},
+        "whole_step": {"hbm_bytes_per_step": (tot_f + tot_w) / a.steps, "fetch_bytes_per_step": tot_f / a.steps,
+                       "write_bytes_per_step": tot_w / a.steps},
+        "corrections": "fetch = 2 x FETCH_SIZE KB (gfx950 128-B requests tallied at 64 B); write = WRITE_SIZE KB",
+    }
+    print(json.dumps(res, indent=1))
+    if a.json:
+        json.dump(res, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
