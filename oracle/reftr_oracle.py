@@ -51,6 +51,9 @@ class Cfg:
     aux_loss: bool = True
     resnet_layers: tuple = (3, 4, 6, 3)
     bert: BertCfg = field(default_factory=BertCfg)
+    masks: bool = False           # RefTRSeg (reftr_segmentation.py): RES head on top of the single-phrase REC model
+    mask_loss_coef: float = 1.0   # main_vg.py (default 1)
+    dice_loss_coef: float = 1.0
     bbox_loss_coef: float = 1.0   # main_vg.py:134 (default 1)
     giou_loss_coef: float = 1.0   # main_vg.py:135 (default 1)
 
@@ -359,7 +362,104 @@ def reftr_forward(P, samples, cfg: Cfg, train=False, q=False):
            "c5": c5, "src": src, "pos5": pos5, "kpm": kpm, "feats": feats, "hs": hs}
     if cfg.aux_loss:
         out["aux_outputs"] = [{"pred_boxes": b, "phrase_mask": phrase_mask} for b in boxes[:-1]]
+    if cfg.masks:
+        out.update(seg_forward(P, out, samples, cfg, q=q))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# RES head (models/reftr_segmentation.py:151-280): MHAttentionMap + MaskHeadSmallConv
+# ----------------------------------------------------------------------------------------------
+def mh_attention_map(P, qv, k, mask, nheads, pfx="bbox_attention.", q=False):
+    """MHAttentionMap.forward (reftr_segmentation.py:196-208): softmax over (heads, h, w) JOINTLY; dropout 0.
+    qv [B,Q,E], k [B,E,h,w], mask [B,h,w] bool (True = pad) -> [B,Q,nheads,h,w]."""
+    E = qv.shape[-1]
+    qq = linear(qv, P, pfx + "q_linear.", q)
+    kk = F.conv2d(rq(k, q), rq_fwd(P[pfx + "k_linear.weight"], q)[:, :, None, None], P[pfx + "k_linear.bias"])
+    qh = qq.view(qq.shape[0], qq.shape[1], nheads, E // nheads)
+    kh = kk.view(kk.shape[0], nheads, E // nheads, kk.shape[-2], kk.shape[-1])
+    w = torch.einsum("bqnc,bnchw->bqnhw", qh * float(E / nheads) ** -0.5, kh)
+    w = w.masked_fill(mask[:, None, None], float("-inf"))
+    return F.softmax(w.flatten(2), dim=-1).view_as(w)
+
+
+def mask_head(P, x, bbox_mask, fpns, pfx="mask_head.", q=False):
+    """MaskHeadSmallConv.forward (reftr_segmentation.py:240-280).  x [B,2E,h,w], bbox_mask [B,Q,n,h,w],
+    fpns = [stride16, stride8, stride4 features].  Returns (mask logits [B*Q,1,4h',4w'..], last feature)."""
+    Q = bbox_mask.shape[1]
+
+    def expand(t, n):
+        return t.unsqueeze(1).repeat(1, int(n), 1, 1, 1).flatten(0, 1)
+
+    def conv(t, name, pad):
+        return F.conv2d(rq(t, q), rq_fwd(P[pfx + name + ".weight"], q), P[pfx + name + ".bias"], padding=pad)
+
+    def gn(t, name):
+        return F.relu(F.group_norm(t, 8, P[pfx + name + ".weight"], P[pfx + name + ".bias"], 1e-5))
+
+    x = torch.cat([expand(x, Q), bbox_mask.flatten(0, 1)], 1)
+    x = gn(conv(x, "lay1", 1), "gn1")
+    x = gn(conv(x, "lay2", 1), "gn2")
+    for i, f in enumerate(fpns):
+        cur = conv(f, f"adapter{i + 1}", 0)
+        if cur.shape[0] != x.shape[0]:
+            cur = expand(cur, x.shape[0] // cur.shape[0])
+        x = cur + F.interpolate(x, size=cur.shape[-2:], mode="nearest")
+        x = gn(conv(x, f"lay{i + 3}", 1), f"gn{i + 3}")
+    return conv(x, "out_lay", 1), x
+
+
+def seg_forward(P, out, samples, cfg: Cfg, q=False):
+    """RefTRSeg.forward's RES part (reftr_segmentation.py:136-176): last decoder layer only, n_ph = 1."""
+    L = samples["sentence"].shape[1]
+    B = samples["img"].shape[0]
+    src = out["src"]
+    h, w = src.shape[-2:]
+    mem_vis = out["memory"][L:].permute(1, 2, 0).reshape(B, cfg.hidden, h, w)
+    m5 = mask_downsample(samples["img_mask"], (h, w))
+    hs_last = out["hs"][-1]                                   # [B, n_ph, n_q, E]
+    bbox_mask = mh_attention_map(P, hs_last.reshape(B, -1, cfg.hidden), mem_vis, m5, cfg.nheads, q=q)
+    feats = out["feats"]
+    seg, res_feat = mask_head(P, torch.cat([src, mem_vis], 1), bbox_mask, [feats[2], feats[1], feats[0]], q=q)
+    return {"pred_masks": seg.view(B, -1, seg.shape[-2], seg.shape[-1]), "mask_att": bbox_mask[:, 0], "res_feat": res_feat}
+
+
+def dice_loss(inputs, targets, num_boxes):
+    """models/modeling/segmentation.py:178-194."""
+    inputs = inputs.sigmoid().flatten(1)
+    num = 2 * (inputs * targets).sum(1)
+    den = inputs.sum(-1) + targets.sum(-1)
+    return (1 - (num + 1) / (den + 1)).sum() / num_boxes
+
+
+def sigmoid_focal_loss(inputs, targets, num_boxes, alpha=0.25, gamma=2.0):
+    """models/modeling/segmentation.py:197-221."""
+    prob = inputs.sigmoid()
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean(1).sum() / num_boxes
+
+
+def pad_masks(targets):
+    """nested_tensor_from_tensor_list over t['masks'] ([1,h,w] bool): zero-pad to the batch maximum (util/misc.py:288-305)."""
+    hs = max(t["masks"].shape[-2] for t in targets); ws = max(t["masks"].shape[-1] for t in targets)
+    out = torch.zeros(len(targets), targets[0]["masks"].shape[0], hs, ws)
+    for i, t in enumerate(targets):
+        m = t["masks"]
+        out[i, :, :m.shape[-2], :m.shape[-1]] = m.float()
+    return out
+
+
+def loss_masks(pred_masks, targets):
+    """CriterionVGOnePhraseSeg.loss_masks (reftr_segmentation.py:314-337): bilinear upsample (align_corners=False) to the
+    padded target size; both losses normalised by bs * num_q."""
+    bs, nq = pred_masks.shape[:2]
+    tm = pad_masks(targets).to(pred_masks)
+    src = F.interpolate(pred_masks, size=tm.shape[-2:], mode="bilinear", align_corners=False)
+    src = src.view(bs * nq, -1); tm = tm.view(bs * nq, -1)
+    return {"loss_mask": sigmoid_focal_loss(src, tm, bs * nq), "loss_dice": dice_loss(src, tm, bs * nq)}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -409,6 +509,8 @@ def criterion(out, targets, world_size=1, global_num_boxes=None):
     nb = sum(len(t["labels"]) for t in targets) if global_num_boxes is None else global_num_boxes
     nb = max(nb / world_size, 1.0)
     losses = dict(loss_boxes(out["pred_boxes"], out["phrase_mask"], targets, nb))
+    if "pred_masks" in out:       # CriterionVGOnePhraseSeg: losses = ['masks', 'boxes'] (reftr_segmentation.py:388)
+        losses.update(loss_masks(out["pred_masks"], targets))
     for i, aux in enumerate(out.get("aux_outputs", [])):
         for k_, v in loss_boxes(aux["pred_boxes"], aux["phrase_mask"], targets, nb).items():
             losses[f"{k_}_{i}"] = v
@@ -418,6 +520,8 @@ def criterion(out, targets, world_size=1, global_num_boxes=None):
 def weight_dict(cfg: Cfg):
     """models/reftr_transformer.py:320-329."""
     wd = {"loss_giou": cfg.giou_loss_coef, "loss_bbox": cfg.bbox_loss_coef}
+    if cfg.masks:                 # build_reftr_seg, reftr_segmentation.py:349-351
+        wd.update({"loss_dice": cfg.dice_loss_coef, "loss_mask": cfg.mask_loss_coef, "loss_cem": 1.0})
     if cfg.aux_loss:
         aux = {}
         for i in range(cfg.dec_layers - 1):

@@ -97,4 +97,15 @@ def param_shapes(cfg):
     lin(q + "context_out.0.", E, E); ln(q + "context_out.1.", E)
     s["input_proj.0.0.weight"] = (E, 2048, 1, 1); s["input_proj.0.0.bias"] = (E,)
     ln("input_proj.0.1.", E)
+    if getattr(cfg, "masks", False):      # RefTRSeg: bbox_attention + mask_head (reftr_segmentation.py:59-60,180-238)
+        lin("bbox_attention.q_linear.", E, E); lin("bbox_attention.k_linear.", E, E)
+        dim = 2 * E + cfg.nheads
+        inter = [dim, E // 2, E // 4, E // 8, E // 16, E // 64]
+        mh = "mask_head."
+        for i, (ci, co) in enumerate(((dim, dim), (dim, inter[1]), (inter[1], inter[2]), (inter[2], inter[3]), (inter[3], inter[4]))):
+            s[f"{mh}lay{i + 1}.weight"] = (co, ci, 3, 3); s[f"{mh}lay{i + 1}.bias"] = (co,)
+            ln(f"{mh}gn{i + 1}.", co)
+        s[mh + "out_lay.weight"] = (1, inter[4], 3, 3); s[mh + "out_lay.bias"] = (1,)
+        for i, (fd, co) in enumerate(((1024, inter[1]), (512, inter[2]), (256, inter[3]))):
+            s[f"{mh}adapter{i + 1}.weight"] = (co, fd, 1, 1); s[f"{mh}adapter{i + 1}.bias"] = (co,)
     return s
