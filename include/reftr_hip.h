@@ -198,6 +198,84 @@ typedef struct rt_groupnorm_bwd_desc {
 int rt_groupnorm_bwd(const rt_groupnorm_bwd_desc* d, rt_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * RES head (RefTRSeg, models/reftr_segmentation.py).  The 3x3 / 1x1 convolutions of MaskHeadSmallConv (:216-238) and
+ * the k/q projections of MHAttentionMap (:186-187) run through rt_conv_gemm / rt_conv_wgrad with channel counts padded
+ * to multiples of 64 (zero weights / activations in the padding); the entry points below are everything around them.
+ *
+ * rt_gn_nhwc_fwd / _bwd — GroupNorm(8, C) + ReLU (:242-248,256-258,...) over x[b][p][c] (fp32 conv output, row stride
+ *   ldx); writes the next convolution's bf16 operand with row stride ldy >= C, padding zero-filled.
+ *   stats / bstats: [B, G, 2] workspaces (sum, sumsq) kept for backward.  dy fp32 (row stride lddy), dx bf16 (lddx).
+ * rt_upsample_add / _bwd — `cur_fpn + F.interpolate(x, size, mode="nearest")` (:253,262,271).  Backward returns the
+ *   pixel-summed gradient of the coarse operand and a bf16 copy of dy (the adapter convolution's output gradient).
+ * rt_attn_map_fwd / _bwd — MHAttentionMap.forward (:196-208): softmax over (heads, h, w) jointly of
+ *   norm * <q_head, k_head>, padded pixels (mask != 0) -> -inf.  k rows: (b * k_rows_per_img + k_row_off + p) * ldk.
+ *   The probabilities are also written (bf16) into columns concat_col.. of the mask head's input rows.
+ * rt_seg_concat — torch.cat([img_src_proj, memory_visual, bbox_mask]) of refer_segmentation (:165) / mask_head (:241).
+ * rt_mask_loss — CriterionVGOnePhraseSeg.loss_masks (:314-337): bilinear (align_corners=False) upsample of the logits
+ *   to the padded target size + sigmoid_focal_loss(alpha .25, gamma 2) + dice_loss (modeling/segmentation.py:178-221).
+ *   dpred == NULL: forward (sums [B,4] workspace, losses[2] = {focal, dice}); else backward, accumulating into dpred.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_gn_nhwc_desc {
+    const float* x; const float* gamma; const float* beta;
+    float* stats; void* y_bf16;
+    int32_t B, HW, C, G, ldx, ldy, act;
+    float eps;
+} rt_gn_nhwc_desc;
+int rt_gn_nhwc_fwd(const rt_gn_nhwc_desc* d, rt_stream_t stream);
+
+typedef struct rt_gn_nhwc_bwd_desc {
+    const float* dy; const float* x; const float* gamma; const float* beta;
+    const float* stats; float* bstats;
+    void* dx_bf16; float* dgamma; float* dbeta;
+    int32_t B, HW, C, G, ldx, lddy, lddx, act;
+    float eps;
+} rt_gn_nhwc_bwd_desc;
+int rt_gn_nhwc_bwd(const rt_gn_nhwc_bwd_desc* d, rt_stream_t stream);
+
+typedef struct rt_upsample_add_desc {
+    const float* fpn; const void* a_bf16; void* out_bf16;
+    int32_t B, H, W, h, w, C, ldf, lda, ldo;
+} rt_upsample_add_desc;
+int rt_upsample_add(const rt_upsample_add_desc* d, rt_stream_t stream);
+
+typedef struct rt_upsample_add_bwd_desc {
+    const float* dy; float* da; void* dy_bf16;
+    int32_t B, H, W, h, w, C, lddy, ldda, lddyb;
+} rt_upsample_add_bwd_desc;
+int rt_upsample_add_bwd(const rt_upsample_add_bwd_desc* d, rt_stream_t stream);
+
+typedef struct rt_attn_map_desc {
+    const float* q; const float* k; const uint8_t* mask;
+    float* P; void* concat_bf16;
+    int32_t B, HW, E, nh, ldk, k_rows_per_img, k_row_off, ld_concat, concat_col;
+    float norm;
+} rt_attn_map_desc;
+int rt_attn_map_fwd(const rt_attn_map_desc* d, rt_stream_t stream);
+
+typedef struct rt_attn_map_bwd_desc {
+    const float* q; const float* k; const float* P; const float* dconcat;
+    float* dq; float* dk;
+    int32_t B, HW, E, nh, ldk, k_rows_per_img, k_row_off, ld_dconcat, concat_col;
+    float norm;
+} rt_attn_map_bwd_desc;
+int rt_attn_map_bwd(const rt_attn_map_bwd_desc* d, rt_stream_t stream);
+
+typedef struct rt_seg_concat_desc {
+    const float* src; const float* mem; void* out_bf16;
+    int32_t B, HW, E, nh, ldo, mem_rows_per_img, mem_row_off;
+} rt_seg_concat_desc;
+int rt_seg_concat(const rt_seg_concat_desc* d, rt_stream_t stream);
+
+typedef struct rt_mask_loss_desc {
+    const float* pred; const uint8_t* target;
+    float* sums; float* losses;
+    float* dpred; const float* g_focal; const float* g_dice;
+    int32_t B, h, w, Ht, Wt, ldp, lddp;
+    float inv_norm;
+} rt_mask_loss_desc;
+int rt_mask_loss(const rt_mask_loss_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * rt_attn_fwd / rt_attn_bwd — softmax(scale * Q K^T + key_padding_mask) V per (batch, head), the core of
  * nn.MultiheadAttention (models/modeling/transformer.py:174-175,234-246) and of HF BertSelfAttention.
  * Element (b, i, h, d) of q/k/v/out lives at ptr[(b*S + i)*ld + h*dh + d] so packed projection outputs are

@@ -1,0 +1,428 @@
+// RES head (RefTRSeg, models/reftr_segmentation.py:151-280, 314-337) — the kernels around the implicit-GEMM convolutions:
+// GroupNorm(8) + ReLU over NHWC rows with padded channel strides, nearest-upsample + FPN add, the joint-softmax
+// attention map of MHAttentionMap, the concat that builds the mask head's input, and the bilinear + focal + dice loss.
+// All HBM-bound streaming kernels: 16-B row accesses where the channel count allows, fp32 statistics.
+#include "rt_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm over x[b][p][c] (row stride ldx), C real channels in G groups; stats[b][g] = {sum, sumsq}.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_nhwc_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                            int HW, int C, int ldx, int G, int pix_per_block) {
+    __shared__ float sm[2 * 64];
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
+    const int cpg = C / G;
+    for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int total = (p1 - p0) * C;
+    // a thread walks elements e = t, t+256, ...: consecutive threads -> consecutive channels of a pixel (coalesced)
+    float s = 0.f, ss = 0.f; int cur = -1;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int pix = e / C, c = e - pix * C;
+        const int g = c / cpg;
+        if (g != cur) {
+            if (cur >= 0) { atomicAdd(&sm[2 * cur], s); atomicAdd(&sm[2 * cur + 1], ss); }
+            cur = g; s = 0.f; ss = 0.f;
+        }
+        const float v = x[((size_t)b * HW + p0 + pix) * ldx + c];
+        s += v; ss += v * v;
+    }
+    if (cur >= 0) { atomicAdd(&sm[2 * cur], s); atomicAdd(&sm[2 * cur + 1], ss); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(stats + (size_t)b * G * 2 + i, sm[i]);
+}
+
+__global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(const rt_gn_nhwc_desc p) {
+    const size_t rows = (size_t)p.B * p.HW;
+    const int cpg = p.C / p.G;
+    const float inv_n = 1.f / ((float)cpg * (float)p.HW);
+    bf16_t* yb = (bf16_t*)p.y_bf16;
+    const size_t total = rows * p.ldy;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / p.ldy; const int c = (int)(i - row * p.ldy);
+        float y = 0.f;
+        if (c < p.C) {
+            const int b = (int)(row / p.HW), g = c / cpg;
+            const float mean = p.stats[((size_t)b * p.G + g) * 2] * inv_n;
+            const float var = fmaxf(p.stats[((size_t)b * p.G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+            y = (p.x[row * p.ldx + c] - mean) * rsqrtf(var + p.eps) * p.gamma[c] + p.beta[c];
+            if (p.act == RT_ACT_RELU) y = fmaxf(y, 0.f);
+        }
+        yb[i] = (bf16_t)y;          // channels C..ldy-1 are the zero padding the next convolution's K tiles expect
+    }
+}
+
+// backward, pass 1: bstats[b][g] = {sum g, sum g*xhat} with g = dy*gamma (dy through the ReLU mask); dgamma / dbeta
+__global__ __launch_bounds__(256) void gn_nhwc_bstats_kernel(const rt_gn_nhwc_bwd_desc p, int pix_per_block) {
+    __shared__ float sm[2 * 64];
+    extern __shared__ float dgb[];         // [2][C]
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, p.HW);
+    const int cpg = p.C / p.G;
+    const float inv_n = 1.f / ((float)cpg * (float)p.HW);
+    for (int i = threadIdx.x; i < 2 * p.G; i += 256) sm[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * p.C; i += 256) dgb[i] = 0.f;
+    __syncthreads();
+    const int total = (p1 - p0) * p.C;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int pix = e / p.C, c = e - pix * p.C;
+        const int g = c / cpg;
+        const size_t row = (size_t)b * p.HW + p0 + pix;
+        const float mean = p.stats[((size_t)b * p.G + g) * 2] * inv_n;
+        const float var = fmaxf(p.stats[((size_t)b * p.G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+        const float xh = (p.x[row * p.ldx + c] - mean) * rsqrtf(var + p.eps);
+        float d = p.dy[row * p.lddy + c];
+        if (p.act == RT_ACT_RELU && xh * p.gamma[c] + p.beta[c] <= 0.f) d = 0.f;
+        atomicAdd(&dgb[c], d * xh); atomicAdd(&dgb[p.C + c], d);
+        const float gg = d * p.gamma[c];
+        atomicAdd(&sm[2 * g], gg); atomicAdd(&sm[2 * g + 1], gg * xh);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * p.G; i += 256) atomicAdd(p.bstats + (size_t)b * p.G * 2 + i, sm[i]);
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        if (p.dgamma) atomicAdd(p.dgamma + c, dgb[c]);
+        if (p.dbeta) atomicAdd(p.dbeta + c, dgb[p.C + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_nhwc_bwd_apply_kernel(const rt_gn_nhwc_bwd_desc p) {
+    const size_t rows = (size_t)p.B * p.HW;
+    const int cpg = p.C / p.G;
+    const float inv_n = 1.f / ((float)cpg * (float)p.HW);
+    bf16_t* dxb = (bf16_t*)p.dx_bf16;
+    const size_t total = rows * p.lddx;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / p.lddx; const int c = (int)(i - row * p.lddx);
+        float dx = 0.f;
+        if (c < p.C) {
+            const int b = (int)(row / p.HW), g = c / cpg;
+            const float mean = p.stats[((size_t)b * p.G + g) * 2] * inv_n;
+            const float var = fmaxf(p.stats[((size_t)b * p.G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + p.eps);
+            const float xh = (p.x[row * p.ldx + c] - mean) * rstd;
+            float d = p.dy[row * p.lddy + c];
+            if (p.act == RT_ACT_RELU && xh * p.gamma[c] + p.beta[c] <= 0.f) d = 0.f;
+            const float m1 = p.bstats[((size_t)b * p.G + g) * 2] * inv_n, m2 = p.bstats[((size_t)b * p.G + g) * 2 + 1] * inv_n;
+            dx = rstd * (d * p.gamma[c] - m1 - xh * m2);
+        }
+        dxb[i] = (bf16_t)dx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[b][y][x][c] = fpn[b][y][x][c] + a[b][y*h/H][x*w/W][c]   (F.interpolate nearest: src = floor(dst * in / out))
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_add_kernel(const rt_upsample_add_desc p) {
+    bf16_t* out = (bf16_t*)p.out_bf16; const bf16_t* a = (const bf16_t*)p.a_bf16;
+    const size_t total = (size_t)p.B * p.H * p.W * p.ldo;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / p.ldo; const int c = (int)(i - row * p.ldo);
+        float v = 0.f;
+        if (c < p.C) {
+            const int x = (int)(row % p.W); const size_t t = row / p.W; const int y = (int)(t % p.H); const int b = (int)(t / p.H);
+            const int ys = min((int)((long long)y * p.h / p.H), p.h - 1), xs = min((int)((long long)x * p.w / p.W), p.w - 1);
+            v = p.fpn[row * p.ldf + c] + (float)a[(((size_t)b * p.h + ys) * p.w + xs) * p.lda + c];
+        }
+        out[i] = (bf16_t)v;
+    }
+}
+
+// backward: dyb = bf16(dy) (the FPN adapter's output gradient), da[b][ys][xs][c] = sum of dy over the pixels mapped there
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const rt_upsample_add_bwd_desc p) {
+    bf16_t* dyb = (bf16_t*)p.dy_bf16;
+    const size_t nsrc = (size_t)p.B * p.h * p.w * p.C, ndst = (size_t)p.B * p.H * p.W * p.lddyb;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nsrc + ndst; i += (size_t)gridDim.x * 256) {
+        if (i < nsrc) {
+            const int c = (int)(i % p.C); size_t t = i / p.C;
+            const int xs = (int)(t % p.w); t /= p.w; const int ys = (int)(t % p.h); const int b = (int)(t / p.h);
+            const int y0 = (int)(((long long)ys * p.H + p.h - 1) / p.h), y1 = (int)(((long long)(ys + 1) * p.H + p.h - 1) / p.h);
+            const int x0 = (int)(((long long)xs * p.W + p.w - 1) / p.w), x1 = (int)(((long long)(xs + 1) * p.W + p.w - 1) / p.w);
+            float s = 0.f;
+            for (int y = y0; y < y1 && y < p.H; ++y)
+                for (int x = x0; x < x1 && x < p.W; ++x) s += p.dy[(((size_t)b * p.H + y) * p.W + x) * p.lddy + c];
+            p.da[(((size_t)b * p.h + ys) * p.w + xs) * p.ldda + c] = s;
+        } else if (dyb) {
+            const size_t j = i - nsrc;
+            const size_t row = j / p.lddyb; const int c = (int)(j - row * p.lddyb);
+            dyb[j] = (bf16_t)(c < p.C ? p.dy[row * p.lddy + c] : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MHAttentionMap (reftr_segmentation.py:196-208): P[b][n][p] = softmax over (n, p) JOINTLY of
+// norm * <q[b][n*dh..], k[b][p][n*dh..]>, padded pixels -> -inf.  One workgroup per image.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_map_fwd_kernel(const rt_attn_map_desc p) {
+    extern __shared__ float lg[];            // [nh * HW] logits, then probabilities
+    __shared__ float red[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int dh = p.E / p.nh, n_ent = p.nh * p.HW;
+    const float* q = p.q + (size_t)b * p.E;
+    float mx = -INFINITY;
+    for (int e = t; e < n_ent; e += 256) {
+        const int n = e / p.HW, pix = e - n * p.HW;
+        float v = -INFINITY;
+        if (!p.mask[(size_t)b * p.HW + pix]) {
+            const float* kr = p.k + ((size_t)b * p.k_rows_per_img + p.k_row_off + pix) * p.ldk + n * dh;
+            float s = 0.f;
+            for (int c = 0; c < dh; ++c) s += q[n * dh + c] * kr[c];
+            v = s * p.norm;
+        }
+        lg[e] = v; mx = fmaxf(mx, v);
+    }
+    mx = rt_wave_max(mx);
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int e = t; e < n_ent; e += 256) { const float v = __expf(lg[e] - mx); lg[e] = v; sum += v; }
+    sum = rt_wave_sum(sum);
+    __syncthreads();
+    if ((t & 63) == 0) red[4 + (t >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    bf16_t* xc = (bf16_t*)p.concat_bf16;
+    for (int e = t; e < n_ent; e += 256) {
+        const int n = e / p.HW, pix = e - n * p.HW;
+        const float pr = lg[e] * inv;
+        p.P[(size_t)b * n_ent + e] = pr;
+        if (xc) xc[((size_t)b * p.HW + pix) * p.ld_concat + p.concat_col + n] = (bf16_t)pr;
+    }
+}
+
+// dlogit = norm * P * (dP - sum(P * dP));  dq[n*dh+c] = sum_p dlogit[n][p] k[p][n*dh+c];  dk[p][n*dh+c] = dlogit[n][p] q[n*dh+c]
+__global__ __launch_bounds__(256) void attn_map_bwd_kernel(const rt_attn_map_bwd_desc p) {
+    extern __shared__ float dl[];            // [nh * HW]
+    __shared__ float red[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int dh = p.E / p.nh, n_ent = p.nh * p.HW;
+    float dot = 0.f;
+    for (int e = t; e < n_ent; e += 256) {
+        const int n = e / p.HW, pix = e - n * p.HW;
+        const float pr = p.P[(size_t)b * n_ent + e];
+        const float dp = p.dconcat[((size_t)b * p.HW + pix) * p.ld_dconcat + p.concat_col + n];
+        dl[e] = dp; dot += pr * dp;
+    }
+    dot = rt_wave_sum(dot);
+    if ((t & 63) == 0) red[t >> 6] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    for (int e = t; e < n_ent; e += 256) dl[e] = p.norm * p.P[(size_t)b * n_ent + e] * (dl[e] - dot);
+    __syncthreads();
+    // thread t <-> feature f = n*dh + c (E <= 256)
+    if (t < p.E) {
+        const int n = t / dh;
+        const float qv = p.q[(size_t)b * p.E + t];
+        float acc = 0.f;
+        for (int pix = 0; pix < p.HW; ++pix) {
+            const float d = dl[n * p.HW + pix];
+            const size_t kr = ((size_t)b * p.k_rows_per_img + p.k_row_off + pix) * p.ldk + t;
+            acc += d * p.k[kr];
+            p.dk[kr] = d * qv;
+        }
+        p.dq[(size_t)b * p.E + t] = acc;
+    }
+}
+
+// X0[b*HW+p] = [ bf16(src[b][p][0:E]) | bf16(mem[b*S + off + p][0:E]) | (attention map, written by attn_map_fwd) | 0 ]
+__global__ __launch_bounds__(256) void seg_concat_kernel(const rt_seg_concat_desc p) {
+    bf16_t* out = (bf16_t*)p.out_bf16;
+    const size_t total = (size_t)p.B * p.HW * p.ldo;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / p.ldo; const int c = (int)(i - row * p.ldo);
+        const int b = (int)(row / p.HW), pix = (int)(row - (size_t)b * p.HW);
+        if (c < p.E) out[i] = (bf16_t)p.src[row * p.E + c];
+        else if (c < 2 * p.E) out[i] = (bf16_t)p.mem[((size_t)b * p.mem_rows_per_img + p.mem_row_off + pix) * p.E + (c - p.E)];
+        else if (c >= 2 * p.E + p.nh) out[i] = (bf16_t)0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// loss_masks (reftr_segmentation.py:314-337): bilinear upsample (align_corners=False) of the mask logits to the
+// padded target size, sigmoid focal loss (alpha 0.25, gamma 2) and dice loss.
+// sums[b] = {focal sum, sum p*t, sum p, sum t}
+// ---------------------------------------------------------------------------------------------------------------
+struct Bilin { int y0, y1, x0, x1; float wy, wx; };
+__device__ __forceinline__ Bilin bilin(int y, int x, int h, int w, float sy, float sx) {
+    Bilin r;
+    float fy = fmaxf(((float)y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)x + 0.5f) * sx - 0.5f, 0.f);
+    r.y0 = min((int)fy, h - 1); r.x0 = min((int)fx, w - 1);
+    r.y1 = min(r.y0 + 1, h - 1); r.x1 = min(r.x0 + 1, w - 1);
+    r.wy = fy - (float)r.y0; r.wx = fx - (float)r.x0;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const rt_mask_loss_desc p) {
+    __shared__ float sm[4][4];
+    const int b = blockIdx.y;
+    const float sy = (float)p.h / (float)p.Ht, sx = (float)p.w / (float)p.Wt;
+    const float* z = p.pred + (size_t)b * p.h * p.w * p.ldp;
+    float f = 0.f, it = 0.f, ps = 0.f, ts = 0.f;
+    const int total = p.Ht * p.Wt;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int y = i / p.Wt, x = i - y * p.Wt;
+        const Bilin bl = bilin(y, x, p.h, p.w, sy, sx);
+        const float v = (1.f - bl.wy) * ((1.f - bl.wx) * z[((size_t)bl.y0 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y0 * p.w + bl.x1) * p.ldp])
+                      + bl.wy * ((1.f - bl.wx) * z[((size_t)bl.y1 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y1 * p.w + bl.x1) * p.ldp]);
+        const float t = p.target[(size_t)b * total + i] ? 1.f : 0.f;
+        const float pr = 1.f / (1.f + __expf(-v));
+        const float ce = fmaxf(v, 0.f) - v * t + log1pf(__expf(-fabsf(v)));
+        const float pt = pr * t + (1.f - pr) * (1.f - t);
+        const float at = 0.25f * t + 0.75f * (1.f - t);
+        f += at * ce * (1.f - pt) * (1.f - pt);
+        it += pr * t; ps += pr; ts += t;
+    }
+    f = rt_wave_sum(f); it = rt_wave_sum(it); ps = rt_wave_sum(ps); ts = rt_wave_sum(ts);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[wv][0] = f; sm[wv][1] = it; sm[wv][2] = ps; sm[wv][3] = ts; }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(p.sums + b * 4 + threadIdx.x, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// losses[0] = focal, losses[1] = dice (both already divided by the normaliser B*Q)
+__global__ void mask_loss_final_kernel(const float* __restrict__ sums, float* __restrict__ losses, int B, int npix, float inv_norm) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float f = 0.f, d = 0.f;
+    for (int b = 0; b < B; ++b) {
+        f += sums[b * 4] / (float)npix;
+        d += 1.f - (2.f * sums[b * 4 + 1] + 1.f) / (sums[b * 4 + 2] + sums[b * 4 + 3] + 1.f);
+    }
+    losses[0] = f * inv_norm; losses[1] = d * inv_norm;
+}
+
+// dpred[b][y][x] += sum over target pixels of (w_focal * dfocal/dz + w_dice * ddice/dz) * bilinear weight
+__global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const rt_mask_loss_desc p) {
+    const int b = blockIdx.y;
+    const float sy = (float)p.h / (float)p.Ht, sx = (float)p.w / (float)p.Wt;
+    const float* z = p.pred + (size_t)b * p.h * p.w * p.ldp;
+    float* dz = p.dpred + (size_t)b * p.h * p.w * p.lddp;
+    const int total = p.Ht * p.Wt;
+    const float num = 2.f * p.sums[b * 4 + 1] + 1.f, den = p.sums[b * 4 + 2] + p.sums[b * 4 + 3] + 1.f;
+    const float gf = p.g_focal[0] * p.inv_norm / (float)total, gd = p.g_dice[0] * p.inv_norm;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int y = i / p.Wt, x = i - y * p.Wt;
+        const Bilin bl = bilin(y, x, p.h, p.w, sy, sx);
+        const float v = (1.f - bl.wy) * ((1.f - bl.wx) * z[((size_t)bl.y0 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y0 * p.w + bl.x1) * p.ldp])
+                      + bl.wy * ((1.f - bl.wx) * z[((size_t)bl.y1 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y1 * p.w + bl.x1) * p.ldp]);
+        const float t = p.target[(size_t)b * total + i] ? 1.f : 0.f;
+        const float pr = 1.f / (1.f + __expf(-v));
+        const float ce = fmaxf(v, 0.f) - v * t + log1pf(__expf(-fabsf(v)));
+        const float pt = pr * t + (1.f - pr) * (1.f - t);
+        const float at = 0.25f * t + 0.75f * (1.f - t);
+        const float dpr = pr * (1.f - pr);
+        // d/dz [ce * (1-pt)^2] = (pr - t) * (1-pt)^2 - 2 ce (1-pt) * dpt/dz,  dpt/dz = (2t-1) * pr(1-pr)
+        const float dfocal = at * ((pr - t) * (1.f - pt) * (1.f - pt) - 2.f * ce * (1.f - pt) * (2.f * t - 1.f) * dpr);
+        // dice = 1 - num/den: d/dz = -(2 t den - num) / den^2 * pr(1-pr)
+        const float ddice = -(2.f * t * den - num) / (den * den) * dpr;
+        const float g = gf * dfocal + gd * ddice;
+        atomicAdd(dz + ((size_t)bl.y0 * p.w + bl.x0) * p.lddp, g * (1.f - bl.wy) * (1.f - bl.wx));
+        atomicAdd(dz + ((size_t)bl.y0 * p.w + bl.x1) * p.lddp, g * (1.f - bl.wy) * bl.wx);
+        atomicAdd(dz + ((size_t)bl.y1 * p.w + bl.x0) * p.lddp, g * bl.wy * (1.f - bl.wx));
+        atomicAdd(dz + ((size_t)bl.y1 * p.w + bl.x1) * p.lddp, g * bl.wy * bl.wx);
+    }
+}
+
+static inline int grid_for(size_t total, int cap = 4096) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > (size_t)cap ? cap : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int rt_gn_nhwc_fwd(const rt_gn_nhwc_desc* d, rt_stream_t stream) {
+    if (!d || !d->x || !d->gamma || !d->beta || !d->stats || !d->y_bf16) return RT_ERR_BADARG;
+    if (d->C <= 0 || d->G <= 0 || d->G > 64 || (d->C % d->G) || d->ldx < d->C || d->ldy < d->C || d->B <= 0 || d->HW <= 0) return RT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = rt_zero_f32(d->stats, 2 * (size_t)d->B * d->G, s);
+    if (e != hipSuccess) return (int)e;
+    int ppb = (int)((16384 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel, dim3((d->HW + ppb - 1) / ppb, d->B), dim3(256), 0, s, d->x, d->stats, d->HW, d->C, d->ldx, d->G, ppb);
+    RT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel, dim3(grid_for((size_t)d->B * d->HW * d->ldy)), dim3(256), 0, s, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_gn_nhwc_bwd(const rt_gn_nhwc_bwd_desc* d, rt_stream_t stream) {
+    if (!d || !d->x || !d->dy || !d->gamma || !d->beta || !d->stats || !d->bstats || !d->dx_bf16) return RT_ERR_BADARG;
+    if (d->C <= 0 || d->G <= 0 || d->G > 64 || (d->C % d->G) || d->ldx < d->C || d->lddy < d->C || d->lddx < d->C || d->C > 4096) return RT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = rt_zero_f32(d->bstats, 2 * (size_t)d->B * d->G, s);
+    if (e != hipSuccess) return (int)e;
+    int ppb = (int)((16384 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
+    hipLaunchKernelGGL(gn_nhwc_bstats_kernel, dim3((d->HW + ppb - 1) / ppb, d->B), dim3(256), 2 * d->C * sizeof(float), s, *d, ppb);
+    RT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_nhwc_bwd_apply_kernel, dim3(grid_for((size_t)d->B * d->HW * d->lddx)), dim3(256), 0, s, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_upsample_add(const rt_upsample_add_desc* d, rt_stream_t stream) {
+    if (!d || !d->fpn || !d->a_bf16 || !d->out_bf16) return RT_ERR_BADARG;
+    if (d->C <= 0 || d->ldf < d->C || d->lda < d->C || d->ldo < d->C || d->h <= 0 || d->w <= 0 || d->H < d->h || d->W < d->w) return RT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((size_t)d->B * d->H * d->W * d->ldo)), dim3(256), 0, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_upsample_add_bwd(const rt_upsample_add_bwd_desc* d, rt_stream_t stream) {
+    if (!d || !d->dy || !d->da) return RT_ERR_BADARG;
+    if (d->C <= 0 || d->lddy < d->C || d->ldda < d->C || (d->dy_bf16 && d->lddyb < d->C)) return RT_ERR_UNSUPPORTED;
+    const size_t total = (size_t)d->B * d->h * d->w * d->C + (d->dy_bf16 ? (size_t)d->B * d->H * d->W * d->lddyb : 0);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_attn_map_fwd(const rt_attn_map_desc* d, rt_stream_t stream) {
+    if (!d || !d->q || !d->k || !d->mask || !d->P) return RT_ERR_BADARG;
+    if (d->E <= 0 || d->nh <= 0 || (d->E % d->nh) || d->HW <= 0 || (size_t)d->nh * d->HW * 4 > 150000) return RT_ERR_UNSUPPORTED;
+    const size_t smem = (size_t)d->nh * d->HW * sizeof(float);
+    if (smem > 65536) (void)hipFuncSetAttribute((const void*)attn_map_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(attn_map_fwd_kernel, dim3(d->B), dim3(256), smem, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_attn_map_bwd(const rt_attn_map_bwd_desc* d, rt_stream_t stream) {
+    if (!d || !d->q || !d->k || !d->P || !d->dconcat || !d->dq || !d->dk) return RT_ERR_BADARG;
+    if (d->E <= 0 || d->E > 256 || d->nh <= 0 || (d->E % d->nh) || (size_t)d->nh * d->HW * 4 > 150000) return RT_ERR_UNSUPPORTED;
+    const size_t smem = (size_t)d->nh * d->HW * sizeof(float);
+    if (smem > 65536) (void)hipFuncSetAttribute((const void*)attn_map_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(attn_map_bwd_kernel, dim3(d->B), dim3(256), smem, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_seg_concat(const rt_seg_concat_desc* d, rt_stream_t stream) {
+    if (!d || !d->src || !d->mem || !d->out_bf16) return RT_ERR_BADARG;
+    if (d->ldo < 2 * d->E + d->nh || d->E <= 0) return RT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(seg_concat_kernel, dim3(grid_for((size_t)d->B * d->HW * d->ldo)), dim3(256), 0, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_mask_loss(const rt_mask_loss_desc* d, rt_stream_t stream) {
+    if (!d || !d->pred || !d->target || !d->sums) return RT_ERR_BADARG;
+    if (d->B <= 0 || d->h <= 0 || d->w <= 0 || d->Ht <= 0 || d->Wt <= 0 || d->ldp <= 0) return RT_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = grid_for((size_t)d->Ht * d->Wt, 256);
+    if (!d->dpred) {
+        if (!d->losses) return RT_ERR_BADARG;
+        hipError_t e = rt_zero_f32(d->sums, 4 * (size_t)d->B, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(gx, d->B), dim3(256), 0, s, *d);
+        RT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mask_loss_final_kernel, dim3(1), dim3(64), 0, s, d->sums, d->losses, d->B, d->Ht * d->Wt, d->inv_norm);
+        RT_CHECK_LAUNCH();
+    } else {
+        if (!d->g_focal || !d->g_dice || d->lddp <= 0) return RT_ERR_BADARG;
+        hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(gx, d->B), dim3(256), 0, s, *d);
+        RT_CHECK_LAUNCH();
+    }
+    return RT_OK;
+}

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -142,6 +142,58 @@ class AdamWDesc(Structure):
 
 # name -> (restype, argtypes); every symbol include/reftr_hip.h declares must be listed here
 # (tests/test_abi.py cross-checks this table against the header).
+class GnNhwcDesc(Structure):
+    _fields_ = [("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("stats", c_void_p), ("y_bf16", c_void_p),
+                ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("G", c_int32), ("ldx", c_int32), ("ldy", c_int32),
+                ("act", c_int32), ("eps", c_float)]
+
+
+class GnNhwcBwdDesc(Structure):
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("stats", c_void_p),
+                ("bstats", c_void_p), ("dx_bf16", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p),
+                ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("G", c_int32), ("ldx", c_int32), ("lddy", c_int32),
+                ("lddx", c_int32), ("act", c_int32), ("eps", c_float)]
+
+
+class UpsampleAddDesc(Structure):
+    _fields_ = [("fpn", c_void_p), ("a_bf16", c_void_p), ("out_bf16", c_void_p),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("h", c_int32), ("w", c_int32), ("C", c_int32),
+                ("ldf", c_int32), ("lda", c_int32), ("ldo", c_int32)]
+
+
+class UpsampleAddBwdDesc(Structure):
+    _fields_ = [("dy", c_void_p), ("da", c_void_p), ("dy_bf16", c_void_p),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("h", c_int32), ("w", c_int32), ("C", c_int32),
+                ("lddy", c_int32), ("ldda", c_int32), ("lddyb", c_int32)]
+
+
+class AttnMapDesc(Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("mask", c_void_p), ("P", c_void_p), ("concat_bf16", c_void_p),
+                ("B", c_int32), ("HW", c_int32), ("E", c_int32), ("nh", c_int32), ("ldk", c_int32),
+                ("k_rows_per_img", c_int32), ("k_row_off", c_int32), ("ld_concat", c_int32), ("concat_col", c_int32),
+                ("norm", c_float)]
+
+
+class AttnMapBwdDesc(Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("P", c_void_p), ("dconcat", c_void_p), ("dq", c_void_p), ("dk", c_void_p),
+                ("B", c_int32), ("HW", c_int32), ("E", c_int32), ("nh", c_int32), ("ldk", c_int32),
+                ("k_rows_per_img", c_int32), ("k_row_off", c_int32), ("ld_dconcat", c_int32), ("concat_col", c_int32),
+                ("norm", c_float)]
+
+
+class SegConcatDesc(Structure):
+    _fields_ = [("src", c_void_p), ("mem", c_void_p), ("out_bf16", c_void_p),
+                ("B", c_int32), ("HW", c_int32), ("E", c_int32), ("nh", c_int32), ("ldo", c_int32),
+                ("mem_rows_per_img", c_int32), ("mem_row_off", c_int32)]
+
+
+class MaskLossDesc(Structure):
+    _fields_ = [("pred", c_void_p), ("target", c_void_p), ("sums", c_void_p), ("losses", c_void_p),
+                ("dpred", c_void_p), ("g_focal", c_void_p), ("g_dice", c_void_p),
+                ("B", c_int32), ("h", c_int32), ("w", c_int32), ("Ht", c_int32), ("Wt", c_int32), ("ldp", c_int32),
+                ("lddp", c_int32), ("inv_norm", c_float)]
+
+
 _SIGNATURES = {
     "rt_abi_version": (c_int, []),
     "rt_device_arch": (c_int, [c_int, c_char_p, c_int]),
@@ -174,6 +226,14 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
+    "rt_gn_nhwc_fwd": (c_int, [POINTER(GnNhwcDesc), c_void_p]),
+    "rt_gn_nhwc_bwd": (c_int, [POINTER(GnNhwcBwdDesc), c_void_p]),
+    "rt_upsample_add": (c_int, [POINTER(UpsampleAddDesc), c_void_p]),
+    "rt_upsample_add_bwd": (c_int, [POINTER(UpsampleAddBwdDesc), c_void_p]),
+    "rt_attn_map_fwd": (c_int, [POINTER(AttnMapDesc), c_void_p]),
+    "rt_attn_map_bwd": (c_int, [POINTER(AttnMapBwdDesc), c_void_p]),
+    "rt_seg_concat": (c_int, [POINTER(SegConcatDesc), c_void_p]),
+    "rt_mask_loss": (c_int, [POINTER(MaskLossDesc), c_void_p]),
 }
 
 _lib = None
@@ -657,6 +717,103 @@ class WeightPrepBatch:
         if self.table is None:
             self.table = torch.tensor(self.jobs, dtype=torch.int64).to(self.device)
         _check(lib().rt_weight_prep_batched(_p(self.table), len(self.jobs), self.tiles, _stream()), "rt_weight_prep_batched")
+
+
+# --------------------------------------------------------------------------------------------
+# RES head (RefTRSeg) kernels
+# --------------------------------------------------------------------------------------------
+def gn_nhwc_fwd(x, gamma, beta, B, HW, C, G=8, ldy=None, act=ACT_RELU, eps=1e-5):
+    """y = [relu](GroupNorm(G, C)(x)) as a bf16 [B*HW, ldy] operand (padding zero); returns (y_bf16, stats)."""
+    _req(x, torch.float32, "x"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    ldx = x.shape[-1]
+    ldy = ldy or ldx
+    assert x.numel() == B * HW * ldx and gamma.numel() >= C
+    y = torch.empty((B * HW, ldy), dtype=torch.bfloat16, device=x.device)
+    stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+    d = GnNhwcDesc(_p(x), _p(gamma), _p(beta), _p(stats), _p(y), B, HW, C, G, ldx, ldy, act, eps)
+    _check(lib().rt_gn_nhwc_fwd(ctypes.byref(d), _stream()), "rt_gn_nhwc_fwd")
+    return y, stats
+
+
+def gn_nhwc_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, B, HW, C, G=8, lddx=None, act=ACT_RELU, eps=1e-5):
+    """dx (bf16 [B*HW, lddx], the producing convolution's output gradient); dgamma / dbeta accumulated."""
+    _req(dy, torch.float32, "dy"); _req(x, torch.float32, "x")
+    ldx, lddy = x.shape[-1], dy.shape[-1]
+    lddx = lddx or ldx
+    dx = torch.empty((B * HW, lddx), dtype=torch.bfloat16, device=x.device)
+    bst = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+    d = GnNhwcBwdDesc(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(bst), _p(dx), _p(dgamma), _p(dbeta),
+                      B, HW, C, G, ldx, lddy, lddx, act, eps)
+    _check(lib().rt_gn_nhwc_bwd(ctypes.byref(d), _stream()), "rt_gn_nhwc_bwd")
+    return dx
+
+
+def upsample_add(fpn, a, B, H, W, h, w, C, ldo=None):
+    """bf16(fpn + nearest_upsample(a)): fpn fp32 [B*H*W, ldf], a bf16 [B*h*w, lda] -> bf16 [B*H*W, ldo]."""
+    _req(fpn, torch.float32, "fpn"); _req(a, torch.bfloat16, "a")
+    ldf, lda = fpn.shape[-1], a.shape[-1]
+    ldo = ldo or ldf
+    out = torch.empty((B * H * W, ldo), dtype=torch.bfloat16, device=fpn.device)
+    d = UpsampleAddDesc(_p(fpn), _p(a), _p(out), B, H, W, h, w, C, ldf, lda, ldo)
+    _check(lib().rt_upsample_add(ctypes.byref(d), _stream()), "rt_upsample_add")
+    return out
+
+
+def upsample_add_bwd(dy, B, H, W, h, w, C, ldda=None, lddyb=None):
+    """dy fp32 [B*H*W, lddy] -> (da fp32 [B*h*w, ldda] (padding zero), bf16 copy of dy [B*H*W, lddyb])."""
+    _req(dy, torch.float32, "dy")
+    lddy = dy.shape[-1]
+    ldda = ldda or C; lddyb = lddyb or lddy
+    da = torch.zeros((B * h * w, ldda), dtype=torch.float32, device=dy.device) if ldda > C else \
+        torch.empty((B * h * w, ldda), dtype=torch.float32, device=dy.device)
+    dyb = torch.empty((B * H * W, lddyb), dtype=torch.bfloat16, device=dy.device)
+    d = UpsampleAddBwdDesc(_p(dy), _p(da), _p(dyb), B, H, W, h, w, C, lddy, ldda, lddyb)
+    _check(lib().rt_upsample_add_bwd(ctypes.byref(d), _stream()), "rt_upsample_add_bwd")
+    return da, dyb
+
+
+def attn_map_fwd(q, k, mask_u8, B, HW, E, nh, k_rows_per_img, k_row_off, concat=None, concat_col=0):
+    _req(q, torch.float32, "q"); _req(k, torch.float32, "k"); _req(mask_u8, torch.uint8, "mask")
+    P = torch.empty((B, nh, HW), dtype=torch.float32, device=q.device)
+    d = AttnMapDesc(_p(q), _p(k), _p(mask_u8), _p(P), _p(concat), B, HW, E, nh, k.shape[-1], k_rows_per_img, k_row_off,
+                    concat.shape[-1] if concat is not None else 0, concat_col, float(E / nh) ** -0.5)
+    _check(lib().rt_attn_map_fwd(ctypes.byref(d), _stream()), "rt_attn_map_fwd")
+    return P
+
+
+def attn_map_bwd(q, k, P, dconcat, B, HW, E, nh, k_rows_per_img, k_row_off, concat_col):
+    """Returns (dq fp32 [B,E], dk fp32 shaped like k: rows outside the image block are zero)."""
+    _req(dconcat, torch.float32, "dconcat")
+    dq = torch.empty((B, E), dtype=torch.float32, device=q.device)
+    dk = torch.zeros_like(k)
+    d = AttnMapBwdDesc(_p(q), _p(k), _p(P), _p(dconcat), _p(dq), _p(dk), B, HW, E, nh, k.shape[-1], k_rows_per_img,
+                       k_row_off, dconcat.shape[-1], concat_col, float(E / nh) ** -0.5)
+    _check(lib().rt_attn_map_bwd(ctypes.byref(d), _stream()), "rt_attn_map_bwd")
+    return dq, dk
+
+
+def seg_concat(src, mem, out, B, HW, E, nh, mem_rows_per_img, mem_row_off):
+    _req(src, torch.float32, "src"); _req(mem, torch.float32, "mem"); _req(out, torch.bfloat16, "out")
+    d = SegConcatDesc(_p(src), _p(mem), _p(out), B, HW, E, nh, out.shape[-1], mem_rows_per_img, mem_row_off)
+    _check(lib().rt_seg_concat(ctypes.byref(d), _stream()), "rt_seg_concat")
+    return out
+
+
+def mask_loss(pred, target_u8, B, h, w, Ht, Wt, ldp, norm, sums=None, dpred=None, g_focal=None, g_dice=None):
+    """Forward (dpred None): returns (losses[2] = {focal, dice}, sums [B,4]).  Backward: accumulates into dpred."""
+    _req(pred, torch.float32, "pred"); _req(target_u8, torch.uint8, "target")
+    assert target_u8.numel() == B * Ht * Wt
+    if dpred is None:
+        sums = torch.empty((B, 4), dtype=torch.float32, device=pred.device)
+        losses = torch.empty(2, dtype=torch.float32, device=pred.device)
+        d = MaskLossDesc(_p(pred), _p(target_u8), _p(sums), _p(losses), None, None, None, B, h, w, Ht, Wt, ldp, 0, 1.0 / norm)
+        _check(lib().rt_mask_loss(ctypes.byref(d), _stream()), "rt_mask_loss")
+        return losses, sums
+    _req(dpred, torch.float32, "dpred"); _req(g_focal, torch.float32, "g_focal"); _req(g_dice, torch.float32, "g_dice")
+    d = MaskLossDesc(_p(pred), _p(target_u8), _p(sums), None, _p(dpred), _p(g_focal), _p(g_dice), B, h, w, Ht, Wt, ldp,
+                     dpred.shape[-1], 1.0 / norm)
+    _check(lib().rt_mask_loss(ctypes.byref(d), _stream()), "rt_mask_loss")
+    return dpred
 
 
 class SideStream:

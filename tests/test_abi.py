@@ -50,7 +50,11 @@ def test_struct_layouts_match_header(built):
                "rt_groupnorm_desc": hip.GroupNormDesc, "rt_groupnorm_bwd_desc": hip.GroupNormBwdDesc,
                "rt_attn_desc": hip.AttnDesc, "rt_attn_bwd_desc": hip.AttnBwdDesc,
                "rt_mask_posenc_desc": hip.MaskPosencDesc, "rt_rows_add_desc": hip.RowsAddDesc,
-               "rt_box_loss_desc": hip.BoxLossDesc, "rt_adamw_desc": hip.AdamWDesc}
+               "rt_box_loss_desc": hip.BoxLossDesc, "rt_adamw_desc": hip.AdamWDesc,
+               "rt_gn_nhwc_desc": hip.GnNhwcDesc, "rt_gn_nhwc_bwd_desc": hip.GnNhwcBwdDesc,
+               "rt_upsample_add_desc": hip.UpsampleAddDesc, "rt_upsample_add_bwd_desc": hip.UpsampleAddBwdDesc,
+               "rt_attn_map_desc": hip.AttnMapDesc, "rt_attn_map_bwd_desc": hip.AttnMapBwdDesc,
+               "rt_seg_concat_desc": hip.SegConcatDesc, "rt_mask_loss_desc": hip.MaskLossDesc}
     assert sorted(binding) == names
     prog = '#include <stdio.h>\n#include "reftr_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
