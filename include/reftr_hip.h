@@ -262,7 +262,7 @@ int rt_attn_map_bwd(const rt_attn_map_bwd_desc* d, rt_stream_t stream);
 
 typedef struct rt_seg_concat_desc {
     const float* src; const float* mem; void* out_bf16;
-    int32_t B, HW, E, nh, ldo, mem_rows_per_img, mem_row_off;
+    int32_t B, HW, E, nh, ldo, mem_rows_per_img, mem_row_off, src_rows_per_img, src_row_off;
 } rt_seg_concat_desc;
 int rt_seg_concat(const rt_seg_concat_desc* d, rt_stream_t stream);
 

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void seg_concat_kernel(const rt_seg_concat_des
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / p.ldo; const int c = (int)(i - row * p.ldo);
         const int b = (int)(row / p.HW), pix = (int)(row - (size_t)b * p.HW);
-        if (c < p.E) out[i] = (bf16_t)p.src[row * p.E + c];
+        if (c < p.E) out[i] = (bf16_t)p.src[((size_t)b * p.src_rows_per_img + p.src_row_off + pix) * p.E + c];
         else if (c < 2 * p.E) out[i] = (bf16_t)p.mem[((size_t)b * p.mem_rows_per_img + p.mem_row_off + pix) * p.E + (c - p.E)];
         else if (c >= 2 * p.E + p.nh) out[i] = (bf16_t)0.f;
     }

@@ -184,7 +184,7 @@ class AttnMapBwdDesc(Structure):
 class SegConcatDesc(Structure):
     _fields_ = [("src", c_void_p), ("mem", c_void_p), ("out_bf16", c_void_p),
                 ("B", c_int32), ("HW", c_int32), ("E", c_int32), ("nh", c_int32), ("ldo", c_int32),
-                ("mem_rows_per_img", c_int32), ("mem_row_off", c_int32)]
+                ("mem_rows_per_img", c_int32), ("mem_row_off", c_int32), ("src_rows_per_img", c_int32), ("src_row_off", c_int32)]
 
 
 class MaskLossDesc(Structure):
@@ -792,9 +792,11 @@ def attn_map_bwd(q, k, P, dconcat, B, HW, E, nh, k_rows_per_img, k_row_off, conc
     return dq, dk
 
 
-def seg_concat(src, mem, out, B, HW, E, nh, mem_rows_per_img, mem_row_off):
+def seg_concat(src, mem, out, B, HW, E, nh, rows_per_img, row_off, src_dense=False):
+    """src / mem rows of image b, pixel p: (b * rows_per_img + row_off + p); src_dense: src is a dense [B*HW, E]."""
     _req(src, torch.float32, "src"); _req(mem, torch.float32, "mem"); _req(out, torch.bfloat16, "out")
-    d = SegConcatDesc(_p(src), _p(mem), _p(out), B, HW, E, nh, out.shape[-1], mem_rows_per_img, mem_row_off)
+    d = SegConcatDesc(_p(src), _p(mem), _p(out), B, HW, E, nh, out.shape[-1], rows_per_img, row_off,
+                      HW if src_dense else rows_per_img, 0 if src_dense else row_off)
     _check(lib().rt_seg_concat(ctypes.byref(d), _stream()), "rt_seg_concat")
     return out
 

@@ -23,7 +23,7 @@ class ConvSpec:
 
 
 class BlockSpec:
-    __slots__ = ("conv1", "conv2", "conv3", "down", "trainable", "first_trainable")
+    __slots__ = ("conv1", "conv2", "conv3", "down", "trainable", "first_trainable", "stage_in")
 
 
 class ResNetBody:
@@ -48,6 +48,7 @@ class ResNetBody:
                 b.down = ConvSpec(p + "downsample.0.weight", p + "downsample.1.", inpl, planes * 4, 1, s, tr) if bi == 0 else None
                 b.trainable = tr
                 b.first_trainable = (li == 1 and bi == 0)     # its input (layer1 output) needs no gradient
+                b.stage_in = li - 1 if bi == 0 and li > 0 else None     # index of the stage output that is this block's input
                 stage.append(b)
                 inpl = planes * 4
             self.blocks.append(stage)
@@ -132,14 +133,17 @@ class ResNetBody:
         dw, sc = self.store.phys(c.name, grad=True), self.bn[c.bn][0]
         self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc), g, x)
 
-    def _dgrad(self, g, c, geom, res=None, gate=None):
+    def _dgrad(self, g, c, geom, res=None, gate=None, res_f32=None):
         B, SH, SW, SC, DH, DW, N, KH, KW, s, p = geom
         geom_t = (B, DH, DW, N, SH, SW, SC, KH, KW, s, p)
-        y, _ = H.conv_gemm(g, self.W[c.name + ".t"], geom=geom_t, transposed=True, res_bf16=res, gate=gate)
+        y, _ = H.conv_gemm(g, self.W[c.name + ".t"], geom=geom_t, transposed=True, res_bf16=res, res_f32=res_f32, gate=gate)
         return y
 
-    def backward(self, saved, g_out):
-        """g_out: bf16 [M, 2048] = dL/d(pre-ReLU of the layer4 output) (already gated by the producer)."""
+    def backward(self, saved, g_out, extra=None):
+        """g_out: bf16 [M, 2048] = dL/d(pre-ReLU of the layer4 output) (already gated by the producer).
+        extra: {stage index: fp32 [M, C]} additional UNGATED gradients w.r.t. intermediate stage outputs (the RES head's
+        FPN adapters read layer2 / layer3 outputs); they join the residual sum before the ReLU gate."""
+        extra = extra or {}
         for b, rec in reversed(saved):
             x, h1, h2 = rec["x"], rec["h1"], rec["h2"]
             self._wgrad(g_out, h2, b.conv3, rec["g3"])
@@ -152,4 +156,4 @@ class ResNetBody:
             if b.first_trainable:
                 break                                   # layer1 is frozen: no gradient w.r.t. its output
             g_idt = self._dgrad(g_out, b.down, rec["gd"]) if b.down is not None else g_out
-            g_out = self._dgrad(g_h1, b.conv1, rec["g1"], res=g_idt, gate=x)
+            g_out = self._dgrad(g_h1, b.conv1, rec["g1"], res=g_idt, gate=x, res_f32=extra.get(b.stage_in))

@@ -77,3 +77,54 @@ class CriterionVGMultiPhrase(nn.Module):
             out[f"loss_bbox_{i}"] = losses[i, 0]
             out[f"loss_giou_{i}"] = losses[i, 1]
         return out
+
+
+class _MaskLossFunction(torch.autograd.Function):
+    """Bilinear upsample + sigmoid focal + dice (rt_mask_loss); returns losses[2] = {loss_mask, loss_dice}."""
+
+    @staticmethod
+    def forward(ctx, pred, target_u8, norm):
+        B, _, h, w = pred.shape
+        Ht, Wt = target_u8.shape[-2:]
+        pred = pred.contiguous()
+        losses, sums = H.mask_loss(pred.view(-1, 1), target_u8, B, h, w, Ht, Wt, 1, norm)
+        ctx.save_for_backward(pred, target_u8, sums)
+        ctx.norm = norm
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target_u8, sums = ctx.saved_tensors
+        B, _, h, w = pred.shape
+        Ht, Wt = target_u8.shape[-2:]
+        g = g.contiguous().float()
+        dpred = torch.zeros(B * h * w, 1, dtype=torch.float32, device=pred.device)
+        H.mask_loss(pred.view(-1, 1), target_u8, B, h, w, Ht, Wt, 1, ctx.norm, sums=sums, dpred=dpred,
+                    g_focal=g[0:1].contiguous(), g_dice=g[1:2].contiguous())
+        return dpred.view_as(pred), None, None
+
+
+class CriterionVGOnePhraseSeg(CriterionVGMultiPhrase):
+    """models/reftr_segmentation.py:305-337: losses = ['masks', 'boxes']; the mask losses are normalised by bs * num_q
+    and computed against the zero-padded batch of target masks (nested_tensor_from_tensor_list, util/misc.py:288-305)."""
+
+    def _padded_masks(self, targets, device):
+        ms = [t["masks"] for t in targets]
+        Ht = max(m.shape[-2] for m in ms); Wt = max(m.shape[-1] for m in ms)
+        out = torch.zeros(len(ms), ms[0].shape[0], Ht, Wt, dtype=torch.uint8, device=device)
+        for i, m in enumerate(ms):
+            out[i, :, :m.shape[-2], :m.shape[-1]] = m.to(device, torch.uint8)
+        return out
+
+    def forward(self, outputs, targets):
+        losses = {}
+        if "masks" in self.losses:
+            assert "pred_masks" in outputs
+            pm = outputs["pred_masks"]
+            bs, nq = pm.shape[:2]
+            assert nq == 1, "RefTRSeg predicts one mask per image (n_ph = n_q = 1)"
+            tgt = self._padded_masks(targets, pm.device)
+            lm = _MaskLossFunction.apply(pm, tgt, float(bs * nq))
+            losses["loss_mask"], losses["loss_dice"] = lm[0], lm[1]
+        losses.update(super().forward(outputs, targets))
+        return losses

@@ -36,6 +36,7 @@ class ModelConfig:
     n_q: int = 1                       # num_queries_per_phrase
     aux_loss: bool = True
     resnet_layers: tuple = (3, 4, 6, 3)   # resnet50; resnet101 = (3, 4, 23, 3)
+    masks: bool = False                   # RefTRSeg: RES head (bbox_attention + mask_head), single phrase, no aux loss
     bert: BertConfig = field(default_factory=BertConfig)
 
 
@@ -150,7 +151,48 @@ def main_table(cfg: ModelConfig):
     return t
 
 
+def pad64(c):
+    return (c + 63) // 64 * 64
+
+
+def seg_convs(cfg: ModelConfig):
+    """MaskHeadSmallConv (models/reftr_segmentation.py:216-232): [(name, cin, cout, k)] in forward order."""
+    E = cfg.hidden
+    dim = 2 * E + cfg.nheads
+    inter = [dim, E // 2, E // 4, E // 8, E // 16, E // 64]
+    mh = "mask_head."
+    convs = [(mh + "lay1", dim, dim, 3), (mh + "lay2", dim, inter[1], 3), (mh + "lay3", inter[1], inter[2], 3),
+             (mh + "lay4", inter[2], inter[3], 3), (mh + "lay5", inter[3], inter[4], 3), (mh + "out_lay", inter[4], 1, 3),
+             (mh + "adapter1", 1024, inter[1], 1), (mh + "adapter2", 512, inter[2], 1), (mh + "adapter3", 256, inter[3], 1)]
+    return convs
+
+
+def seg_table(cfg: ModelConfig):
+    """bbox_attention + mask_head tensors (reference names, reftr_segmentation.py:59-60)."""
+    E = cfg.hidden
+    t = []
+    for n in ("q_linear.", "k_linear."):
+        t.append(("bbox_attention." + n + "weight", (E, E), "param")); t.append(("bbox_attention." + n + "bias", (E,), "param"))
+    for name, ci, co, k in seg_convs(cfg):
+        t.append((name + ".weight", (co, ci, k, k), "param")); t.append((name + ".bias", (co,), "param"))
+    for i, (_, _, co, _) in enumerate(seg_convs(cfg)[:5]):
+        t.append((f"mask_head.gn{i + 1}.weight", (co,), "param")); t.append((f"mask_head.gn{i + 1}.bias", (co,), "param"))
+    return t
+
+
+def phys_dims(cfg: ModelConfig):
+    """Physical (stored) shapes of tensors whose channel counts are padded to multiples of 64 so that they are legal
+    implicit-GEMM operands: conv weight [Cout_pad][kh][kw][Cin_pad], bias [Cout_pad]; the padding stays zero (zero
+    gradients, zero AdamW updates).  The logical tensors are strided views of the unpadded corner."""
+    d = {}
+    if cfg.masks:
+        for name, ci, co, k in seg_convs(cfg):
+            d[name + ".weight"] = (pad64(co), k, k, pad64(ci))
+            d[name + ".bias"] = (pad64(co),)
+    return d
+
+
 def full_table(cfg: ModelConfig):
     """All tensors of the model.  Trainable ones are listed group by group (main, backbone, bert) in the
     order they are laid out in the flat parameter buffer."""
-    return main_table(cfg) + resnet_table("img_backbone.0.body.", cfg.resnet_layers) + bert_table("lang_backbone.", cfg.bert)
+    return main_table(cfg) + (seg_table(cfg) if cfg.masks else []) + resnet_table("img_backbone.0.body.", cfg.resnet_layers) + bert_table("lang_backbone.", cfg.bert)

@@ -88,6 +88,9 @@ class Net:
         for i in range(3):
             p = f"bbox_embed.layers.{i}."
             self._lin(p, p + "weight", p + "bias")
+        if cfg.masks:                    # MHAttentionMap projections (reftr_segmentation.py:186-187)
+            for n in ("q_linear.", "k_linear."):
+                self._lin("bbox_attention." + n, "bbox_attention." + n + "weight", "bbox_attention." + n + "bias")
         # input_proj 1x1 conv [E, 2048, 1, 1] used as a Linear over pixels
         w = st.phys("input_proj.0.0.weight").view(E, 2048)
         gw = st.phys("input_proj.0.0.weight", grad=True).view(E, 2048)

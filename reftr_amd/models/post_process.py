@@ -22,3 +22,26 @@ class PostProcessVGMultiPhrase(nn.Module):
                 boxes = boxes * torch.stack([img_w, img_h, img_w, img_h], dim=1)
             results.append({"boxes": boxes})
         return results
+
+
+class PostProcessSegm(nn.Module):
+    """models/reftr_segmentation.py:282-302 (eval only: bilinear resize -> sigmoid > threshold -> crop to the padded-free
+    size -> nearest resize to the original size).  Plain torch ops: exact decisions on float inputs, not a hot path."""
+
+    def __init__(self, threshold=0.5):
+        super().__init__()
+        self.threshold = threshold
+
+    @torch.no_grad()
+    def forward(self, results, outputs, orig_target_sizes, max_target_sizes):
+        import torch.nn.functional as F
+        assert len(orig_target_sizes) == len(max_target_sizes)
+        max_h, max_w = max_target_sizes.max(0)[0].tolist()
+        masks = outputs["pred_masks"].squeeze(2)
+        masks = F.interpolate(masks, size=(max_h, max_w), mode="bilinear", align_corners=False)
+        masks = masks.sigmoid() > self.threshold
+        for i, (cur, t, tt) in enumerate(zip(masks, max_target_sizes, orig_target_sizes)):
+            img_h, img_w = int(t[0]), int(t[1])
+            results[i]["masks"] = cur[:, :img_h, :img_w].unsqueeze(1)
+            results[i]["masks_origin"] = F.interpolate(results[i]["masks"].float(), size=tuple(tt.tolist()), mode="nearest").byte()
+        return results

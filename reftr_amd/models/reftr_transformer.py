@@ -17,6 +17,7 @@ from ..util.misc import NestedTensor, nested_tensor_from_tensor_list
 from . import layout as L
 from .backbone import ResNetBody
 from .net import Net, RELU
+from .segmentation import SegHead
 from .store import ParamStore, build_module_tree, rebind
 
 
@@ -32,18 +33,34 @@ class _RefTRFunction(torch.autograd.Function):
         return None, None, None
 
 
+class _RefTRSegFunction(torch.autograd.Function):
+    """RefTRSeg: two differentiable outputs (box logits, mask logits), one hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, samples):
+        ctx.model = model
+        logits = model._forward_impl(samples)
+        return logits, model._saved["pred_masks"]
+
+    @staticmethod
+    def backward(ctx, dlogits, dmasks):
+        ctx.model._backward_impl(dlogits.contiguous(), dmasks.contiguous())
+        return None, None, None
+
+
 class RefTR(nn.Module):
     def __init__(self, cfg: L.ModelConfig, device="cuda", aux_loss=True):
         super().__init__()
         assert cfg.n_q == 1, "num_queries_per_phrase = 1 (every reference config); n_q > 1 is not wired yet"
         self.cfg = cfg
-        self.aux_loss = aux_loss
+        self.aux_loss = aux_loss and not cfg.masks       # RefTRSeg is built with aux_loss=False (reftr_segmentation.py:52)
         self.num_queries_per_phrase = cfg.n_q
         self.hidden_dim = cfg.hidden
         self.store = ParamStore(cfg, device)
         build_module_tree(self, self.store)
         self.body = ResNetBody(self.store, cfg)
         self.net = Net(self.store, cfg)
+        self.seg = SegHead(self.store, cfg, self.net) if cfg.masks else None
         self._anchor = torch.zeros((), device=device, requires_grad=True)
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)   # dropout step-seed (advanced on device)
         self._operands_dirty = True       # bf16 operands must be rebuilt (after init / load / optimizer step)
@@ -111,6 +128,8 @@ class RefTR(nn.Module):
             return
         self.body.refresh(self._full_refresh)
         self.net.refresh()
+        if self.seg is not None:
+            self.seg.refresh()
         self._operands_dirty, self._full_refresh = False, False
 
     def state_dict(self, *args, **kwargs):
@@ -133,6 +152,7 @@ class RefTR(nn.Module):
             rebind(self, self.store)
             self.body = ResNetBody(self.store, self.cfg)
             self.net = Net(self.store, self.cfg)
+            self.seg = SegHead(self.store, self.cfg, self.net) if self.cfg.masks else None
             self._anchor = torch.zeros((), device=probe.device, requires_grad=True)
             self.seed_dev = self.seed_dev.to(probe.device)
             self.mark_dirty(full=True)
@@ -148,10 +168,18 @@ class RefTR(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, samples):
         self.refresh_operands()
-        logits = _RefTRFunction.apply(self._anchor, self, samples)          # [NL, B, P, K, 4]
+        pred_masks = None
+        if self.seg is not None:
+            assert "phrase" not in samples, "RefTRSeg is single-phrase (reftr_segmentation.py:101-103)"
+            logits, pred_masks = _RefTRSegFunction.apply(self._anchor, self, samples)
+        else:
+            logits = _RefTRFunction.apply(self._anchor, self, samples)      # [NL, B, P, K, 4]
         boxes = logits.sigmoid()
         phrase_mask = self._saved["phrase_mask"]
         out = {"pred_boxes": boxes[-1], "phrase_mask": phrase_mask, "pred_logits": logits}
+        if pred_masks is not None:                                          # reftr_segmentation.py:147-148
+            out["pred_masks"] = pred_masks
+            out["mask_att"] = self._saved["mask_att"]
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_boxes": b, "phrase_mask": phrase_mask} for b in boxes[:-1]]
         return out
@@ -222,6 +250,7 @@ class RefTR(nn.Module):
         cat_rows = cat16.view(2 * N, E)
         _, mp_ctx = net.mlp_fwd(ph_pooled16, "map_phrase.", y_bf16=cat_rows, want_f32=False, rowmap=(1, 2, 1))
 
+        src32 = x32                        # sequence buffer whose image rows hold input_proj + GroupNorm (img_src_proj)
         enc = []
         for i in range(cfg.enc_layers):
             x32, x16, xp16, r = net.enc_layer_fwd(f"{vt}encoder.layers.{i}.", x32, x16, xp16, pos, kpm, B, S)
@@ -273,11 +302,15 @@ class RefTR(nn.Module):
             memp16=memp16, mem32=mem32, cls16=cls16, lang16=lang16, kq=kq, qs=qs, vs=vs, qw=qw, c16=c16, co=co,
             cst=(cm, cr), fq_ctx=fq_ctx, dec=dec, hs_stats=hs_stats, t3s=t3s, hs16=hs16, y1=y1, y2=y2, pooled16=pooled16,
             phrase_mask=(qmask == 0).view(B, T), memory=mem32)
+        if self.seg is not None:            # RES head on the last decoder layer (reftr_segmentation.py:136-146)
+            pad_u8 = kpm[:, Lq:].contiguous()
+            pred_masks, mask_att, seg_sv = self.seg.forward(hs16[(NL - 1) * N:], mem16, mem32, src32, pad_u8, feats, B, S, Lq, h, w)
+            self._saved.update(pred_masks=pred_masks, mask_att=mask_att, seg=seg_sv)
         H.set_seed_dev(None)
         return logits.view(NL, B, Pn, cfg.n_q, 4)
 
     # ------------------------------------------------------------------ backward
-    def _backward_impl(self, dlogits):
+    def _backward_impl(self, dlogits, dmasks=None):
         cfg, net, st, sv = self.cfg, self.net, self.store, self._saved
         E = cfg.hidden
         dev = st.device
@@ -297,9 +330,15 @@ class RefTR(nn.Module):
         dy2 = H.small_dgrad(dl, l2.w32, gate=sv["y2"])
         dy1, _ = net.lin_bwd("bbox_embed.layers.1.", dy2, sv["y1"], gate=sv["y1"])
         _, dhs = net.lin_bwd("bbox_embed.layers.0.", dy1, sv["hs16"], out_bf16=False, out_f32=True)
+        dmem = f32z(M, E); dmemp = f32z(M, E); dqpos = f32z(N, E)
+
+        # ---- RES head (its gradients enter the last decoder output, the encoder memory, input_proj and the ResNet)
+        seg_dsrc, seg_extra = None, None
+        if dmasks is not None:
+            d_hs, seg_dsrc, seg_extra = self.seg.backward(sv["seg"], dmasks, dmem)
+            dhs[(NL - 1) * N:] += d_hs
 
         # ---- decoder
-        dmem = f32z(M, E); dmemp = f32z(M, E); dqpos = f32z(N, E)
         ga = gb = None
         for i in reversed(range(NL)):
             hm, hr = sv["hs_stats"][i]
@@ -352,6 +391,8 @@ class RefTR(nn.Module):
 
         # ---- sequence inputs: map_sentence (language rows) and input_proj + GroupNorm (image rows)
         d_seq = net.mlp_bwd(sv["ms_ctx"], dxa, "map_sentence.", dy_rowmap=(Lq, S, 0), dy2=dxb)
+        if seg_dsrc is not None:
+            H.rows_add(B * HW, E, a_f32=seg_dsrc, out_f32=dxa, accumulate=True, o_map=(HW, S, Lq))
         _, dip16 = H.groupnorm_bwd(dxa, sv["ip"].view(B, HW, E), st.P["input_proj.0.1.weight"], sv["gn_stats"],
                                    st.G["input_proj.0.1.weight"], st.G["input_proj.0.1.bias"], 32, 1e-5, dy2=dxb,
                                    rows_per_img=S, row_off=Lq)
@@ -374,7 +415,7 @@ class RefTR(nn.Module):
         g_c5, _ = net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], gate=sv["c5"])
         if getattr(self, "_debug", False):
             self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=g_c5.clone())
-        self._pending = (sv["bb_saved"], g_c5)
+        self._pending = (sv["bb_saved"], g_c5, seg_extra)
         if two_phase:
             net.wg.join()
             for hook in self._mid_backward_hooks:
@@ -385,9 +426,9 @@ class RefTR(nn.Module):
 
     def finish_backward(self):
         """Phase 2 of backward: the ResNet body (its gradients are the last to become final)."""
-        bb_saved, g_c5 = self._pending
+        bb_saved, g_c5, extra = self._pending
         self._pending = None
-        self.body.backward(bb_saved, g_c5)
+        self.body.backward(bb_saved, g_c5, extra)
         self.net.side.join()
         self.net.wg.join()
         H.set_seed_dev(None)
@@ -404,7 +445,8 @@ def build_config(args):
     return L.ModelConfig(hidden=args.hidden_dim, nheads=args.nheads, enc_layers=args.enc_layers,
                          dec_layers=0 if getattr(args, "no_decoder", False) else args.dec_layers,
                          ffn=args.dim_feedforward, dropout=args.dropout, max_lang_seq=args.max_lang_seq,
-                         n_q=args.num_queries_per_phrase, aux_loss=args.aux_loss, resnet_layers=layers, bert=bc)
+                         n_q=args.num_queries_per_phrase, aux_loss=args.aux_loss, resnet_layers=layers, bert=bc,
+                         masks=bool(getattr(args, "masks", False)))
 
 
 def build_reftr(args):
@@ -423,5 +465,31 @@ def build_reftr(args):
         weight_dict.update(aux)
     criterion = CriterionVGMultiPhrase(weight_dict, losses=["boxes"])
     postprocessors = {"bbox": PostProcessVGMultiPhrase()}
+    criterion.to(device)
+    return model, criterion, postprocessors
+
+
+def build_reftr_seg(args):
+    """models/reftr_segmentation.py:343-391: RefTRSeg + CriterionVGOnePhraseSeg + {'bbox', 'segm'} post-processors."""
+    from .criterion import CriterionVGOnePhraseSeg
+    from .post_process import PostProcessSegm, PostProcessVGMultiPhrase
+    if args.reftr_type != "transformer_single_phrase":
+        raise NotImplementedError                                   # as the reference (:389-390)
+    if getattr(args, "ablation", "none") == "cem_loss":
+        raise NotImplementedError("--ablation cem_loss (CEM block, reftr_segmentation.py:16-41) is not built")
+    device = torch.device(args.device)
+    cfg = build_config(args)
+    assert cfg.masks
+    model = RefTR(cfg, device=device, aux_loss=False)
+    weight_dict = {"loss_giou": args.giou_loss_coef, "loss_bbox": args.bbox_loss_coef,
+                   "loss_dice": args.dice_loss_coef, "loss_mask": args.mask_loss_coef, "loss_cem": 1.0}
+    if args.aux_loss:
+        aux = {}
+        for i in range(cfg.dec_layers - 1):
+            aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
+        aux.update({k + "_enc": v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    criterion = CriterionVGOnePhraseSeg(weight_dict, losses=["masks", "boxes"])
+    postprocessors = {"bbox": PostProcessVGMultiPhrase(), "segm": PostProcessSegm()}
     criterion.to(device)
     return model, criterion, postprocessors

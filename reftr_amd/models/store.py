@@ -36,6 +36,7 @@ class ParamStore:
         self.table = L.full_table(cfg)
         self.shapes = {n: s for n, s, _ in self.table}
         self.kinds = {n: k for n, _, k in self.table}
+        self.physd = L.phys_dims(cfg)      # name -> padded physical shape (RES head convolutions)
         # ---- offsets
         self.offset = {}          # name -> (buffer id, offset)
         self.group_range = {}     # lr group -> (begin, end)
@@ -44,9 +45,10 @@ class ParamStore:
             begin = off
             for n, s, k in self.table:
                 if k == "param" and L.lr_group(n) == grp:
-                    assert _numel(s) % 4 == 0, (n, s)
+                    ne = _numel(self.physd.get(n, s))
+                    assert ne % 4 == 0, (n, s)
                     self.offset[n] = ("p", off)
-                    off += _numel(s)
+                    off += ne
             off = _pad(off, self.ALIGN)
             self.group_range[grp] = (begin, off)
         self.n_train = off
@@ -78,6 +80,13 @@ class ParamStore:
 
     def _view(self, buf, name, off):
         shape = self.shapes[name]
+        if name in self.physd:             # padded storage: logical tensor = unpadded corner of the physical one
+            ps = self.physd[name]
+            flat = buf[off:off + _numel(ps)]
+            if len(ps) == 4:
+                co, ci, kh, kw = shape
+                return flat.view(ps)[:co, :, :, :ci].permute(0, 3, 1, 2)
+            return flat.view(ps)[:shape[0]]
         flat = buf[off:off + _numel(shape)]
         if len(shape) == 4:     # conv weight: physical [Cout][kh][kw][Cin], logical [Cout, Cin, kh, kw]
             co, ci, kh, kw = shape
@@ -86,6 +95,12 @@ class ParamStore:
 
     def phys(self, name, grad=False):
         """Physical (contiguous) tensor of a conv weight / its gradient: [Cout, kh*kw, Cin]."""
+        if name in self.physd:             # padded: the whole physical block [Cout_pad, kh*kw, Cin_pad] / [Cout_pad]
+            ps = self.physd[name]
+            b, off = self.offset[name]
+            buf = self.flat_g if grad else self.flat[b]
+            flat = buf[off:off + _numel(ps)]
+            return flat.view(ps[0], ps[1] * ps[2], ps[3]) if len(ps) == 4 else flat
         t = (self.G if grad else self.P)[name]
         co, ci, kh, kw = self.shapes[name]
         return t.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)    # a view: permute back to storage order

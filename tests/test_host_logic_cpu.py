@@ -74,8 +74,29 @@ def test_build_reftr_factory_and_weight_dict():
     assert set(post) == {"bbox"}
     wd = criterion.weight_dict                       # models/reftr_transformer.py:320-329
     assert set(wd) == {"loss_giou", "loss_bbox", "loss_giou_0", "loss_bbox_0", "loss_giou_enc", "loss_bbox_enc"}
+    # --masks -> RefTRSeg (models/__init__.py:5-7, reftr_segmentation.py:343-391)
+    seg_args = ref_args(masks=True, aux_loss=False, reftr_type="transformer_single_phrase", dice_loss_coef=1.0, mask_loss_coef=1.0)
+    model, criterion, post = build_reftr(seg_args)
+    assert set(post) == {"bbox", "segm"} and model.cfg.masks and not model.aux_loss
+    assert set(criterion.weight_dict) == {"loss_giou", "loss_bbox", "loss_dice", "loss_mask", "loss_cem"}
+    sd = model.state_dict()
+    from oracle.shapes import param_shapes
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in param_shapes(ocfg).items()}
+    w = sd["mask_head.lay1.weight"]
+    assert w.shape == (520, 520, 3, 3) and w.is_contiguous()        # padded storage is invisible outside
     with pytest.raises(NotImplementedError):
-        build_reftr(ref_args(masks=True))
+        build_reftr(ref_args(masks=True, aux_loss=False, reftr_type="transformer_multi_phrase", dice_loss_coef=1.0, mask_loss_coef=1.0))
+
+
+def test_post_process_segm_matches_reference_golden_exactly():
+    from reftr_amd.models.post_process import PostProcessSegm
+    g = np.load(os.path.join(ROOT, "tests", "golden", "seg_single.npz"))
+    res = PostProcessSegm()([{} for _ in range(2)], {"pred_masks": torch.from_numpy(g["pred_masks"])},
+                            torch.from_numpy(g["post_orig"]), torch.from_numpy(g["post_sizes"]))
+    for i in range(2):
+        assert torch.equal(res[i]["masks"], torch.from_numpy(g[f"post_masks{i}"]))
+        assert torch.equal(res[i]["masks_origin"], torch.from_numpy(g[f"post_masks_origin{i}"]))
 
 
 def test_no_cpu_fallback_exists():

@@ -99,3 +99,39 @@ def test_bf16_point_mode_stays_close():
         a = O.reftr_forward(P, samples, cfg)["logits"]
         b = O.reftr_forward(P, samples, cfg, q=True)["logits"]
     assert rel(b, a) < 5e-2
+
+
+def seg_batch(g):
+    """The seg_single fixture's inputs: formula-built batch + the target masks stored in the fixture."""
+    samples, targets = make_inputs("seg_single", B=2, H=96, W=128, L=12)
+    targets = [dict(t, masks=torch.from_numpy(g[f"target_mask{i}"])) for i, t in enumerate(targets)]
+    return samples, targets
+
+
+def test_refer_segmentation_golden():
+    """RefTRSeg (reftr_segmentation.py) restatement vs the imported reference's outputs, losses and gradients."""
+    g = gold("seg_single")
+    cfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False)
+    P = formula_state(param_shapes(cfg))
+    samples, targets = seg_batch(g)
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(names) == sorted(k for k in P if O.is_trainable(k))
+    leaves = {k: P[k].requires_grad_(True) for k in names}
+    out = O.reftr_forward(P, samples, cfg)
+    assert rel(out["pred_masks"], g["pred_masks"]) < 1e-5 and rel(out["mask_att"], g["mask_att"]) < 1e-5
+    assert rel(out["pred_boxes"], g["pred_boxes"]) < 1e-5
+    losses = O.criterion(out, targets)
+    for k in ("loss_mask", "loss_dice", "loss_bbox", "loss_giou"):
+        assert abs(float(losses[k]) - float(g["loss." + k])) < 1e-5 * max(1.0, abs(float(g["loss." + k]))), k
+    total = O.total_loss(losses, O.weight_dict(cfg))
+    assert abs(float(total) - float(g["total_loss"])) < 1e-5 * float(g["total_loss"])
+    grads = dict(zip(names, torch.autograd.grad(total, [leaves[k] for k in names])))
+    gn = {str(n): float(v) for n, v in zip(g["grad_names"], g["grad_norms"])}
+    for k in names:
+        assert abs(float(grads[k].norm()) - gn[k]) < 1e-4 * max(gn[k], 1e-6) + 1e-9, k
+    for key in g.files:
+        if key.startswith("grad."):
+            k = key[5:]
+            ref = torch.from_numpy(g[key])
+            mine = grads[k][:8] if grads[k].dim() > 1 and grads[k].shape[0] > 8 else grads[k]
+            assert rel(mine, ref) < 1e-4, k

@@ -1,0 +1,130 @@
+"""GPU end-to-end parity of the RES head (RefTRSeg, cfg4) through the C ABI against the golden vectors minted from the
+imported reference (tests/golden/seg_single.npz; oracle/gen_golden_seg.py).
+
+Tolerances (bf16 operands vs the reference's fp32): mask logits / attention map rel-L2 <= 2e-2, boxes <= 5e-3, the four
+losses <= 1e-2 relative; gradients of the head tensors <= 0.1 rel-L2 and cosine >= 0.995 (measured: 1-6 %, the
+FPN adapters sit behind three GroupNorm+ReLU stages whose masks flip under bf16 noise); global gradient (all
+tensors) rel-L2 <= 0.25, cosine >= 0.97 (noise floor of ReLU-mask flips).  Post-processed masks are
+compared as decisions (> 99 % of the pixels equal: logits within bf16 noise of 0 flip; measured 99.46 %)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reftr_oracle as O
+from oracle.shapes import param_shapes
+from oracle.synth import make_inputs
+from oracle.weights import formula_state
+from test_model_gpu import rel, to_cuda
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build_seg():
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGOnePhraseSeg
+    from reftr_amd.models.reftr_transformer import RefTR
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False)
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), masks=True)
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda", aux_loss=False)
+    model.load_state_dict(P, strict=True)
+    crit = CriterionVGOnePhraseSeg(O.weight_dict(ocfg), ["masks", "boxes"])
+    return model, crit, P, ocfg
+
+
+def seg_batch(g):
+    samples, targets = make_inputs("seg_single", B=2, H=96, W=128, L=12)
+    targets = [dict(t, masks=torch.from_numpy(g[f"target_mask{i}"])) for i, t in enumerate(targets)]
+    return samples, targets
+
+
+def test_refer_segmentation_vs_reference_golden(hip):
+    g = np.load(os.path.join(GOLD, "seg_single.npz"))
+    model, crit, P, ocfg = build_seg()
+    model.eval()
+    samples, targets = seg_batch(g)
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    assert out["pred_masks"].shape == g["pred_masks"].shape and out["mask_att"].shape == g["mask_att"].shape
+    assert rel(out["pred_masks"], g["pred_masks"]) < 2e-2
+    assert rel(out["mask_att"], g["mask_att"]) < 2e-2
+    assert rel(out["pred_boxes"], g["pred_boxes"]) < 5e-3
+    losses = crit(out, tg)
+    for k in ("loss_mask", "loss_dice", "loss_bbox", "loss_giou"):
+        ref = float(g["loss." + k])
+        assert abs(float(losses[k]) - ref) < 1e-2 * max(abs(ref), 0.1), (k, float(losses[k]), ref)
+    wd = crit.weight_dict
+    total = sum(losses[k] * wd[k] for k in losses if k in wd)
+    model.store.flat_g.zero_()
+    total.backward()
+    G = model.store.G
+    for key in g.files:
+        if not key.startswith("grad."):
+            continue
+        k = key[5:]
+        ref = torch.from_numpy(g[key])
+        mine = G[k].detach().float().cpu()
+        mine = mine[:8] if mine.dim() > 1 and mine.shape[0] > 8 else mine
+        if k.startswith("mask_head.") or k.startswith("bbox_attention."):
+            cos = float((mine * ref).sum() / (mine.norm() * ref.norm() + 1e-30))
+            assert rel(mine, ref) < 0.1 and cos > 0.995, (k, rel(mine, ref), cos)
+    names = [str(n) for n in g["grad_names"]]
+    gn_ref = torch.tensor(g["grad_norms"])
+    gn = torch.tensor([float(G[k].norm()) for k in names])
+    assert float((gn - gn_ref).norm() / gn_ref.norm()) < 0.1
+    # padding of the padded storage never receives gradient
+    ph = model.store.phys("mask_head.lay1.weight", grad=True)
+    assert float(ph[:, :, 520:].abs().max()) == 0.0 and float(ph[520:].abs().max()) == 0.0
+    # post-processing decisions
+    from reftr_amd.models.post_process import PostProcessSegm
+    res = PostProcessSegm()([{} for _ in range(2)], {"pred_masks": out["pred_masks"].detach().cpu()},
+                            torch.from_numpy(g["post_orig"]), torch.from_numpy(g["post_sizes"]))
+    for i in range(2):
+        same = (res[i]["masks"] == torch.from_numpy(g[f"post_masks{i}"])).float().mean()
+        assert float(same) > 0.99
+
+
+def test_seg_gradients_vs_oracle_global(hip):
+    g = np.load(os.path.join(GOLD, "seg_single.npz"))
+    model, crit, P, ocfg = build_seg()
+    model.eval()
+    samples, targets = seg_batch(g)
+    names = [k for k in P if O.is_trainable(k) and torch.is_floating_point(P[k])]
+    leaves = {k: P[k].clone().requires_grad_(True) for k in names}
+    Pl = dict(P); Pl.update(leaves)
+    o = O.reftr_forward(Pl, samples, ocfg, train=False, q=False)
+    tot = O.total_loss(O.criterion(o, targets), O.weight_dict(ocfg))
+    ref = dict(zip(names, torch.autograd.grad(tot, [leaves[k] for k in names])))
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    ld = crit(out, tg)
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    model.store.flat_g.zero_()
+    total.backward()
+    a = torch.cat([model.store.G[k].detach().float().cpu().reshape(-1) for k in names])
+    b = torch.cat([ref[k].reshape(-1) for k in names])
+    assert float((a - b).norm() / b.norm()) < 0.25
+    assert float((a * b).sum() / (a.norm() * b.norm())) > 0.97
+    # the ResNet stages that only the RES head's FPN adapters reach more directly
+    for k in ("img_backbone.0.body.layer3.5.conv3.weight", "img_backbone.0.body.layer2.3.conv3.weight"):
+        x, y = model.store.G[k].detach().float().cpu().reshape(-1), ref[k].reshape(-1)
+        assert float((x * y).sum() / (x.norm() * y.norm())) > 0.95, k
+
+
+def test_seg_training_steps_run(hip):
+    """Three optimiser steps of the REC+RES multitask step (train mode, dropout on) stay finite and reduce the loss."""
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.optim import FusedAdamW
+    g = np.load(os.path.join(GOLD, "seg_single.npz"))
+    model, crit, P, ocfg = build_seg()
+    model.train()
+    opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    samples, targets = seg_batch(g)
+    s, tg = to_cuda(samples, targets)
+    hist = [train_step(model, crit, s, tg, opt, None, max_norm=0.1)[0] for _ in range(4)]
+    assert all(np.isfinite(h) for h in hist) and hist[-1] < hist[0], hist
+    ph = model.store.phys("mask_head.lay1.weight")
+    assert float(ph[:, :, 520:].abs().max()) == 0.0            # padded weights stay exactly zero through AdamW

@@ -84,7 +84,7 @@ def test_seg_concat(hip):
     g = torch.Generator().manual_seed(3)
     src = torch.randn(B * HW, E, generator=g); mem = torch.randn(B * (L + HW), E, generator=g)
     out = torch.full((B * HW, 576), 9.0, dtype=torch.bfloat16, device="cuda")
-    hip.seg_concat(src.cuda(), mem.cuda(), out, B, HW, E, nh, L + HW, L)
+    hip.seg_concat(src.cuda(), mem.cuda(), out, B, HW, E, nh, L + HW, L, src_dense=True)
     o = out.float().cpu()
     assert torch.equal(o[:, :E], src.bfloat16().float())
     assert torch.equal(o[:, E:2 * E], mem.view(B, L + HW, E)[:, L:].reshape(B * HW, E).bfloat16().float())
