@@ -256,11 +256,15 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
 
 @torch.no_grad()
 def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=None, visualize=False):
-    """REC part of engine_vg.evaluate (engine_vg.py:82-225): Acc@0.5 and mean IoU of the predicted boxes."""
+    """engine_vg.evaluate (engine_vg.py:82-225) without the image dumps of `visualize`: losses, Acc@0.5 / mean IoU of the
+    predicted boxes (:127-140), mask IoU when a 'segm' post-processor is present (:143-152), boxes scaled to the
+    original image size in the returned results dict (:141,203)."""
+    from .util.box_ops import mask_iou
     model.eval()
     criterion.eval()
     metric_logger = utils.MetricLogger(delimiter="  ")
-    sum_accu = torch.zeros(1, device=device); sum_iou = torch.zeros(1, device=device); cnt = torch.zeros(1, device=device)
+    sum_accu = torch.zeros((), device=device); sum_iou = torch.zeros((), device=device); cnt = torch.zeros((), device=device)
+    seg_iou = torch.zeros((), device=device); cnt_seg = 0.0
     results_dict = {}
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
@@ -269,21 +273,38 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
         loss_dict = criterion(outputs, targets)
         weight_dict = criterion.weight_dict
         red = utils.reduce_dict(loss_dict)
-        metric_logger.update(loss=sum(v * weight_dict[k] for k, v in red.items() if k in weight_dict))
-        sizes = torch.stack([t["size"] for t in targets], dim=0)
-        results = postprocessors["bbox"](outputs, sizes, scale_to_original_shape=False)
+        scaled = {k: v * weight_dict[k] for k, v in red.items() if k in weight_dict}
+        metric_logger.update(loss=sum(scaled.values()), **scaled, **{f"{k}_unscaled": v for k, v in red.items()})
+        key = "orig_size" if "orig_size" in targets[0] else "size"
+        orig_sizes = torch.stack([t[key] for t in targets], dim=0)
+        results = postprocessors["bbox"](outputs, orig_sizes)
         for res, tg in zip(results, targets):
             gt = box_cxcywh_to_xyxy(tg["boxes"])
-            iou = torch.diag(box_iou(res["boxes"], gt)[0])
-            sum_accu += (iou > 0.5).float().sum(); sum_iou += iou.sum(); cnt += iou.numel()      # engine_vg.py:131-140
+            assert gt.size(0) == res["boxes"].size(0), (res, gt)
+            iou = torch.diag(box_iou(gt, res["boxes"])[0])
+            sum_accu += (iou > 0.5).float().sum(); sum_iou += iou.sum(); cnt += len(tg["boxes"])
+        results_scaled = postprocessors["bbox"](outputs, orig_sizes, scale_to_original_shape=True)
+        if "segm" in postprocessors:
+            target_sizes = torch.stack([t["size"] for t in targets], dim=0)
+            results = postprocessors["segm"](results, outputs, orig_sizes, target_sizes)
+            for res, tg in zip(results, targets):
+                seg_iou += mask_iou(res["masks"][0][0], tg["masks"])
+                cnt_seg += 1
+        for tg, res in zip(targets, results_scaled):
             if "image_id" in tg:
-                results_dict[int(tg["image_id"])] = res["boxes"].cpu()
+                results_dict[int(tg["image_id"])] = res["boxes"].cpu().numpy().tolist()
         samples, targets = prefetcher.next()
+    metric_logger.synchronize_between_processes()
+    stats = {k: meter.global_avg for k, meter in metric_logger.meters.items()}
     if utils.is_dist_avail_and_initialized():
         for t in (sum_accu, sum_iou, cnt):
             torch.distributed.all_reduce(t)
-    metric_logger.synchronize_between_processes()
-    stats = {k: meter.global_avg for k, meter in metric_logger.meters.items()}
     stats["accuracy_iou0.5"] = float(sum_accu / cnt.clamp(min=1))
     stats["miou"] = float(sum_iou / cnt.clamp(min=1))
+    if "segm" in postprocessors:
+        if utils.is_dist_avail_and_initialized():
+            torch.distributed.all_reduce(seg_iou)
+            cnt_seg = utils.get_world_size() * cnt_seg
+        stats["seg_miou"] = float(seg_iou / max(cnt_seg, 1.0))
+    stats = {k: v for k, v in stats.items() if k.split("_")[-1] not in ("unscaled", "0", "1", "2")}      # engine_vg.py:221
     return stats, results_dict

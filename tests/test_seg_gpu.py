@@ -128,3 +128,47 @@ def test_seg_training_steps_run(hip):
     assert all(np.isfinite(h) for h in hist) and hist[-1] < hist[0], hist
     ph = model.store.phys("mask_head.lay1.weight")
     assert float(ph[:, :, 520:].abs().max()) == 0.0            # padded weights stay exactly zero through AdamW
+
+
+def test_evaluate_rec_and_res_metrics(hip):
+    """engine_vg.evaluate (engine_vg.py:82-225): Acc@0.5 / mIoU of the boxes and the mask IoU, on a two-batch loader,
+    against the same metrics recomputed from the model outputs with plain torch ops (exact decisions)."""
+    import torch.nn.functional as F
+    from reftr_amd.engine_vg import evaluate
+    from reftr_amd.models.post_process import PostProcessSegm, PostProcessVGMultiPhrase
+    from reftr_amd.util import box_ops
+    from reftr_amd.util.misc import NestedTensor
+    g = np.load(os.path.join(GOLD, "seg_single.npz"))
+    model, crit, P, ocfg = build_seg()
+    samples, targets = seg_batch(g)
+    for i, t in enumerate(targets):
+        h, w = t["masks"].shape[-2:]
+        t.update(size=torch.tensor([h, w]), orig_size=torch.tensor([2 * h + 1, 3 * w]), image_id=torch.tensor(10 + i),
+                 dataset_id=torch.tensor(i))
+    s = {k: v for k, v in samples.items() if k not in ("img", "img_mask")}
+    s["img"] = NestedTensor(samples["img"], samples["img_mask"])
+    loader = [(s, targets), (s, targets)]
+    post = {"bbox": PostProcessVGMultiPhrase(), "segm": PostProcessSegm()}
+    stats, results = evaluate(model, crit, post, loader, torch.device("cuda"))
+    assert {"accuracy_iou0.5", "miou", "seg_miou", "loss", "loss_mask", "loss_dice", "loss_bbox", "loss_giou"} <= set(stats)
+    assert not any(k.endswith("_unscaled") for k in stats)
+    # independent recomputation
+    model.eval()
+    cs, ct = to_cuda(samples, targets)
+    out = model(cs)
+    ious, sious = [], []
+    pm = F.interpolate(out["pred_masks"].squeeze(2), size=tuple(torch.stack([t["size"] for t in targets]).max(0)[0].tolist()),
+                       mode="bilinear", align_corners=False).sigmoid() > 0.5
+    for i, t in enumerate(ct):
+        b = box_ops.box_cxcywh_to_xyxy(out["pred_boxes"][i, 0])
+        ious.append(torch.diag(box_ops.box_iou(box_ops.box_cxcywh_to_xyxy(t["boxes"]), b)[0]))
+        h, w = t["masks"].shape[-2:]
+        sious.append(box_ops.mask_iou(pm[i, :, :h, :w][0], t["masks"][0]))
+    iou = torch.cat(ious)
+    assert abs(stats["accuracy_iou0.5"] - float((iou > 0.5).float().mean())) < 1e-6
+    assert abs(stats["miou"] - float(iou.mean())) < 1e-5
+    assert abs(stats["seg_miou"] - float(torch.stack(sious).mean())) < 1e-5
+    assert set(results) == {10, 11} and len(results[10][0]) == 4
+    sc = torch.tensor(results[10][0]); nb = box_ops.box_cxcywh_to_xyxy(out["pred_boxes"][0, 0]).cpu()[0]
+    oh, ow = [float(v) for v in targets[0]["orig_size"]]
+    assert torch.allclose(sc, nb * torch.tensor([ow, oh, ow, oh]), rtol=1e-4, atol=1e-3)
