@@ -7,6 +7,7 @@ Differences that are deliberate and documented in INTEGRATION.md:
     torch.cuda.Stream() unconditionally, engine_vg.py:240).
 """
 import math
+import os
 import sys
 
 import torch
@@ -62,13 +63,21 @@ class data_prefetcher:
         return s, t
 
 
+def _total(criterion, loss_dict):
+    """engine_vg.py:43.  The HIP criterion offers the same weighted sum as one fused reduction."""
+    if hasattr(criterion, "weighted_total") and os.environ.get("REFTR_FUSED_TOTAL", "1") != "0":
+        return criterion.weighted_total(loss_dict)
+    wd = criterion.weight_dict
+    return sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
+
+
 def train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0):
     """The loop body, engine_vg.py:40-72.  Returns (loss_value, reduced scaled dict, reduced unscaled dict,
     grad_norm tensor)."""
     outputs = model(samples)
     loss_dict = criterion(outputs, targets)
     weight_dict = criterion.weight_dict
-    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+    losses = _total(criterion, loss_dict)
     loss_dict_reduced = utils.reduce_dict(loss_dict)
     unscaled = {f"{k}_unscaled": v for k, v in loss_dict_reduced.items()}
     scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
@@ -194,8 +203,7 @@ class CapturedTrainStep:
     def _fwd_bwd(self):
         outputs = self.model(self.s)
         loss_dict = self.criterion(outputs, self.t)
-        wd = self.criterion.weight_dict
-        losses = sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
+        losses = _total(self.criterion, loss_dict)
         self.optimizer.zero_grad()
         losses.backward()
         return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}

@@ -71,12 +71,37 @@ class CriterionVGMultiPhrase(nn.Module):
         boxes, off = self._targets(targets, device)
         valid = outputs["phrase_mask"].to(torch.uint8).contiguous()
         losses = _BoxLossFunction.apply(logits, valid, boxes, off, num_boxes)     # [NL, 2]
+        self._last_box = losses
         nl = losses.shape[0]
         out = {"loss_bbox": losses[nl - 1, 0], "loss_giou": losses[nl - 1, 1]}
         for i in range(nl - 1):
             out[f"loss_bbox_{i}"] = losses[i, 0]
             out[f"loss_giou_{i}"] = losses[i, 1]
         return out
+
+
+def _weighted_total(crit, loss_dict):
+    """engine_vg.py:43 (`sum(loss_dict[k] * weight_dict[k] ...)`) as ONE weighted reduction over the loss tensors the
+    kernels produced, instead of ~4 tiny autograd kernels per loss key (12 keys with aux losses)."""
+    box = crit._last_box                                  # [NL, 2] = (loss_bbox, loss_giou) per decoder layer
+    nl = box.shape[0]
+    key = (nl, box.device)
+    if getattr(crit, "_wkey", None) != key:
+        wd = crit.weight_dict
+        w = torch.zeros(nl, 2)
+        for i in range(nl):
+            sfx = "" if i == nl - 1 else f"_{i}"
+            w[i, 0] = wd.get("loss_bbox" + sfx, 0.0); w[i, 1] = wd.get("loss_giou" + sfx, 0.0)
+        crit._wbox = w.to(box.device)
+        crit._wmask = torch.tensor([wd.get("loss_mask", 0.0), wd.get("loss_dice", 0.0)], device=box.device)
+        crit._wkey = key
+    total = (box * crit._wbox).sum()
+    if getattr(crit, "_last_mask", None) is not None and "loss_mask" in loss_dict:
+        total = total + (crit._last_mask * crit._wmask).sum()
+    return total
+
+
+CriterionVGMultiPhrase.weighted_total = _weighted_total
 
 
 class _MaskLossFunction(torch.autograd.Function):
@@ -125,6 +150,7 @@ class CriterionVGOnePhraseSeg(CriterionVGMultiPhrase):
             assert nq == 1, "RefTRSeg predicts one mask per image (n_ph = n_q = 1)"
             tgt = self._padded_masks(targets, pm.device)
             lm = _MaskLossFunction.apply(pm, tgt, float(bs * nq))
+            self._last_mask = lm
             losses["loss_mask"], losses["loss_dice"] = lm[0], lm[1]
         losses.update(super().forward(outputs, targets))
         return losses

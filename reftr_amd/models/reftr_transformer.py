@@ -8,6 +8,7 @@ sees ONE node for the whole model (`_RefTRFunction`), whose backward runs the ha
 and leaves every parameter gradient in the flat gradient buffer.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -69,6 +70,7 @@ class RefTR(nn.Module):
         self._saved = None
         self._mid_backward_hooks = []     # after phase 1 of backward (everything but the ResNet): early DP exchange
         self._post_backward_hooks = []
+        self._lin_refresh_pending = False
         self._defer_phase2 = False        # engine-driven: stop after phase 1, `finish_backward()` runs the ResNet part
         self._pending = None
         self.reset_parameters()
@@ -127,7 +129,11 @@ class RefTR(nn.Module):
         if not self._operands_dirty:
             return
         self.body.refresh(self._full_refresh)
-        self.net.refresh()
+        # the Linear operands (BERT + transformer, 85 % of the bytes) are refreshed at the head of the BERT side stream
+        # inside _forward_impl, concurrently with the stem / layer1 of the ResNet
+        self._lin_refresh_pending = True
+        if os.environ.get("REFTR_PREP_SIDE", "1") == "0":
+            self.net.refresh(); self._lin_refresh_pending = False
         if self.seg is not None:
             self.seg.refresh()
         self._operands_dirty, self._full_refresh = False, False
@@ -205,7 +211,12 @@ class RefTR(nn.Module):
         smask_u8 = samples["sentence_mask"].to(dev).to(torch.uint8).contiguous()
         Lq = ids.shape[1]
         # language branch (BERT) on the side stream, concurrently with the ResNet branch below
-        seq16, pooled16, bctx = net.side.run(lambda: net.bert_fwd(ids, smask_u8), ids, smask_u8)
+        def _lang_branch():
+            if self._lin_refresh_pending:
+                net.refresh()
+                self._lin_refresh_pending = False
+            return net.bert_fwd(ids, smask_u8)
+        seq16, pooled16, bctx = net.side.run(_lang_branch, ids, smask_u8)
         feats, bb_saved = self.body.forward(x)
         c5, (_, h, w) = feats[-1]
         HW = h * w
