@@ -40,7 +40,7 @@ class ModelConfig:
     bert: BertConfig = field(default_factory=BertConfig)
 
 
-GROUP_MAIN, GROUP_BACKBONE, GROUP_BERT = 0, 1, 2
+GROUP_MAIN, GROUP_BACKBONE, GROUP_BERT, GROUP_MASK = 0, 1, 2, 3
 
 
 def lr_group(name):
@@ -49,6 +49,8 @@ def lr_group(name):
         return GROUP_BACKBONE
     if "lang_backbone" in name:
         return GROUP_BERT
+    if "bbox_attention" in name or "mask_head" in name:       # lr_mask_branch_names, main_vg.py:31,256-261
+        return GROUP_MASK
     return GROUP_MAIN
 
 
@@ -196,3 +198,69 @@ def full_table(cfg: ModelConfig):
     """All tensors of the model.  Trainable ones are listed group by group (main, backbone, bert) in the
     order they are laid out in the flat parameter buffer."""
     return main_table(cfg) + (seg_table(cfg) if cfg.masks else []) + resnet_table("img_backbone.0.body.", cfg.resnet_layers) + bert_table("lang_backbone.", cfg.bert)
+
+
+def reference_param_order(cfg: ModelConfig):
+    """Names of the TRAINABLE tensors in the order the reference's `model.named_parameters()` yields them (module
+    registration order of RefTR / RefTRSeg, torchvision ResNet, HF BertModel, DETR-style transformer layers).  A
+    torch.optim.AdamW state_dict refers to parameters by their index in this order within each param group
+    (main_vg.py:234-262), so this is what converts optimizer state to / from reference checkpoints."""
+    E = cfg.hidden
+    names = []
+    pfx = "img_backbone.0.body."
+    for li, n in enumerate(cfg.resnet_layers):
+        if li == 0:
+            continue                      # conv1 / layer1 are frozen (backbone.py:87-89): not in any param group
+        for bi in range(n):
+            p = f"{pfx}layer{li + 1}.{bi}."
+            for c in ("conv1", "conv2", "conv3"):
+                names.append(p + c + ".weight")
+            if bi == 0:
+                names.append(p + "downsample.0.weight")
+    lb = "lang_backbone."
+    e = lb + "embeddings."
+    names += [e + "word_embeddings.weight", e + "position_embeddings.weight", e + "token_type_embeddings.weight",
+              e + "LayerNorm.weight", e + "LayerNorm.bias"]
+
+    def wb(p):
+        names.append(p + "weight"); names.append(p + "bias")
+    for i in range(cfg.bert.layers):
+        lp = f"{lb}encoder.layer.{i}."
+        for n in ("attention.self.query.", "attention.self.key.", "attention.self.value.", "attention.output.dense.",
+                  "attention.output.LayerNorm.", "intermediate.dense.", "output.dense.", "output.LayerNorm."):
+            wb(lp + n)
+    wb(lb + "pooler.dense.")
+    vt = "vl_transformer."
+    names += [vt + "level_embed", vt + "lang_pos_embeddings.weight", vt + "token_type_embeddings.weight"]
+
+    def mha(p):
+        names.append(p + "in_proj_weight"); names.append(p + "in_proj_bias"); wb(p + "out_proj.")
+    for i in range(cfg.enc_layers):
+        p = f"{vt}encoder.layers.{i}."
+        mha(p + "self_attn."); wb(p + "linear1."); wb(p + "linear2."); wb(p + "norm1."); wb(p + "norm2.")
+    for i in range(cfg.dec_layers):
+        p = f"{vt}decoder.layers.{i}."
+        mha(p + "self_attn."); mha(p + "multihead_attn."); wb(p + "linear1."); wb(p + "linear2.")
+        wb(p + "norm1."); wb(p + "norm2."); wb(p + "norm3.")
+    if cfg.dec_layers > 0:
+        wb(vt + "decoder.norm.")
+    for i in range(3):
+        wb(f"bbox_embed.layers.{i}.")
+    for m in ("map_sentence.", "map_phrase."):
+        for j in ("0.", "1.", "4.", "5."):
+            wb(m + j)
+    q = "query_encoder."
+    names.append(q + "query_embed.weight")
+    for n in ("linear1.", "linear2.", "linear3.", "fuse_encoder_query.0.", "fuse_encoder_query.1.", "fuse_encoder_query.4.",
+              "fuse_encoder_query.5.", "context_out.0.", "context_out.1."):
+        wb(q + n)
+    wb("input_proj.0.0."); wb("input_proj.0.1.")
+    if cfg.masks:
+        wb("bbox_attention.q_linear."); wb("bbox_attention.k_linear.")
+        mh = "mask_head."
+        for i in range(1, 6):
+            wb(f"{mh}lay{i}."); wb(f"{mh}gn{i}.")
+        wb(mh + "out_lay.")
+        for i in range(1, 4):
+            wb(f"{mh}adapter{i}.")
+    return names

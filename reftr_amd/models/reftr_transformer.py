@@ -171,6 +171,12 @@ class RefTR(nn.Module):
         bb.update(enc)
         self.load_state_dict(bb, strict=False)
 
+    def init_from_pretrained(self, state_dict):
+        """RefTRSeg.init_from_pretrained (models/reftr_segmentation.py:66-74): non-strict load of a REC checkpoint."""
+        missing, unexpected = self.load_state_dict(state_dict, strict=False)
+        print("Unexpected keys: ", unexpected)
+        print("Missing keys: ", missing)
+
     # ------------------------------------------------------------------ forward
     def forward(self, samples):
         self.refresh_operands()

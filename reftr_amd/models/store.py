@@ -41,7 +41,7 @@ class ParamStore:
         self.offset = {}          # name -> (buffer id, offset)
         self.group_range = {}     # lr group -> (begin, end)
         off = 0
-        for grp in (L.GROUP_MAIN, L.GROUP_BACKBONE, L.GROUP_BERT):
+        for grp in (L.GROUP_MAIN, L.GROUP_MASK, L.GROUP_BACKBONE, L.GROUP_BERT):
             begin = off
             for n, s, k in self.table:
                 if k == "param" and L.lr_group(n) == grp:
@@ -92,6 +92,12 @@ class ParamStore:
             co, ci, kh, kw = shape
             return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
         return flat.view(shape)
+
+    def view_of(self, buf, name):
+        """The logical view of tensor `name` inside another flat buffer laid out like flat_p (optimizer moments)."""
+        b, off = self.offset[name]
+        assert b == "p"
+        return self._view(buf, name, off)
 
     def phys(self, name, grad=False):
         """Physical (contiguous) tensor of a conv weight / its gradient: [Cout, kh*kw, Cin]."""

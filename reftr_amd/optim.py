@@ -2,7 +2,7 @@
 engine_vg.py:62-66) as two kernels over the model's flat parameter / gradient buffers.
 
 It is a torch.optim.Optimizer so `lr_scheduler.step()` (StepLR / LambdaLR, main_vg.py:269-287) and
-`optimizer.param_groups[0]["lr"]` (engine_vg.py:71) keep working; the three param groups are the
+`optimizer.param_groups[0]["lr"]` (engine_vg.py:71) keep working; the four param groups are the
 reference's (default lr / lr_backbone names 'img_backbone.0' / lr_bert names 'lang_backbone', the latter
 also at args.lr_backbone — main_vg.py:251-255).
 """
@@ -13,15 +13,22 @@ from .models import layout as L
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, model, lr=1e-4, lr_backbone=1e-5, lr_bert=None, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model, lr=1e-4, lr_backbone=1e-5, lr_bert=None, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 lr_mask_branch_proj=1.0):
         self.model = getattr(model, "module", model)
         st = self.model.store
         named = dict(self.model.named_parameters())
         groups = []
+        # the reference's four param groups, in its order, each in its named_parameters() order (main_vg.py:234-262)
+        order = L.reference_param_order(self.model.cfg)
+        assert sorted(order) == sorted(n for n, _, k in st.table if k == "param")
+        self._names = []
         for grp, glr in ((L.GROUP_MAIN, lr), (L.GROUP_BACKBONE, lr_backbone),
-                         (L.GROUP_BERT, lr_backbone if lr_bert is None else lr_bert)):
-            ps = [named[n] for n, _, k in st.table if k == "param" and L.lr_group(n) == grp]
-            groups.append({"params": ps, "lr": glr, "group_id": grp})
+                         (L.GROUP_BERT, lr_backbone if lr_bert is None else lr_bert),
+                         (L.GROUP_MASK, lr * lr_mask_branch_proj)):
+            ns = [n for n in order if L.lr_group(n) == grp]
+            self._names.append(ns)
+            groups.append({"params": [named[n] for n in ns], "lr": glr, "group_id": grp})
         super().__init__(groups, dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps))
         dev = st.device
         self.m = torch.zeros_like(st.flat_p)
@@ -64,16 +71,48 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model.mark_dirty()
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.AdamW's format (what the reference writes into checkpoint['optimizer'], main_vg.py:377-384):
+        per-parameter `step`, `exp_avg`, `exp_avg_sq` keyed by the parameter's index in the reference's group order, so a
+        checkpoint written here resumes under the reference and vice versa."""
+        st = self.model.store
+        state, groups, idx = {}, [], 0
+        for g, ns in zip(self.param_groups, self._names):
+            ids = []
+            for n in ns:
+                if self.step_count > 0:
+                    state[idx] = {"step": torch.tensor(float(self.step_count)),
+                                  "exp_avg": st.view_of(self.m, n).detach().clone(memory_format=torch.contiguous_format),
+                                  "exp_avg_sq": st.view_of(self.v, n).detach().clone(memory_format=torch.contiguous_format)}
+                ids.append(idx); idx += 1
+            pg = {k: v for k, v in g.items() if k not in ("params", "group_id")}
+            pg.update(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None, params=ids)
+            groups.append(pg)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.step_count = int(sd["step"])
+        """Accepts a torch.optim.AdamW state_dict with the reference's grouping (as written by the reference or by
+        state_dict() above); hyper-parameters of the groups are taken over like torch does."""
+        st = self.model.store
+        flat = [n for ns in self._names for n in ns]
+        groups = sd["param_groups"]
+        # the reference leaves its 4th (mask branch) group empty for REC models; older checkpoints may have 3 groups
+        assert sum(len(g["params"]) for g in groups) == len(flat), "optimizer state does not match this model's parameters"
+        steps = set()
+        with torch.no_grad():
+            for i, s_ in sd["state"].items():
+                n = flat[int(i)]
+                st.view_of(self.m, n).copy_(s_["exp_avg"]); st.view_of(self.v, n).copy_(s_["exp_avg_sq"])
+                steps.add(int(float(s_["step"])))
+        assert len(steps) <= 1, "per-parameter step counts differ: not representable by the fused optimizer"
+        self.step_count = steps.pop() if steps else 0
         self.step_dev.fill_(self.step_count)
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        for g, s_ in zip(self.param_groups, groups):
+            for k in ("lr", "weight_decay", "betas", "eps", "initial_lr"):
+                if k in s_:
+                    g[k] = s_[k]
 
 
 def build_optimizer(model, args):
     """The optimizer main_vg.py:234-268 builds, on the fused kernels."""
-    return FusedAdamW(model, lr=args.lr, lr_backbone=args.lr_backbone, weight_decay=args.weight_decay)
+    return FusedAdamW(model, lr=args.lr, lr_backbone=args.lr_backbone, weight_decay=args.weight_decay,
+                      lr_mask_branch_proj=getattr(args, "lr_mask_branch_proj", 1.0))

@@ -15,7 +15,7 @@ from torch import nn
 
 
 class DistributedDataParallel(nn.Module):
-    """Exchange schedule: the flat gradient buffer is laid out [main | ResNet | BERT] (models/store.py).  Backward
+    """Exchange schedule: the flat gradient buffer is laid out [main | mask head | ResNet | BERT] (models/store.py).  Backward
     finishes the main and BERT ranges first (phase 1); their all-reduces are launched asynchronously at that point and
     run on RCCL's stream while the ResNet backward (phase 2) computes; the ResNet range follows, then everything is
     waited for.  `reduce_early` / `reduce_late` are the two hook points; CapturedTrainStep calls them between its
@@ -48,6 +48,8 @@ class DistributedDataParallel(nn.Module):
         return self.module(samples)
 
     def _split(self, a, b, max_elems):
+        if b <= a:
+            return []
         n = max(1, -(-(b - a) // max_elems))
         step = -(-(b - a) // n)
         step = (step + 1023) // 1024 * 1024
@@ -66,7 +68,7 @@ class DistributedDataParallel(nn.Module):
         total = st.flat_g.numel()
         per = max(1, -(-total // self.n_chunks))
         early = []
-        for grp in (L.GROUP_MAIN, L.GROUP_BERT):
+        for grp in (L.GROUP_MAIN, L.GROUP_MASK, L.GROUP_BERT):
             a, b = st.group_range[grp]
             early += self._split(a, b, per)
         a, b = st.group_range[L.GROUP_BACKBONE]

@@ -64,6 +64,12 @@ def is_main_process():
     return get_rank() == 0
 
 
+def save_on_master(*args, **kwargs):
+    """util/misc.py:387-389."""
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
 def init_distributed_mode(args):
     """env:// rendezvous, one process per GPU; backend 'nccl' is RCCL on ROCm (util/misc.py:392-431)."""
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:

@@ -143,7 +143,8 @@ def test_optimizer_groups_follow_reference_param_groups():
     m = RefTR(cfg, device="cpu")
     opt = FusedAdamW(m, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
     lrs = [g["lr"] for g in opt.param_groups]
-    assert lrs == [1e-4, 1e-5, 1e-5]                 # main_vg.py:234-262 (BERT group also uses lr_backbone)
+    assert lrs == [1e-4, 1e-5, 1e-5, 1e-4]           # main_vg.py:234-262 (BERT group also uses lr_backbone; 4th = mask
+    assert opt.param_groups[3]["params"] == []      # branch, lr * lr_mask_branch_proj, empty for REC models)
     n = sum(p.numel() for g in opt.param_groups for p in g["params"])
     assert n == sum(p.numel() for p in m.parameters() if p.requires_grad)
     sched = torch.optim.lr_scheduler.StepLR(opt, 2)  # engine_vg.py:67: stepped per iteration
@@ -152,3 +153,56 @@ def test_optimizer_groups_follow_reference_param_groups():
     for _ in range(2):
         sched.step()
     assert abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12
+
+
+def test_reference_param_order_matches_fixture():
+    """layout.reference_param_order == the imported reference's named_parameters() order (fixture minted in the build
+    container from RefTR / RefTRSeg themselves, oracle/gen_golden*.py recipe)."""
+    from reftr_amd.models import layout as L
+    g = np.load(os.path.join(ROOT, "tests", "golden", "param_order.npz"))
+    for tag, masks in (("rec", False), ("seg", True)):
+        cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), masks=masks)
+        assert L.reference_param_order(cfg) == [str(x) for x in g[tag]]
+
+
+@pytest.mark.parametrize("masks", [False, True])
+def test_optimizer_state_roundtrip_with_torch_adamw(masks):
+    """checkpoint['optimizer'] compatibility (main_vg.py:320-324,377-384): FusedAdamW.state_dict() loads into a real
+    torch.optim.AdamW built with the reference's param groups, and that optimizer's state_dict loads back."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.optim import FusedAdamW
+    cfg = L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=1), masks=masks)
+    model = RefTR(cfg, device="cpu")
+    opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(5)
+    opt.m.copy_(torch.randn(opt.m.shape, generator=g)); opt.v.copy_(torch.rand(opt.v.shape, generator=g))
+    opt.step_count = 7
+    sd = opt.state_dict()
+    named = dict(model.named_parameters())
+    order = L.reference_param_order(cfg)
+
+    def match(n, keys):
+        return any(k in n for k in keys)
+    bk, bert, mb = ["img_backbone.0"], ["lang_backbone"], ["bbox_attention", "mask_head"]
+    groups = [
+        {"params": [named[n] for n in order if not match(n, bk) and not match(n, bert) and not match(n, mb)], "lr": 1e-4},
+        {"params": [named[n] for n in order if match(n, bk)], "lr": 1e-5},
+        {"params": [named[n] for n in order if match(n, bert)], "lr": 1e-5},
+        {"params": [named[n] for n in order if match(n, mb)], "lr": 1e-4}]
+    ref = torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)       # main_vg.py:234-268
+    ref.load_state_dict(sd)
+    k = "vl_transformer.encoder.layers.0.linear1.weight"
+    assert torch.equal(ref.state[named[k]]["exp_avg"], model.store.view_of(opt.m, k))
+    if masks:
+        k = "mask_head.lay1.weight"       # padded storage <-> logical [520, 520, 3, 3] tensor
+        assert ref.state[named[k]]["exp_avg_sq"].shape == (520, 520, 3, 3)
+        assert torch.equal(ref.state[named[k]]["exp_avg_sq"], model.store.view_of(opt.v, k))
+    assert float(ref.state[named[k]]["step"]) == 7.0
+    back = FusedAdamW(model, lr=3e-4, lr_backbone=3e-5, weight_decay=0.0)
+    back.load_state_dict(ref.state_dict())
+    pad = torch.ones_like(opt.m, dtype=torch.bool)      # compare everything except padding (never part of a state_dict)
+    for n in order:
+        model.store.view_of(pad, n).fill_(False)
+    assert torch.equal(back.m[~pad], opt.m[~pad]) and torch.equal(back.v[~pad], opt.v[~pad]) and back.step_count == 7
+    assert [g_["lr"] for g_ in back.param_groups] == [1e-4, 1e-5, 1e-5, 1e-4] and back.param_groups[0]["weight_decay"] == 1e-4

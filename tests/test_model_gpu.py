@@ -210,3 +210,35 @@ def test_state_dict_roundtrip_and_errors(hip):
         assert torch.equal(sd[k].cpu(), P[k]) and sd[k].is_contiguous()
     with pytest.raises(AssertionError):
         crit({"pred_boxes": None}, [])
+
+
+def test_checkpoint_resume_is_exact(hip, tmp_path):
+    """Save after two steps in the reference's checkpoint format (main_vg.py:377-384), resume in a fresh model / optimizer
+    / scheduler (main_vg.py:306-337), take one more step: same loss and parameters as the uninterrupted run."""
+    from reftr_amd.checkpoint import load_checkpoint, save_checkpoint
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.optim import FusedAdamW
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+
+    def fresh():
+        model, crit, P, ocfg = build(small=True)
+        model.eval()
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        sch = torch.optim.lr_scheduler.StepLR(opt, 100)
+        return model, crit, opt, sch
+    model, crit, opt, sch = fresh()
+    for _ in range(2):
+        train_step(model, crit, s, tg, opt, sch, max_norm=0.1)
+    path = tmp_path / "checkpoint.pth"
+    save_checkpoint(path, model, opt, sch, epoch=3, best_val_acc=0.5)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch", "args", "best_val_acc"}
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["param_groups"]) == 4
+    l_ref = train_step(model, crit, s, tg, opt, sch, max_norm=0.1)[0]
+    model2, crit2, opt2, sch2 = fresh()
+    start, best, missing, unexpected = load_checkpoint(str(path), model2, opt2, sch2)
+    assert start == 4 and best == 0.5 and not missing and not unexpected and opt2.step_count == 2
+    l_res = train_step(model2, crit2, s, tg, opt2, sch2, max_norm=0.1)[0]
+    assert abs(l_res - l_ref) < 1e-5 * abs(l_ref)
+    assert rel(model2.store.flat_p, model.store.flat_p) < 1e-6
