@@ -440,6 +440,21 @@ int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream);
 /* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */
 int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Host input pipeline on the device — integer / byte work, bit-exact.
+ * rt_resample_u8 — one pass (axis 0 = vertical, 1 = horizontal) of Pillow's 8-bit ImagingResample, the resampler behind
+ *   datasets/transforms.py:81-116 (torchvision F.resize of a PIL image, bilinear + antialias): src uint8 [n0][n1][C];
+ *   out[o] = clip8((2^21 + sum_t src[lo_o + t] * k_o[t]) >> 22) with bounds[o] = {lo, taps} and coeffs[o][ksize] the 22-bit
+ *   fixed-point taps (computed by the caller in double precision as Pillow does, reftr_amd/data/resample.py).
+ * rt_img_collate_norm — ToTensor + Normalize (transforms.py:233-235,247-250) + nested_tensor_from_tensor_list
+ *   (util/collate_fn.py:24-41): table[b] = {device pointer of image b (uint8 [h][w][3]), h, w} ->
+ *   out fp32 [B,3,H,W] = (u8/255 - mean)/std zero-padded, mask uint8 [B,H,W] (1 = padding).
+ * ------------------------------------------------------------------------------------------ */
+int rt_resample_u8(const void* src, void* dst, const int32_t* bounds, const int32_t* coeffs, int n0, int n1, int C,
+                   int out_len, int ksize, int axis, rt_stream_t stream);
+int rt_img_collate_norm(const int64_t* table, float* out, uint8_t* mask, int B, int H, int W, const float* mean3,
+                        const float* std3, rt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -226,6 +226,8 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
+    "rt_resample_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_img_collate_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "rt_gn_nhwc_fwd": (c_int, [POINTER(GnNhwcDesc), c_void_p]),
     "rt_gn_nhwc_bwd": (c_int, [POINTER(GnNhwcBwdDesc), c_void_p]),
     "rt_upsample_add": (c_int, [POINTER(UpsampleAddDesc), c_void_p]),
@@ -816,6 +818,35 @@ def mask_loss(pred, target_u8, B, h, w, Ht, Wt, ldp, norm, sums=None, dpred=None
                      dpred.shape[-1], 1.0 / norm)
     _check(lib().rt_mask_loss(ctypes.byref(d), _stream()), "rt_mask_loss")
     return dpred
+
+
+# --------------------------------------------------------------------------------------------
+# input pipeline kernels
+# --------------------------------------------------------------------------------------------
+def resample_u8(src, bounds, coeffs, out_len, axis):
+    """One Pillow-compatible resampling pass of a uint8 [n0, n1, C] image along `axis` (0 vertical / 1 horizontal)."""
+    _req(src, torch.uint8, "src"); _req(bounds, torch.int32, "bounds"); _req(coeffs, torch.int32, "coeffs")
+    n0, n1, C = src.shape
+    shape = (out_len, n1, C) if axis == 0 else (n0, out_len, C)
+    dst = torch.empty(shape, dtype=torch.uint8, device=src.device)
+    _check(lib().rt_resample_u8(_p(src), _p(dst), _p(bounds), _p(coeffs), n0, n1, C, out_len, coeffs.shape[1], axis, _stream()),
+           "rt_resample_u8")
+    return dst
+
+
+def img_collate_norm(images, H, W, mean, std):
+    """images: list of uint8 [h, w, 3] device tensors -> (fp32 [B,3,H,W] normalised + zero padded, uint8 mask [B,H,W])."""
+    B = len(images)
+    for im in images:
+        _req(im, torch.uint8, "image")
+        assert im.dim() == 3 and im.shape[2] == 3 and im.shape[0] <= H and im.shape[1] <= W
+    dev = images[0].device
+    tab = torch.tensor([[im.data_ptr(), im.shape[0], im.shape[1]] for im in images], dtype=torch.int64).to(dev, non_blocking=True)
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    m = (c_float * 3)(*[float(v) for v in mean]); s_ = (c_float * 3)(*[float(v) for v in std])
+    _check(lib().rt_img_collate_norm(_p(tab), _p(out), _p(mask), B, H, W, m, s_, _stream()), "rt_img_collate_norm")
+    return out, mask
 
 
 class SideStream:
