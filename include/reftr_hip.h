@@ -377,9 +377,12 @@ typedef struct rt_rows_add_desc {
 int rt_rows_add(const rt_rows_add_desc* d, rt_stream_t stream);
 
 int rt_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
-                      float* out, int rows, int L, int D, rt_stream_t stream);
+                      float* out, int rows, int L, int D, const int32_t* pos_ids, rt_stream_t stream);
 int rt_bert_embed_bwd(const int64_t* ids, const float* de, float* dword, float* dpos, float* dtype0,
-                      int rows, int L, int D, rt_stream_t stream);
+                      int rows, int L, int D, const int32_t* pos_ids, rt_stream_t stream);
+/* pos_ids (optional, int32 [rows]): explicit position ids; NULL = row % L (BERT).  rt_roberta_pos_ids fills them as HF
+ * RobertaEmbeddings does (create_position_ids_from_input_ids: cumsum(ids != pad) * (ids != pad) + pad), exact integers. */
+int rt_roberta_pos_ids(const int64_t* ids, int32_t* pos_ids, int B, int L, int pad_idx, rt_stream_t stream);
 int rt_context_mask(const uint8_t* smask, const uint8_t* phrase_mask, const int64_t* pos_l, const int64_t* pos_r,
                     uint8_t* ctx, uint8_t* qmask, int B, int L, int P, int Lp, rt_stream_t stream);
 int rt_qenc_attn_fwd(const float* k, const float* qs, const float* vs, const uint8_t* ctx, float* w, float* c,

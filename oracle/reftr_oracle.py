@@ -36,6 +36,11 @@ class BertCfg:
     type_vocab: int = 2
     eps: float = 1e-12
     dropout: float = 0.1
+    pad_idx: int = -1      # >= 0: RoBERTa position ids (HF create_position_ids_from_input_ids)
+
+
+def roberta_cfg(layers=12):
+    return BertCfg(vocab_size=50265, max_pos=514, type_vocab=1, eps=1e-5, pad_idx=1, layers=layers)
 
 
 @dataclass
@@ -233,8 +238,13 @@ def decoder_layer(t, memory, qpos, pos, tgt_kpm, mem_kpm, P, pfx, cfg, train=Fal
 def bert_forward(P, ids, attn_mask, bc: BertCfg, pfx="lang_backbone.", train=False, q=False):
     B, L = ids.shape
     e = pfx + "embeddings."
-    h = P[e + "word_embeddings.weight"][ids] + P[e + "position_embeddings.weight"][:L][None] \
-        + P[e + "token_type_embeddings.weight"][0][None, None]
+    if bc.pad_idx >= 0:       # HF RobertaEmbeddings: positions count the non-pad tokens, offset by the padding index
+        tok = ids.ne(bc.pad_idx).int()
+        pos_ids = (torch.cumsum(tok, dim=1) * tok).long() + bc.pad_idx
+        pe = P[e + "position_embeddings.weight"][pos_ids]
+    else:
+        pe = P[e + "position_embeddings.weight"][:L][None]
+    h = P[e + "word_embeddings.weight"][ids] + pe + P[e + "token_type_embeddings.weight"][0][None, None]
     h = drop(layer_norm(h, P, e + "LayerNorm.", bc.eps), bc.dropout, train)
     dh = bc.hidden // bc.heads
     # HF extended mask: (1 - mask) * finfo.min added to the scores

@@ -52,3 +52,12 @@ def make_inputs(name, B, H, W, L, n_phrase=0, Lp=6):
     return samples, targets
 
 
+
+
+def roberta_inputs():
+    """The e2e_roberta fixture's batch: multi-phrase, RoBERTa token conventions (padding id 1, real ids >= 2)."""
+    samples, targets = make_inputs("e2e_roberta", B=2, H=96, W=128, L=12, n_phrase=3)
+    for k in ("sentence", "phrase"):
+        m = samples[k + "_mask"].bool()
+        samples[k] = torch.where(m, samples[k].clamp(min=2), torch.ones_like(samples[k]))
+    return samples, targets

@@ -54,26 +54,40 @@ __global__ __launch_bounds__(256) void rows_add_kernel(const rt_rows_add_desc p)
 
 // ---------------------------------------------------------------- BERT embeddings
 // e[r, :] = word[ids[r]] + pos[r % L] + type[0]   (HF BertEmbeddings)
+// RoBERTa (HF create_position_ids_from_input_ids): pos = cumsum(ids != pad) * (ids != pad) + pad -- integer, exact
+__global__ void roberta_pos_ids_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ pos_ids, int B, int L, int pad) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int run = 0;
+    for (int l = 0; l < L; ++l) {
+        const bool tok = ids[(size_t)b * L + l] != pad;
+        run += tok ? 1 : 0;
+        pos_ids[(size_t)b * L + l] = tok ? run + pad : pad;
+    }
+}
 __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
                                                          const float* __restrict__ pos, const float* __restrict__ type0,
-                                                         float* __restrict__ out, int rows, int L, int D) {
+                                                         float* __restrict__ out, int rows, int L, int D,
+                                                         const int32_t* __restrict__ pos_ids) {
     const size_t total = (size_t)rows * D;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % D);
         const int r = (int)(i / D);
-        out[i] = word[(size_t)ids[r] * D + c] + pos[(size_t)(r % L) * D + c] + type0[c];
+        const int pi = pos_ids ? pos_ids[r] : r % L;
+        out[i] = word[(size_t)ids[r] * D + c] + pos[(size_t)pi * D + c] + type0[c];
     }
 }
 __global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ de,
                                                              float* __restrict__ dword, float* __restrict__ dpos,
-                                                             float* __restrict__ dtype0, int rows, int L, int D) {
+                                                             float* __restrict__ dtype0, int rows, int L, int D,
+                                                             const int32_t* __restrict__ pos_ids) {
     const size_t total = (size_t)rows * D;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % D);
         const int r = (int)(i / D);
         const float g = de[i];
         atomicAdd(dword + (size_t)ids[r] * D + c, g);
-        atomicAdd(dpos + (size_t)(r % L) * D + c, g);
+        atomicAdd(dpos + (size_t)(pos_ids ? pos_ids[r] : r % L) * D + c, g);
         atomicAdd(dtype0 + c, g);
     }
 }
@@ -246,22 +260,29 @@ extern "C" int rt_rows_add(const rt_rows_add_desc* d, rt_stream_t stream) {
     return RT_OK;
 }
 
+extern "C" int rt_roberta_pos_ids(const int64_t* ids, int32_t* pos_ids, int B, int L, int pad_idx, rt_stream_t stream) {
+    if (!ids || !pos_ids || B <= 0 || L <= 0) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(roberta_pos_ids_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, ids, pos_ids, B, L, pad_idx);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
 extern "C" int rt_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0,
-                                 float* out, int rows, int L, int D, rt_stream_t stream) {
+                                 float* out, int rows, int L, int D, const int32_t* pos_ids, rt_stream_t stream) {
     if (!ids || !word || !pos || !type0 || !out) return RT_ERR_BADARG;
     const size_t total = (size_t)rows * D;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bert_embed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, out, rows, L, D);
+    hipLaunchKernelGGL(bert_embed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, out, rows, L, D, pos_ids);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
 
 extern "C" int rt_bert_embed_bwd(const int64_t* ids, const float* de, float* dword, float* dpos, float* dtype0,
-                                 int rows, int L, int D, rt_stream_t stream) {
+                                 int rows, int L, int D, const int32_t* pos_ids, rt_stream_t stream) {
     if (!ids || !de || !dword || !dpos || !dtype0) return RT_ERR_BADARG;
     const size_t total = (size_t)rows * D;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, de, dword, dpos, dtype0, rows, L, D);
+    hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, de, dword, dpos, dtype0, rows, L, D, pos_ids);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

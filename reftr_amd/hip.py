@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -215,8 +215,9 @@ _SIGNATURES = {
     "rt_mask_posenc": (c_int, [POINTER(MaskPosencDesc), c_void_p]),
     "rt_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "rt_rows_add": (c_int, [POINTER(RowsAddDesc), c_void_p]),
-    "rt_bert_embed_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "rt_bert_embed_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rt_bert_embed_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rt_bert_embed_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rt_roberta_pos_ids": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rt_context_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_qenc_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_qenc_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -600,18 +601,25 @@ def rows_add(rows, D, *, a_f32=None, a_bf16=None, b_f32=None, out_f32=None, out_
     _check(lib().rt_rows_add(ctypes.byref(d), _stream()), "rt_rows_add")
 
 
-def bert_embed_fwd(ids, word, pos, type_emb, L):
+def roberta_pos_ids(ids, pad_idx):
+    B, L = ids.shape
+    out = torch.empty((B, L), dtype=torch.int32, device=ids.device)
+    _check(lib().rt_roberta_pos_ids(_p(ids), _p(out), B, L, pad_idx, _stream()), "rt_roberta_pos_ids")
+    return out
+
+
+def bert_embed_fwd(ids, word, pos, type_emb, L, pos_ids=None):
     rows = ids.numel()
     D = word.shape[1]
     out = _new((rows, D), torch.float32, word)
-    _check(lib().rt_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type_emb), _p(out), rows, L, D, _stream()),
+    _check(lib().rt_bert_embed_fwd(_p(ids), _p(word), _p(pos), _p(type_emb), _p(out), rows, L, D, _p(pos_ids), _stream()),
            "rt_bert_embed_fwd")
     return out
 
 
-def bert_embed_bwd(ids, de, dword, dpos, dtype_emb, L):
+def bert_embed_bwd(ids, de, dword, dpos, dtype_emb, L, pos_ids=None):
     rows, D = de.shape
-    _check(lib().rt_bert_embed_bwd(_p(ids), _p(de), _p(dword), _p(dpos), _p(dtype_emb), rows, L, D, _stream()),
+    _check(lib().rt_bert_embed_bwd(_p(ids), _p(de), _p(dword), _p(dpos), _p(dtype_emb), rows, L, D, _p(pos_ids), _stream()),
            "rt_bert_embed_bwd")
 
 

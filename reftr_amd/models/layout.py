@@ -22,6 +22,13 @@ class BertConfig:
     type_vocab: int = 2
     eps: float = 1e-12
     dropout: float = 0.1
+    pad_idx: int = -1          # >= 0: RoBERTa-style position ids (HF create_position_ids_from_input_ids)
+
+
+def roberta_config(layers=12):
+    """roberta-base (configs/flickr30k/RefTR_flickr_roberta.sh:17): same encoder, vocabulary 50265, 514 positions offset
+    by the padding index 1, one token type, LayerNorm eps 1e-5."""
+    return BertConfig(vocab_size=50265, max_pos=514, type_vocab=1, eps=1e-5, pad_idx=1, layers=layers)
 
 
 @dataclass

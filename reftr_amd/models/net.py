@@ -159,11 +159,12 @@ class Net:
         pfx = "lang_backbone."
         e = pfx + "embeddings."
         kpm = (mask_u8 == 0).to(torch.uint8)
+        pos_ids = H.roberta_pos_ids(ids, bc.pad_idx) if bc.pad_idx >= 0 else None
         emb = H.bert_embed_fwd(ids, self.P(e + "word_embeddings.weight"), self.P(e + "position_embeddings.weight"),
-                               self.P(e + "token_type_embeddings.weight"), L)
+                               self.P(e + "token_type_embeddings.weight"), L, pos_ids=pos_ids)
         dp, ds = self._drop(bc.dropout)
         h32, h16, _, mean, rstd = self.ln_fwd(emb, e + "LayerNorm.", bc.eps, drop_p=dp, drop_seed=ds)
-        ctx = {"ids": ids, "kpm": kpm, "B": B, "L": L, "emb": emb, "emb_stats": (mean, rstd, dp, ds), "layers": []}
+        ctx = {"ids": ids, "pos_ids": pos_ids, "kpm": kpm, "B": B, "L": L, "emb": emb, "emb_stats": (mean, rstd, dp, ds), "layers": []}
         dh = Hd // bc.heads
         scale = 1.0 / math.sqrt(dh)
         for i in range(bc.layers):
@@ -227,7 +228,7 @@ class Net:
         mean, rstd, dp, ds = ctx["emb_stats"]
         de, _ = self.ln_bwd(dh32, ctx["emb"], e + "LayerNorm.", mean, rstd, drop_p=dp, drop_seed=ds, want_bf16=False)
         H.bert_embed_bwd(ctx["ids"], de, self.G(e + "word_embeddings.weight"), self.G(e + "position_embeddings.weight"),
-                         self.G(e + "token_type_embeddings.weight"), L)
+                         self.G(e + "token_type_embeddings.weight"), L, pos_ids=ctx["pos_ids"])
 
     # ------------------------------------------------------------------ mlp_mapping (reftr_transformer.py:14-23)
     def mlp_fwd(self, x16, pfx, **out_kw):

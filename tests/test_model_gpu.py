@@ -242,3 +242,36 @@ def test_checkpoint_resume_is_exact(hip, tmp_path):
     l_res = train_step(model2, crit2, s, tg, opt2, sch2, max_norm=0.1)[0]
     assert abs(l_res - l_ref) < 1e-5 * abs(l_ref)
     assert rel(model2.store.flat_p, model.store.flat_p) < 1e-6
+
+
+def test_roberta_backbone_vs_reference_golden(hip):
+    """RoBERTa language backbone (f4): exact integer position ids + the same encoder kernels, against the golden vectors
+    minted from the reference with HF RobertaModel."""
+    from oracle.synth import roberta_inputs
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    g = np.load(os.path.join(GOLD, "e2e_roberta.npz"))
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.roberta_cfg(layers=2))
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.roberta_config(layers=2))
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda")
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    samples, targets = roberta_inputs()
+    s, tg = to_cuda(samples, targets)
+    # exact integer check of the position ids
+    tok = samples["sentence"].ne(1).int()
+    assert torch.equal(hip.roberta_pos_ids(s["sentence"], 1).cpu().long(), (torch.cumsum(tok, 1) * tok).long() + 1)
+    out = model(s)
+    assert rel(out["pred_logits"].sigmoid(), g["boxes"]) < 5e-3
+    ld = crit(out, tg)
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    assert abs(float(total) - float(g["total_loss"])) < 5e-3 * float(g["total_loss"])
+    model.store.flat_g.zero_()
+    total.backward()
+    gp = model.store.G["lang_backbone.embeddings.position_embeddings.weight"][:20].float().cpu()
+    ref = torch.from_numpy(g["grad_pos_emb"])
+    assert float((gp * ref).sum() / (gp.norm() * ref.norm())) > 0.97
+    assert rel(model.store.G["bbox_embed.layers.2.weight"], g["grad_bbox2_w"]) < 3e-2

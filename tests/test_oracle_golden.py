@@ -135,3 +135,25 @@ def test_refer_segmentation_golden():
             ref = torch.from_numpy(g[key])
             mine = grads[k][:8] if grads[k].dim() > 1 and grads[k].shape[0] > 8 else grads[k]
             assert rel(mine, ref) < 1e-4, k
+
+
+def test_roberta_backbone_golden():
+    """RefTR with a HF RobertaModel language backbone (configs/flickr30k/RefTR_flickr_roberta.sh): position ids from the
+    padding index, one token type, eps 1e-5."""
+    from oracle.synth import roberta_inputs
+    g = gold("e2e_roberta")
+    cfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.roberta_cfg(layers=2))
+    P = formula_state(param_shapes(cfg))
+    samples, targets = roberta_inputs()
+    names = [k for k in P if O.is_trainable(k)]
+    leaves = {k: P[k].requires_grad_(True) for k in names}
+    out = O.reftr_forward(P, samples, cfg)
+    assert rel(out["logits"].sigmoid(), g["boxes"]) < 1e-5
+    losses = O.criterion(out, targets)
+    total = O.total_loss(losses, O.weight_dict(cfg))
+    assert abs(float(total) - float(g["total_loss"])) < 1e-5 * float(g["total_loss"])
+    gp, gw = torch.autograd.grad(total, [leaves["lang_backbone.embeddings.position_embeddings.weight"],
+                                         leaves["lang_backbone.embeddings.word_embeddings.weight"]])
+    assert rel(gp[:20], g["grad_pos_emb"]) < 1e-4 and rel(gw[[101, 102]], g["grad_word_rows"]) < 1e-4
+    # rows 0 / 1 (unused / padding position: masked keys pass no gradient) stay zero, token positions start at 2
+    assert float(gp[:2].abs().sum()) == 0 and float(gp[2:14].abs().sum()) > 0
