@@ -89,6 +89,13 @@ def test_build_reftr_factory_and_weight_dict():
         build_reftr(ref_args(masks=True, aux_loss=False, reftr_type="transformer_multi_phrase", dice_loss_coef=1.0, mask_loss_coef=1.0))
 
 
+def test_unsupported_options_raise():
+    from reftr_amd import build_reftr
+    with pytest.raises(NotImplementedError):
+        build_reftr(ref_args(num_feature_levels=4))
+    assert build_reftr(ref_args(bert_model="roberta-base"))[0].cfg.bert.pad_idx == 1
+
+
 def test_post_process_segm_matches_reference_golden_exactly():
     from reftr_amd.models.post_process import PostProcessSegm
     g = np.load(os.path.join(ROOT, "tests", "golden", "seg_single.npz"))
