@@ -21,7 +21,7 @@ struct GemmArgs {
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed;
-    int M, K, sshift, xcd;
+    int M, K, sshift, xcd, early;
     unsigned src_bytes, wgt_bytes;
     const uint32_t* seed_dev;
 };
@@ -443,13 +443,27 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_tile(s);
     int cbuf = 0, lbuf = NS - 1;
-    for (int kt = 0; kt < nk; ++kt) {
-        rt_wait_vmcnt<(NS - 2) * LPT>();           // tile kt has landed (this thread's part)
-        __syncthreads();                           // ... everyone's part; and stage lbuf (tile kt-1) is no longer read
-        issue_tile(lbuf);                          // tile kt+NS-1
-        compute(cbuf);
-        cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
-        lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+    if (p.early) {
+        // issue-before-wait schedule: tile kt+NS-1 is requested BEFORE the wait for tile kt, so NS-1 tiles (not NS-2) are
+        // in flight while the workgroup is parked; the price is a second barrier per K tile (stage release).
+        for (int kt = 0; kt < nk; ++kt) {
+            issue_tile(lbuf);                          // its stage was released by the barrier that ended iteration kt-1
+            rt_wait_vmcnt<(NS - 1) * LPT>();           // tile kt has landed (this thread's part)
+            __syncthreads();
+            compute(cbuf);
+            __syncthreads();                           // everyone is done reading stage cbuf
+            cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+            lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            rt_wait_vmcnt<(NS - 2) * LPT>();           // tile kt has landed (this thread's part)
+            __syncthreads();                           // ... everyone's part; and stage lbuf (tile kt-1) is no longer read
+            issue_tile(lbuf);                          // tile kt+NS-1
+            compute(cbuf);
+            cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+            lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+        }
     }
     rt_wait_vmcnt<0>();                            // drain the over-fetched tail before the workgroup's LDS is released
 
@@ -572,6 +586,8 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.M = (int)M; a.K = d->KH * d->KW * d->SC; a.sshift = d->stride == 2 ? 1 : 0;
     static const int xcd_env = getenv("REFTR_XCD") ? atoi(getenv("REFTR_XCD")) : 1;
     a.xcd = xcd_env;
+    static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
+    a.early = early_env & 1;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;
@@ -594,7 +610,15 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         else if (a.N > 64 && t128 >= 384) hint = 1;
         else if (t12864 >= 256) hint = 2;
         else hint = 3;
-        if (dma) {          // LDS-DMA staging; deeper stages once K is long enough to fill them
+        static const int tilev = getenv("REFTR_TILEV") ? atoi(getenv("REFTR_TILEV")) : 1;
+        if (dma && tilev) {
+            // with the issue-before-wait schedule (profiles/r01g_tile_sweep_early.txt): short K streams best through
+            // 64x64 workgroups; 128x128 pays off from K >= 1024 with >= 1.5 waves of tiles; 128x64 in between
+            if (a.K < 1024) hint = 31;
+            else if (a.N > 64 && t128 >= 384) hint = 11;
+            else if (t12864 >= 256) hint = 21;
+            else hint = 33;
+        } else if (dma) {   // previous choice (A/B)
             if (hint == 1) hint = 11;
             else if (hint == 2) hint = a.K >= 1024 ? 22 : 21;
             else hint = a.K >= 1024 ? 33 : 31;

@@ -20,7 +20,7 @@ struct WgradArgs {
     const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
     int M, chunks_per_block, c_tiles;
-    float* part; int out_elems; int xcd;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
+    float* part; int out_elems; int xcd, early;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
     unsigned dy_bytes, x_bytes;
 };
 
@@ -391,13 +391,25 @@ __global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t*
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
     int cbuf = 0, lbuf = NS - 1;
-    for (int c = 0; c < nch; ++c) {
-        wg_wait_vmcnt<(NS - 2) * LPT>();
-        __syncthreads();
-        issue(lbuf);
-        compute(cbuf);
-        cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
-        lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+    if (p.early) {          // issue-before-wait (see rt_gemm.hip): NS-1 chunks in flight while parked, two barriers per chunk
+        for (int c = 0; c < nch; ++c) {
+            issue(lbuf);
+            wg_wait_vmcnt<(NS - 1) * LPT>();
+            __syncthreads();
+            compute(cbuf);
+            __syncthreads();
+            cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+            lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+        }
+    } else {
+        for (int c = 0; c < nch; ++c) {
+            wg_wait_vmcnt<(NS - 2) * LPT>();
+            __syncthreads();
+            issue(lbuf);
+            compute(cbuf);
+            cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+            lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+        }
     }
     wg_wait_vmcnt<0>();
 
@@ -586,6 +598,8 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0; a.part = nullptr; a.out_elems = 0;
     static const int xcd_env = getenv("REFTR_XCD") ? atoi(getenv("REFTR_XCD")) : 1;
     a.xcd = xcd_env;
+    static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
+    a.early = early_env & 2 ? 1 : 0;
     a.dy_bytes = (unsigned)(M * d->N * 2);
     a.x_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;
