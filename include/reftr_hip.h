@@ -113,6 +113,15 @@ typedef struct rt_conv_wgrad_desc {
 } rt_conv_wgrad_desc;
 int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
 
+/* rt_small_wgrad_grouped — dw_i[N,K] += dy_i[M,N]^T x_i[M,K], dbias_i[N] += colsum(dy_i) for up to any number of independent
+ * Linear weight gradients with M <= 16 token rows (decoder / query-encoder / box-head layers, transformer.py:231-252) in one
+ * launch per 64 problems; `jobs` is a HOST array, copied into the kernel arguments. */
+typedef struct rt_small_wgrad_job {
+    const void* dy; const void* x; float* dw; float* dbias;
+    int32_t M, N, K, reserved;
+} rt_small_wgrad_job;
+int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * rt_layernorm_fwd / rt_layernorm_bwd — nn.LayerNorm over the last axis, fp32 statistics, one wave per row.
  * Replaces: encoder/decoder norm1-3 and decoder.norm (models/modeling/transformer.py:157-158,217-219,

@@ -499,6 +499,34 @@ __global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __rest
     }
 }
 
+// Grouped form of small_m_wgrad_kernel: up to 64 independent (dy, x, dw) problems per launch, descriptors passed BY VALUE in
+// the kernel arguments (3 KB) so a captured hipGraph needs no device-side table.  The decoder / query-encoder Linears over
+// B*n_q token rows produce ~50 of these per step; none of them is on the backward-data dependency chain.
+struct SmallJobs { rt_small_wgrad_job j[64]; int first[65]; int n; };
+__global__ __launch_bounds__(256) void small_m_wgrad_grouped_kernel(const SmallJobs p) {
+    int lo = 0, hi = p.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (p.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const rt_small_wgrad_job& q = p.j[lo];
+    const bf16_t* dy = (const bf16_t*)q.dy; const bf16_t* x = (const bf16_t*)q.x;
+    const int k4 = q.K >> 2;
+    const size_t total = (size_t)q.N * k4;
+    const size_t i = (size_t)(blockIdx.x - p.first[lo]) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int kk = (int)(i % k4) * 4, n = (int)(i / k4);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    float gs = 0.f;
+    for (int m = 0; m < q.M; ++m) {
+        const float g = (float)dy[(size_t)m * q.N + n];
+        gs += g;
+        const bf16x4 xv = *reinterpret_cast<const bf16x4*>(x + (size_t)m * q.K + kk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += g * (float)xv[r];
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(q.dw + (size_t)n * q.K + kk);
+    *o = *o + a;
+    if (q.dbias && kk == 0) q.dbias[n] += gs;
+}
+
 template <int BN, int BC>
 int launch_wgrad(WgradArgs a, int msplit, hipStream_t s) {
     const int nt = (a.N + BN - 1) / BN;
@@ -634,4 +662,23 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (a.N >= 128) return launch_wgrad<128, 64>(a, d->msplit, s);
     if (a.SC >= 128) return launch_wgrad<64, 128>(a, d->msplit, s);
     return launch_wgrad<64, 64>(a, d->msplit, s);
+}
+
+extern "C" int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream) {
+    if (!jobs || njobs <= 0) return RT_ERR_BADARG;
+    for (int base = 0; base < njobs; base += 64) {
+        SmallJobs p;
+        p.n = njobs - base < 64 ? njobs - base : 64;
+        int blocks = 0;
+        for (int i = 0; i < p.n; ++i) {
+            const rt_small_wgrad_job& q = jobs[base + i];
+            if (!q.dy || !q.x || !q.dw || q.M <= 0 || q.M > 16 || q.N <= 0 || q.K <= 0 || (q.K & 3)) return RT_ERR_BADARG;
+            p.j[i] = q; p.first[i] = blocks;
+            blocks += (int)(((size_t)q.N * (q.K >> 2) + 255) / 256);
+        }
+        p.first[p.n] = blocks;
+        hipLaunchKernelGGL(small_m_wgrad_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        RT_CHECK_LAUNCH();
+    }
+    return RT_OK;
 }

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -142,6 +142,11 @@ class AdamWDesc(Structure):
 
 # name -> (restype, argtypes); every symbol include/reftr_hip.h declares must be listed here
 # (tests/test_abi.py cross-checks this table against the header).
+class SmallWgradJob(Structure):
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
+                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("reserved", c_int32)]
+
+
 class GnNhwcDesc(Structure):
     _fields_ = [("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("stats", c_void_p), ("y_bf16", c_void_p),
                 ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("G", c_int32), ("ldx", c_int32), ("ldy", c_int32),
@@ -227,6 +232,7 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
+    "rt_small_wgrad_grouped": (c_int, [POINTER(SmallWgradJob), c_int, c_void_p]),
     "rt_resample_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_img_collate_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "rt_gn_nhwc_fwd": (c_int, [POINTER(GnNhwcDesc), c_void_p]),
@@ -705,6 +711,29 @@ def pos_grad(dpos, d_lang_pos, d_type, d_level, B, S, L):
 
 def counter_add(ctr, inc=1):
     _check(lib().rt_counter_add(_p(ctr), inc, _stream()), "rt_counter_add")
+
+
+class SmallWgradBatch:
+    """Weight gradients of Linears over <= 16 token rows, queued during backward and launched together
+    (rt_small_wgrad_grouped): they are off the backward-data dependency chain, so ~50 launch latencies become one."""
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def add(self, dy, x, dw, dbias=None):
+        _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(dbias, torch.float32, "dbias")
+        M, N = dy.shape
+        K = x.shape[1]
+        assert M <= 16 and x.shape[0] == M and dw.numel() == N * K and K % 4 == 0
+        self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, 0))
+        self.keep.append((dy, x))
+
+    def run(self):
+        if not self.jobs:
+            return
+        arr = (SmallWgradJob * len(self.jobs))(*self.jobs)
+        _check(lib().rt_small_wgrad_grouped(arr, len(self.jobs), _stream()), "rt_small_wgrad_grouped")
+        self.jobs, self.keep = [], []
 
 
 class WeightPrepBatch:

@@ -46,6 +46,7 @@ class Net:
         on = int(os.environ.get("REFTR_STREAMS", "1")) if str(store.device).startswith("cuda") else 0
         self.wg = H.SideStream(bool(on & 2), defer=True)
         self.side = H.SideStream(bool(on & 1))
+        self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
         self._build_lins()
 
     # ------------------------------------------------------------------ operand bank
@@ -132,7 +133,10 @@ class Net:
     def lin_bwd(self, key, dy, x, need_dx=True, **kw):
         """weight + bias gradient of a Linear (accumulated) and, if asked, its input gradient."""
         l = self.lins[key]
-        self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb), dy, x)
+        if self.small_wg is not None and dy.shape[0] <= 16:       # decoder-side rows: queued, launched as one group
+            self.small_wg.add(dy, x, l.gw, l.gb)
+        else:
+            self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb), dy, x)
         if need_dx:
             return H.linear(dy, l.WT, **kw)
         return None
@@ -229,6 +233,8 @@ class Net:
         de, _ = self.ln_bwd(dh32, ctx["emb"], e + "LayerNorm.", mean, rstd, drop_p=dp, drop_seed=ds, want_bf16=False)
         H.bert_embed_bwd(ctx["ids"], de, self.G(e + "word_embeddings.weight"), self.G(e + "position_embeddings.weight"),
                          self.G(e + "token_type_embeddings.weight"), L, pos_ids=ctx["pos_ids"])
+        if self.small_wg is not None:
+            self.small_wg.run()      # pooler (B rows): on this stream, before a second BERT pass can queue the same weights
 
     # ------------------------------------------------------------------ mlp_mapping (reftr_transformer.py:14-23)
     def mlp_fwd(self, x16, pfx, **out_kw):

@@ -396,6 +396,9 @@ class RefTR(nn.Module):
             dpool = net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False,
                                 dtanh=sv["pctx"]["pooled"])
 
+        if net.small_wg is not None:
+            net.small_wg.run()           # decoder / query-encoder / map_phrase weight gradients (token rows <= 16): one launch
+
         # ---- encoder
         H.rows_add(M, E, a_f32=dmemp, out_f32=dmem, accumulate=True)      # K-side input of every cross-attention = memory + pos
         dpos = dmemp
@@ -446,6 +449,8 @@ class RefTR(nn.Module):
         bb_saved, g_c5, extra = self._pending
         self._pending = None
         self.body.backward(bb_saved, g_c5, extra)
+        if self.net.small_wg is not None:
+            self.net.small_wg.run()
         self.net.side.join()
         self.net.wg.join()
         H.set_seed_dev(None)

@@ -17,7 +17,7 @@ def declared_functions():
 
 def declared_structs():
     src = open(HEADER).read()
-    return sorted(set(re.findall(r"}\s*(rt_[a-z0-9_]+_desc)\s*;", src)))
+    return sorted(set(re.findall(r"}\s*(rt_[a-z0-9_]+_(?:desc|job))\s*;", src)))
 
 
 @pytest.fixture(scope="module")
@@ -54,7 +54,8 @@ def test_struct_layouts_match_header(built):
                "rt_gn_nhwc_desc": hip.GnNhwcDesc, "rt_gn_nhwc_bwd_desc": hip.GnNhwcBwdDesc,
                "rt_upsample_add_desc": hip.UpsampleAddDesc, "rt_upsample_add_bwd_desc": hip.UpsampleAddBwdDesc,
                "rt_attn_map_desc": hip.AttnMapDesc, "rt_attn_map_bwd_desc": hip.AttnMapBwdDesc,
-               "rt_seg_concat_desc": hip.SegConcatDesc, "rt_mask_loss_desc": hip.MaskLossDesc}
+               "rt_seg_concat_desc": hip.SegConcatDesc, "rt_mask_loss_desc": hip.MaskLossDesc,
+               "rt_small_wgrad_job": hip.SmallWgradJob}
     assert sorted(binding) == names
     prog = '#include <stdio.h>\n#include "reftr_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"

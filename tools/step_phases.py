@@ -1,0 +1,24 @@
+"""Phase timeline of ONE replayed step from a rocprofv3 kernel trace (single-stream run): time between marker kernels."""
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
+# last adamw = end of the last step; previous adamw = end of the step before
+ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
+a, b = ad[-2] + 1, ad[-1] + 1
+step = rows[a:b]
+t0 = step[0][1]
+marks = [("weight prep + pack", "img_pack"), ("stem", "stem_conv"), ("ResNet fwd (+BERT if 1 stream)", "maxpool"), ("input_proj+GN", "gn_stats_kernel"),
+         ("encoder fwd", "gn_apply"), ("query encoder + decoder fwd + head", "qenc_attn_fwd"), ("loss", "box_loss"),
+         ("head + decoder bwd", "box_loss"), ("qenc bwd + encoder bwd", "qenc_attn_bwd"), ("GN/input_proj bwd", "gn_bwd_stats"),
+         ("ResNet bwd (+BERT bwd)", "gn_bwd_apply"), ("optimizer", "sqnorm")]
+idx, pos = [], 0
+for label, key in marks:
+    for i in range(pos, len(step)):
+        if key in step[i][0]:
+            idx.append((label, i)); pos = i + 1; break
+print("step: %d kernels, %.2f ms (kernel-busy %.2f ms)" % (len(step), (step[-1][2] - t0) / 1e6, sum(r[2] - r[1] for r in step) / 1e6))
+for n, (label, i) in enumerate(idx):
+    j = idx[n + 1][1] if n + 1 < len(idx) else len(step)
+    seg = step[i:j]
+    print("  %-40s %4d kernels  %7.3f ms  (busy %7.3f)" % (label, len(seg), (seg[-1][2] - seg[0][1]) / 1e6, sum(r[2] - r[1] for r in seg) / 1e6))
+print("  %-40s %4d kernels  %7.3f ms" % ("(before first marker: zero-fill, prep)", idx[0][1], (step[idx[0][1]][1] - t0) / 1e6))
