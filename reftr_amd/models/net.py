@@ -47,6 +47,7 @@ class Net:
         self.wg = H.SideStream(bool(on & 2), defer=True)
         self.side = H.SideStream(bool(on & 1))
         self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
+        self.trivial_sa = os.environ.get("REFTR_TRIVIAL_SA", "1") != "0"
         self._build_lins()
 
     # ------------------------------------------------------------------ operand bank
@@ -315,11 +316,20 @@ class Net:
         dh = E // Hh
         sc = dh ** -0.5
         r = {"t16": t16, "tq16": tq16}
-        qk, _ = self.lin_fwd(p + "self_attn.qk", tq16)
         v, _ = self.lin_fwd(p + "self_attn.v", t16)
         r["ad"] = self._drop(cfg.dropout)
-        o, lse = H.attn_fwd(qk[:, :E], qk[:, E:], v, qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh, scale=sc,
-                            drop_p=r["ad"][0], drop_seed=r["ad"][1])
+        # One query per image and no padded phrase: the self-attention softmax runs over a single key, so it is exactly 1
+        # whatever q and k are, and dq = dk = 0 exactly -- the q/k projection, its backward and its (zero) weight gradient
+        # are skipped; the attention kernel still applies the per-head probability dropout and the value path.
+        trivial = T == 1 and self.trivial_sa
+        r["trivial"] = trivial
+        if trivial:
+            qk = None
+            o, lse = H.attn_fwd(v, v, v, qmask, B=B, H=Hh, Sq=1, Sk=1, dh=dh, scale=sc, drop_p=r["ad"][0], drop_seed=r["ad"][1])
+        else:
+            qk, _ = self.lin_fwd(p + "self_attn.qk", tq16)
+            o, lse = H.attn_fwd(qk[:, :E], qk[:, E:], v, qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh, scale=sc,
+                                drop_p=r["ad"][0], drop_seed=r["ad"][1])
         r.update(qk=qk, v=v, o=o, lse=lse)
         r["d1"] = self._drop(cfg.dropout)
         _, u = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=t32,
@@ -370,6 +380,11 @@ class Net:
         du, dub = self.ln_bwd(du2, r["u"], p + "norm1.", *r["st1"], dy2=dt1q, drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
         do, _ = self.lin_bwd(p + "self_attn.out_proj.", dub, r["o"])
         qk, v = r["qk"], r["v"]
+        if r["trivial"]:
+            _, _, dv = H.attn_bwd(v, v, v, r["o"], do, r["lse"], qmask, B=B, H=Hh, Sq=1, Sk=1, dh=dh,
+                                  scale=sc, drop_p=r["ad"][0], drop_seed=r["ad"][1])
+            _, dta = self.lin_bwd(p + "self_attn.v", dv, r["t16"], res_f32=du, out_bf16=False, out_f32=True)
+            return dta, None
         dqk = torch.empty_like(qk)
         _, _, dv = H.attn_bwd(qk[:, :E], qk[:, E:], v, r["o"], do, r["lse"], qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh,
                               scale=sc, drop_p=r["ad"][0], drop_seed=r["ad"][1], dq=dqk[:, :E], dk=dqk[:, E:])

@@ -361,7 +361,9 @@ class RefTR(nn.Module):
             hm, hr = sv["hs_stats"][i]
             dnorm, _ = net.ln_bwd(dhs[i * N:(i + 1) * N], sv["t3s"][i], vt + "decoder.norm.", hm, hr, want_bf16=False)
             extra = None
-            if ga is not None:
+            if ga is not None and gb is None:
+                extra = ga
+            elif ga is not None:
                 extra = torch.empty(N, E, dtype=torch.float32, device=dev)
                 H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=extra)
             ga, gb = net.dec_layer_bwd(f"{vt}decoder.layers.{i}.", sv["dec"][i], dnorm, extra, sv["mem16"], sv["memp16"],
@@ -369,10 +371,14 @@ class RefTR(nn.Module):
 
         # ---- QueryEncoder backward
         gqe = st.G[qe + "query_embed.weight"].view(2, E)
-        H.colsum(ga, gqe[0]); H.colsum(gb, gqe[0]); H.colsum(dqpos, gqe[1])
+        H.colsum(ga, gqe[0]); H.colsum(dqpos, gqe[1])
         df = torch.empty(N, E, dtype=torch.float32, device=dev)
-        H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=df)
-        H.rows_add(N, E, a_f32=dqpos, out_f32=df, accumulate=True)
+        if gb is None:                  # trivial self-attention (one query per image): no gradient through t + query_pos
+            H.rows_add(N, E, a_f32=ga, b_f32=dqpos, out_f32=df)
+        else:
+            H.colsum(gb, gqe[0])
+            H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=df)
+            H.rows_add(N, E, a_f32=dqpos, out_f32=df, accumulate=True)
         dcat = net.mlp_bwd(sv["fq_ctx"], df, qe + "fuse_encoder_query.")            # fp32 [N, 2E]
         dcat_rows = dcat.view(2 * N, E)
         _, dcob = net.ln_bwd(dcat_rows, sv["co"], qe + "context_out.1.", *sv["cst"], rowmap=(1, 2, 0), want_f32=False)
