@@ -122,6 +122,14 @@ typedef struct rt_small_wgrad_job {
 } rt_small_wgrad_job;
 int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream);
 
+/* rt_conv_wgrad_grouped — `n` independent weight gradients (HOST array of descriptors) queued during backward and launched
+ * together: the plain Linear ones (1x1, N and SC >= 128, more than 16 rows, variant = msplit = 0) share ONE launch of the
+ * 128x128 kernel per 24 problems (descriptors by value in the kernel arguments) plus one grouped reduction of their split
+ * partials, carved out of `workspace`; every other descriptor is forwarded to rt_conv_wgrad unchanged.  Results equal the
+ * individual launches.  A transformer layer's weight gradients are 50-250 workgroups each and off the backward-data
+ * dependency chain: grouped they fill the 256 CUs instead of serialising ~20 us launches.  Not re-entrant per device. */
+int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes, rt_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * rt_layernorm_fwd / rt_layernorm_bwd — nn.LayerNorm over the last axis, fp32 statistics, one wave per row.
  * Replaces: encoder/decoder norm1-3 and decoder.norm (models/modeling/transformer.py:157-158,217-219,

@@ -242,9 +242,11 @@ template <int RB> __device__ __forceinline__ int wg_swz(int row) {      // XOR a
     return RB >= 256 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
 }
 
-template <int BN, int BC, bool SIMPLE, int CR, int NS, int MINB>
-__global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t* __restrict__ dyp,
-                                                                   const bf16_t* __restrict__ xp, const WgradArgs p) {
+// `lin_raw` = linear workgroup id inside this problem's (gx x gy) grid: the kernel is launched either alone
+// (conv_wgrad_dma_kernel) or as one of up to 24 problems of a grouped launch (conv_wgrad_dma_grouped_kernel).
+template <int BN, int BC, bool SIMPLE, int CR, int NS>
+__device__ __forceinline__ void wgrad_dma_body(const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ xp, const WgradArgs& p,
+                                               const int lin_raw, const int grid_x, const int grid_y) {
     constexpr int TN = BN / 32, TC = BC / 32;
     constexpr int RBA = BN * 2, RBB = BC * 2;            // LDS row bytes
     constexpr int SPRA = BN / 8, SPRB = BC / 8;          // 16-B slots per row
@@ -264,9 +266,9 @@ __global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t*
 
     const int n_tiles = (p.N + BN - 1) / BN;
     // linear workgroup id -> (tile, split) with every split's tiles on one XCD (they read the same dy / x rows)
-    const int lin = rt_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, p.xcd);
-    const int by = __builtin_amdgcn_readfirstlane(lin / (int)gridDim.x);      // (integer division goes through VALU)
-    const int bx = __builtin_amdgcn_readfirstlane(lin - by * (int)gridDim.x);
+    const int lin = rt_xcd_remap(lin_raw, grid_x * grid_y, p.xcd);
+    const int by = __builtin_amdgcn_readfirstlane(lin / grid_x);      // (integer division goes through VALU)
+    const int bx = __builtin_amdgcn_readfirstlane(lin - by * grid_x);
     const int tile_n = bx % n_tiles;
     const int rest = bx / n_tiles;
     const int tile_c = rest % p.c_tiles;
@@ -445,6 +447,29 @@ __global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t*
     }
 }
 
+template <int BN, int BC, bool SIMPLE, int CR, int NS, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_kernel(const bf16_t* __restrict__ dyp,
+                                                                   const bf16_t* __restrict__ xp, const WgradArgs p) {
+    wgrad_dma_body<BN, BC, SIMPLE, CR, NS>(dyp, xp, p, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y);
+}
+
+// Grouped launch: up to 24 independent weight-gradient problems (descriptors BY VALUE in the kernel arguments, so a captured
+// hipGraph needs no device table).  A transformer layer's Linear weight gradients are ~50-250 workgroups each -- a fraction of
+// the 256 CUs -- and none is on the backward-data dependency chain: queued and launched together they fill the chip.
+// first[] is padded to multiples of 8 so the XCD map of a problem stays aligned with the hardware's round-robin.
+struct WgradGroup { WgradArgs j[24]; int first[25]; int gx[24]; int gy[24]; int n; };
+template <int BN, int BC, int CR, int NS, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_grouped_kernel(const WgradGroup g) {
+    int lo = 0, hi = g.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (g.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const int lin = (int)blockIdx.x - g.first[lo];
+    if (lin >= g.gx[lo] * g.gy[lo]) return;
+    wgrad_dma_body<BN, BC, true, CR, NS>(g.j[lo].dy, g.j[lo].x, g.j[lo], lin, g.gx[lo], g.gy[lo]);
+}
+
+struct ReduceGroup { const float* part[24]; float* dw[24]; const float* scale[24]; int out_elems[24], row_elems[24], nsplit[24], first[25]; int n; };
+
 // dw[i] += scale[i / row_elems] * sum_s part[s][i].  A workgroup owns 64 float4 columns; its 4 thread rows take the
 // splits round-robin (4 independent loads in flight each) and meet in LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
@@ -465,6 +490,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         for (; sidx < nsplit; sidx += 4) a += *reinterpret_cast<const f32x4*>(part + (size_t)sidx * out_elems + i);
     }
+    if (ty) red[ty - 1][tx] = a;
+    __syncthreads();
+    if (ty || !ok) return;
+    a += red[0][tx] + red[1][tx] + red[2][tx];
+    if (scale) a *= scale[i / row_elems];
+    f32x4* o = reinterpret_cast<f32x4*>(dw + i);
+    *o = *o + a;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const ReduceGroup g) {
+    __shared__ f32x4 red[3][64];
+    int lo = 0, hi = g.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (g.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const float* part = g.part[lo]; float* dw = g.dw[lo]; const float* scale = g.scale[lo];
+    const int out_elems = g.out_elems[lo], row_elems = g.row_elems[lo], nsplit = g.nsplit[lo];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = (((int)blockIdx.x - g.first[lo]) * 64 + tx) * 4;
+    const bool ok = i < out_elems;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+        for (int sidx = ty; sidx < nsplit; sidx += 4) a += *reinterpret_cast<const f32x4*>(part + (size_t)sidx * out_elems + i);
     if (ty) red[ty - 1][tx] = a;
     __syncthreads();
     if (ty || !ok) return;
@@ -612,11 +659,86 @@ int launch_wgrad_dma(WgradArgs a, int msplit, float* ws, long long ws_bytes, hip
 
 }  // namespace
 
-extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
+static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a);
+
+// The Linear weight gradients a grouped launch accepts: plain [M,N]^T [M,K] products on the 128x128 DMA kernel.
+static bool groupable(const rt_conv_wgrad_desc& d) {
+    const long long M = (long long)d.B * d.DH * d.DW;
+    return d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && d.N >= 128 && d.SC >= 128 && (d.N & 7) == 0 && M > 16 &&
+           d.variant == 0 && d.msplit <= 0;
+}
+
+extern "C" int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes,
+                                     rt_stream_t stream) {
+    if (!descs || n <= 0) return RT_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int BN = 128, BC = 128, CR = 32, NS = 3, MINB = 2;
+    static WgradGroup g; static ReduceGroup r;            // host-side staging (single caller thread per device, see header)
+    g.n = 0; r.n = 0;
+    int blocks = 0, rblocks = 0;
+    long long ws_off = 0;
+    auto flush = [&]() -> int {
+        if (g.n > 0) {
+            g.first[g.n] = blocks;
+            constexpr size_t smem = (size_t)NS * CR * (BN * 2 + BC * 2);
+            hipLaunchKernelGGL((conv_wgrad_dma_grouped_kernel<BN, BC, CR, NS, MINB>), dim3(blocks), dim3(256), smem, s, g);
+            RT_CHECK_LAUNCH();
+        }
+        if (r.n > 0) {
+            r.first[r.n] = rblocks;
+            hipLaunchKernelGGL(wgrad_reduce_grouped_kernel, dim3(rblocks), dim3(256), 0, s, r);
+            RT_CHECK_LAUNCH();
+        }
+        g.n = 0; r.n = 0; blocks = 0; rblocks = 0; ws_off = 0;
+        return RT_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const rt_conv_wgrad_desc& d = descs[i];
+        if (!groupable(d)) {                               // anything else keeps its own launch
+            const int rc = rt_conv_wgrad(&d, stream);
+            if (rc != RT_OK) return rc;
+            continue;
+        }
+        WgradArgs a;
+        const int rc = fill_wgrad_args(&d, a);
+        if (rc != RT_OK) return rc;
+        // same split rule as the single launch (launch_wgrad_dma)
+        const int nt = (a.N + BN - 1) / BN;
+        a.c_tiles = (a.SC + BC - 1) / BC;
+        const int total_chunks = (a.M + CR - 1) / CR;
+        const long long base_blocks = (long long)nt * a.c_tiles;
+        const long long out_elems = (long long)a.N * a.SC;
+        const int minrows = out_elems * 4 <= (512 << 10) ? 256 : 512;
+        long long want = (512 + base_blocks - 1) / base_blocks, maxs = (long long)total_chunks * CR / minrows;
+        if (maxs < 1) maxs = 1;
+        if (want > maxs) want = maxs;
+        int msplit = (int)(want < 1 ? 1 : want);
+        if (msplit > total_chunks) msplit = total_chunks;
+        a.chunks_per_block = (total_chunks + msplit - 1) / msplit;
+        const int gy = (total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
+        const long long need = gy > 1 ? (long long)gy * out_elems * 4 : 0;
+        if (g.n == 24 || (need > 0 && workspace && ws_off + need > workspace_bytes && g.n > 0)) {
+            const int frc = flush();
+            if (frc != RT_OK) return frc;
+        }
+        const bool use_ws = gy > 1 && workspace && ws_off + need <= workspace_bytes;
+        a.part = use_ws ? workspace + ws_off / 4 : nullptr; a.out_elems = (int)out_elems;
+        g.j[g.n] = a; g.first[g.n] = blocks; g.gx[g.n] = (int)base_blocks; g.gy[g.n] = gy; ++g.n;
+        blocks += (int)((base_blocks * gy + 7) / 8 * 8);
+        if (use_ws) {
+            r.part[r.n] = a.part; r.dw[r.n] = a.dw; r.scale[r.n] = a.scale; r.out_elems[r.n] = (int)out_elems; r.row_elems[r.n] = a.SC;
+            r.nsplit[r.n] = gy; r.first[r.n] = rblocks; ++r.n;
+            rblocks += (int)((out_elems / 4 + 63) / 64);
+            ws_off += (need + 255) / 256 * 256;
+        }
+    }
+    return flush();
+}
+
+static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a) {
     if (!d || !d->dy || !d->x || !d->dw) return RT_ERR_BADARG;
     if (d->SC <= 0 || (d->SC & 15) || (d->N & 3) || d->N <= 0) return RT_ERR_UNSUPPORTED;
     if (d->KH <= 0 || d->KW <= 0 || d->B <= 0 || d->DH <= 0 || d->DW <= 0 || d->stride <= 0) return RT_ERR_BADARG;
-    WgradArgs a;
     a.dy = (const bf16_t*)d->dy; a.x = (const bf16_t*)d->x; a.dw = d->dw; a.scale = d->scale; a.dbias = d->dbias;
     a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
@@ -630,6 +752,13 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     a.early = early_env & 2 ? 1 : 0;
     a.dy_bytes = (unsigned)(M * d->N * 2);
     a.x_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
+    return RT_OK;
+}
+
+extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
+    WgradArgs a;
+    const int frc = fill_wgrad_args(d, a);
+    if (frc != RT_OK) return frc;
     hipStream_t s = (hipStream_t)stream;
     if (a.M <= 16 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && (a.SC & 3) == 0) {
         const size_t total = (size_t)a.N * (a.SC >> 2);

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -232,6 +232,7 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
+    "rt_conv_wgrad_grouped": (c_int, [POINTER(ConvWgradDesc), c_int, c_void_p, ctypes.c_int64, c_void_p]),
     "rt_small_wgrad_grouped": (c_int, [POINTER(SmallWgradJob), c_int, c_void_p]),
     "rt_resample_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_img_collate_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
@@ -711,6 +712,36 @@ def pos_grad(dpos, d_lang_pos, d_type, d_level, B, S, L):
 
 def counter_add(ctr, inc=1):
     _check(lib().rt_counter_add(_p(ctr), inc, _stream()), "rt_counter_add")
+
+
+class WgradBatch:
+    """Linear weight gradients queued during backward (they are off the backward-data dependency chain) and launched as
+    one group (rt_conv_wgrad_grouped).  `workspace_mb`: scratch for the split partials of the whole group."""
+
+    _WS = {}
+
+    def __init__(self, workspace_mb=512):
+        self.descs, self.keep, self.ws_bytes = [], [], workspace_mb << 20
+
+    def add(self, dy, x, dw, dbias=None):
+        _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(dbias, torch.float32, "dbias")
+        M, N = dy.shape
+        K = x.shape[1]
+        assert x.shape[0] == M and dw.numel() == N * K
+        self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), None, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, _p(dbias), 0, None, 0))
+        self.keep.append((dy, x))
+
+    def run(self):
+        if not self.descs:
+            return
+        dev = self.keep[0][0].device
+        key = (dev.index, torch.cuda.current_stream().cuda_stream, self.ws_bytes)
+        ws = WgradBatch._WS.get(key)
+        if ws is None:
+            ws = WgradBatch._WS[key] = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=dev)
+        arr = (ConvWgradDesc * len(self.descs))(*self.descs)
+        _check(lib().rt_conv_wgrad_grouped(arr, len(self.descs), _p(ws), self.ws_bytes, _stream()), "rt_conv_wgrad_grouped")
+        self.descs, self.keep = [], []
 
 
 class SmallWgradBatch:

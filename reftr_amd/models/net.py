@@ -48,6 +48,7 @@ class Net:
         self.side = H.SideStream(bool(on & 1))
         self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
         self.trivial_sa = os.environ.get("REFTR_TRIVIAL_SA", "1") != "0"
+        self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
 
     # ------------------------------------------------------------------ operand bank
@@ -136,11 +137,20 @@ class Net:
         l = self.lins[key]
         if self.small_wg is not None and dy.shape[0] <= 16:       # decoder-side rows: queued, launched as one group
             self.small_wg.add(dy, x, l.gw, l.gb)
+        elif self.big_wg is not None and dy.shape[0] > 16:
+            self.big_wg.add(dy, x, l.gw, l.gb)                     # flushed per section (flush_wgrads)
         else:
             self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb), dy, x)
         if need_dx:
             return H.linear(dy, l.WT, **kw)
         return None
+
+    def flush_wgrads(self):
+        """Launch every queued weight gradient (on the current stream; the queued dy / x tensors were produced on it)."""
+        if self.small_wg is not None:
+            self.small_wg.run()
+        if self.big_wg is not None:
+            self.big_wg.run()
 
     def P(self, name):
         return self.store.P[name]
@@ -234,8 +244,7 @@ class Net:
         de, _ = self.ln_bwd(dh32, ctx["emb"], e + "LayerNorm.", mean, rstd, drop_p=dp, drop_seed=ds, want_bf16=False)
         H.bert_embed_bwd(ctx["ids"], de, self.G(e + "word_embeddings.weight"), self.G(e + "position_embeddings.weight"),
                          self.G(e + "token_type_embeddings.weight"), L, pos_ids=ctx["pos_ids"])
-        if self.small_wg is not None:
-            self.small_wg.run()      # pooler (B rows): on this stream, before a second BERT pass can queue the same weights
+        self.flush_wgrads()          # on this stream, and before a second BERT pass can queue the same weights
 
     # ------------------------------------------------------------------ mlp_mapping (reftr_transformer.py:14-23)
     def mlp_fwd(self, x16, pfx, **out_kw):

@@ -402,8 +402,7 @@ class RefTR(nn.Module):
             dpool = net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False,
                                 dtanh=sv["pctx"]["pooled"])
 
-        if net.small_wg is not None:
-            net.small_wg.run()           # decoder / query-encoder / map_phrase weight gradients (token rows <= 16): one launch
+        net.flush_wgrads()               # decoder / query-encoder / map_phrase / head weight gradients: grouped launches
 
         # ---- encoder
         H.rows_add(M, E, a_f32=dmemp, out_f32=dmem, accumulate=True)      # K-side input of every cross-attention = memory + pos
@@ -433,6 +432,7 @@ class RefTR(nn.Module):
                 net.bert_bwd(sv["pctx"], None, dpool)
             net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
         net.wg.flush()               # transformer weight gradients queued so far -> their own stream, from here
+        net.flush_wgrads()           # encoder / map_sentence weight gradients, before the BERT branch forks off
         two_phase = self._defer_phase2 or bool(self._mid_backward_hooks)
         if two_phase:
             _bert_bwd()
@@ -443,6 +443,7 @@ class RefTR(nn.Module):
             self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=g_c5.clone())
         self._pending = (sv["bb_saved"], g_c5, seg_extra)
         if two_phase:
+            net.flush_wgrads()       # input_proj's weight gradient belongs to the early (main-group) exchange
             net.wg.join()
             for hook in self._mid_backward_hooks:
                 hook()
@@ -455,8 +456,7 @@ class RefTR(nn.Module):
         bb_saved, g_c5, extra = self._pending
         self._pending = None
         self.body.backward(bb_saved, g_c5, extra)
-        if self.net.small_wg is not None:
-            self.net.small_wg.run()
+        self.net.flush_wgrads()
         self.net.side.join()
         self.net.wg.join()
         H.set_seed_dev(None)

@@ -200,6 +200,27 @@ def test_linear_wgrad_dma_variants(hip, variant, M, K, N):
     assert rel(db, dy.float().sum(0)) < 1e-5
 
 
+def test_grouped_wgrad_equals_individual_launches(hip):
+    """rt_conv_wgrad_grouped: a mix of groupable Linear weight gradients (incl. > 24 of them, ragged M, split and unsplit)
+    and non-groupable ones gives the same dw / dbias as one rt_conv_wgrad call each."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(3520, 256, 256), (3520, 256, 2048), (3520, 2048, 256), (320, 768, 768), (320, 768, 3072), (48, 256, 256),
+              (3520, 256, 512), (1000, 128, 136), (200, 256, 64)] * 3 + [(77, 64, 72)]
+    batch = hip.WgradBatch(workspace_mb=64)
+    refs = []
+    for i, (M, K, N) in enumerate(shapes):
+        x = bf(torch.randn(M, K, generator=g)).cuda(); dy = bf(torch.randn(M, N, generator=g)).cuda()
+        dw = torch.full((N, K), 0.5, device="cuda"); db = torch.zeros(N, device="cuda")
+        dw2 = torch.full((N, K), 0.5, device="cuda"); db2 = torch.zeros(N, device="cuda")
+        hip.linear_wgrad(dy, x, dw2, dbias=db2)
+        batch.add(dy, x, dw, db)
+        refs.append((dw, db, dw2, db2, dy, x))
+    batch.run()
+    for dw, db, dw2, db2, dy, x in refs:
+        assert rel(dw, dw2) < 2e-6 and rel(db, db2) < 1e-6
+        assert rel(dw - 0.5, dy.float().T @ x.float()) < TOL_F32
+
+
 def test_errors_are_loud(hip):
     x = torch.zeros(4, 48, dtype=torch.bfloat16, device="cuda")      # K not a multiple of 64
     w = torch.zeros(8, 48, dtype=torch.bfloat16, device="cuda")
