@@ -731,6 +731,14 @@ class WgradBatch:
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), None, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, _p(dbias), 0, None, 0))
         self.keep.append((dy, x))
 
+    def add_conv(self, dy, x, dw, geom, scale=None):
+        """A convolution weight gradient (any geometry: the non-groupable ones are forwarded to rt_conv_wgrad at run())."""
+        B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
+        _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(scale, torch.float32, "scale")
+        self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, 0, None, 0,
+                                        None, 0))
+        self.keep.append((dy, x, scale))
+
     def run(self):
         if not self.descs:
             return
@@ -739,6 +747,9 @@ class WgradBatch:
         ws = WgradBatch._WS.get(key)
         if ws is None:
             ws = WgradBatch._WS[key] = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=dev)
+        single = _wgrad_workspace(dev)          # for the descriptors that are forwarded to rt_conv_wgrad (this stream's)
+        for d in self.descs:
+            d.workspace, d.workspace_bytes = _p(single), WGRAD_WS_BYTES
         arr = (ConvWgradDesc * len(self.descs))(*self.descs)
         _check(lib().rt_conv_wgrad_grouped(arr, len(self.descs), _p(ws), self.ws_bytes, _stream()), "rt_conv_wgrad_grouped")
         self.descs, self.keep = [], []

@@ -53,6 +53,10 @@ class ResNetBody:
                 inpl = planes * 4
             self.blocks.append(stage)
         self.wg = H.SideStream(False)     # conv weight gradients stay inline (they fill the chip on their own)
+        import os
+        gc = int(os.environ.get("REFTR_GROUP_CONV", "1")) if str(store.device).startswith("cuda") else 0
+        self.batch = H.WgradBatch(workspace_mb=1024) if gc else None
+        self.wgs = H.SideStream(gc == 2)
         self.W = {}      # bf16 operands: name -> [N][T][C]; name + '.t' -> [C][T][N]
         self.bn = {}     # bn prefix -> (scale, shift) fp32
         self.all_convs = [c for st in self.blocks for b in st for c in (b.conv1, b.conv2, b.conv3, b.down) if c is not None]
@@ -131,7 +135,10 @@ class ResNetBody:
     # ------------------------------------------------------------------ backward
     def _wgrad(self, g, x, c, geom):
         dw, sc = self.store.phys(c.name, grad=True), self.bn[c.bn][0]
-        self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc), g, x)
+        if self.batch is not None:
+            self.batch.add_conv(g, x, dw, geom, scale=sc)
+        else:
+            self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc), g, x)
 
     def _dgrad(self, g, c, geom, res=None, gate=None, res_f32=None):
         B, SH, SW, SC, DH, DW, N, KH, KW, s, p = geom
@@ -144,6 +151,12 @@ class ResNetBody:
         extra: {stage index: fp32 [M, C]} additional UNGATED gradients w.r.t. intermediate stage outputs (the RES head's
         FPN adapters read layer2 / layer3 outputs); they join the residual sum before the ReLU gate."""
         extra = extra or {}
+        try:
+            return self._backward(saved, g_out, extra)
+        finally:
+            self.wgs.join()
+
+    def _backward(self, saved, g_out, extra):
         for b, rec in reversed(saved):
             x, h1, h2 = rec["x"], rec["h1"], rec["h2"]
             self._wgrad(g_out, h2, b.conv3, rec["g3"])
@@ -153,6 +166,11 @@ class ResNetBody:
             self._wgrad(g_h1, x, b.conv1, rec["g1"])
             if b.down is not None:
                 self._wgrad(g_out, x, b.down, rec["gd"])
+            if self.batch is not None and b.down is not None:
+                # end of a stage: its queued weight gradients go out together -- on the side stream when enabled, under the
+                # next stage's backward-data chain
+                alive = [t for k in self.batch.keep for t in k if t is not None]      # until the side stream is joined
+                self.wgs.run(self.batch.run, *alive)
             if b.first_trainable:
                 break                                   # layer1 is frozen: no gradient w.r.t. its output
             g_idt = self._dgrad(g_out, b.down, rec["gd"]) if b.down is not None else g_out
