@@ -210,18 +210,18 @@ def main():
         fl = sum(r["flops"] for r in recs)
         tm = sum(r["start"].elapsed_time(r["end"]) for r in recs) * 1e-3
         ach = fl / tm / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_gemm_kernel+conv_wgrad_kernel (rt_conv_gemm / rt_conv_wgrad)",
+        roof = {"bound": "mfma", "kernel": "rt_conv_gemm / rt_conv_wgrad(+_grouped) kernels (conv_gemm_dma_kernel, conv_wgrad_dma*_kernel, skinny / small-M)",
                 "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                 "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
                 "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3}
     if roof is not None:
         # HBM bytes per launch from the PMC passes of this same command (benchmarks/pmc_passes.sh -> tools/pmc_traffic.py;
         # FETCH_SIZE and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected inside the timed process)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01h_pmc_traffic.json")
         if os.path.exists(pmc) and B == 8 and S_ == 640:
             t = json.load(open(pmc))["gemm_family"]
             roof["traffic"] = t["hbm_bytes_per_step"] / max(len(recs), 1)
-            roof["traffic_unit"] = "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01e_pmc_traffic.json)"
+            roof["traffic_unit"] = "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01h_pmc_traffic.json)"
             roof["algorithmic_bytes_per_launch"] = sum(r["bytes"] for r in recs) / max(len(recs), 1)
     out = {
         "metric": "images/sec training step, RefCOCO R50 640x640 bs=8/GPU", "value": value, "unit": "images/s",

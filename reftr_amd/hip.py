@@ -319,7 +319,7 @@ def _algo_bytes(tag):
     return 2.0 * (B * SH * SW * SC + N * KH * KW * SC + M * N)
 
 
-def _timed(kind, flops, fn, tag=None):
+def _timed(kind, flops, fn, tag=None, nbytes=None):
     if _TIMER is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -327,7 +327,7 @@ def _timed(kind, flops, fn, tag=None):
     r = fn()
     e1.record()
     _TIMER.append({"kind": kind, "flops": float(flops), "start": e0, "end": e1, "tag": tag,
-                   "bytes": _algo_bytes(tag) if tag is not None else 0.0})
+                   "bytes": nbytes if nbytes is not None else (_algo_bytes(tag) if tag is not None else 0.0)})
     return r
 
 
@@ -722,6 +722,11 @@ class WgradBatch:
 
     def __init__(self, workspace_mb=512):
         self.descs, self.keep, self.ws_bytes = [], [], workspace_mb << 20
+        self.flops = self.nbytes = 0.0
+
+    def _account(self, geom):
+        self.flops += 2.0 * geom[0] * geom[4] * geom[5] * geom[6] * geom[7] * geom[8] * geom[3]
+        self.nbytes += _algo_bytes(("W",) + tuple(geom))
 
     def add(self, dy, x, dw, dbias=None):
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(dbias, torch.float32, "dbias")
@@ -730,6 +735,7 @@ class WgradBatch:
         assert x.shape[0] == M and dw.numel() == N * K
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), None, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, _p(dbias), 0, None, 0))
         self.keep.append((dy, x))
+        self._account((M, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
 
     def add_conv(self, dy, x, dw, geom, scale=None):
         """A convolution weight gradient (any geometry: the non-groupable ones are forwarded to rt_conv_wgrad at run())."""
@@ -738,6 +744,7 @@ class WgradBatch:
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, 0, None, 0,
                                         None, 0))
         self.keep.append((dy, x, scale))
+        self._account(geom)
 
     def run(self):
         if not self.descs:
@@ -751,8 +758,12 @@ class WgradBatch:
         for d in self.descs:
             d.workspace, d.workspace_bytes = _p(single), WGRAD_WS_BYTES
         arr = (ConvWgradDesc * len(self.descs))(*self.descs)
-        _check(lib().rt_conv_wgrad_grouped(arr, len(self.descs), _p(ws), self.ws_bytes, _stream()), "rt_conv_wgrad_grouped")
+        n = len(self.descs)
+        _timed("conv_wgrad_grouped", self.flops,
+               lambda: _check(lib().rt_conv_wgrad_grouped(arr, n, _p(ws), self.ws_bytes, _stream()), "rt_conv_wgrad_grouped"),
+               nbytes=self.nbytes)
         self.descs, self.keep = [], []
+        self.flops = self.nbytes = 0.0
 
 
 class SmallWgradBatch:
@@ -761,6 +772,7 @@ class SmallWgradBatch:
 
     def __init__(self):
         self.jobs, self.keep = [], []
+        self.flops = self.nbytes = 0.0
 
     def add(self, dy, x, dw, dbias=None):
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(dbias, torch.float32, "dbias")
@@ -769,13 +781,17 @@ class SmallWgradBatch:
         assert M <= 16 and x.shape[0] == M and dw.numel() == N * K and K % 4 == 0
         self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, 0))
         self.keep.append((dy, x))
+        self.flops += 2.0 * M * N * K; self.nbytes += 2.0 * M * (N + K) + 4.0 * N * K
 
     def run(self):
         if not self.jobs:
             return
         arr = (SmallWgradJob * len(self.jobs))(*self.jobs)
-        _check(lib().rt_small_wgrad_grouped(arr, len(self.jobs), _stream()), "rt_small_wgrad_grouped")
+        n = len(self.jobs)
+        _timed("small_wgrad_grouped", self.flops,
+               lambda: _check(lib().rt_small_wgrad_grouped(arr, n, _stream()), "rt_small_wgrad_grouped"), nbytes=self.nbytes)
         self.jobs, self.keep = [], []
+        self.flops = self.nbytes = 0.0
 
 
 class WeightPrepBatch:
