@@ -393,7 +393,7 @@ extern "C" int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stre
     if (d->act == RT_ACT_RELU && !d->beta) return RT_ERR_BADARG;
     // few, fat workgroups: every block ends with D atomics per parameter vector, so contention (not bandwidth)
     // is what scales with the block count
-    static const int lnb = getenv("REFTR_LNB") ? atoi(getenv("REFTR_LNB")) : 512;
+    static const int lnb = getenv("REFTR_LNB") ? atoi(getenv("REFTR_LNB")) : 256;   // A/B on the step: 64..1024, the per-block dgamma/dbeta atomics dominate
     int blocks = (d->M + 3) / 4;
     if (blocks > lnb) blocks = lnb;
     if (!d->dgamma && !d->dbeta) { blocks = (d->M + 3) / 4; if (blocks > 1024) blocks = 1024; }
