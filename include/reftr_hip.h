@@ -180,8 +180,22 @@ typedef struct rt_layernorm_bwd_desc {
     float    drop2_p; uint32_t drop2_seed;   /* dropout of the producing sub-layer (index r*D + c) */
     int32_t grp_rows, grp_stride, grp_off;
     const uint32_t* seed_dev;   /* optional, applies to both dropout seeds */
+    float*   partials;     /* optional [n_blocks][2][D] scratch: per-workgroup dgamma / dbeta partial sums are STORED there
+                              (no atomics); the caller reduces them later with rt_ln_param_grad_grouped.  dgamma / dbeta
+                              are then not touched.  n_blocks is returned through *n_blocks_out. */
+    int32_t* n_blocks_out; /* host pointer, written when partials != NULL */
 } rt_layernorm_bwd_desc;
 int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stream);
+
+/* rt_ln_param_grad_grouped — dgamma_i[D] += sum_b partials_i[b][0][:], dbeta_i[D] += sum_b partials_i[b][1][:] for any number
+ * of LayerNorm backward launches (HOST array, descriptors by value in the kernel arguments).  The LayerNorm parameter
+ * gradients are off the backward-data dependency chain: one launch per 64 of them instead of ~2*D contended atomics per
+ * workgroup inside every rt_layernorm_bwd. */
+typedef struct rt_ln_pg_job {
+    const float* partials; float* dgamma; float* dbeta;
+    int32_t n_blocks, D;
+} rt_ln_pg_job;
+int rt_ln_param_grad_grouped(const rt_ln_pg_job* jobs, int n, rt_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * rt_groupnorm_fwd / rt_groupnorm_bwd — nn.GroupNorm(G, C) of input_proj (models/reftr_transformer.py:

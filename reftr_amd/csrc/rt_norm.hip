@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const rt_layernorm_b
             }
         }
     }
-    if (!p.dgamma && !p.dbeta) return;
+    if (!p.dgamma && !p.dbeta && !p.partials) return;
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         const int c = lane + (i << 6);
@@ -127,8 +127,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const rt_layernorm_b
     for (int c = threadIdx.x; c < D; c += 256) {
         const float a = sm_g[0][c] + sm_g[1][c] + sm_g[2][c] + sm_g[3][c];
         const float b = sm_b[0][c] + sm_b[1][c] + sm_b[2][c] + sm_b[3][c];
-        if (p.dgamma) atomicAdd(p.dgamma + c, a);
-        if (p.dbeta) atomicAdd(p.dbeta + c, b);
+        if (p.partials) {
+            p.partials[((size_t)blockIdx.x * 2) * D + c] = a; p.partials[((size_t)blockIdx.x * 2 + 1) * D + c] = b;
+        } else {
+            if (p.dgamma) atomicAdd(p.dgamma + c, a);
+            if (p.dbeta) atomicAdd(p.dbeta + c, b);
+        }
     }
 }
 
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const rt_layerno
             }
         }
     }
-    if (!p.dgamma && !p.dbeta) return;
+    if (!p.dgamma && !p.dbeta && !p.partials) return;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         *reinterpret_cast<f32x4*>(&sm_g[wave][(i * 64 + lane) * 4]) = dg[i];
@@ -269,8 +273,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const rt_layerno
     for (int c = threadIdx.x; c < D; c += 256) {
         const float a = sm_g[0][c] + sm_g[1][c] + sm_g[2][c] + sm_g[3][c];
         const float b = sm_b[0][c] + sm_b[1][c] + sm_b[2][c] + sm_b[3][c];
-        if (p.dgamma) atomicAdd(p.dgamma + c, a);
-        if (p.dbeta) atomicAdd(p.dbeta + c, b);
+        if (p.partials) {
+            p.partials[((size_t)blockIdx.x * 2) * D + c] = a; p.partials[((size_t)blockIdx.x * 2 + 1) * D + c] = b;
+        } else {
+            if (p.dgamma) atomicAdd(p.dgamma + c, a);
+            if (p.dbeta) atomicAdd(p.dbeta + c, b);
+        }
     }
 }
 
@@ -372,6 +380,36 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const rt_groupnorm_bw
     }
 }
 
+struct LnPgJobs { rt_ln_pg_job j[64]; int first[65]; int n; };
+// one workgroup = 64 channels of one job x 4 row lanes (4 loads in flight each), combined through LDS
+__global__ __launch_bounds__(256) void ln_param_grad_grouped_kernel(const LnPgJobs p) {
+    __shared__ float red[2][3][64];
+    int lo = 0, hi = p.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (p.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const rt_ln_pg_job& q = p.j[lo];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - p.first[lo]) * 64 + tx;
+    const bool ok = c < q.D;
+    float a = 0.f, b = 0.f;
+    if (ok) {
+        int r = ty;
+        for (; r + 12 < q.n_blocks; r += 16) {
+            const float* p0 = q.partials + ((size_t)r * 2) * q.D + c;
+            const size_t st = (size_t)8 * q.D;               // 4 partial rows (x2 vectors) ahead
+            const float a0 = p0[0], b0 = p0[q.D], a1 = p0[st], b1 = p0[st + q.D], a2 = p0[2 * st], b2 = p0[2 * st + q.D],
+                        a3 = p0[3 * st], b3 = p0[3 * st + q.D];
+            a += (a0 + a1) + (a2 + a3); b += (b0 + b1) + (b2 + b3);
+        }
+        for (; r < q.n_blocks; r += 4) { a += q.partials[((size_t)r * 2) * q.D + c]; b += q.partials[((size_t)r * 2 + 1) * q.D + c]; }
+    }
+    if (ty) { red[0][ty - 1][tx] = a; red[1][ty - 1][tx] = b; }
+    __syncthreads();
+    if (ty || !ok) return;
+    a += red[0][0][tx] + red[0][1][tx] + red[0][2][tx]; b += red[1][0][tx] + red[1][1][tx] + red[1][2][tx];
+    if (q.dgamma) atomicAdd(q.dgamma + c, a);        // atomics: one LayerNorm (decoder.norm) can appear several times in a group
+    if (q.dbeta) atomicAdd(q.dbeta + c, b);
+}
+
 }  // namespace
 
 extern "C" int rt_layernorm_fwd(const rt_layernorm_desc* d, rt_stream_t stream) {
@@ -396,7 +434,10 @@ extern "C" int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stre
     static const int lnb = getenv("REFTR_LNB") ? atoi(getenv("REFTR_LNB")) : 256;   // A/B on the step: 64..1024, the per-block dgamma/dbeta atomics dominate
     int blocks = (d->M + 3) / 4;
     if (blocks > lnb) blocks = lnb;
-    if (!d->dgamma && !d->dbeta) { blocks = (d->M + 3) / 4; if (blocks > 1024) blocks = 1024; }
+    if (!d->dgamma && !d->dbeta && !d->partials) { blocks = (d->M + 3) / 4; if (blocks > 1024) blocks = 1024; }
+    static const int lnpb = getenv("REFTR_LNPB") ? atoi(getenv("REFTR_LNPB")) : 512;
+    if (d->partials) { blocks = (d->M + 3) / 4; if (blocks > lnpb) blocks = lnpb; }
+    if (d->partials && d->n_blocks_out) *d->n_blocks_out = blocks;
     static const int vec = getenv("REFTR_LNVEC") ? atoi(getenv("REFTR_LNVEC")) : 1;
     if (vec && d->D == 256)      hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
     else if (vec && d->D == 768) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
@@ -433,5 +474,23 @@ extern "C" int rt_groupnorm_bwd(const rt_groupnorm_bwd_desc* d, rt_stream_t stre
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, *d);
     RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_ln_param_grad_grouped(const rt_ln_pg_job* jobs, int n, rt_stream_t stream) {
+    if (!jobs || n <= 0) return RT_ERR_BADARG;
+    for (int base = 0; base < n; base += 64) {
+        LnPgJobs p;
+        p.n = n - base < 64 ? n - base : 64;
+        int blocks = 0;
+        for (int i = 0; i < p.n; ++i) {
+            const rt_ln_pg_job& q = jobs[base + i];
+            if (!q.partials || q.n_blocks <= 0 || q.D <= 0) return RT_ERR_BADARG;
+            p.j[i] = q; p.first[i] = blocks; blocks += (q.D + 63) / 64;
+        }
+        p.first[p.n] = blocks;
+        hipLaunchKernelGGL(ln_param_grad_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        RT_CHECK_LAUNCH();
+    }
     return RT_OK;
 }

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -61,7 +61,12 @@ class LayerNormBwdDesc(Structure):
         ("M", c_int32), ("D", c_int32), ("act", c_int32),
         ("drop_p", c_float), ("drop_seed", c_uint32), ("drop2_p", c_float), ("drop2_seed", c_uint32),
         ("grp_rows", c_int32), ("grp_stride", c_int32), ("grp_off", c_int32), ("seed_dev", c_void_p),
+        ("partials", c_void_p), ("n_blocks_out", POINTER(c_int32)),
     ]
+
+
+class LnPgJob(Structure):
+    _fields_ = [("partials", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("n_blocks", c_int32), ("D", c_int32)]
 
 
 class GroupNormDesc(Structure):
@@ -232,6 +237,7 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
+    "rt_ln_param_grad_grouped": (c_int, [POINTER(LnPgJob), c_int, c_void_p]),
     "rt_conv_wgrad_grouped": (c_int, [POINTER(ConvWgradDesc), c_int, c_void_p, ctypes.c_int64, c_void_p]),
     "rt_small_wgrad_grouped": (c_int, [POINTER(SmallWgradJob), c_int, c_void_p]),
     "rt_resample_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -456,17 +462,38 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, *, act=ACT_NONE, drop_p=0.0, drop_se
     return y_f32, y_bf16, ypos_bf16, mean, rstd
 
 
+class LnGradBatch:
+    """LayerNorm parameter gradients of many rt_layernorm_bwd launches, reduced together (rt_ln_param_grad_grouped)."""
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def run(self):
+        if not self.jobs:
+            return
+        arr = (LnPgJob * len(self.jobs))(*self.jobs)
+        _check(lib().rt_ln_param_grad_grouped(arr, len(self.jobs), _stream()), "rt_ln_param_grad_grouped")
+        self.jobs, self.keep = [], []
+
+
 def layernorm_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta, *, dy2=None, act=ACT_NONE, drop_p=0.0,
-                  drop_seed=0, drop2_p=0.0, drop2_seed=0, rowmap=(0, 0, 0), want_f32=True, want_bf16=True):
-    """Returns (dx_f32 [M,D], dx_bf16 [M,D] = bf16(dx * dropout2-mask)); dgamma/dbeta accumulated in place."""
+                  drop_seed=0, drop2_p=0.0, drop2_seed=0, rowmap=(0, 0, 0), want_f32=True, want_bf16=True, pg_batch=None):
+    """Returns (dx_f32 [M,D], dx_bf16 [M,D] = bf16(dx * dropout2-mask)); dgamma/dbeta accumulated in place, or -- with
+    `pg_batch` (LnGradBatch) -- queued as per-workgroup partial sums that pg_batch.run() reduces later."""
     M, D = x.shape
     _req(dy, torch.float32, "dy"); _req(dy2, torch.float32, "dy2"); _req(x, torch.float32, "x")
     dx_f32 = _new((M, D), torch.float32, x) if want_f32 else None
     dx_bf16 = _new((M, D), torch.bfloat16, x) if want_bf16 else None
+    part, nb = None, c_int32(0)
+    if pg_batch is not None and (dgamma is not None or dbeta is not None):
+        part = _new((min((M + 3) // 4, 1024), 2, D), torch.float32, x)
     d = LayerNormBwdDesc(_p(dy), _p(dy2), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx_f32), _p(dx_bf16),
                          _p(dgamma), _p(dbeta), M, D, act, drop_p, drop_seed & 0xFFFFFFFF, drop2_p,
-                         drop2_seed & 0xFFFFFFFF, *rowmap, _seedp(max(drop_p, drop2_p)))
+                         drop2_seed & 0xFFFFFFFF, *rowmap, _seedp(max(drop_p, drop2_p)), _p(part), ctypes.pointer(nb))
     _check(lib().rt_layernorm_bwd(ctypes.byref(d), _stream()), "rt_layernorm_bwd")
+    if part is not None:
+        pg_batch.jobs.append(LnPgJob(_p(part), _p(dgamma), _p(dbeta), nb.value, D))
+        pg_batch.keep.append(part)
     return dx_f32, dx_bf16
 
 

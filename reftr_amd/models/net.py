@@ -48,6 +48,7 @@ class Net:
         self.side = H.SideStream(bool(on & 1))
         self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
         self.trivial_sa = os.environ.get("REFTR_TRIVIAL_SA", "1") != "0"
+        self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "0") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
 
@@ -151,6 +152,8 @@ class Net:
             self.small_wg.run()
         if self.big_wg is not None:
             self.big_wg.run()
+        if self.ln_batch is not None:
+            self.ln_batch.run()
 
     def P(self, name):
         return self.store.P[name]
@@ -163,7 +166,7 @@ class Net:
 
     def ln_bwd(self, dy, x, pfx, mean, rstd, **kw):
         return H.layernorm_bwd(dy, x, self.P(pfx + "weight"), self.P(pfx + "bias"), mean, rstd,
-                               self.G(pfx + "weight"), self.G(pfx + "bias"), **kw)
+                               self.G(pfx + "weight"), self.G(pfx + "bias"), pg_batch=self.ln_batch, **kw)
 
     # ------------------------------------------------------------------ BERT
     def bert_fwd(self, ids, mask_u8):
