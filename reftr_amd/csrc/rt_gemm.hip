@@ -21,7 +21,7 @@ struct GemmArgs {
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed;
-    int M, K, sshift, xcd, early;
+    int M, K, sshift, xcd, early, epi_lds;
     unsigned src_bytes, wgt_bytes;
     const uint32_t* seed_dev;
 };
@@ -92,6 +92,80 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
 #pragma unroll
         for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
         *reinterpret_cast<bf16x4*>(p.out_bf16 + o) = ov;
+    }
+}
+
+// Same epilogue on 8 consecutive output features of row m (the LDS-staged, row-coalesced path of the DMA kernel):
+// every global access is a full 16-B (bf16) / 32-B (fp32) contiguous piece of one output row.
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, f32x8 v) {
+    const size_t o = (size_t)m * p.N + n;
+    if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+    }
+    if (p.out_preact) {
+        bf16x8 pv;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pv[r] = (bf16_t)v[r];
+        *reinterpret_cast<bf16x8*>(p.out_preact + o) = pv;
+    }
+    auto add_res = [&]() __attribute__((always_inline)) {
+        if (p.res_f32) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(p.res_f32 + o), r1 = *reinterpret_cast<const f32x4*>(p.res_f32 + o + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+        }
+        if (p.res_bf16) {
+            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.res_bf16 + o);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += (float)rr[r];
+        }
+    };
+    if (p.res_first) add_res();
+    if (p.act == RT_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (p.act == RT_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = rt_gelu(v[r]);
+    } else if (p.act == RT_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
+    }
+    if (p.drop_p > 0.f) {
+        const uint32_t thresh = rt_drop_thresh(p.drop_p);
+        const float keep_scale = 1.0f / (1.0f - p.drop_p);
+        const uint32_t seed = rt_site_seed(p.seed_dev, p.drop_seed);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = (rt_hash32(seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
+    }
+    if (!p.res_first) add_res();
+    if (p.gate) {
+        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(p.gate + o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = ((float)gg[r] > 0.f) ? v[r] * p.gate_scale : 0.f;
+    }
+    if (p.preact) {
+        const bf16x8 uu = *reinterpret_cast<const bf16x8*>(p.preact + o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= rt_gelu_grad((float)uu[r]);
+    }
+    if (p.dtanh) {
+        const bf16x8 tt = *reinterpret_cast<const bf16x8*>(p.dtanh + o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= (1.f - (float)tt[r] * (float)tt[r]);
+    }
+    if (p.out_f32) {
+        *reinterpret_cast<f32x4*>(p.out_f32 + o) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p.out_f32 + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    if (p.out_bf16) {
+        bf16x8 ov;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+        *reinterpret_cast<bf16x8*>(p.out_bf16 + o) = ov;
     }
 }
 
@@ -467,6 +541,38 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
     }
     rt_wait_vmcnt<0>();                            // drain the over-fetched tail before the workgroup's LDS is released
 
+    // Row-coalesced epilogue: the MFMA C/D layout gives a lane 4 channels of one pixel, i.e. 8-B (bf16) pieces on 16
+    // different rows per store instruction.  Staging the fp32 tile through LDS (the operand stages are dead now) turns every
+    // residual / gate read and every store into 16-B pieces of ONE row per lane, 128+ contiguous bytes per row.
+    constexpr int EP_LD = BN + 4;                                  // padded fp32 row (bank spread)
+    constexpr bool EP_FITS = (size_t)BM * EP_LD * 4 <= (size_t)NS * BUF_BYTES;
+    if (EP_FITS && p.epi_lds && (p.N & 7) == 0) {
+        float* tile = reinterpret_cast<float*>(smem);
+        __syncthreads();        // every wave has drained its own DMA tail (vmcnt 0 above) and finished reading the stages
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+                *reinterpret_cast<f32x4*>(tile + (wm * (BM / 2) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4) = acc[a][b];
+        __syncthreads();
+        constexpr int CPR = BN / 8;                                // 8-channel pieces per row
+#pragma unroll
+        for (int i = 0; i < BM * CPR / 256; ++i) {
+            const int idx = i * 256 + t;
+            const int rl = idx / CPR, cl = (idx - rl * CPR) * 8;
+            int m = m0 + rl;
+            const int n = n0 + cl;
+            if (m >= Mloc || n >= p.N) continue;
+            if (MODE == 3) {
+                const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
+                m = (bb * p.DH + 2 * yy + cy) * p.DW + 2 * xx + cx;
+            }
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl), hi4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl + 4);
+            epilogue8(p, m, n, f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]});
+        }
+        return;
+    }
+
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
         const int n = n0 + wn * (BN / 2) + a * 16 + lg * 4;
@@ -588,6 +694,8 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.xcd = xcd_env;
     static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
     a.early = early_env & 1;
+    static const int epi_env = getenv("REFTR_EPI") ? atoi(getenv("REFTR_EPI")) : 1;
+    a.epi_lds = epi_env;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;
