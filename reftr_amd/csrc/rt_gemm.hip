@@ -694,8 +694,8 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.xcd = xcd_env;
     static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
     a.early = early_env & 1;
-    static const int epi_env = getenv("REFTR_EPI") ? atoi(getenv("REFTR_EPI")) : 1;
-    a.epi_lds = epi_env;
+    static const int epi_env = getenv("REFTR_EPI") ? atoi(getenv("REFTR_EPI")) : 3;
+    a.epi_lds = epi_env & 1;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
     hipStream_t s = (hipStream_t)stream;

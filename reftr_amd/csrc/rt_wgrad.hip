@@ -20,7 +20,7 @@ struct WgradArgs {
     const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
     int M, chunks_per_block, c_tiles;
-    float* part; int out_elems; int xcd, early;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
+    float* part; int out_elems; int xcd, early, epi_lds;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
     unsigned dy_bytes, x_bytes;
 };
 
@@ -426,6 +426,40 @@ __device__ __forceinline__ void wgrad_dma_body(const bf16_t* __restrict__ dyp, c
     // dependent load-add-store chain per lane would be slower than fire-and-forget atomics).
     const int mode = p.part ? 0 : 2;
     float* const dst = p.part ? p.part + (size_t)by * p.out_elems : p.dw;
+    if (mode == 0 && p.epi_lds) {
+        // Row-coalesced partial stores: the C/D layout gives 64-B pieces (16 lanes x 4 B) on 4 rows per store instruction;
+        // staged through LDS (the operand stages are dead; everyone drained its DMA tail above) a wave writes 1 KB = two
+        // full 512-B rows of the partial tile per instruction.  Done in n-halves when the fp32 tile exceeds the LDS.
+        constexpr int EP_LD = BC + 4;
+        constexpr int HALVES = ((size_t)BN * EP_LD * 4 > (size_t)NS * BUF_BYTES) ? 2 : 1;
+        constexpr int ROWS = BN / HALVES;
+        static_assert((size_t)ROWS * EP_LD * 4 <= (size_t)NS * BUF_BYTES, "partial tile does not fit the LDS stages");
+        float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+            __syncthreads();
+            if (HALVES == 1 || wn == h) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TC; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            tile[((HALVES == 1 ? wn * (BN / 2) : 0) + a * 16 + lg * 4 + r) * EP_LD + wc * (BC / 2) + b * 16 + li] = acc[a][b][r];
+            }
+            __syncthreads();
+            constexpr int PPR = BC / 4;                    // f32x4 pieces per row
+#pragma unroll
+            for (int i = 0; i < ROWS * PPR / 256; ++i) {
+                const int idx = i * 256 + t;
+                const int rl = idx / PPR, cl = (idx - rl * PPR) * 4;
+                const int n = n0 + h * ROWS + rl, c = c0 + cl;
+                if (n >= p.N || c >= p.SC) continue;
+                *reinterpret_cast<f32x4*>(dst + ((size_t)n * taps + tap) * p.SC + c) = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
         const int nb = n0 + wn * (BN / 2) + a * 16 + lg * 4;
@@ -750,6 +784,8 @@ static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a) {
     a.xcd = xcd_env;
     static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
     a.early = early_env & 2 ? 1 : 0;
+    static const int epi_env = getenv("REFTR_EPI") ? atoi(getenv("REFTR_EPI")) : 3;
+    a.epi_lds = epi_env & 2 ? 1 : 0;
     a.dy_bytes = (unsigned)(M * d->N * 2);
     a.x_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     return RT_OK;
