@@ -182,10 +182,13 @@ __global__ __launch_bounds__(256) void qenc_attn_bwd_kernel(const float* __restr
     __syncthreads();
     for (int l = threadIdx.x; l < L; l += 256) sds[l] = wr[l] * (sds[l] - dot);
     __syncthreads();
+    // blockIdx.y splits the token range of this last (atomic-issue bound) loop four ways
+    const int l0 = (int)blockIdx.y * ((L + (int)gridDim.y - 1) / (int)gridDim.y);
+    const int l1 = min(L, l0 + (L + (int)gridDim.y - 1) / (int)gridDim.y);
     for (int d = threadIdx.x; d < E; d += 256) {
         float gk = 0.f;
         const float kd = k[(size_t)b * E + d], dcd = dcr[d];
-        for (int l = 0; l < L; ++l) {
+        for (int l = l0; l < l1; ++l) {
             const size_t o = ((size_t)b * L + l) * E + d;
             gk += sds[l] * qs[o];
             atomicAdd(dqs + o, sds[l] * kd);
@@ -309,7 +312,7 @@ extern "C" int rt_qenc_attn_bwd(const float* k, const float* qs, const float* vs
                                 float* dk, float* dqs, float* dvs, int B, int P, int L, int E, rt_stream_t stream) {
     if (!k || !qs || !vs || !w || !dc || !dk || !dqs || !dvs) return RT_ERR_BADARG;
     if (L > 128 || L <= 0) return RT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(qenc_attn_bwd_kernel, dim3(B * P), dim3(256), 0, (hipStream_t)stream, k, qs, vs, w, dc, dk, dqs, dvs, P, L, E);
+    hipLaunchKernelGGL(qenc_attn_bwd_kernel, dim3(B * P, 4), dim3(256), 0, (hipStream_t)stream, k, qs, vs, w, dc, dk, dqs, dvs, P, L, E);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
