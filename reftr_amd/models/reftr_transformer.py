@@ -217,33 +217,40 @@ class RefTR(nn.Module):
         smask_u8 = samples["sentence_mask"].to(dev).to(torch.uint8).contiguous()
         Lq = ids.shape[1]
         # language branch (BERT) on the side stream, concurrently with the ResNet branch below
-        def _lang_branch():
-            if self._lin_refresh_pending:
-                net.refresh()
-                self._lin_refresh_pending = False
-            return net.bert_fwd(ids, smask_u8)
-        seq16, pooled16, bctx = net.side.run(_lang_branch, ids, smask_u8)
-        feats, bb_saved = self.body.forward(x)
-        c5, (_, h, w) = feats[-1]
+        # c5 geometry from the image size (stem 7x7/2, maxpool 3x3/2, three stride-2 stages): the positional / mask work below
+        # only needs the padding mask, so it rides on the language side stream behind BERT
+        h, w = x.shape[2], x.shape[3]
+        for _ in range(5):
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         HW = h * w
         assert Lq <= cfg.max_lang_seq                                       # models/reftr.py:81
         S = Lq + HW
         M = B * S
+        vt = "vl_transformer."
+
+        def _lang_branch():
+            if self._lin_refresh_pending:
+                net.refresh()
+                self._lin_refresh_pending = False
+            r = net.bert_fwd(ids, smask_u8)
+            pos = torch.empty(M, E, dtype=torch.float32, device=dev)
+            kpm = torch.empty(B, S, dtype=torch.uint8, device=dev)
+            kpm[:, :Lq] = (smask_u8 == 0)                                   # models/reftr.py:92
+            H.rows_add(B * Lq, E, a_f32=st.P[vt + "lang_pos_embeddings.weight"], a_map=(Lq, 0, 0),
+                       b_f32=st.P[vt + "token_type_embeddings.weight"], b_map=(-(B * Lq), 0, 0),
+                       out_f32=pos, o_map=(Lq, S, 0))
+            addv = torch.empty(E, dtype=torch.float32, device=dev)
+            H.rows_add(1, E, a_f32=st.P[vt + "level_embed"], b_f32=st.P[vt + "token_type_embeddings.weight"],
+                       b_map=(-1, 0, 1), out_f32=addv)
+            H.mask_posenc(mask_u8, h, w, E, addv, kpm, Lq, pos, S, Lq)
+            return r + (pos, kpm)
+        seq16, pooled16, bctx, pos, kpm = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
+        feats, bb_saved = self.body.forward(x)
+        c5, (_, h5, w5) = feats[-1]
+        assert (h5, w5) == (h, w)
         x32 = torch.empty(M, E, dtype=torch.float32, device=dev)
         x16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
         xp16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
-        pos = torch.empty(M, E, dtype=torch.float32, device=dev)
-        kpm = torch.empty(B, S, dtype=torch.uint8, device=dev)
-        kpm[:, :Lq] = (smask_u8 == 0)                                       # models/reftr.py:92
-        vt = "vl_transformer."
-        H.rows_add(B * Lq, E, a_f32=st.P[vt + "lang_pos_embeddings.weight"], a_map=(Lq, 0, 0),
-                   b_f32=st.P[vt + "token_type_embeddings.weight"], b_map=(-(B * Lq), 0, 0),
-                   out_f32=pos, o_map=(Lq, S, 0))
-        addv = torch.empty(E, dtype=torch.float32, device=dev)
-        H.rows_add(1, E, a_f32=st.P[vt + "level_embed"], b_f32=st.P[vt + "token_type_embeddings.weight"],
-                   b_map=(-1, 0, 1), out_f32=addv)
-        H.mask_posenc(mask_u8, h, w, E, addv, kpm, Lq, pos, S, Lq)
-
         net.side.join()
         _, ms_ctx = net.mlp_fwd(seq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos, rowmap=(Lq, S, 0))
         _, ip = net.lin_fwd("input_proj.0.0.", c5, out_bf16=False, out_f32=True)
