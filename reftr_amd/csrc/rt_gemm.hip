@@ -545,30 +545,37 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
     // different rows per store instruction.  Staging the fp32 tile through LDS (the operand stages are dead now) turns every
     // residual / gate read and every store into 16-B pieces of ONE row per lane, 128+ contiguous bytes per row.
     constexpr int EP_LD = BN + 4;                                  // padded fp32 row (bank spread)
-    constexpr bool EP_FITS = (size_t)BM * EP_LD * 4 <= (size_t)NS * BUF_BYTES;
-    if (EP_FITS && p.epi_lds && (p.N & 7) == 0) {
+    constexpr int HALVES = ((size_t)BM * EP_LD * 4 > (size_t)NS * BUF_BYTES) ? 2 : 1;    // 128x128 / 2 stages: two m-halves
+    constexpr int ROWS = BM / HALVES;
+    static_assert((size_t)ROWS * EP_LD * 4 <= (size_t)NS * BUF_BYTES, "epilogue tile does not fit the LDS stages");
+    if (p.epi_lds && (p.N & 7) == 0) {
         float* tile = reinterpret_cast<float*>(smem);
-        __syncthreads();        // every wave has drained its own DMA tail (vmcnt 0 above) and finished reading the stages
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+        for (int h = 0; h < HALVES; ++h) {
+            __syncthreads();    // every wave has drained its own DMA tail (vmcnt 0 above) and finished reading the stages / tile
+            if (HALVES == 1 || wm == h) {
 #pragma unroll
-            for (int b = 0; b < TM; ++b)
-                *reinterpret_cast<f32x4*>(tile + (wm * (BM / 2) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4) = acc[a][b];
-        __syncthreads();
-        constexpr int CPR = BN / 8;                                // 8-channel pieces per row
+                for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int i = 0; i < BM * CPR / 256; ++i) {
-            const int idx = i * 256 + t;
-            const int rl = idx / CPR, cl = (idx - rl * CPR) * 8;
-            int m = m0 + rl;
-            const int n = n0 + cl;
-            if (m >= Mloc || n >= p.N) continue;
-            if (MODE == 3) {
-                const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
-                m = (bb * p.DH + 2 * yy + cy) * p.DW + 2 * xx + cx;
+                    for (int b = 0; b < TM; ++b)
+                        *reinterpret_cast<f32x4*>(tile + ((HALVES == 1 ? wm * (BM / 2) : 0) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4) = acc[a][b];
             }
-            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl), hi4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl + 4);
-            epilogue8(p, m, n, f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]});
+            __syncthreads();
+            constexpr int CPR = BN / 8;                            // 8-channel pieces per row
+#pragma unroll
+            for (int i = 0; i < ROWS * CPR / 256; ++i) {
+                const int idx = i * 256 + t;
+                const int rl = idx / CPR, cl = (idx - rl * CPR) * 8;
+                int m = m0 + h * ROWS + rl;
+                const int n = n0 + cl;
+                if (m >= Mloc || n >= p.N) continue;
+                if (MODE == 3) {
+                    const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
+                    m = (bb * p.DH + 2 * yy + cy) * p.DW + 2 * xx + cx;
+                }
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl), hi4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl + 4);
+                epilogue8(p, m, n, f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]});
+            }
         }
         return;
     }
