@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
     }
 }
 
-// One launch for all per-step operand refreshes: job table in device memory, 32(n) x 32(c) tiles per tap; the
-// transposed copy goes through a padded LDS tile so both global writes are coalesced.
+// One launch for all per-step operand refreshes: job table in device memory, 64(n) x 64(c) tiles per tap (both bf16 copies
+// are written in 128-B row pieces: a 32-wide tile gave 64-B pieces); the transposed copy goes through a padded LDS tile.
 __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const int64_t* __restrict__ table, int njobs) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     int lo = 0, hi = njobs - 1;                       // last job whose first_tile <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -147,26 +147,26 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const int64_t*
     bf16_t* dst_t = reinterpret_cast<bf16_t*>(j[3]);
     const int N = (int)j[4], T = (int)j[5], C = (int)j[6];
     const int local = blockIdx.x - (int)j[7];
-    const int ct = (C + 31) >> 5, nt = (N + 31) >> 5;
+    const int ct = (C + 63) >> 6, nt = (N + 63) >> 6;
     const int tc = local % ct, tn = (local / ct) % nt, tap = local / (ct * nt);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = tn * 32 + ty + r * 8, c = tc * 32 + tx;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int n = tn * 64 + ty + r * 4, c = tc * 64 + tx;
         float v = 0.f;
         if (n < N && c < C) {
             v = src[((size_t)n * T + tap) * C + c];
             if (scale) v *= scale[n];
             if (dst) dst[((size_t)n * T + tap) * C + c] = (bf16_t)v;
         }
-        tile[ty + r * 8][tx] = v;
+        tile[ty + r * 4][tx] = v;
     }
     if (!dst_t) return;
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int c = tc * 32 + ty + r * 8, n = tn * 32 + tx;
-        if (n < N && c < C) dst_t[((size_t)c * T + tap) * N + n] = (bf16_t)tile[tx][ty + r * 8];
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int c = tc * 64 + ty + r * 4, n = tn * 64 + tx;
+        if (n < N && c < C) dst_t[((size_t)c * T + tap) * N + n] = (bf16_t)tile[tx][ty + r * 4];
     }
 }
 

@@ -831,7 +831,7 @@ class WeightPrepBatch:
     def add(self, src, N, T, C, scale=None, dst=None, dst_t=None):
         assert src.is_contiguous() and src.numel() == N * T * C
         self.jobs.append([_p(src), _p(scale) or 0, _p(dst) or 0, _p(dst_t) or 0, N, T, C, self.tiles])
-        self.tiles += ((N + 31) // 32) * ((C + 31) // 32) * T
+        self.tiles += ((N + 63) // 64) * ((C + 63) // 64) * T
         self._keep.append((src, scale, dst, dst_t))
         self.table = None
 
