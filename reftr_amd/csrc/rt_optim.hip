@@ -3,6 +3,7 @@
 //   rt_adamw_flat  gradient scale (1/world) + clip coefficient + decoupled-weight-decay AdamW, 28 B/param of
 //                  HBM traffic in a single streaming pass, per-range learning rates (param groups)
 #include "rt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p) {
+__global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p, const int nontemporal) {
     const float total = sqrtf(p.gnorm_sq ? p.gnorm_sq[0] : 0.f) * p.grad_scale;
     float coef = 1.f;
     if (p.max_norm > 0.f) coef = fminf(1.f, p.max_norm / (total + 1e-6f));
@@ -41,7 +42,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             if (r < p.n_ranges && e >= (size_t)p.range_begin[r] && e < (size_t)p.range_end[r]) { lr = p.range_lr[r]; wd = p.range_wd[r]; }
-        float4 pv = P4[i]; const float4 gv = G4[i]; float4 mv = M4[i]; float4 vv = V4[i];
+        float4 pv, gv, mv, vv;
+        if (nontemporal) {         // streamed once per step: do not displace the activations / operands in L2 and the MALL
+            auto ntl = [](const float4* q) __attribute__((always_inline)) {
+                const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+                return make_float4(t4[0], t4[1], t4[2], t4[3]);
+            };
+            pv = ntl(P4 + i); gv = ntl(G4 + i); mv = ntl(M4 + i); vv = ntl(V4 + i);
+        } else { pv = P4[i]; gv = G4[i]; mv = M4[i]; vv = V4[i]; }
         float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -52,7 +60,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p) {
             const float denom = sqrtf(vp[c]) * inv_sqrt_bc2 + p.eps;
             pp[c] -= (lr / bc1) * (mp[c] / denom);
         }
-        P4[i] = pv; M4[i] = mv; V4[i] = vv;
+        if (nontemporal) { P4[i] = pv; __builtin_nontemporal_store(f32x4{mv.x, mv.y, mv.z, mv.w}, reinterpret_cast<f32x4*>(M4 + i)); __builtin_nontemporal_store(f32x4{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f32x4*>(V4 + i)); }
+        else { P4[i] = pv; M4[i] = mv; V4[i] = vv; }
     }
 }
 
@@ -83,7 +92,8 @@ extern "C" int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream) {
         return RT_ERR_BADARG;
     for (int r = 0; r < d->n_ranges; ++r) if ((d->range_begin[r] & 3) || (d->range_end[r] & 3)) return RT_ERR_BADARG;
     int blocks = (int)(((size_t)d->n / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    static const int nt_env = getenv("REFTR_ADAMW_NT") ? atoi(getenv("REFTR_ADAMW_NT")) : 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, nt_env);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
