@@ -1,0 +1,15 @@
+# Regenerates the judged measurement artefacts of the current build on the GPU box:
+#   bash benchmarks/round_artifacts.sh r01j
+# -> gpurun_out/$TAG_bench.json, $TAG_kernel_stats_graph.md, $TAG_pmc_traffic.json, $TAG_pmc_kernels.txt, $TAG_phases.txt
+TAG=${1:-rXX}; export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out; mkdir -p $O
+python bench.py > $O/${TAG}_bench.log 2>&1; tail -1 $O/${TAG}_bench.log > $O/${TAG}_bench.json; cut -c1-400 $O/${TAG}_bench.json
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats -- python $R/bench.py --no-cpu-baseline > $O/${TAG}_stats.log 2>&1
+cd $R
+DB=$(find $O/${TAG}_stats -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB > $O/${TAG}_kernel_stats_graph.md 2>$O/${TAG}_stats.err; head -12 $O/${TAG}_kernel_stats_graph.md
+python tools/step_phases.py $DB > $O/${TAG}_phases.txt 2>&1; tail -15 $O/${TAG}_phases.txt
+bash benchmarks/pmc_passes.sh > $O/${TAG}_pmc.log 2>&1
+F=$(find $O/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*.db" | head -1)
+python tools/pmc_traffic.py $F $W --steps 5 --json $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_kernels.txt 2>&1; head -14 $O/${TAG}_pmc_kernels.txt
+rm -rf $O/${TAG}_stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE

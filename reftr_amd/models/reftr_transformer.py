@@ -473,7 +473,9 @@ class RefTR(nn.Module):
 
 def build_config(args):
     if int(getattr(args, "num_feature_levels", 1)) != 1:
-        raise NotImplementedError("num_feature_levels > 1 (models/reftr_transformer.py:99-117): every reference config uses 1")
+        raise NotImplementedError("num_feature_levels > 1: the reference's own forward raises for every such value "
+                                  "(models/reftr_transformer.py:171-175 feeds the 1024-channel map to the 512-channel input_proj[0] "
+                                  "of :100-108) and every reference config uses 1, so there is no behaviour to match")
     # models/reftr_transformer.py:315-318: RobertaModel when args.bert_model starts with 'roberta', BertModel otherwise
     bc = L.roberta_config() if str(getattr(args, "bert_model", "bert-base-uncased")).split("-")[0] == "roberta" else L.BertConfig()
     layers = (3, 4, 23, 3) if getattr(args, "backbone", "resnet50") == "resnet101" else (3, 4, 6, 3)
