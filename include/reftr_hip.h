@@ -202,6 +202,8 @@ int rt_ln_param_grad_grouped(const rt_ln_pg_job* jobs, int n, rt_stream_t stream
  * 121-125,174) on the token-major image x[b][pixel][c]; statistics per (image, group) over HW * C/G values.
  * Output rows go to (b * out_rows_per_img + out_row_off + pixel) so the image tokens land behind the
  * language tokens of the [B, S, C] sequence (models/reftr.py:115-117).  stats/bstats: [B, G, 2] workspaces.
+ * The forward statistics are reduced in a fixed order (per-chunk partial sums, then a fixed shuffle tree): no atomics, so
+ * the eval-mode forward is bit-reproducible run to run like the reference's.
  * ------------------------------------------------------------------------------------------ */
 typedef struct rt_groupnorm_desc {
     const float* x;        /* [B, HW, C] */
@@ -212,6 +214,8 @@ typedef struct rt_groupnorm_desc {
     int32_t B, HW, C, G;
     float   eps;
     int32_t out_rows_per_img, out_row_off;
+    float*  partials;      /* [B, chunks, G, 2] workspace: per-pixel-chunk sums, 1 <= chunks <= 64 */
+    int32_t chunks;
 } rt_groupnorm_desc;
 int rt_groupnorm_fwd(const rt_groupnorm_desc* d, rt_stream_t stream);
 
@@ -236,6 +240,8 @@ int rt_groupnorm_bwd(const rt_groupnorm_bwd_desc* d, rt_stream_t stream);
  * rt_gn_nhwc_fwd / _bwd — GroupNorm(8, C) + ReLU (:242-248,256-258,...) over x[b][p][c] (fp32 conv output, row stride
  *   ldx); writes the next convolution's bf16 operand with row stride ldy >= C, padding zero-filled.
  *   stats / bstats: [B, G, 2] workspaces (sum, sumsq) kept for backward.  dy fp32 (row stride lddy), dx bf16 (lddx).
+ *   Forward statistics go through `partials` ([B, partial_blocks, G, 2], partial_blocks >= ceil(HW / ceil(16384 / C))) and
+ *   are added in a fixed order (no atomics): the eval-mode mask logits are bit-reproducible run to run.
  * rt_upsample_add / _bwd — `cur_fpn + F.interpolate(x, size, mode="nearest")` (:253,262,271).  Backward returns the
  *   pixel-summed gradient of the coarse operand and a bf16 copy of dy (the adapter convolution's output gradient).
  * rt_attn_map_fwd / _bwd — MHAttentionMap.forward (:196-208): softmax over (heads, h, w) jointly of
@@ -251,6 +257,7 @@ typedef struct rt_gn_nhwc_desc {
     float* stats; void* y_bf16;
     int32_t B, HW, C, G, ldx, ldy, act;
     float eps;
+    float* partials; int32_t partial_blocks;
 } rt_gn_nhwc_desc;
 int rt_gn_nhwc_fwd(const rt_gn_nhwc_desc* d, rt_stream_t stream);
 

@@ -285,37 +285,52 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const rt_layerno
 }
 
 // ---------------- GroupNorm over token-major images x[b][p][c], groups of C/G channels ----------------
-// stats[b][g] = {sum, sumsq}; a block covers (b, 64-pixel chunk) with one thread per channel.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
-                                                       int HW, int C, int G) {
+// part[b][chunk][g] = {sum, sumsq} of one pixel chunk, one thread per channel; the apply kernel adds the chunks in a fixed
+// order (no atomics: the forward is bit-reproducible run to run).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                       int HW, int C, int G, int pix_per_chunk) {
     const int b = blockIdx.y, c = threadIdx.x;
-    const int p0 = blockIdx.x * GN_PIX;
-    const int p1 = min(p0 + GN_PIX, HW);
+    const int p0 = blockIdx.x * pix_per_chunk;
+    const int p1 = min(p0 + pix_per_chunk, HW);
     float s = 0.f, ss = 0.f;
     if (c < C)
         for (int pix = p0; pix < p1; ++pix) { const float v = x[((size_t)b * HW + pix) * C + c]; s += v; ss += v * v; }
     const int cpg = C / G;             // channels per group (power of two <= 64 assumed)
     for (int o = cpg >> 1; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
     if (c < C && (c % cpg) == 0) {
-        atomicAdd(stats + ((size_t)b * G + c / cpg) * 2, s);
-        atomicAdd(stats + ((size_t)b * G + c / cpg) * 2 + 1, ss);
+        float* dst = part + (((size_t)b * gridDim.x + blockIdx.x) * G + c / cpg) * 2;
+        dst[0] = s; dst[1] = ss;
     }
 }
 
+// grid (row blocks, B): every block first reduces its image's chunk partials (wave per group, xor butterfly: the same
+// value in every block), block x = 0 keeps the sums for backward, then rows blockIdx.x, + gridDim.x, ... are normalised.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const rt_groupnorm_desc p) {
-    const size_t total = (size_t)p.B * p.HW * p.C;
+    __shared__ float sm[256][2];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpg = p.C / p.G;
+    for (int g = wave; g < p.G; g += 4) {
+        float s = 0.f, ss = 0.f;
+        for (int ch = lane; ch < p.chunks; ch += 64) {
+            const float* q = p.partials + (((size_t)b * p.chunks + ch) * p.G + g) * 2;
+            s += q[0]; ss += q[1];
+        }
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+        if (lane == 0) {
+            sm[g][0] = s; sm[g][1] = ss;
+            if (blockIdx.x == 0) { p.stats[((size_t)b * p.G + g) * 2] = s; p.stats[((size_t)b * p.G + g) * 2 + 1] = ss; }
+        }
+    }
+    __syncthreads();
+    const int c = tid;
+    if (c >= p.C) return;
     const float inv_n = 1.f / (float)(cpg * p.HW);
+    const float mean = sm[c / cpg][0] * inv_n;
+    const float var = fmaxf(sm[c / cpg][1] * inv_n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps);
     bf16_t* yb = (bf16_t*)p.y_bf16; bf16_t* ypb = (bf16_t*)p.ypos_bf16;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % p.C);
-        const size_t pixg = i / p.C;
-        const int b = (int)(pixg / p.HW);
-        const int pix = (int)(pixg % p.HW);
-        const float* st = p.stats + ((size_t)b * p.G + c / cpg) * 2;
-        const float mean = st[0] * inv_n;
-        const float var = fmaxf(st[1] * inv_n - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + p.eps);
+    for (int pix = blockIdx.x; pix < p.HW; pix += gridDim.x) {
+        const size_t i = ((size_t)b * p.HW + pix) * p.C + c;
         const float y = (p.x[i] - mean) * rstd * p.gamma[c] + p.beta[c];
         const size_t o = ((size_t)b * p.out_rows_per_img + p.out_row_off + pix) * p.C + c;
         if (p.y_f32) p.y_f32[o] = y;
@@ -452,14 +467,13 @@ extern "C" int rt_groupnorm_fwd(const rt_groupnorm_desc* d, rt_stream_t stream) 
     if (!d || !d->x || !d->gamma || !d->beta || !d->stats) return RT_ERR_BADARG;
     if (d->C <= 0 || d->C > 256 || d->G <= 0 || (d->C % d->G) || (d->C / d->G) > 64 || ((d->C / d->G) & (d->C / d->G - 1)))
         return RT_ERR_UNSUPPORTED;
+    if (!d->partials || d->chunks < 1 || d->chunks > 64) return RT_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = rt_zero_f32(d->stats, 2 * (size_t)d->B * d->G, s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((d->HW + GN_PIX - 1) / GN_PIX, d->B), dim3(256), 0, s, d->x, d->stats, d->HW, d->C, d->G);
+    const int ppc = (d->HW + d->chunks - 1) / d->chunks;          // chunks past the last pixel write zeros
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(d->chunks, d->B), dim3(256), 0, s, d->x, d->partials, d->HW, d->C, d->G, ppc);
     RT_CHECK_LAUNCH();
-    const size_t total = (size_t)d->B * d->HW * d->C;
-    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, *d);
+    int rows = d->HW < 64 ? d->HW : 64;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(rows, d->B), dim3(256), 0, s, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

@@ -9,30 +9,47 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm over x[b][p][c] (row stride ldx), C real channels in G groups; stats[b][g] = {sum, sumsq}.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_nhwc_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+// Deterministic: a thread adds into its own LDS slot per group, the block folds the 256 slots per group with a fixed tree and
+// writes part[b][block][g]; gn_nhwc_finalize_kernel adds the blocks in a fixed order.  (G <= 16: 2 * G * 256 floats of LDS.)
+__global__ __launch_bounds__(256) void gn_nhwc_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                             int HW, int C, int ldx, int G, int pix_per_block) {
-    __shared__ float sm[2 * 64];
-    const int b = blockIdx.y;
+    extern __shared__ float sm[];                  // [G][2][256]
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(p0 + pix_per_block, HW);
     const int cpg = C / G;
-    for (int i = threadIdx.x; i < 2 * G; i += 256) sm[i] = 0.f;
-    __syncthreads();
+    for (int i = tid; i < 2 * G * 256; i += 256) sm[i] = 0.f;      // only the thread's own slots: no barrier needed
     const int total = (p1 - p0) * C;
     // a thread walks elements e = t, t+256, ...: consecutive threads -> consecutive channels of a pixel (coalesced)
     float s = 0.f, ss = 0.f; int cur = -1;
-    for (int e = threadIdx.x; e < total; e += 256) {
+    for (int e = tid; e < total; e += 256) {
         const int pix = e / C, c = e - pix * C;
         const int g = c / cpg;
         if (g != cur) {
-            if (cur >= 0) { atomicAdd(&sm[2 * cur], s); atomicAdd(&sm[2 * cur + 1], ss); }
+            if (cur >= 0) { sm[(2 * cur) * 256 + tid] += s; sm[(2 * cur + 1) * 256 + tid] += ss; }
             cur = g; s = 0.f; ss = 0.f;
         }
         const float v = x[((size_t)b * HW + p0 + pix) * ldx + c];
         s += v; ss += v * v;
     }
-    if (cur >= 0) { atomicAdd(&sm[2 * cur], s); atomicAdd(&sm[2 * cur + 1], ss); }
+    if (cur >= 0) { sm[(2 * cur) * 256 + tid] += s; sm[(2 * cur + 1) * 256 + tid] += ss; }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(stats + (size_t)b * G * 2 + i, sm[i]);
+    // wave w folds rows w, w+4, ... of the [2G][256] table: 4 slots per lane, then an xor butterfly
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < 2 * G; r += 4) {
+        float v = (sm[r * 256 + lane] + sm[r * 256 + 64 + lane]) + (sm[r * 256 + 128 + lane] + sm[r * 256 + 192 + lane]);
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) part[((size_t)b * gridDim.x + blockIdx.x) * 2 * G + r] = v;
+    }
+}
+
+// stats[b][g][k] = sum over blocks of part[b][block][g][k], one wave per (b, g, k) row, fixed order
+__global__ __launch_bounds__(64) void gn_nhwc_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                              int nblk, int G2) {
+    const int b = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    float v = 0.f;
+    for (int k = lane; k < nblk; k += 64) v += part[((size_t)b * nblk + k) * G2 + r];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) stats[(size_t)b * G2 + r] = v;
 }
 
 __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(const rt_gn_nhwc_desc p) {
@@ -336,11 +353,15 @@ static inline int grid_for(size_t total, int cap = 4096) {
 extern "C" int rt_gn_nhwc_fwd(const rt_gn_nhwc_desc* d, rt_stream_t stream) {
     if (!d || !d->x || !d->gamma || !d->beta || !d->stats || !d->y_bf16) return RT_ERR_BADARG;
     if (d->C <= 0 || d->G <= 0 || d->G > 64 || (d->C % d->G) || d->ldx < d->C || d->ldy < d->C || d->B <= 0 || d->HW <= 0) return RT_ERR_UNSUPPORTED;
+    if (d->G > 16) return RT_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = rt_zero_f32(d->stats, 2 * (size_t)d->B * d->G, s);
-    if (e != hipSuccess) return (int)e;
     int ppb = (int)((16384 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
-    hipLaunchKernelGGL(gn_nhwc_stats_kernel, dim3((d->HW + ppb - 1) / ppb, d->B), dim3(256), 0, s, d->x, d->stats, d->HW, d->C, d->ldx, d->G, ppb);
+    const int nblk = (d->HW + ppb - 1) / ppb;
+    if (!d->partials || d->partial_blocks < nblk) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel, dim3(nblk, d->B), dim3(256), 2 * d->G * 256 * sizeof(float), s,
+                       d->x, d->partials, d->HW, d->C, d->ldx, d->G, ppb);
+    RT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_nhwc_finalize_kernel, dim3(2 * d->G, d->B), dim3(64), 0, s, d->partials, d->stats, nblk, 2 * d->G);
     RT_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_nhwc_apply_kernel, dim3(grid_for((size_t)d->B * d->HW * d->ldy)), dim3(256), 0, s, *d);
     RT_CHECK_LAUNCH();

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -74,7 +74,7 @@ class GroupNormDesc(Structure):
         ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("stats", c_void_p),
         ("y_f32", c_void_p), ("y_bf16", c_void_p), ("pos", c_void_p), ("ypos_bf16", c_void_p),
         ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("G", c_int32), ("eps", c_float),
-        ("out_rows_per_img", c_int32), ("out_row_off", c_int32),
+        ("out_rows_per_img", c_int32), ("out_row_off", c_int32), ("partials", c_void_p), ("chunks", c_int32),
     ]
 
 
@@ -155,7 +155,7 @@ class SmallWgradJob(Structure):
 class GnNhwcDesc(Structure):
     _fields_ = [("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("stats", c_void_p), ("y_bf16", c_void_p),
                 ("B", c_int32), ("HW", c_int32), ("C", c_int32), ("G", c_int32), ("ldx", c_int32), ("ldy", c_int32),
-                ("act", c_int32), ("eps", c_float)]
+                ("act", c_int32), ("eps", c_float), ("partials", c_void_p), ("partial_blocks", c_int32)]
 
 
 class GnNhwcBwdDesc(Structure):
@@ -504,8 +504,10 @@ def groupnorm_fwd(x, gamma, beta, G, eps, *, y_f32=None, y_bf16=None, pos=None, 
     _req(x, torch.float32, "x")
     rows_per_img = HW if rows_per_img is None else rows_per_img
     stats = _new((B, G, 2), torch.float32, x)
+    chunks = min(64, (HW + 7) // 8)
+    partials = _new((B, chunks, G, 2), torch.float32, x)
     d = GroupNormDesc(_p(x), _p(gamma), _p(beta), _p(stats), _p(y_f32), _p(y_bf16), _p(pos), _p(ypos_bf16),
-                      B, HW, C, G, eps, rows_per_img, row_off)
+                      B, HW, C, G, eps, rows_per_img, row_off, _p(partials), chunks)
     _check(lib().rt_groupnorm_fwd(ctypes.byref(d), _stream()), "rt_groupnorm_fwd")
     return stats
 
@@ -854,7 +856,10 @@ def gn_nhwc_fwd(x, gamma, beta, B, HW, C, G=8, ldy=None, act=ACT_RELU, eps=1e-5)
     assert x.numel() == B * HW * ldx and gamma.numel() >= C
     y = torch.empty((B * HW, ldy), dtype=torch.bfloat16, device=x.device)
     stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
-    d = GnNhwcDesc(_p(x), _p(gamma), _p(beta), _p(stats), _p(y), B, HW, C, G, ldx, ldy, act, eps)
+    ppb = max(1, (16384 + C - 1) // C)
+    nblk = (HW + ppb - 1) // ppb
+    partials = torch.empty((B, nblk, G, 2), dtype=torch.float32, device=x.device)
+    d = GnNhwcDesc(_p(x), _p(gamma), _p(beta), _p(stats), _p(y), B, HW, C, G, ldx, ldy, act, eps, _p(partials), nblk)
     _check(lib().rt_gn_nhwc_fwd(ctypes.byref(d), _stream()), "rt_gn_nhwc_fwd")
     return y, stats
 

@@ -151,7 +151,12 @@ def test_three_training_steps(hip):
 def test_captured_step_matches_eager(hip, two_phase):
     """CapturedTrainStep (hipGraph replay; two_phase = the data-parallel schedule with backward split in
     [everything but the ResNet | the ResNet]) must walk the same trajectory as the eager loop body: same kernels, so
-    only atomics-order noise separates them."""
+    only the summation order of the backward's atomics separates them.
+
+    Step 1 is compared tightly (loss, gradients, updated weights).  Later steps only loosely: a 1-ulp difference in
+    the weights flips single bf16 roundings in the next forward, and on this fixture (formula weights that sit on the
+    bf16 grid) one such flip moves the loss by 4e-4 at step 2 and up to 1.2e-2 at step 3 -- two EAGER runs differ by that
+    much from each other in ~20 % of the runs (benchmarks/debug_graph_vs_eager.py)."""
     from reftr_amd.engine_vg import CapturedTrainStep, train_step
     from reftr_amd.optim import FusedAdamW
     samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
@@ -168,7 +173,7 @@ def test_captured_step_matches_eager(hip, two_phase):
             # capture warm-up steps moved the weights: restore the initial state before comparing trajectories
             model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
             model.mark_dirty(full=True)
-        losses, norms = [], []
+        losses, norms, first = [], [], None
         for it in range(3):
             if mode == "eager":
                 lv, _, _, gn = train_step(model, crit, s, tg, opt, None, max_norm=0.1)
@@ -176,13 +181,18 @@ def test_captured_step_matches_eager(hip, two_phase):
                 l, _, gn = cap(s, tg)
                 lv = float(l)
             losses.append(lv); norms.append(float(gn))
-        runs.append((losses, norms, model.store.flat_p.clone()))
-    (l0, n0, p_e), (l1, n1, p_g) = runs
-    for a, b in zip(l0, l1):
-        assert abs(a - b) < 2e-3 * abs(a), (l0, l1)
+            if it == 0:
+                torch.cuda.synchronize()
+                first = (model.store.flat_g.clone(), model.store.flat_p.clone())
+        runs.append((losses, norms, model.store.flat_p.clone(), first))
+    (l0, n0, p_e, f_e), (l1, n1, p_g, f_g) = runs
+    assert abs(l0[0] - l1[0]) < 1e-6 * abs(l0[0]) and abs(n0[0] - n1[0]) < 1e-5 * n0[0], (l0, l1, n0, n1)
+    assert rel(f_g[0], f_e[0]) < 1e-6 and rel(f_g[1], f_e[1]) < 1e-7        # gradients / weights after the first step
+    for a, b, tol in zip(l0[1:], l1[1:], (1e-3, 2e-2)):
+        assert abs(a - b) < tol * abs(a), (l0, l1)
     for a, b in zip(n0, n1):
-        assert abs(a - b) < 2e-2 * abs(a), (n0, n1)
-    assert rel(p_g, p_e) < 1e-5
+        assert abs(a - b) < 3e-2 * abs(a), (n0, n1)
+    assert rel(p_g, p_e) < 3e-5             # three Adam steps of lr 1e-4 on sign-of-noise gradients of dead parameters
 
 
 def test_dropout_train_mode_runs_and_is_reproducible(hip):

@@ -4,7 +4,10 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
 # last adamw = end of the last step; previous adamw = end of the step before
 ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
-a, b = ad[-2] + 1, ad[-1] + 1
+# the shortest step of the run (skips warm-up and bench.py's backlogged roofline pass behind a spin kernel)
+cands = [(rows[ad[i + 1]][2] - rows[ad[i] + 1][1], ad[i] + 1, ad[i + 1] + 1) for i in range(len(ad) - 1)
+         if not any("spin_kernel" in r[0] for r in rows[ad[i] + 1:ad[i + 1] + 1])]
+_, a, b = min(cands)
 step = rows[a:b]
 t0 = step[0][1]
 marks = [("weight prep + pack", "img_pack"), ("stem", "stem_conv"), ("ResNet fwd (+BERT if 1 stream)", "maxpool"), ("input_proj+GN", "gn_stats_kernel"),
