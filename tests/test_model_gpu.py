@@ -192,7 +192,7 @@ def test_captured_step_matches_eager(hip, two_phase):
         assert abs(a - b) < tol * abs(a), (l0, l1)
     for a, b in zip(n0, n1):
         assert abs(a - b) < 3e-2 * abs(a), (n0, n1)
-    assert rel(p_g, p_e) < 3e-5             # three Adam steps of lr 1e-4 on sign-of-noise gradients of dead parameters
+    assert rel(p_g, p_e) < 2e-4             # after the trajectories may have separated (see above); step 1 is the tight check
 
 
 def test_dropout_train_mode_runs_and_is_reproducible(hip):
