@@ -240,9 +240,15 @@ def main():
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, S_, S_, Lq)
-        print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    # RCCL writes a banner ("Librccl path : ...") through C stdio, which is block-buffered on a pipe and would otherwise
+    # surface AFTER the JSON line at exit: drain it first so that the JSON line is the last line of stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

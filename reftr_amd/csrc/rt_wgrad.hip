@@ -743,7 +743,8 @@ extern "C" int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, flo
         const long long base_blocks = (long long)nt * a.c_tiles;
         const long long out_elems = (long long)a.N * a.SC;
         const int minrows = out_elems * 4 <= (512 << 10) ? 256 : 512;
-        long long want = (512 + base_blocks - 1) / base_blocks, maxs = (long long)total_chunks * CR / minrows;
+        static const int gtarget = getenv("REFTR_WG_TARGET") ? atoi(getenv("REFTR_WG_TARGET")) : 512;
+        long long want = (gtarget + base_blocks - 1) / base_blocks, maxs = (long long)total_chunks * CR / minrows;
         if (maxs < 1) maxs = 1;
         if (want > maxs) want = maxs;
         int msplit = (int)(want < 1 ? 1 : want);
