@@ -463,6 +463,11 @@ int rt_pos_grad(const float* dpos, float* d_lang_pos, float* d_type, float* d_le
  * rt_adamw_flat  g' = g * grad_scale; total = sqrt(gnorm_sq) * grad_scale; coef = min(1, max_norm/(total+1e-6))
  *                (clip_grad_norm_, skipped when max_norm <= 0); AdamW with decoupled weight decay, bias
  *                correction at `step` (1-based); per-range lr / wd = the reference's param groups.
+ *                span_begin < span_end restricts the pass to that element span (the update of one step may be issued as
+ *                several launches on different streams, e.g. the BERT slice concurrently with the ResNet forward);
+ *                `active` (DEVICE word, optional): the launch is a no-op while it is 0 (nothing pending under graph
+ *                replay); `lr_dev` (DEVICE float[n_ranges], optional) overrides range_lr, so a replayed graph follows
+ *                the learning-rate schedule without re-capture.
  * ------------------------------------------------------------------------------------------ */
 int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stream);
 
@@ -476,6 +481,9 @@ typedef struct rt_adamw_desc {
     int64_t range_begin[8], range_end[8];
     float   range_lr[8], range_wd[8];
     const int32_t* step_dev;  /* optional DEVICE word overriding `step` (the optimizer step counter under hipGraph replay) */
+    const int32_t* active;    /* optional DEVICE word: 0 = skip this launch */
+    const float*   lr_dev;    /* optional DEVICE [n_ranges] learning rates overriding range_lr */
+    int64_t span_begin, span_end;   /* element span to update (multiples of 4); 0, 0 = the whole buffer */
 } rt_adamw_desc;
 int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream);
 /* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */

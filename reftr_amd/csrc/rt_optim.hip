@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p, const int nontemporal) {
+    if (p.active && p.active[0] == 0) return;
     const float total = sqrtf(p.gnorm_sq ? p.gnorm_sq[0] : 0.f) * p.grad_scale;
     float coef = 1.f;
     if (p.max_norm > 0.f) coef = fminf(1.f, p.max_norm / (total + 1e-6f));
@@ -31,17 +32,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p, const
     const float bc1 = 1.f - powf(p.beta1, (float)step);
     const float bc2 = 1.f - powf(p.beta2, (float)step);
     const float inv_sqrt_bc2 = rsqrtf(bc2);
-    const size_t n4 = p.n >> 2;
+    const size_t i0 = (size_t)p.span_begin >> 2, n4 = (size_t)p.span_end >> 2;
     float4* P4 = reinterpret_cast<float4*>(p.p);
     const float4* G4 = reinterpret_cast<const float4*>(p.g);
     float4* M4 = reinterpret_cast<float4*>(p.m);
     float4* V4 = reinterpret_cast<float4*>(p.v);
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    for (size_t i = i0 + blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const size_t e = i << 2;
         float lr = 0.f, wd = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-            if (r < p.n_ranges && e >= (size_t)p.range_begin[r] && e < (size_t)p.range_end[r]) { lr = p.range_lr[r]; wd = p.range_wd[r]; }
+            if (r < p.n_ranges && e >= (size_t)p.range_begin[r] && e < (size_t)p.range_end[r]) {
+                lr = p.lr_dev ? p.lr_dev[r] : p.range_lr[r]; wd = p.range_wd[r];
+            }
         float4 pv, gv, mv, vv;
         if (nontemporal) {         // streamed once per step: do not displace the activations / operands in L2 and the MALL
             auto ntl = [](const float4* q) __attribute__((always_inline)) {
@@ -91,9 +94,12 @@ extern "C" int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream) {
     if (!d || !d->p || !d->g || !d->m || !d->v || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8 || (d->step < 1 && !d->step_dev))
         return RT_ERR_BADARG;
     for (int r = 0; r < d->n_ranges; ++r) if ((d->range_begin[r] & 3) || (d->range_end[r] & 3)) return RT_ERR_BADARG;
-    int blocks = (int)(((size_t)d->n / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    rt_adamw_desc a = *d;
+    if (a.span_begin == 0 && a.span_end == 0) a.span_end = a.n;
+    if (a.span_begin < 0 || a.span_end > a.n || a.span_begin >= a.span_end || (a.span_begin & 3) || (a.span_end & 3)) return RT_ERR_BADARG;
+    int blocks = (int)(((size_t)(a.span_end - a.span_begin) / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;
     static const int nt_env = getenv("REFTR_ADAMW_NT") ? atoi(getenv("REFTR_ADAMW_NT")) : 1;
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, nt_env);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, nt_env);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

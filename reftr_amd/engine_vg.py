@@ -134,6 +134,14 @@ class CapturedTrainStep:
     three graphs (forward + backward phase 1 | ResNet backward | clip + AdamW) around the two eager, asynchronous
     gradient exchanges of reftr_amd.parallel.DistributedDataParallel.  Learning-rate changes re-capture the optimizer
     part (`refresh_lr()`), shapes other than the captured one must use `train_step`.
+
+    Single-process runs use the DEFERRED optimizer schedule (one graph): iteration i ends with the gradient norm, its
+    AdamW update is applied at the head of iteration i+1 -- the ResNet / transformer slice first on the main stream, the
+    BERT slice (72 % of the 4.25 GB pass) on the language stream in front of the BERT operand refresh, concurrently with
+    the ResNet forward.  Same arithmetic, same order of updates; whoever reads the weights or the optimizer state in
+    between (`model(...)` outside the replay, `state_dict()`, `optimizer.step()`) first gets the pending update applied
+    (`flush()`).  The learning rates are device words (`optimizer.lr_dev`): the update of iteration i uses the rates that
+    were current when iteration i ran, and schedule changes need no re-capture.
     """
 
     def __init__(self, model, criterion, optimizer, max_norm, samples, targets, warmup=2, force_two_phase=False):
@@ -159,6 +167,12 @@ class CapturedTrainStep:
         # gradient exchange runs under the second graph
         self.two_phase = bool(self._mid) or force_two_phase
         inner._defer_phase2 = self.two_phase
+        self.deferred = (not self.two_phase and not self._post and hasattr(optimizer, "enable_deferred")
+                         and os.environ.get("REFTR_DEFER_OPT", "1") == "1")
+        self._pending = False
+        if self.deferred:
+            self._init_deferred(warmup)
+            return
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -186,6 +200,71 @@ class CapturedTrainStep:
             inner._defer_phase2 = False
             criterion.num_boxes_static = None
 
+    # ------------------------------------------------------------------ deferred optimizer schedule
+    def _init_deferred(self, warmup):
+        from .models import layout as L
+        inner, opt = self.inner, self.optimizer
+        opt.enable_deferred()
+        bb, be = inner.store.group_range[L.GROUP_BERT]
+        assert be == inner.store.flat_p.numel() or be > bb, "BERT is the last group of the flat buffers"
+        self._hooks = ((lambda: opt.apply_pending(span=(0, bb)) if bb > 0 else None),
+                       (lambda: opt.apply_pending(span=(bb, be))))
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._step_deferred()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_fb, capture_error_mode=_CAPTURE_MODE):
+                self.out = self._step_deferred()
+            self.g_bb = self.g_opt = None
+            self.grad_norm = opt.grad_norm
+            self._pending = True                       # the last warm-up iteration's update
+            self._set_flush(True)
+        finally:
+            inner._mid_backward_hooks, inner._post_backward_hooks = self._mid, self._post
+            inner._defer_phase2 = False
+            self.criterion.num_boxes_static = None
+
+    def _set_flush(self, on):
+        f = self.flush if on else None
+        self.inner._flush_pending = f
+        self.optimizer._flush_pending = f
+
+    def _step_deferred(self):
+        """[AdamW of the previous iteration | forward | loss | backward | gradient norm] -- eagerly or under capture."""
+        inner, opt = self.inner, self.optimizer
+        self._set_flush(False)
+        inner._pre_update = self._hooks
+        inner._zero_grad_side = os.environ.get("REFTR_ZERO_SIDE", "0") == "1" and inner.net.side.enabled
+        try:
+            out = self._fwd_bwd(zero=not inner._zero_grad_side)
+        finally:
+            inner._pre_update = None
+            inner._zero_grad_side = False
+        opt.finish_step(self.max_norm)
+        return out
+
+    def flush(self):
+        """Applies the pending update now (before an eager forward, a checkpoint, an optimizer.step())."""
+        if not (self.deferred and self._pending):
+            return
+        self._pending = False
+        self._set_flush(False)
+        self.optimizer.apply_pending()
+        self.optimizer.clear_pending()
+        self.inner.mark_dirty()
+
+    def reset_pending(self):
+        """Forgets the pending update (after the caller has restored weights / optimizer state by hand)."""
+        self._pending = False
+        if self.deferred:
+            self.optimizer.clear_pending()
+            self._set_flush(False)
+
     def _refresh_num_boxes(self, targets):
         if self.nb is None:
             return
@@ -200,11 +279,12 @@ class CapturedTrainStep:
             k.append((n, tuple(v.tensors.shape) if isinstance(v, utils.NestedTensor) else tuple(v.shape)))
         return tuple(k) + tuple(int(t["boxes"].shape[0]) for t in targets)
 
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, zero=True):
         outputs = self.model(self.s)
         loss_dict = self.criterion(outputs, self.t)
         losses = _total(self.criterion, loss_dict)
-        self.optimizer.zero_grad()
+        if zero:
+            self.optimizer.zero_grad()
         losses.backward()
         return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}
 
@@ -219,6 +299,17 @@ class CapturedTrainStep:
 
     def __call__(self, samples, targets):
         assert self.shape_key(samples, targets) == self.key, "captured for another input shape; use train_step"
+        if self.deferred:
+            _copy_batch(self.s, self.t, samples, targets)
+            self.g_fb.replay()                # applies iteration i-1's update with the rates synced at iteration i-1
+            lrs = [g["lr"] for g in self.optimizer.param_groups]
+            if lrs != self._lrs:              # this iteration's rates, for the update the NEXT replay (or flush) applies
+                self._lrs = lrs
+                self.optimizer.sync_lr()
+            self.optimizer.step_count += 1
+            self._pending = True
+            self._set_flush(True)
+            return self.out[0], self.out[1], self.grad_norm
         if [g["lr"] for g in self.optimizer.param_groups] != self._lrs:
             self.refresh_lr()
         _copy_batch(self.s, self.t, samples, targets)

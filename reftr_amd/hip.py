@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -141,7 +141,7 @@ class AdamWDesc(Structure):
         ("grad_scale", c_float), ("max_norm", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
         ("step", c_int32), ("n_ranges", c_int32),
         ("range_begin", c_int64 * 8), ("range_end", c_int64 * 8), ("range_lr", c_float * 8), ("range_wd", c_float * 8),
-        ("step_dev", c_void_p),
+        ("step_dev", c_void_p), ("active", c_void_p), ("lr_dev", c_void_p), ("span_begin", c_int64), ("span_end", c_int64),
     ]
 
 
@@ -712,14 +712,16 @@ def sqnorm(g, out):
 
 
 def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_scale=1.0, max_norm=0.0,
-               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None):
-    """ranges = [(begin, end, lr, wd), ...] element ranges of the flat buffers (multiples of 4)."""
+               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None, active=None, lr_dev=None, span=None):
+    """ranges = [(begin, end, lr, wd), ...] element ranges of the flat buffers (multiples of 4); span = (begin, end)
+    restricts the launch to that element span; active / lr_dev: device words (see rt_adamw_desc)."""
     d = AdamWDesc()
     d.p, d.g, d.m, d.v, d.n = _p(p), _p(g), _p(m), _p(v), p.numel()
     d.gnorm_sq, d.gnorm_out = _p(gnorm_sq), _p(gnorm_out)
     d.grad_scale, d.max_norm, d.beta1, d.beta2, d.eps = grad_scale, max_norm, beta1, beta2, eps
     d.step, d.n_ranges = step, len(ranges)
-    d.step_dev = _p(step_dev)
+    d.step_dev, d.active, d.lr_dev = _p(step_dev), _p(active), _p(lr_dev)
+    d.span_begin, d.span_end = (0, 0) if span is None else span
     for i, (b, e, lr, wd) in enumerate(ranges):
         d.range_begin[i], d.range_end[i], d.range_lr[i], d.range_wd[i] = b, e, lr, wd
     _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")

@@ -72,6 +72,12 @@ class RefTR(nn.Module):
         self._post_backward_hooks = []
         self._lin_refresh_pending = False
         self._defer_phase2 = False        # engine-driven: stop after phase 1, `finish_backward()` runs the ResNet part
+        # deferred optimizer (engine_vg.CapturedTrainStep): (main-stream fn, language-stream fn) that apply the previous
+        # iteration's AdamW update at the head of this forward -- the BERT slice on the language stream, concurrently with
+        # the ResNet forward -- and the engine's callback that applies a still-pending update before anyone else reads
+        self._pre_update = None
+        self._flush_pending = None
+        self._zero_grad_side = False      # engine-driven: clear the gradient buffer on the language stream under the encoder
         self._pending = None
         self.reset_parameters()
 
@@ -132,13 +138,15 @@ class RefTR(nn.Module):
         # the Linear operands (BERT + transformer, 85 % of the bytes) are refreshed at the head of the BERT side stream
         # inside _forward_impl, concurrently with the stem / layer1 of the ResNet
         self._lin_refresh_pending = True
-        if os.environ.get("REFTR_PREP_SIDE", "1") == "0":
+        if os.environ.get("REFTR_PREP_SIDE", "1") == "0" and self._pre_update is None:
             self.net.refresh(); self._lin_refresh_pending = False
         if self.seg is not None:
             self.seg.refresh()
         self._operands_dirty, self._full_refresh = False, False
 
     def state_dict(self, *args, **kwargs):
+        if self._flush_pending is not None:
+            self._flush_pending()
         sd = super().state_dict(*args, **kwargs)
         for k in list(sd.keys()):     # views of the flat buffer -> standalone, contiguous tensors
             sd[k] = sd[k].detach().clone(memory_format=torch.contiguous_format)
@@ -179,6 +187,11 @@ class RefTR(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, samples):
+        if self._pre_update is not None:
+            self._pre_update[0]()
+            self.mark_dirty()
+        elif self._flush_pending is not None:
+            self._flush_pending()
         self.refresh_operands()
         pred_masks = None
         if self.seg is not None:
@@ -229,6 +242,8 @@ class RefTR(nn.Module):
         vt = "vl_transformer."
 
         def _lang_branch():
+            if self._pre_update is not None:
+                self._pre_update[1]()
             if self._lin_refresh_pending:
                 net.refresh()
                 self._lin_refresh_pending = False
@@ -252,6 +267,9 @@ class RefTR(nn.Module):
         x16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
         xp16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
         net.side.join()
+        if self._zero_grad_side:
+            # 607 MB of zeros: off the critical path, under the (latency-bound) encoder / decoder forward; backward joins
+            net.side.run(st.flat_g.zero_)
         _, ms_ctx = net.mlp_fwd(seq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos, rowmap=(Lq, S, 0))
         _, ip = net.lin_fwd("input_proj.0.0.", c5, out_bf16=False, out_f32=True)
         gn_stats = H.groupnorm_fwd(ip.view(B, HW, E), st.P["input_proj.0.1.weight"], st.P["input_proj.0.1.bias"], 32, 1e-5,
@@ -339,6 +357,8 @@ class RefTR(nn.Module):
         E = cfg.hidden
         dev = st.device
         H.set_seed_dev(self.seed_dev)
+        if self._zero_grad_side:
+            net.side.join()
         B, S, Lq, HW, Pn, N, T, NL = (sv[k] for k in ("B", "S", "Lq", "HW", "Pn", "N", "T", "NL"))
         vt, qe = "vl_transformer.", "query_encoder."
         M = B * S

@@ -39,6 +39,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)    # device-resident step counter (graph replay)
         self._max_norm = 0.0
         self._have_sq = False
+        # deferred mode (engine_vg.CapturedTrainStep): the update of step i is applied at the head of step i+1
+        self.active = None            # device word: != 0 while an update is pending
+        self.lr_dev = None            # device learning rates (one per non-empty param group) read by the kernel
+        self._flush_pending = None    # set by the engine: applies a pending update before anyone reads weights / state
 
     def zero_grad(self, set_to_none=False):
         """One memset of the flat gradient buffer (param.grad views are kept)."""
@@ -51,29 +55,87 @@ class FusedAdamW(torch.optim.Optimizer):
         self._max_norm, self._have_sq = float(max_norm), True
         return self.grad_norm
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def _ranges(self):
         st = self.model.store
-        self.step_count += 1
-        H.counter_add(self.step_dev, 1)
-        if not self._have_sq:
-            H.sqnorm(st.flat_g, self.sq)
         ranges = []
         for g in self.param_groups:
             b, e = st.group_range[g["group_id"]]
             if e > b:
                 ranges.append((b, e, g["lr"], g["weight_decay"]))
+        return ranges
+
+    def _launch(self, span=None):
+        st = self.model.store
         b1, b2 = self.defaults["betas"]
-        H.adamw_flat(st.flat_p, st.flat_g, self.m, self.v, step=self.step_count, ranges=ranges, gnorm_sq=self.sq,
+        H.adamw_flat(st.flat_p, st.flat_g, self.m, self.v, step=max(self.step_count, 1), ranges=self._ranges(), gnorm_sq=self.sq,
                      gnorm_out=self.grad_norm, grad_scale=getattr(self.model, "_grad_scale", 1.0),
-                     max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"], step_dev=self.step_dev)
+                     max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"], step_dev=self.step_dev,
+                     active=self.active, lr_dev=self.lr_dev, span=span)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self._flush_pending is not None:
+            self._flush_pending()
+        st = self.model.store
+        self.step_count += 1
+        H.counter_add(self.step_dev, 1)
+        if not self._have_sq:
+            H.sqnorm(st.flat_g, self.sq)
+        act, self.active = self.active, None          # an immediate step is never conditional
+        try:
+            self._launch()
+        finally:
+            self.active = act
         self._have_sq = False
         self.model.mark_dirty()
+
+    # ---- deferred mode: [finish_step at the end of iteration i] ... [apply_pending at the head of iteration i+1] ----
+    def enable_deferred(self):
+        dev = self.model.store.device
+        if self.active is None:
+            self.active = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.lr_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+            self.sync_lr()
+
+    def sync_lr(self):
+        """Copies the param groups' current learning rates to the device words the kernel reads (stream-ordered: a
+        replay enqueued before this call still sees the old values)."""
+        lrs = [r[2] for r in self._ranges()]
+        host = torch.tensor(lrs + [0.0] * (8 - len(lrs)), dtype=torch.float32).pin_memory()
+        self.lr_dev.copy_(host, non_blocking=True)
+        self._lr_host = host          # keep the staging buffer alive until the copy has run
+        return lrs
+
+    @torch.no_grad()
+    def finish_step(self, max_norm):
+        """End of an iteration in deferred mode: total gradient norm, step counter, 'update pending' flag.  The weights
+        are NOT touched; grad_norm holds this iteration's (pre-clip) norm like clip_grad_norm_'s return value."""
+        H.sqnorm(self.model.store.flat_g, self.sq)
+        self._max_norm = float(max_norm)
+        H.counter_add(self.step_dev, 1)
+        H.counter_add(self.active, 1)
+        torch.sqrt(self.sq, out=self.grad_norm)
+        gs = getattr(self.model, "_grad_scale", 1.0)
+        if gs != 1.0:
+            self.grad_norm.mul_(gs)
+        return self.grad_norm
+
+    @torch.no_grad()
+    def apply_pending(self, span=None):
+        """The AdamW pass over `span` (default: everything) for the pending update; a no-op kernel while nothing is
+        pending.  May be issued as several spans on different streams."""
+        self._launch(span)
+
+    def clear_pending(self):
+        if self.active is not None:
+            self.active.zero_()
 
     def state_dict(self):
         """torch.optim.AdamW's format (what the reference writes into checkpoint['optimizer'], main_vg.py:377-384):
         per-parameter `step`, `exp_avg`, `exp_avg_sq` keyed by the parameter's index in the reference's group order, so a
         checkpoint written here resumes under the reference and vice versa."""
+        if self._flush_pending is not None:
+            self._flush_pending()
         st = self.model.store
         state, groups, idx = {}, [], 0
         for g, ns in zip(self.param_groups, self._names):
@@ -92,6 +154,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         """Accepts a torch.optim.AdamW state_dict with the reference's grouping (as written by the reference or by
         state_dict() above); hyper-parameters of the groups are taken over like torch does."""
+        if self._flush_pending is not None:
+            self._flush_pending()
         st = self.model.store
         flat = [n for ns in self._names for n in ns]
         groups = sd["param_groups"]
