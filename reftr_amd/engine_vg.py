@@ -132,8 +132,8 @@ class CapturedTrainStep:
     that changes from step to step lives in device memory (dropout step-seed word, optimizer step counter, the
     input batch copied into static buffers), so replays are real training steps.  With world_size > 1 the body is
     three graphs (forward + backward phase 1 | ResNet backward | clip + AdamW) around the two eager, asynchronous
-    gradient exchanges of reftr_amd.parallel.DistributedDataParallel.  Learning-rate changes re-capture the optimizer
-    part (`refresh_lr()`), shapes other than the captured one must use `train_step`.
+    gradient exchanges of reftr_amd.parallel.DistributedDataParallel.  Shapes other than the captured one must use
+    `train_step`.
 
     Single-process runs use the DEFERRED optimizer schedule (one graph): iteration i ends with the gradient norm, its
     AdamW update is applied at the head of iteration i+1 -- the ResNet / transformer slice first on the main stream, the
@@ -173,6 +173,8 @@ class CapturedTrainStep:
         if self.deferred:
             self._init_deferred(warmup)
             return
+        if hasattr(optimizer, "enable_device_lr"):
+            optimizer.enable_device_lr()
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -310,8 +312,13 @@ class CapturedTrainStep:
             self._pending = True
             self._set_flush(True)
             return self.out[0], self.out[1], self.grad_norm
-        if [g["lr"] for g in self.optimizer.param_groups] != self._lrs:
-            self.refresh_lr()
+        lrs = [g["lr"] for g in self.optimizer.param_groups]
+        if lrs != self._lrs:
+            if getattr(self.optimizer, "lr_dev", None) is not None:
+                self._lrs = lrs
+                self.optimizer.sync_lr()          # stream-ordered, in front of this iteration's optimizer graph
+            else:
+                self.refresh_lr()
         _copy_batch(self.s, self.t, samples, targets)
         self._refresh_num_boxes(targets)
         self.g_fb.replay()

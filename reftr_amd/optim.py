@@ -90,12 +90,17 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model.mark_dirty()
 
     # ---- deferred mode: [finish_step at the end of iteration i] ... [apply_pending at the head of iteration i+1] ----
-    def enable_deferred(self):
-        dev = self.model.store.device
-        if self.active is None:
-            self.active = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.lr_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+    def enable_device_lr(self):
+        """The kernel reads the learning rates from device words (kept current with `sync_lr`): a captured optimizer
+        launch follows the schedule without re-capture."""
+        if self.lr_dev is None:
+            self.lr_dev = torch.zeros(8, dtype=torch.float32, device=self.model.store.device)
             self.sync_lr()
+
+    def enable_deferred(self):
+        self.enable_device_lr()
+        if self.active is None:
+            self.active = torch.zeros(1, dtype=torch.int32, device=self.model.store.device)
 
     def sync_lr(self):
         """Copies the param groups' current learning rates to the device words the kernel reads (stream-ordered: a

@@ -202,7 +202,8 @@ def test_captured_step_matches_eager(hip, two_phase):
     assert rel(p_g, p_e) < 2e-4             # after the trajectories may have separated (see above); step 1 is the tight check
 
 
-def test_captured_deferred_update_follows_the_lr_schedule(hip):
+@pytest.mark.parametrize("two_phase", [False, True])
+def test_captured_deferred_update_follows_the_lr_schedule(hip, two_phase):
     """Deferred schedule: the update of iteration i is applied at the head of replay i+1 but must use the learning rates
     of iteration i (device words synced after each replay), with no re-capture when the schedule moves."""
     from reftr_amd.engine_vg import CapturedTrainStep, train_step
@@ -218,8 +219,8 @@ def test_captured_deferred_update_follows_the_lr_schedule(hip):
         opt = FusedAdamW(model, lr=sched[0][0], lr_backbone=sched[0][1], weight_decay=1e-4)
         if mode == "graph":
             p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
-            cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg, warmup=1)
-            assert cap.deferred
+            cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg, warmup=1, force_two_phase=two_phase)
+            assert cap.deferred == (not two_phase)
             cap.reset_pending()
             model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
             graph_id = id(cap.g_fb)
@@ -231,7 +232,7 @@ def test_captured_deferred_update_follows_the_lr_schedule(hip):
             else:
                 cap(s, tg)
         if mode == "graph":
-            assert id(cap.g_fb) == graph_id and cap._pending
+            assert id(cap.g_fb) == graph_id and cap._pending == (not two_phase)
             sd = model.state_dict()                      # applies the pending (4th) update first
             assert not cap._pending
             w = sd[key].float().cpu()
