@@ -36,7 +36,7 @@ hip.set_launch_timer(None)
 agg = collections.OrderedDict()
 for r in recs:
     t = r["start"].elapsed_time(r["end"]) * 1e3
-    a = agg.setdefault(r["tag"], [0, 0.0, 0.0, 0.0])
+    a = agg.setdefault(r["tag"] or ("grp", r["kind"]), [0, 0.0, 0.0, 0.0])
     a[0] += 1; a[1] += t; a[2] += r["flops"]; a[3] += r["bytes"]
 def roof(f, b): return max(f / 2.5e15, b / 6.3e12) * 1e6
 rows = sorted(agg.items(), key=lambda kv: -(kv[1][1] - roof(kv[1][2], kv[1][3])))

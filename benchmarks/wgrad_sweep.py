@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reftr_amd import hip
 from tile_sweep import graph_time
-VARS = [9, 0, 1, 2, 3, 5]      # 9 = register-staged kernel, 0 = default LDS-DMA choice
+VARS = [int(v) for v in os.environ.get('VARS', '9,0,1,2,3,5').split(',')]      # 9 = register-staged kernel, 0 = default LDS-DMA choice
 WS = os.environ.get('WS', '1') == '1'
 # (name, B, H, Cin, Cout, k, stride)
 CONVS = [("l1 1x1 64->256 @160", 8, 160, 64, 256, 1, 1), ("l1 1x1 256->64 @160", 8, 160, 256, 64, 1, 1), ("l1 3x3 64 @160", 8, 160, 64, 64, 3, 1),
