@@ -429,7 +429,7 @@ class RefTR(nn.Module):
             dpool = net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False,
                                 dtanh=sv["pctx"]["pooled"])
 
-        net.flush_wgrads()               # decoder / query-encoder / map_phrase / head weight gradients: grouped launches
+        net.flush_wgrads_side(1)         # decoder / query-encoder / map_phrase / head weight gradients: grouped launches
 
         # ---- encoder
         H.rows_add(M, E, a_f32=dmemp, out_f32=dmem, accumulate=True)      # K-side input of every cross-attention = memory + pos
@@ -438,6 +438,8 @@ class RefTR(nn.Module):
         dxa, dxb = dmem, None
         for i in reversed(range(cfg.enc_layers)):
             dxa, dxb = net.enc_layer_bwd(f"{vt}encoder.layers.{i}.", sv["enc"][i], dxa, dxb, sv["kpm"], B, S, dpos)
+            if i == cfg.enc_layers // 2:
+                net.flush_wgrads_side(2) # first half of the encoder's weight gradients, beside the second half's chain
         H.pos_grad(dpos, st.G[vt + "lang_pos_embeddings.weight"], st.G[vt + "token_type_embeddings.weight"],
                    st.G[vt + "level_embed"], B, S, Lq)
 
@@ -459,7 +461,7 @@ class RefTR(nn.Module):
                 net.bert_bwd(sv["pctx"], None, dpool)
             net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
         net.wg.flush()               # transformer weight gradients queued so far -> their own stream, from here
-        net.flush_wgrads()           # encoder / map_sentence weight gradients, before the BERT branch forks off
+        net.flush_wgrads_side(4)     # encoder / map_sentence weight gradients: language stream, in front of the BERT branch
         two_phase = self._defer_phase2 or bool(self._mid_backward_hooks)
         if two_phase:
             _bert_bwd()
@@ -471,6 +473,7 @@ class RefTR(nn.Module):
         self._pending = (sv["bb_saved"], g_c5, seg_extra)
         if two_phase:
             net.flush_wgrads()       # input_proj's weight gradient belongs to the early (main-group) exchange
+            net.side.join()          # ... and so do the transformer weight gradients running on the language stream
             net.wg.join()
             for hook in self._mid_backward_hooks:
                 hook()
