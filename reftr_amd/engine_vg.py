@@ -360,6 +360,51 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
 
 
+class CapturedForward:
+    """Inference forward replayed from one hipGraph per input shape (RefCOCO-style evaluation pads every image to the same
+    square, datasets/transforms.py: NormalizeAndPad): ~600 launches become one replay.  The forward has no atomics, so the
+    replayed outputs are bit-identical to the eager ones (tests/test_model_gpu.py).  Outputs are static buffers that the
+    next replay overwrites."""
+
+    def __init__(self, model):
+        self.model, self.graphs = model, {}
+
+    @staticmethod
+    def shape_key(samples):
+        return tuple((n, tuple(v.tensors.shape) if isinstance(v, utils.NestedTensor) else tuple(v.shape))
+                     for n, v in sorted(samples.items()) if isinstance(v, utils.NestedTensor) or torch.is_tensor(v))
+
+    @torch.no_grad()
+    def __call__(self, samples):
+        if not isinstance(samples.get("img"), utils.NestedTensor):
+            return self.model(samples)
+        key = self.shape_key(samples)
+        ent = self.graphs.get(key)
+        if ent is None:
+            s, _ = _clone_batch(samples, [])
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.model(s)                        # warm-up: operand refresh, workspaces, descriptor tables
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+                out = self.model(s)
+            ent = self.graphs[key] = (g, s, out)
+        g, s, out = ent
+        inner = getattr(self.model, "module", self.model)
+        if inner._flush_pending is not None:
+            inner._flush_pending()
+        if inner._operands_dirty:                    # weights changed since the capture: rebuild the bf16 operands eagerly
+            inner.refresh_operands()
+            if inner._lin_refresh_pending:
+                inner.net.refresh(); inner._lin_refresh_pending = False
+        _copy_batch(s, [], samples, [])
+        g.replay()
+        return out
+
+
 @torch.no_grad()
 def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=None, visualize=False):
     """engine_vg.evaluate (engine_vg.py:82-225) without the image dumps of `visualize`: losses, Acc@0.5 / mean IoU of the
@@ -374,8 +419,10 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
     results_dict = {}
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
+    # REFTR_EVAL_GRAPH=1: replay the forward from a hipGraph per input shape (fixed-size evaluation sets)
+    fwd = CapturedForward(model) if (os.environ.get("REFTR_EVAL_GRAPH") == "1" and torch.device(device).type == "cuda") else model
     for _ in metric_logger.log_every(range(len(data_loader)), 50, "Test:"):
-        outputs = model(samples)
+        outputs = fwd(samples)
         loss_dict = criterion(outputs, targets)
         weight_dict = criterion.weight_dict
         red = utils.reduce_dict(loss_dict)

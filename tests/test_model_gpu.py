@@ -246,6 +246,28 @@ def test_captured_deferred_update_follows_the_lr_schedule(hip, two_phase):
     assert rel(d_g, d_e) < 0.1, rel(d_g, d_e)
 
 
+def test_captured_forward_is_bit_identical_to_eager(hip):
+    """engine_vg.CapturedForward: the eval forward replayed from a hipGraph returns exactly the eager forward's tensors
+    (no atomics in the forward), also after the weights changed and for a second batch of the same shape."""
+    from reftr_amd.engine_vg import CapturedForward
+    model, crit, P, ocfg = build(small=True)
+    model.eval()
+    s1, _ = to_cuda(*make_inputs("e2e_single", B=2, H=96, W=128, L=12))
+    s2, _ = to_cuda(*make_inputs("steps_single", B=2, H=96, W=128, L=12))
+    fwd = CapturedForward(model)
+    with torch.no_grad():
+        for s in (s1, s2, s1):
+            a = {k: v.clone() for k, v in model(s).items() if torch.is_tensor(v)}
+            b = fwd(s)
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        assert len(fwd.graphs) == 1
+        model.store.P["bbox_embed.layers.2.weight"].mul_(1.5); model.mark_dirty()
+        b = fwd(s2)["pred_boxes"].clone()            # rebuilds the bf16 operands the graph reads
+        model.mark_dirty()
+        assert torch.equal(model(s2)["pred_boxes"], b)
+
+
 def test_dropout_train_mode_runs_and_is_reproducible(hip):
     model, crit, P, ocfg = build(small=True)
     model.train()
