@@ -144,7 +144,7 @@ class CapturedTrainStep:
     were current when iteration i ran, and schedule changes need no re-capture.
     """
 
-    def __init__(self, model, criterion, optimizer, max_norm, samples, targets, warmup=2, force_two_phase=False):
+    def __init__(self, model, criterion, optimizer, max_norm, samples, targets, warmup=2, force_two_phase=False, force_phases=None):
         self.model, self.criterion, self.optimizer, self.max_norm = model, criterion, optimizer, max_norm
         self.inner = getattr(model, "module", model)
         self.ddp = model if model is not self.inner else None
@@ -161,12 +161,17 @@ class CapturedTrainStep:
             self._refresh_num_boxes(targets)
             criterion.num_boxes_static = self.nb
         # collectives stay outside the graphs: the engine calls the hooks between replays
-        self._mid, inner._mid_backward_hooks = inner._mid_backward_hooks, []
+        self._phase_hooks, inner._phase_hooks = inner._phase_hooks, {}
         self._post, inner._post_backward_hooks = inner._post_backward_hooks, []
-        # data parallel: backward is captured in two graphs (everything but the ResNet | the ResNet) so that the first
-        # gradient exchange runs under the second graph
-        self.two_phase = bool(self._mid) or force_two_phase
-        inner._defer_phase2 = self.two_phase
+        # data parallel: backward is captured as one graph per segment between the exchange points the wrapper registered
+        # (RefTR.BOUNDARIES), so that each slice's all-reduce is issued the moment it is final and runs under the next graphs
+        self.phases = [b for b in inner.active_boundaries() if self._phase_hooks.get(b)]
+        if force_phases is not None:
+            self.phases = [b for b in inner.active_boundaries() if b in force_phases]
+        elif force_two_phase and not self.phases:
+            self.phases = ["bert"]                   # [everything but the ResNet | the ResNet]
+        self.two_phase = bool(self.phases)
+        inner._stops = frozenset(self.phases)
         self.deferred = (not self.two_phase and not self._post and hasattr(optimizer, "enable_deferred")
                          and os.environ.get("REFTR_DEFER_OPT", "1") == "1")
         self._pending = False
@@ -180,26 +185,30 @@ class CapturedTrainStep:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    self._fwd_bwd(); self._run(self._mid)
-                    if self.two_phase:
-                        inner.finish_backward()
+                    self._fwd_bwd()
+                    for name in self.phases:
+                        self._run(self._phase_hooks.get(name, ()))
+                        inner.continue_backward()
                     self._run(self._post); self._opt()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()     # no collective in flight while capturing (see _CAPTURE_MODE)
             self.g_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=_CAPTURE_MODE):
                 self.out = self._fwd_bwd()
-            self.g_bb = None
-            if self.two_phase:
-                self.g_bb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_bb, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
-                    inner.finish_backward()
+            self.g_seg = []
+            for name in self.phases:                 # the segment that FOLLOWS boundary `name`
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
+                    stopped = inner.continue_backward()
+                self.g_seg.append(g)
+            assert inner._bwd_gen is None, "backward did not run to its end during capture"
+            self.g_bb = self.g_seg[-1] if self.g_seg else None
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._opt()
         finally:
-            inner._mid_backward_hooks, inner._post_backward_hooks = self._mid, self._post
-            inner._defer_phase2 = False
+            inner._phase_hooks, inner._post_backward_hooks = self._phase_hooks, self._post
+            inner._stops = frozenset()
             criterion.num_boxes_static = None
 
     # ------------------------------------------------------------------ deferred optimizer schedule
@@ -227,8 +236,8 @@ class CapturedTrainStep:
             self._pending = True                       # the last warm-up iteration's update
             self._set_flush(True)
         finally:
-            inner._mid_backward_hooks, inner._post_backward_hooks = self._mid, self._post
-            inner._defer_phase2 = False
+            inner._phase_hooks, inner._post_backward_hooks = self._phase_hooks, self._post
+            inner._stops = frozenset()
             self.criterion.num_boxes_static = None
 
     def _set_flush(self, on):
@@ -322,9 +331,9 @@ class CapturedTrainStep:
         _copy_batch(self.s, self.t, samples, targets)
         self._refresh_num_boxes(targets)
         self.g_fb.replay()
-        self._run(self._mid)
-        if self.g_bb is not None:
-            self.g_bb.replay()
+        for name, g in zip(self.phases, self.g_seg):
+            self._run(self._phase_hooks.get(name, ()))       # this slice is final: its all-reduce goes out now ...
+            g.replay()                                       # ... and runs under the next segment of backward
         self._run(self._post)
         self.g_opt.replay()
         self.optimizer.step_count += 1

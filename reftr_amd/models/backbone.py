@@ -150,9 +150,15 @@ class ResNetBody:
         """g_out: bf16 [M, 2048] = dL/d(pre-ReLU of the layer4 output) (already gated by the producer).
         extra: {stage index: fp32 [M, C]} additional UNGATED gradients w.r.t. intermediate stage outputs (the RES head's
         FPN adapters read layer2 / layer3 outputs); they join the residual sum before the ReLU gate."""
+        for _ in self.backward_stages(saved, g_out, extra):
+            pass
+
+    def backward_stages(self, saved, g_out, extra=None):
+        """backward() as a generator: yields the stage number (4, 3, 2) when that stage's data AND weight gradients have been
+        launched (its slice of the gradient buffer is final once the stream reaches this point)."""
         extra = extra or {}
         try:
-            return self._backward(saved, g_out, extra)
+            yield from self._backward(saved, g_out, extra)
         finally:
             self.wgs.join()
 
@@ -171,6 +177,8 @@ class ResNetBody:
                 # next stage's backward-data chain
                 alive = [t for k in self.batch.keep for t in k if t is not None]      # until the side stream is joined
                 self.wgs.run(self.batch.run, *alive)
+            if b.down is not None:
+                yield b.stage_in + 2                    # layer number (4, 3, 2) whose gradients are all launched now
             if b.first_trainable:
                 break                                   # layer1 is frozen: no gradient w.r.t. its output
             g_idt = self._dgrad(g_out, b.down, rec["gd"]) if b.down is not None else g_out

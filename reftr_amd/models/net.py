@@ -232,6 +232,12 @@ class Net:
     def bert_bwd(self, ctx, d_seq, d_pooled_bf16):
         """d_seq fp32 [B*L, Hd] = dL/d(sequence output) or None; d_pooled_bf16 [B, Hd] = dL/d(pooler PRE-tanh
         output) (callers fold tanh' with the GEMM's dtanh epilogue) or None."""
+        for _ in self.bert_bwd_layers(ctx, d_seq, d_pooled_bf16):
+            pass
+
+    def bert_bwd_layers(self, ctx, d_seq, d_pooled_bf16, stops=()):
+        """bert_bwd as a generator: yields i right after the backward of encoder layer i for every i in `stops`, with the
+        weight gradients queued so far launched (the gradients of layers >= i and of the pooler are final then)."""
         bc = self.cfg.bert
         B, L, Hd = ctx["B"], ctx["L"], bc.hidden
         pfx = "lang_backbone."
@@ -258,6 +264,9 @@ class Net:
                        Sq=L, Sk=L, dh=dh, scale=scale, drop_p=r["adrop"][0], drop_seed=r["adrop"][1],
                        dq=dqkv[:, :Hd], dk=dqkv[:, Hd:2 * Hd], dv=dqkv[:, 2 * Hd:])
             _, dh32 = self.lin_bwd(lp + "qkv", dqkv, r["h16"], res_f32=dt, out_bf16=False, out_f32=True)
+            if i in stops:
+                self.flush_wgrads()
+                yield i
         e = pfx + "embeddings."
         mean, rstd, dp, ds = ctx["emb_stats"]
         de, _ = self.ln_bwd(dh32, ctx["emb"], e + "LayerNorm.", mean, rstd, drop_p=dp, drop_seed=ds, want_bf16=False)

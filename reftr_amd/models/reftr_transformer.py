@@ -68,10 +68,15 @@ class RefTR(nn.Module):
         self._full_refresh = True
         self._step = 0
         self._saved = None
-        self._mid_backward_hooks = []     # after phase 1 of backward (everything but the ResNet): early DP exchange
+        # Data-parallel exchange points of backward, in the order they are reached (BOUNDARIES): at each one a slice of the
+        # flat gradient buffer is final.  `_phase_hooks[name]` run there (the eager loop's asynchronous all-reduces);
+        # `_stops` makes backward return there instead (CapturedTrainStep captures one graph per segment and issues the
+        # collectives between replays; `continue_backward()` resumes).
+        self._phase_hooks = {}
+        self._stops = frozenset()
+        self._bwd_gen = None
         self._post_backward_hooks = []
         self._lin_refresh_pending = False
-        self._defer_phase2 = False        # engine-driven: stop after phase 1, `finish_backward()` runs the ResNet part
         # deferred optimizer (engine_vg.CapturedTrainStep): (main-stream fn, language-stream fn) that apply the previous
         # iteration's AdamW update at the head of this forward -- the BERT slice on the language stream, concurrently with
         # the ResNet forward -- and the engine's callback that applies a still-pending update before anyone else reads
@@ -352,7 +357,43 @@ class RefTR(nn.Module):
         return logits.view(NL, B, Pn, cfg.n_q, 4)
 
     # ------------------------------------------------------------------ backward
+    BOUNDARIES = ("main", "bert_hi", "bert_mid", "bert", "layer4")
+
+    def active_boundaries(self):
+        """The boundaries this model's backward actually passes (BERT is cut in thirds only from 3 layers up)."""
+        return tuple(b for b in self.BOUNDARIES if self.cfg.bert.layers >= 3 or b not in ("bert_hi", "bert_mid"))
+
+    @property
+    def dp_mode(self):
+        return bool(self._stops) or any(self._phase_hooks.values())
+
     def _backward_impl(self, dlogits, dmasks=None):
+        self._bwd_gen = self._backward_phases(dlogits, dmasks)
+        self.continue_backward()
+
+    def continue_backward(self):
+        """Runs backward up to the next boundary listed in `_stops` (returns its name) or to the end (returns None);
+        the hooks of every boundary passed on the way are called."""
+        gen = self._bwd_gen
+        if gen is None:
+            return None
+        for name in gen:
+            for hook in self._phase_hooks.get(name, ()):
+                hook()
+            if name in self._stops:
+                return name
+        self._bwd_gen = None
+        H.set_seed_dev(None)
+        for hook in self._post_backward_hooks:
+            hook()
+        return None
+
+    def finish_backward(self):
+        """Runs whatever is left of a backward that stopped at a boundary."""
+        while self.continue_backward() is not None:
+            pass
+
+    def _backward_phases(self, dlogits, dmasks=None):
         cfg, net, st, sv = self.cfg, self.net, self.store, self._saved
         E = cfg.hidden
         dev = st.device
@@ -450,48 +491,52 @@ class RefTR(nn.Module):
         _, dip16 = H.groupnorm_bwd(dxa, sv["ip"].view(B, HW, E), st.P["input_proj.0.1.weight"], sv["gn_stats"],
                                    st.G["input_proj.0.1.weight"], st.G["input_proj.0.1.bias"], 32, 1e-5, dy2=dxb,
                                    rows_per_img=S, row_off=Lq)
-        # ---- BERT backward (sentence pass; phrase pass for multi-phrase inputs).  Single GPU: on the side stream,
-        # concurrently with the ResNet backward.  Data parallel: on the main stream BEFORE the ResNet backward, so that
-        # phase 1 ends with every non-ResNet gradient final and their all-reduce (>80 % of the bytes) runs under phase 2.
-        def _bert_bwd():
-            if sv["pctx"] is None:
-                net.bert_bwd(sv["bctx"], d_seq, dpool)
-            else:
-                net.bert_bwd(sv["bctx"], d_seq, None)
-                net.bert_bwd(sv["pctx"], None, dpool)
-            net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
-        net.wg.flush()               # transformer weight gradients queued so far -> their own stream, from here
-        net.flush_wgrads_side(4)     # encoder / map_sentence weight gradients: language stream, in front of the BERT branch
-        two_phase = self._defer_phase2 or bool(self._mid_backward_hooks)
-        if two_phase:
-            _bert_bwd()
-        else:
-            net.side.run(_bert_bwd, d_seq, dpool)
+        # input_proj's data / weight gradient (main group) -- in front of the BERT branch so that the main group is final first
         g_c5, _ = net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], gate=sv["c5"])
         if getattr(self, "_debug", False):
             self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=g_c5.clone())
-        self._pending = (sv["bb_saved"], g_c5, seg_extra)
-        if two_phase:
-            net.flush_wgrads()       # input_proj's weight gradient belongs to the early (main-group) exchange
-            net.side.join()          # ... and so do the transformer weight gradients running on the language stream
-            net.wg.join()
-            for hook in self._mid_backward_hooks:
-                hook()
-            if self._defer_phase2:
-                return
-        self.finish_backward()
-
-    def finish_backward(self):
-        """Phase 2 of backward: the ResNet body (its gradients are the last to become final)."""
-        bb_saved, g_c5, extra = self._pending
-        self._pending = None
-        self.body.backward(bb_saved, g_c5, extra)
-        self.net.flush_wgrads()
-        self.net.side.join()
-        self.net.wg.join()
-        H.set_seed_dev(None)
-        for hook in self._post_backward_hooks:
-            hook()
+        net.wg.flush()               # transformer weight gradients queued so far -> their own stream, from here
+        dp = self.dp_mode
+        # ---- BERT backward (sentence pass; phrase pass for multi-phrase inputs).  Single GPU: on the side stream,
+        # concurrently with the ResNet backward.  Data parallel: on the main stream BEFORE the ResNet backward, so that every
+        # non-ResNet gradient (> 80 % of the bytes) is exchanged under the ResNet backward; the exchange of a slice starts as
+        # soon as it is final: the main group before BERT, BERT in thirds (layers 11-8 + pooler | 7-4 | 3-0 + embeddings).
+        if dp:
+            net.flush_wgrads()       # encoder / map_sentence / input_proj weight gradients
+            net.side.join(); net.wg.join()
+            yield "main"
+            nl = cfg.bert.layers
+            cuts = {(2 * nl) // 3: "bert_hi", nl // 3: "bert_mid"} if nl >= 3 else {}
+            if sv["pctx"] is None:
+                passes = [(sv["bctx"], d_seq, dpool)]
+            else:
+                passes = [(sv["bctx"], d_seq, None), (sv["pctx"], None, dpool)]
+            for n, (ctx, a, b_) in enumerate(passes):
+                last = n == len(passes) - 1          # a layer's gradient is final after the LAST pass through it
+                for layer in net.bert_bwd_layers(ctx, a, b_, stops=tuple(cuts) if last else ()):
+                    net.wg.flush(); net.wg.join()
+                    yield cuts[layer]
+            net.wg.flush(); net.wg.join()
+            yield "bert"
+        else:
+            def _bert_bwd():
+                if sv["pctx"] is None:
+                    net.bert_bwd(sv["bctx"], d_seq, dpool)
+                else:
+                    net.bert_bwd(sv["bctx"], d_seq, None)
+                    net.bert_bwd(sv["pctx"], None, dpool)
+                net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
+            net.flush_wgrads_side(4)     # encoder / map_sentence weight gradients: language stream, in front of the BERT branch
+            net.side.run(_bert_bwd, d_seq, dpool)
+        # ---- ResNet body (its gradients are the last to become final); data parallel: layer4's slice (64 % of the ResNet
+        # bytes) is final -- and exchanged -- before layer3 / layer2 run
+        for stage in self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra):
+            if dp and stage == 4:
+                net.flush_wgrads(); self.body.wgs.join()
+                yield "layer4"
+        net.flush_wgrads()
+        net.side.join()
+        net.wg.join()
 
 
 def build_config(args):

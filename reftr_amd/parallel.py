@@ -15,11 +15,18 @@ from torch import nn
 
 
 class DistributedDataParallel(nn.Module):
-    """Exchange schedule: the flat gradient buffer is laid out [main | mask head | ResNet | BERT] (models/store.py).  Backward
-    finishes the main and BERT ranges first (phase 1); their all-reduces are launched asynchronously at that point and
-    run on RCCL's stream while the ResNet backward (phase 2) computes; the ResNet range follows, then everything is
-    waited for.  `reduce_early` / `reduce_late` are the two hook points; CapturedTrainStep calls them between its
-    graphs, the eager loop gets them from the model's backward."""
+    """Exchange schedule: the flat gradient buffer is laid out [main | mask head | ResNet | BERT] (models/store.py).  In data-
+    parallel mode backward finishes the slices in this order (RefTR.BOUNDARIES) and the asynchronous all-reduce of a slice is
+    launched the moment it is final, on RCCL's stream, under the backward that is still running:
+
+        main   decoder / encoder / heads / input_proj (+ mask head)        under the BERT backward
+        bert_hi, bert_mid, bert   BERT layers 11-8 + pooler | 7-4 | 3-0 + embeddings (the layers' flat order is 0..11,
+                                  backward walks 11..0)                    under the rest of BERT and the ResNet backward
+        layer4 ResNet layer4 (64 % of the ResNet bytes)                    under layer3 / layer2
+        (end)  ResNet layer2-3, then everything is waited for.
+
+    `reduce_phase(name)` / `reduce_late` are the hook points; CapturedTrainStep calls them between its graphs, the eager loop
+    gets them from the model's backward."""
 
     def __init__(self, module, n_chunks=8, broadcast=True, overlap=True):
         super().__init__()
@@ -36,12 +43,19 @@ class DistributedDataParallel(nn.Module):
             for buf in module.store.flat.values():
                 dist.broadcast(buf, src=0)
             module.mark_dirty(full=True)
+        self.phases = list(module.active_boundaries()) if overlap else []
         if not self.active:
             return
         if overlap:
-            module._mid_backward_hooks.append(self.reduce_early)
+            # REFTR_DDP_PHASES: comma list of the boundaries to exchange at (default: all); a boundary that is left out hands
+            # its slice to the next one that is kept (the end if none)
+            want = os.environ.get("REFTR_DDP_PHASES")
+            self.phases = [b for b in module.active_boundaries() if want is None or b in want.split(",")]
+            for name in self.phases:
+                module._phase_hooks.setdefault(name, []).append(lambda name=name: self.reduce_phase(name))
             module._post_backward_hooks.append(self.reduce_late)
         else:
+            self.phases = []
             module._post_backward_hooks.append(self.allreduce_gradients)
 
     def forward(self, samples):
@@ -61,28 +75,48 @@ class DistributedDataParallel(nn.Module):
         step = (step + 1023) // 1024 * 1024
         return [(a, min(a + step, n)) for a in range(0, n, step)]
 
-    def phase_bounds(self):
-        """(early, late) lists of [a, b) slices of flat_g: early = main + BERT groups, late = ResNet group."""
+    def slice_bounds(self):
+        """{boundary or 'end': (a, b)} -- the contiguous piece of flat_g that becomes final at each boundary."""
         from .models import layout as L
         st = self.module.store
-        total = st.flat_g.numel()
+        cfg = self.module.cfg
+        off = lambda n: st.offset[n][1]                                   # noqa: E731
+        ma, mb = st.group_range[L.GROUP_MAIN]
+        ka, kb = st.group_range[L.GROUP_MASK]
+        ra, rb = st.group_range[L.GROUP_BACKBONE]
+        ba, bb = st.group_range[L.GROUP_BERT]
+        assert ma == 0 and ka == mb and ra == kb and ba == rb, "flat layout [main | mask | ResNet | BERT]"
+        nl = cfg.bert.layers
+        lay = lambda i: off(f"lang_backbone.encoder.layer.{i}.attention.self.query.weight")   # noqa: E731
+        hi, mid = (lay((2 * nl) // 3), lay(nl // 3)) if nl >= 3 else (ba, ba)
+        l4 = off("img_backbone.0.body.layer4.0.conv1.weight")
+        assert ba <= mid <= hi <= bb and ra <= l4 <= rb
+        return {"main": (ma, kb), "bert_hi": (hi, bb), "bert_mid": (mid, hi), "bert": (ba, mid),
+                "layer4": (l4, rb), "end": (ra, l4)}
+
+    def phase_bounds(self):
+        """{boundary or 'end': [chunk, ...]} with the slices of the boundaries that are not exchanged at (REFTR_DDP_PHASES)
+        merged into the next kept one; chunks are at most 1/n_chunks of the buffer."""
+        sl = self.slice_bounds()
+        total = self.module.store.flat_g.numel()
         per = max(1, -(-total // self.n_chunks))
-        early = []
-        for grp in (L.GROUP_MAIN, L.GROUP_MASK, L.GROUP_BERT):
-            a, b = st.group_range[grp]
-            early += self._split(a, b, per)
-        a, b = st.group_range[L.GROUP_BACKBONE]
-        return early, self._split(a, b, per)
+        out, carry = {}, []
+        for name in list(self.module.BOUNDARIES) + ["end"]:
+            carry.append(sl[name])
+            if name in self.phases or name == "end":
+                out[name] = [c for a, b in carry for c in self._split(a, b, per)]
+                carry = []
+        return out
 
     def _launch(self, bounds):
         g = self.module.store.flat_g
         self._works += [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in bounds if b > a]
 
-    def reduce_early(self):
-        self._launch(self.phase_bounds()[0])
+    def reduce_phase(self, name):
+        self._launch(self.phase_bounds()[name])
 
     def reduce_late(self):
-        self._launch(self.phase_bounds()[1])
+        self._launch(self.phase_bounds()["end"])
         for w in self._works:
             w.wait()
         self._works = []

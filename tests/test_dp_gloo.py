@@ -34,15 +34,20 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(7 + rank)
         local = torch.randn(m.store.flat_g.numel(), generator=g)
         m.store.flat_g.copy_(local)
-        early, late = ddp.phase_bounds()                         # early = main + BERT groups, late = ResNet group
-        spans = sorted(early + late)
+        pb = ddp.phase_bounds()                                  # boundary -> chunks of the slice that is final there
+        assert list(pb) == list(m.active_boundaries()) + ["end"] == ["main", "bert", "layer4", "end"]   # 1 BERT layer: no thirds
+        spans = sorted(c for v in pb.values() for c in v)
         covered = covered and spans[0][0] == 0 and spans[-1][1] == m.store.flat_g.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         from reftr_amd.models import layout as Lm
         bb = m.store.group_range[Lm.GROUP_BACKBONE]
-        covered = covered and late[0][0] == bb[0] and late[-1][1] == bb[1]
-        for hook in m._mid_backward_hooks:                       # phase 1 done -> early exchange in flight
-            hook()
-        for hook in m._post_backward_hooks:                      # phase 2 done -> late exchange + wait for everything
+        be = m.store.group_range[Lm.GROUP_BERT]
+        l4 = m.store.offset["img_backbone.0.body.layer4.0.conv1.weight"][1]
+        covered = covered and pb["end"][0][0] == bb[0] and pb["end"][-1][1] == l4 and pb["layer4"][0][0] == l4 and pb["layer4"][-1][1] == bb[1]
+        covered = covered and pb["bert"][0][0] == be[0] and pb["bert"][-1][1] == be[1] and pb["main"][0][0] == 0
+        for name in m.active_boundaries():                       # backward passes the boundaries in this order
+            for hook in m._phase_hooks[name]:
+                hook()
+        for hook in m._post_backward_hooks:                      # end of backward: last slice + wait for everything
             hook()
         both = [torch.randn(m.store.flat_g.numel(), generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
         ok_sum = torch.allclose(m.store.flat_g, both[0] + both[1], atol=1e-6)

@@ -213,3 +213,36 @@ def test_optimizer_state_roundtrip_with_torch_adamw(masks):
         model.store.view_of(pad, n).fill_(False)
     assert torch.equal(back.m[~pad], opt.m[~pad]) and torch.equal(back.v[~pad], opt.v[~pad]) and back.step_count == 7
     assert [g_["lr"] for g_ in back.param_groups] == [1e-4, 1e-5, 1e-5, 1e-4] and back.param_groups[0]["weight_decay"] == 1e-4
+
+
+def test_dp_exchange_slices_follow_the_backward_order():
+    """reftr_amd.parallel: the slice that is final at each backward boundary (main | BERT thirds, walked 11..0 | layer4 |
+    rest of the ResNet) -- contiguous, disjoint, covering the flat gradient buffer, cut at parameter boundaries."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.parallel import DistributedDataParallel
+    cfg = L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=6))
+    m = RefTR(cfg, device="cpu")
+    ddp = DistributedDataParallel(m, n_chunks=7)
+    assert m.active_boundaries() == ("main", "bert_hi", "bert_mid", "bert", "layer4") and not m.dp_mode
+    sl = ddp.slice_bounds()
+    st = m.store
+    spans = sorted(sl.values())
+    assert spans[0][0] == 0 and spans[-1][1] == st.flat_g.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    off = lambda n: st.offset[n][1]                                       # noqa: E731
+    q = "lang_backbone.encoder.layer.%d.attention.self.query.weight"
+    assert sl["bert_hi"] == (off(q % 4), st.group_range[L.GROUP_BERT][1])                 # layers 4, 5 + pooler
+    assert sl["bert_mid"] == (off(q % 2), off(q % 4)) and sl["bert"] == (st.group_range[L.GROUP_BERT][0], off(q % 2))
+    assert sl["bert"][0] <= off("lang_backbone.embeddings.word_embeddings.weight") < sl["bert"][1]
+    assert sl["bert_hi"][0] <= off("lang_backbone.pooler.dense.weight") < sl["bert_hi"][1]
+    assert sl["layer4"][0] == off("img_backbone.0.body.layer4.0.conv1.weight") and sl["end"][0] == st.group_range[L.GROUP_BACKBONE][0]
+    for k in ("decoder.layers.0.linear1.weight", "encoder.layers.0.linear2.bias"):
+        assert sl["main"][0] <= off("vl_transformer." + k) < sl["main"][1]
+    pb = ddp.phase_bounds()
+    chunks = sorted(c for v in pb.values() for c in v)
+    assert chunks[0][0] == 0 and chunks[-1][1] == st.flat_g.numel() and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+    ddp.phases = ["main", "bert"]                                         # REFTR_DDP_PHASES: skipped boundaries merge forward
+    pb = ddp.phase_bounds()
+    assert set(pb) == {"main", "bert", "end"}
+    assert sorted(pb["bert"])[0][0] == sl["bert"][0] and sorted(pb["bert"])[-1][1] == sl["bert_hi"][1]
+    assert sorted(pb["end"])[0][0] == sl["end"][0] and sorted(pb["end"])[-1][1] == sl["layer4"][1]

@@ -147,7 +147,7 @@ def test_three_training_steps(hip):
     assert 1e-6 < float(d.mean()) < 5e-5
 
 
-@pytest.mark.parametrize("two_phase", [False, True])
+@pytest.mark.parametrize("two_phase", [False, True, "all"])
 def test_captured_step_matches_eager(hip, two_phase):
     """CapturedTrainStep (hipGraph replay; two_phase = the data-parallel schedule with backward split in
     [everything but the ResNet | the ResNet]) must walk the same trajectory as the eager loop body: same kernels, so
@@ -168,8 +168,11 @@ def test_captured_step_matches_eager(hip, two_phase):
         opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
         if mode == "graph":
             p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
-            cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg, warmup=1, force_two_phase=two_phase)
-            assert (cap.g_bb is not None) == two_phase
+            # "all": one graph per exchange boundary of the data-parallel schedule (main | BERT | layer4 | rest of the ResNet)
+            cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg, warmup=1, force_two_phase=two_phase is True,
+                                    force_phases=model.BOUNDARIES if two_phase == "all" else None)
+            assert (cap.g_bb is not None) == bool(two_phase)
+            assert len(cap.g_seg if two_phase else []) == {False: 0, True: 1, "all": 3}[two_phase]
             # capture warm-up steps moved the weights: restore the initial state before comparing trajectories
             cap.reset_pending()
             model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
