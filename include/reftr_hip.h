@@ -470,6 +470,8 @@ int rt_pos_grad(const float* dpos, float* d_lang_pos, float* d_type, float* d_le
  *                the learning-rate schedule without re-capture.
  * ------------------------------------------------------------------------------------------ */
 int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stream);
+/* the same over a bf16 gradient buffer (data-parallel runs exchange the gradients in bf16, reftr_amd/parallel.py) */
+int rt_sqnorm_bf16(const void* g16, int64_t n, float* out, rt_stream_t stream);
 
 typedef struct rt_adamw_desc {
     float* p; const float* g; float* m; float* v;
@@ -484,6 +486,7 @@ typedef struct rt_adamw_desc {
     const int32_t* active;    /* optional DEVICE word: 0 = skip this launch */
     const float*   lr_dev;    /* optional DEVICE [n_ranges] learning rates overriding range_lr */
     int64_t span_begin, span_end;   /* element span to update (multiples of 4); 0, 0 = the whole buffer */
+    const void* g16;          /* optional bf16 gradient buffer read INSTEAD of g (the exchanged gradients of a data-parallel run) */
 } rt_adamw_desc;
 int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream);
 /* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */

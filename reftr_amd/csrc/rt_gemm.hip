@@ -756,7 +756,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     }
 }
 
-extern "C" int rt_abi_version(void) { return 17; }
+extern "C" int rt_abi_version(void) { return 18; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

@@ -21,6 +21,21 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+__global__ __launch_bounds__(256) void sqnorm_bf16_kernel(const bf16_t* __restrict__ g, size_t n, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float s = 0.f;
+    const size_t n8 = n >> 3;
+    const bf16x8* g8 = reinterpret_cast<const bf16x8*>(g);
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const bf16x8 v = g8[i];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float f = (float)v[c]; s += f * f; }
+    }
+    for (size_t i = (n8 << 3) + blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float f = (float)g[i]; s += f * f; }
+    s = rt_block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p, const int nontemporal) {
     if (p.active && p.active[0] == 0) return;
     const float total = sqrtf(p.gnorm_sq ? p.gnorm_sq[0] : 0.f) * p.grad_scale;
@@ -35,6 +50,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p, const
     const size_t i0 = (size_t)p.span_begin >> 2, n4 = (size_t)p.span_end >> 2;
     float4* P4 = reinterpret_cast<float4*>(p.p);
     const float4* G4 = reinterpret_cast<const float4*>(p.g);
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x4_t* G16 = reinterpret_cast<const bf16x4_t*>(p.g16);
     float4* M4 = reinterpret_cast<float4*>(p.m);
     float4* V4 = reinterpret_cast<float4*>(p.v);
     for (size_t i = i0 + blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -51,8 +68,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p, const
                 const f32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
                 return make_float4(t4[0], t4[1], t4[2], t4[3]);
             };
-            pv = ntl(P4 + i); gv = ntl(G4 + i); mv = ntl(M4 + i); vv = ntl(V4 + i);
-        } else { pv = P4[i]; gv = G4[i]; mv = M4[i]; vv = V4[i]; }
+            pv = ntl(P4 + i); mv = ntl(M4 + i); vv = ntl(V4 + i);
+            if (!G16) gv = ntl(G4 + i);
+        } else { pv = P4[i]; mv = M4[i]; vv = V4[i]; if (!G16) gv = G4[i]; }
+        if (G16) { const bf16x4_t h = __builtin_nontemporal_load(G16 + i); gv = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
         float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -90,8 +109,19 @@ extern "C" int rt_sqnorm(const float* g, int64_t n, float* out, rt_stream_t stre
     return RT_OK;
 }
 
+extern "C" int rt_sqnorm_bf16(const void* g16, int64_t n, float* out, rt_stream_t stream) {
+    if (!g16 || !out || n <= 0) return RT_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = rt_zero_f32(out, 1, s);
+    if (e != hipSuccess) return (int)e;
+    int blocks = (int)(((size_t)n / 8 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sqnorm_bf16_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)g16, (size_t)n, out);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
 extern "C" int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream) {
-    if (!d || !d->p || !d->g || !d->m || !d->v || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8 || (d->step < 1 && !d->step_dev))
+    if (!d || !d->p || (!d->g && !d->g16) || !d->m || !d->v || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8 || (d->step < 1 && !d->step_dev))
         return RT_ERR_BADARG;
     for (int r = 0; r < d->n_ranges; ++r) if ((d->range_begin[r] & 3) || (d->range_end[r] & 3)) return RT_ERR_BADARG;
     rt_adamw_desc a = *d;

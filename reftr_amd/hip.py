@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -142,6 +142,7 @@ class AdamWDesc(Structure):
         ("step", c_int32), ("n_ranges", c_int32),
         ("range_begin", c_int64 * 8), ("range_end", c_int64 * 8), ("range_lr", c_float * 8), ("range_wd", c_float * 8),
         ("step_dev", c_void_p), ("active", c_void_p), ("lr_dev", c_void_p), ("span_begin", c_int64), ("span_end", c_int64),
+        ("g16", c_void_p),
     ]
 
 
@@ -235,6 +236,7 @@ _SIGNATURES = {
     "rt_small_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rt_pos_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "rt_sqnorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
     "rt_ln_param_grad_grouped": (c_int, [POINTER(LnPgJob), c_int, c_void_p]),
@@ -708,11 +710,14 @@ def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox=1.0, w_giou=1
 
 
 def sqnorm(g, out):
-    _check(lib().rt_sqnorm(_p(g), g.numel(), _p(out), _stream()), "rt_sqnorm")
+    if g.dtype == torch.bfloat16:
+        _check(lib().rt_sqnorm_bf16(_p(g), g.numel(), _p(out), _stream()), "rt_sqnorm_bf16")
+    else:
+        _check(lib().rt_sqnorm(_p(g), g.numel(), _p(out), _stream()), "rt_sqnorm")
 
 
 def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_scale=1.0, max_norm=0.0,
-               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None, active=None, lr_dev=None, span=None):
+               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None, active=None, lr_dev=None, span=None, g16=None):
     """ranges = [(begin, end, lr, wd), ...] element ranges of the flat buffers (multiples of 4); span = (begin, end)
     restricts the launch to that element span; active / lr_dev: device words (see rt_adamw_desc)."""
     d = AdamWDesc()
@@ -722,6 +727,7 @@ def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_
     d.step, d.n_ranges = step, len(ranges)
     d.step_dev, d.active, d.lr_dev = _p(step_dev), _p(active), _p(lr_dev)
     d.span_begin, d.span_end = (0, 0) if span is None else span
+    d.g16 = _p(g16)
     for i, (b, e, lr, wd) in enumerate(ranges):
         d.range_begin[i], d.range_end[i], d.range_lr[i], d.range_wd[i] = b, e, lr, wd
     _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")

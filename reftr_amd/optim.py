@@ -48,10 +48,16 @@ class FusedAdamW(torch.optim.Optimizer):
         """One memset of the flat gradient buffer (param.grad views are kept)."""
         self.model.store.flat_g.zero_()
 
+    def _grad_buffer(self):
+        """The buffer the update reads: the fp32 gradients, or -- in a data-parallel run that exchanges bf16 -- the bf16 copy
+        the all-reduce produced (reftr_amd.parallel.DistributedDataParallel sets store.flat_g16)."""
+        g16 = getattr(self.model.store, "flat_g16", None)
+        return g16 if g16 is not None else self.model.store.flat_g
+
     def clip_grad_norm_(self, max_norm):
         """Launches the global-norm reduction; the clip coefficient itself is applied inside the AdamW kernel.
         Returns the device scalar that holds the total norm after step()."""
-        H.sqnorm(self.model.store.flat_g, self.sq)
+        H.sqnorm(self._grad_buffer(), self.sq)
         self._max_norm, self._have_sq = float(max_norm), True
         return self.grad_norm
 
@@ -68,6 +74,7 @@ class FusedAdamW(torch.optim.Optimizer):
         st = self.model.store
         b1, b2 = self.defaults["betas"]
         H.adamw_flat(st.flat_p, st.flat_g, self.m, self.v, step=max(self.step_count, 1), ranges=self._ranges(), gnorm_sq=self.sq,
+                     g16=getattr(st, "flat_g16", None),
                      gnorm_out=self.grad_norm, grad_scale=getattr(self.model, "_grad_scale", 1.0),
                      max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"], step_dev=self.step_dev,
                      active=self.active, lr_dev=self.lr_dev, span=span)
@@ -80,7 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.step_count += 1
         H.counter_add(self.step_dev, 1)
         if not self._have_sq:
-            H.sqnorm(st.flat_g, self.sq)
+            H.sqnorm(self._grad_buffer(), self.sq)
         act, self.active = self.active, None          # an immediate step is never conditional
         try:
             self._launch()
@@ -115,7 +122,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def finish_step(self, max_norm):
         """End of an iteration in deferred mode: total gradient norm, step counter, 'update pending' flag.  The weights
         are NOT touched; grad_norm holds this iteration's (pre-clip) norm like clip_grad_norm_'s return value."""
-        H.sqnorm(self.model.store.flat_g, self.sq)
+        H.sqnorm(self._grad_buffer(), self.sq)
         self._max_norm = float(max_norm)
         H.counter_add(self.step_dev, 1)
         H.counter_add(self.active, 1)

@@ -38,6 +38,14 @@ class DistributedDataParallel(nn.Module):
         self.n_chunks = n_chunks
         self.overlap = overlap
         self._works = []
+        # Exchange dtype.  bf16 (default) halves the bytes on the xGMI links -- the exchange is link-bound at 2 and 4 GPUs
+        # and a third of the step at 8: every slice is rounded to bf16 once it is final, summed by RCCL in
+        # bf16, and clip + AdamW read the bf16 sums directly (no unpack pass).  The rounding (2^-9 relative per element) is
+        # below the noise the bf16 GEMM operands already put on every gradient.  REFTR_DDP_DTYPE=fp32: the reference's
+        # fp32 exchange.
+        self.bf16 = self.active and os.environ.get("REFTR_DDP_DTYPE", "bf16") == "bf16"
+        if self.bf16:
+            module.store.flat_g16 = torch.zeros_like(module.store.flat_g, dtype=torch.bfloat16)
         module._grad_scale = 1.0 / self.world
         if self.world > 1 and broadcast:      # DDP constructor: parameters + buffers from rank 0 (C2)
             for buf in module.store.flat.values():
@@ -109,7 +117,14 @@ class DistributedDataParallel(nn.Module):
         return out
 
     def _launch(self, bounds):
-        g = self.module.store.flat_g
+        st = self.module.store
+        g = st.flat_g
+        if self.bf16:
+            g16 = st.flat_g16
+            for a, b in bounds:
+                if b > a:
+                    g16[a:b].copy_(g[a:b])            # round the final slice; the all-reduce is ordered behind it
+            g = g16
         self._works += [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in bounds if b > a]
 
     def reduce_phase(self, name):

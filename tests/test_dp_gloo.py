@@ -15,7 +15,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, dtype):
+    os.environ["REFTR_DDP_DTYPE"] = dtype
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -50,7 +51,13 @@ def _worker(rank, world, port, q):
         for hook in m._post_backward_hooks:                      # end of backward: last slice + wait for everything
             hook()
         both = [torch.randn(m.store.flat_g.numel(), generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
-        ok_sum = torch.allclose(m.store.flat_g, both[0] + both[1], atol=1e-6)
+        if dtype == "fp32":
+            ok_sum = torch.allclose(m.store.flat_g, both[0] + both[1], atol=1e-6) and getattr(m.store, "flat_g16", None) is None
+        else:       # bf16 exchange: every element rounded once per rank, summed in bf16; the fp32 buffer keeps the local gradients
+            want = both[0].bfloat16().float() + both[1].bfloat16().float()
+            got = m.store.flat_g16.float()
+            ok_sum = (m.store.flat_g16.dtype == torch.bfloat16 and torch.allclose(got, want, rtol=2 ** -7, atol=1e-30)
+                      and torch.equal(m.store.flat_g, local))
         nb = torch.tensor([3.0 + rank])
         dist.all_reduce(nb)
         q.put((rank, same, covered, ok_sum, m._grad_scale, float(nb / world)))
@@ -58,11 +65,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gradient_allreduce_world2_gloo():
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_gradient_allreduce_world2_gloo(dtype):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(2)]

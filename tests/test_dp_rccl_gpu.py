@@ -1,0 +1,78 @@
+"""GPU: the data-parallel wrapper + CapturedTrainStep + RCCL on the one-GPU box -- a single-rank `nccl` process group
+(REFTR_DDP_FORCE=1) drives the complete schedule: one hipGraph per backward segment, the slice all-reduces issued eagerly
+between replays (bf16 and fp32 exchange), clip + AdamW on the exchanged buffer.  With one rank the sums are the local
+gradients, so the trajectory must follow the plain eager loop (to bf16 rounding of the gradients in the bf16 mode)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from test_model_gpu import build, make_inputs, rel, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.fixture()
+def single_rank_group(monkeypatch):
+    monkeypatch.setenv("REFTR_DDP_FORCE", "1")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0)
+    try:
+        yield
+    finally:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_dp_schedule_single_rank_rccl_follows_the_eager_loop(hip, single_rank_group, monkeypatch, dtype):
+    from reftr_amd.engine_vg import CapturedTrainStep, train_step
+    from reftr_amd.optim import FusedAdamW
+    from reftr_amd.parallel import DistributedDataParallel
+    monkeypatch.setenv("REFTR_DDP_DTYPE", dtype)
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    out = {}
+    for mode in ("eager", "dp-eager", "dp-graph"):
+        model, crit, P, ocfg = build(small=True)
+        model.eval()
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        runner = model
+        if mode != "eager":
+            runner = DistributedDataParallel(model)
+            assert runner.active and runner.bf16 == (dtype == "bf16") and model.dp_mode
+            assert list(runner.phase_bounds()) == ["main", "bert", "layer4", "end"]
+        if mode == "dp-graph":
+            p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
+            cap = CapturedTrainStep(runner, crit, opt, 0.1, s, tg, warmup=1)
+            assert not cap.deferred and cap.phases == ["main", "bert", "layer4"] and len(cap.g_seg) == 3
+            model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
+            model.mark_dirty(full=True)
+        losses, first = [], None
+        for it in range(3):
+            if mode == "dp-graph":
+                l, _, gn = cap(s, tg); lv = float(l)
+            else:
+                lv, _, _, gn = train_step(runner, crit, s, tg, opt, None, max_norm=0.1)
+            losses.append(lv)
+            if it == 0:
+                torch.cuda.synchronize()
+                g = model.store.flat_g16.float() if getattr(model.store, "flat_g16", None) is not None else model.store.flat_g.clone()
+                first = (g, model.store.flat_p.clone(), float(gn))
+        out[mode] = (losses, first)
+    (le, fe), (l1, f1), (l2, f2) = out["eager"], out["dp-eager"], out["dp-graph"]
+    tol_g = 2 ** -8 if dtype == "bf16" else 1e-6                        # the exchanged gradients: rounded once to bf16, or exact
+    for l, f in ((l1, f1), (l2, f2)):
+        assert abs(l[0] - le[0]) < 1e-6 * abs(le[0])
+        assert rel(f[0], fe[0]) < tol_g and abs(f[2] - fe[2]) < max(tol_g, 1e-5) * fe[2]
+        assert rel(f[1], fe[1]) < (2e-6 if dtype == "bf16" else 1e-7)   # weights after the first update
+        # later steps: the fixture amplifies 1-ulp weight differences (tests/test_model_gpu.py::test_captured_step_matches_eager);
+        # rounding the gradients to bf16 is a larger perturbation of the same kind
+        t3 = 8e-2 if dtype == "bf16" else 3e-2
+        assert abs(l[1] - le[1]) < 2e-3 * abs(le[1]) and abs(l[2] - le[2]) < t3 * abs(le[2]), (l, le)

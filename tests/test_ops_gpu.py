@@ -300,3 +300,42 @@ def test_sqnorm_adamw(hip):
         hip.adamw_flat(pc, gs, m, v, step=step, ranges=ranges, gnorm_sq=sq, gnorm_out=gn, max_norm=0.1)
         assert abs(float(gn) - float(total)) < 1e-5 * float(total)
     assert rel(pc, torch.cat([P["a"], P["b"]])) < 1e-6
+
+
+def test_sqnorm_adamw_bf16_gradients_spans_active_and_device_lr(hip):
+    """The optimizer variants the engine uses: gradients read from a bf16 buffer (the data-parallel exchange format) give
+    exactly what the fp32 path gives on the same (bf16-representable) values; the update issued as two spans equals one
+    launch; a launch with active == 0 changes nothing; lr_dev overrides the descriptor's rates."""
+    g = torch.Generator().manual_seed(5)
+    n = 4096 * 5 + 16
+    p0 = torch.randn(n, generator=g).cuda(); gr16 = (torch.randn(n, generator=g) * 0.01).cuda().bfloat16()
+    gr = gr16.float()
+    ranges = [(0, 8192, 1e-4, 1e-4), (8192, n, 1e-5, 1e-4)]
+
+    def run(ranges=ranges, **kw):
+        p = p0.clone(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+        sq = torch.zeros(1, device="cuda"); gn = torch.zeros(1, device="cuda")
+        src = kw.pop("src")
+        hip.sqnorm(src, sq)
+        spans = kw.pop("spans", [None])
+        for step in (1, 2):
+            for sp in spans:
+                hip.adamw_flat(p, gr, m, v, step=step, ranges=ranges, gnorm_sq=sq, gnorm_out=gn, max_norm=0.05, span=sp, **kw)
+        return p, m, v, float(gn)
+
+    ref = run(src=gr)
+    got = run(src=gr16, g16=gr16)
+    assert abs(got[3] - ref[3]) < 1e-6 * ref[3]
+    for a, b in zip(got[:3], ref[:3]):                 # the norm is summed in another order: the clip factor moves by an ulp
+        assert rel(a, b) < 1e-6
+    two = run(src=gr, spans=[(0, 12288), (12288, n)])
+    for a, b in zip(two[:3], ref[:3]):                 # (the norm's atomics make two runs differ by an ulp of the clip factor)
+        assert rel(a, b) < 1e-6
+    off = torch.zeros(1, dtype=torch.int32, device="cuda")
+    idle = run(src=gr, active=off)
+    assert torch.equal(idle[0], p0) and float(idle[1].abs().max()) == 0.0
+    lr_dev = torch.tensor([1e-4, 1e-5, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device="cuda")
+    wrong = [(0, 8192, 7.0, 1e-4), (8192, n, 9.0, 1e-4)]          # rates by value that the device words must override
+    dev = run(ranges=wrong, src=gr, lr_dev=lr_dev)
+    for a, b in zip(dev[:3], ref[:3]):
+        assert rel(a, b) < 1e-6
