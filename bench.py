@@ -229,7 +229,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"RefCOCO-shaped REC train step, ResNet-50 + BERT-base + VL transformer 6+6, "
                                f"{S_}x{S_}, batch {B}/GPU, L=40, aux loss, dropout on, clip 0.1, AdamW (configs[1])",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "launch": mode + ("+dp-overlap" if (world > 1 or force_dist) else "")},
+                   "global_batch": B * world, "parallelism": f"dp{world}", "launch": mode + ("+dp-overlap" if (world > 1 or force_dist) else ""),
+                   **({"grad_exchange": "bf16" if getattr(runner, "bf16", False) else "fp32"} if (world > 1 or force_dist) else {})},
         "loss": loss_value,
     }
     if rank == 0:
