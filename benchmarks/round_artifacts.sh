@@ -8,7 +8,12 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats -- python $R/ben
 cd $R
 DB=$(find $O/${TAG}_stats -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB > $O/${TAG}_kernel_stats_graph.md 2>$O/${TAG}_stats.err; head -12 $O/${TAG}_kernel_stats_graph.md
-python tools/step_phases.py $DB > $O/${TAG}_phases.txt 2>&1; tail -15 $O/${TAG}_phases.txt
+cd /tmp
+REFTR_STREAMS=0 timeout 600 rocprofv3 --kernel-trace -d $O/${TAG}_trace1 -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-roofline > $O/${TAG}_trace1.log 2>&1
+cd $R
+DB1=$(find $O/${TAG}_trace1 -name "*.db" | head -1)
+python tools/step_phases.py $DB1 > $O/${TAG}_phases.txt 2>&1; tail -16 $O/${TAG}_phases.txt
+rm -rf $O/${TAG}_trace1
 bash benchmarks/pmc_passes.sh > $O/${TAG}_pmc.log 2>&1
 F=$(find $O/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*.db" | head -1)
 python tools/pmc_traffic.py $F $W --steps 5 --json $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_kernels.txt 2>&1; head -14 $O/${TAG}_pmc_kernels.txt

@@ -2,18 +2,18 @@
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
-# last adamw = end of the last step; previous adamw = end of the step before
-ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
+# the gradient-norm kernel ends an iteration in both schedules (deferred: [AdamW of i-1 | fwd | bwd | norm]; eager: [... norm | AdamW])
+ad = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0]]
 # the shortest step of the run (skips warm-up and bench.py's backlogged roofline pass behind a spin kernel)
 cands = [(rows[ad[i + 1]][2] - rows[ad[i] + 1][1], ad[i] + 1, ad[i + 1] + 1) for i in range(len(ad) - 1)
          if not any("spin_kernel" in r[0] for r in rows[ad[i] + 1:ad[i + 1] + 1])]
 _, a, b = min(cands)
 step = rows[a:b]
 t0 = step[0][1]
-marks = [("weight prep + pack", "img_pack"), ("stem", "stem_conv"), ("ResNet fwd (+BERT if 1 stream)", "maxpool"), ("input_proj+GN", "gn_stats_kernel"),
+marks = [("AdamW of the previous step (deferred) + weight prep + pack", "adamw_kernel"), ("pack", "img_pack"), ("stem", "stem_conv"), ("ResNet fwd (+BERT if 1 stream)", "maxpool"), ("input_proj+GN", "gn_stats_kernel"),
          ("encoder fwd", "gn_apply"), ("query encoder + decoder fwd + head", "qenc_attn_fwd"), ("loss", "box_loss"),
          ("head + decoder bwd", "box_loss"), ("qenc bwd + encoder bwd", "qenc_attn_bwd"), ("GN/input_proj bwd", "gn_bwd_stats"),
-         ("ResNet bwd (+BERT bwd)", "gn_bwd_apply"), ("optimizer", "sqnorm")]
+         ("ResNet bwd (+BERT bwd)", "gn_bwd_apply"), ("gradient norm", "sqnorm")]
 idx, pos = [], 0
 for label, key in marks:
     for i in range(pos, len(step)):
