@@ -349,6 +349,56 @@ class CapturedTrainStep:
         self.optimizer.step_count = sc
 
 
+def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4):
+    """`train_step` with the same return value, replayed from hipGraphs: the first batch of an input shape captures a
+    CapturedTrainStep (kept on the model), later batches of that shape replay it.  Falls back to the eager `train_step` for
+    CPU tensors, foreign optimizers and once more than `max_shapes` different shapes have been seen (variable-size data)."""
+    inner = getattr(model, "module", model)
+    caps = inner.__dict__.setdefault("_captured_steps", {})
+    img = samples.get("img")
+    ok = (isinstance(img, utils.NestedTensor) and img.tensors.is_cuda and hasattr(optimizer, "clip_grad_norm_")
+          and os.environ.get("REFTR_TRAIN_GRAPH", "1") == "1")
+    key = None
+    if ok:
+        key = (CapturedTrainStep.shape_key(samples, targets), id(criterion), id(optimizer), float(max_norm), model.training)
+        ok = key in caps or len(caps) < max_shapes
+    if not ok:
+        return train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm)
+    cap = caps.get(key)
+    if cap is None:
+        for other in caps.values():             # one pending (deferred) update at a time
+            other.flush()
+        # the capture's warm-up iterations are real updates on this batch: take them back, so that the loop sees exactly one
+        # update per batch, like the eager loop
+        st = inner.store
+        snap = (st.flat_p.clone(), optimizer.m.clone(), optimizer.v.clone(), optimizer.step_dev.clone(), optimizer.step_count,
+                inner.seed_dev.clone(), inner._step)
+        cap = caps[key] = CapturedTrainStep(model, criterion, optimizer, max_norm, samples, targets)
+        cap.reset_pending()
+        st.flat_p.copy_(snap[0]); optimizer.m.copy_(snap[1]); optimizer.v.copy_(snap[2]); optimizer.step_dev.copy_(snap[3])
+        optimizer.step_count = snap[4]
+        inner.seed_dev.copy_(snap[5]); inner._step = snap[6]
+        inner.mark_dirty(full=True)
+        del snap
+    else:
+        for other in caps.values():
+            if other is not cap:
+                other.flush()
+    losses, loss_dict, grad_total_norm = cap(samples, targets)
+    weight_dict = criterion.weight_dict
+    loss_dict_reduced = utils.reduce_dict(loss_dict)
+    unscaled = {f"{k}_unscaled": v for k, v in loss_dict_reduced.items()}
+    scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
+    loss_value = sum(scaled.values()).item()
+    if not math.isfinite(loss_value):
+        print("Loss is {}, stopping training".format(loss_value))
+        print(loss_dict_reduced)
+        sys.exit(1)
+    if lr_scheduler is not None:
+        lr_scheduler.step()
+    return loss_value, scaled, unscaled, grad_total_norm
+
+
 def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, device, epoch, max_norm=0):
     model.train()
     criterion.train()
@@ -359,7 +409,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
     for _ in metric_logger.log_every(range(len(data_loader)), 50, header):
-        loss_value, scaled, unscaled, gnorm = train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm)
+        # the loop body of engine_vg.py:40-72 -- replayed from hipGraphs for fixed-shape data (RefCOCO: 640 x 640, L = 40)
+        loss_value, scaled, unscaled, gnorm = captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm)
         metric_logger.update(loss=loss_value, **scaled, **unscaled)
         metric_logger.update(lr=optimizer.param_groups[0]["lr"])
         metric_logger.update(grad_norm=gnorm)

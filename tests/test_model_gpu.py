@@ -249,6 +249,45 @@ def test_captured_deferred_update_follows_the_lr_schedule(hip, two_phase):
     assert rel(d_g, d_e) < 0.1, rel(d_g, d_e)
 
 
+def test_train_one_epoch_replays_graphs_and_matches_the_eager_loop(hip, monkeypatch):
+    """engine_vg.train_one_epoch (the reference's entry point, engine_vg.py:22-75): fixed-shape batches are replayed from
+    hipGraphs (one capture per shape, whose warm-up updates are taken back), variable shapes fall back to eager launches;
+    meters and weights follow the purely eager loop."""
+    from reftr_amd.engine_vg import train_one_epoch
+    from reftr_amd.optim import FusedAdamW
+    b1 = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    b2 = make_inputs("steps_single", B=2, H=96, W=128, L=12)
+    loader = [b1, b2, b1, b2]
+    from reftr_amd.util.misc import NestedTensor
+
+    def cpu_batches():
+        out = []
+        for samples, targets in loader:
+            s = {k: v for k, v in samples.items() if k not in ("img", "img_mask")}
+            s["img"] = NestedTensor(samples["img"], samples["img_mask"])
+            out.append((s, targets))
+        return out
+
+    res = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("REFTR_TRAIN_GRAPH", graph)
+        model, crit, P, ocfg = build(small=True)
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)
+        model.cfg.dropout = 0.0                                          # a deterministic trajectory to compare
+        stats = train_one_epoch(model, crit, cpu_batches(), opt, sched, torch.device("cuda"), 0, max_norm=0.1)
+        assert model.training and opt.step_count == 4
+        caps = getattr(model, "_captured_steps", {})
+        assert len(caps) == (1 if graph == "1" else 0)
+        res[graph] = (stats, model.state_dict()["bbox_embed.layers.1.weight"].float().cpu() - P["bbox_embed.layers.1.weight"],
+                      opt.param_groups[0]["lr"])
+    (sg, dg, lrg), (se, de, lre) = res["1"], res["0"]
+    assert lrg == lre == 2.5e-5
+    assert set(sg) == set(se) and {"loss", "loss_bbox", "loss_giou_unscaled", "lr", "grad_norm"} <= set(sg)
+    assert abs(sg["loss"] - se["loss"]) < 2e-2 * se["loss"] and abs(sg["grad_norm"] - se["grad_norm"]) < 5e-2 * se["grad_norm"]
+    assert rel(dg, de) < 0.1                 # four Adam steps under the same schedule (trajectory noise of the fixture: 3.5e-2)
+
+
 def test_captured_forward_is_bit_identical_to_eager(hip):
     """engine_vg.CapturedForward: the eval forward replayed from a hipGraph returns exactly the eager forward's tensors
     (no atomics in the forward), also after the weights changed and for a second batch of the same shape."""
