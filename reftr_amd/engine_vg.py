@@ -426,8 +426,8 @@ class CapturedForward:
     replayed outputs are bit-identical to the eager ones (tests/test_model_gpu.py).  Outputs are static buffers that the
     next replay overwrites."""
 
-    def __init__(self, model):
-        self.model, self.graphs = model, {}
+    def __init__(self, model, max_shapes=4):
+        self.model, self.graphs, self.max_shapes = model, {}, max_shapes
 
     @staticmethod
     def shape_key(samples):
@@ -440,6 +440,8 @@ class CapturedForward:
             return self.model(samples)
         key = self.shape_key(samples)
         ent = self.graphs.get(key)
+        if ent is None and len(self.graphs) >= self.max_shapes:      # variable-size data: eager launches
+            return self.model(samples)
         if ent is None:
             s, _ = _clone_batch(samples, [])
             side = torch.cuda.Stream()
@@ -479,8 +481,9 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
     results_dict = {}
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
-    # REFTR_EVAL_GRAPH=1: replay the forward from a hipGraph per input shape (fixed-size evaluation sets)
-    fwd = CapturedForward(model) if (os.environ.get("REFTR_EVAL_GRAPH") == "1" and torch.device(device).type == "cuda") else model
+    # the forward is replayed from a hipGraph per input shape (fixed-size evaluation sets; bit-identical outputs; up to four
+    # shapes, then eager launches); REFTR_EVAL_GRAPH=0: always eager
+    fwd = CapturedForward(model) if (os.environ.get("REFTR_EVAL_GRAPH", "1") == "1" and torch.device(device).type == "cuda") else model
     for _ in metric_logger.log_every(range(len(data_loader)), 50, "Test:"):
         outputs = fwd(samples)
         loss_dict = criterion(outputs, targets)
