@@ -45,6 +45,10 @@ class CriterionVGMultiPhrase(nn.Module):
                 off.append(off[-1] + n)
             self._off_cache[lens] = torch.tensor(off, dtype=torch.int32, device=device)
         boxes = torch.cat([t["boxes"].to(device, torch.float32) for t in targets], dim=0).contiguous()
+        if boxes.shape[0] == 0:
+            # a batch without any target box (criterion.py:176-180 clamps num_boxes to 1, every loss is an empty sum = 0): the
+            # kernel needs a non-null pointer, the all-zero offsets make every image's target range empty
+            boxes = torch.zeros(1, 4, dtype=torch.float32, device=device)
         return boxes, self._off_cache[lens]
 
     def forward(self, outputs, targets):

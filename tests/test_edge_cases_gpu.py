@@ -1,0 +1,75 @@
+"""GPU: edge cases of the path against the CPU oracle (same formula weights, eval mode): batch of one, image sizes that are
+not multiples of the stride (every stage rounds (n-1)//2+1), an image that is almost all padding, the longest sentence the
+model accepts (max_lang_seq = 128, models/reftr.py:81) and sentences of minimum length, a multi-phrase batch in which one
+image has NO valid phrase, and the all-empty batch (num_boxes clamps to 1, every loss is exactly 0).
+
+An image without a valid phrase is outside the reference's domain: its decoder self-attention runs over a fully masked key
+set (`tgt_key_padding_mask` all True, transformer.py:231-252), the reference's own logits for that image are NaN and so are
+191 of its gradient tensors (checked with the oracle = the reference's arithmetic).  For that input only the forward quantities
+that the reference defines are compared: the validity mask (exact), the boxes of the valid queries and the losses."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reftr_oracle as O
+from oracle.synth import make_inputs
+from test_model_gpu import build, rel, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(samples, targets, tol_box=8e-3, tol_loss=8e-3, backward=True):
+    model, crit, P, ocfg = build(small=True)
+    model.eval()
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    ld = crit(out, tg)
+    ref = O.reftr_forward(P, samples, ocfg, train=False, q=False)
+    rl = O.criterion(ref, targets)
+    boxes = torch.cat([torch.stack([a["pred_boxes"] for a in out["aux_outputs"]]), out["pred_boxes"][None]])
+    valid = ref["phrase_mask"].reshape(-1)
+    assert np.array_equal(out["phrase_mask"].reshape(-1).cpu().numpy(), valid.numpy())          # bool: exact
+    got = boxes.detach().float().cpu().reshape(boxes.shape[0], -1, 4)[:, valid]
+    want = ref["logits"].sigmoid().reshape(boxes.shape[0], -1, 4)[:, valid]
+    if valid.any():
+        assert rel(got, want) < tol_box, rel(got, want)
+    for k, v in ld.items():
+        assert abs(float(v) - float(rl[k])) < tol_loss * max(1.0, abs(float(rl[k]))), (k, float(v), float(rl[k]))
+    if backward:
+        total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        model.store.flat_g.zero_()
+        total.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(model.store.flat_g).all()
+    return model, ld
+
+
+@pytest.mark.parametrize("B,H,W,L", [(1, 75, 101, 5), (3, 33, 64, 12), (2, 130, 97, 128), (2, 64, 64, 4)])
+def test_odd_shapes_single_phrase(hip, B, H, W, L):
+    samples, targets = make_inputs(f"edge_{B}_{H}_{W}_{L}", B=B, H=H, W=W, L=L)
+    compare(samples, targets)
+
+
+def test_image_that_is_almost_all_padding(hip):
+    samples, targets = make_inputs("edge_pad", B=2, H=96, W=128, L=12)
+    samples["img_mask"][1] = True
+    samples["img_mask"][1, :20, :20] = False            # 20 x 20 valid pixels: a single stride-32 cell
+    samples["img"][1] = samples["img"][1] * (~samples["img_mask"][1]).float()
+    compare(samples, targets)
+
+
+def test_multi_phrase_with_an_image_without_valid_phrases(hip):
+    samples, targets = make_inputs("edge_multi", B=3, H=96, W=128, L=14, n_phrase=2)   # image 2 has 0 valid phrases
+    assert targets[2]["boxes"].shape[0] == 0 and int(samples["phrase_mask"][2, :, 2].sum()) == 0
+    model, ld = compare(samples, targets, backward=False)
+    assert float(ld["loss_bbox"]) > 0
+
+
+def test_batch_without_any_box(hip):
+    samples, targets = make_inputs("edge_none", B=2, H=64, W=96, L=8, n_phrase=1)
+    # make every phrase the padding phrase "[CLS] [SEP]" and drop the boxes
+    samples["phrase"][:, :, 2:] = 0; samples["phrase"][:, :, 1] = 102; samples["phrase_mask"][:, :, 2:] = 0
+    samples["phrase_pos_l"][:] = 0; samples["phrase_pos_r"][:] = 1
+    targets = [{"boxes": torch.zeros(0, 4), "labels": torch.zeros(0, dtype=torch.long)} for _ in range(2)]
+    model, ld = compare(samples, targets, backward=False)      # (every query masked: the same out-of-domain NaN as above)
+    assert all(float(v) == 0.0 for v in ld.values())
