@@ -73,3 +73,30 @@ def test_batch_without_any_box(hip):
     targets = [{"boxes": torch.zeros(0, 4), "labels": torch.zeros(0, dtype=torch.long)} for _ in range(2)]
     model, ld = compare(samples, targets, backward=False)      # (every query masked: the same out-of-domain NaN as above)
     assert all(float(v) == 0.0 for v in ld.values())
+
+
+@pytest.mark.parametrize("B,H,W,L", [(1, 75, 101, 6), (3, 64, 130, 9)])
+def test_odd_shapes_refer_segmentation(hip, B, H, W, L):
+    """RefTRSeg on sizes where the FPN levels do not halve evenly (19x26 -> 10x13 -> 5x7 -> 3x4 for 75x101): nearest upsampling
+    to the next level's size, bilinear loss upsampling to the padded target size."""
+    from test_seg_gpu import build_seg
+    samples, targets = make_inputs(f"edge_seg_{B}_{H}_{W}", B=B, H=H, W=W, L=L)
+    g = torch.Generator().manual_seed(3)
+    targets = [dict(t, masks=(torch.rand(1, H, W, generator=g) < 0.3) & ~samples["img_mask"][i][None]) for i, t in enumerate(targets)]
+    model, crit, P, ocfg = build_seg()
+    model.eval()
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    ld = crit(out, tg)
+    ref = O.reftr_forward(P, samples, ocfg, train=False, q=False)
+    rl = O.criterion(ref, targets)
+    assert out["pred_masks"].shape == ref["pred_masks"].shape
+    assert rel(out["pred_masks"], ref["pred_masks"]) < 3e-2 and rel(out["mask_att"], ref["mask_att"]) < 3e-2
+    assert rel(out["pred_boxes"], ref["logits"][-1].sigmoid().reshape(out["pred_boxes"].shape)) < 8e-3
+    for k in ("loss_mask", "loss_dice", "loss_bbox", "loss_giou"):
+        assert abs(float(ld[k]) - float(rl[k])) < 1.5e-2 * max(abs(float(rl[k])), 0.1), (k, float(ld[k]), float(rl[k]))
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    model.store.flat_g.zero_()
+    total.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(model.store.flat_g).all() and float(model.store.G["mask_head.lay1.weight"].abs().max()) > 0
