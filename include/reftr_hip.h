@@ -85,6 +85,12 @@ typedef struct rt_conv_gemm_desc {
     const uint32_t* seed_dev; /* optional DEVICE word: effective dropout seed = hash(*seed_dev, drop_seed) (hipGraph replay) */
 } rt_conv_gemm_desc;
 int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream);
+/* rt_conv_gemm_grouped — n independent rt_conv_gemm problems (HOST array of descriptors).  Dense products with K < 1024 and
+ * more than 16 rows (2 <= n <= 12) run as ONE launch whose descriptors travel by value in the kernel arguments; any other
+ * mix is issued as n single launches in order.  The results are those of n rt_conv_gemm calls either way.  On the
+ * transformer's dependency chains (models/modeling/transformer.py:168-252: q/k and v projections of a layer, the decoder's
+ * cross-attention K / V projections of all layers, pairs of backward-data products) a launch costs ~4.5 us whatever it computes. */
+int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * rt_conv_wgrad — bf16 MFMA weight-gradient GEMM, reduction over rows (pixels / tokens):

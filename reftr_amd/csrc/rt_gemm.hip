@@ -370,9 +370,11 @@ __device__ __forceinline__ void rt_dma16(const i32x4 rsrc, unsigned lds_base, in
                  : "memory", "m0");
 }
 
-template <int BM, int BN, int MODE, int NS, int MINB>
-__global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* __restrict__ src,
-                                                                  const bf16_t* __restrict__ wgt, const GemmArgs p) {
+// The body is a device function: it runs as a kernel of its own (conv_gemm_dma_kernel) or as one of up to 12 independent
+// problems of a grouped launch (conv_gemm_dma_grouped_kernel); bx / by / gx stand for blockIdx.x / blockIdx.y / gridDim.x.
+template <int BM, int BN, int MODE, int NS>
+__device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, const GemmArgs& p,
+                                              const int bx, const int by, const int gx) {
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int AJ = BN / 32, BJ = BM / 32;
     constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, BUF_BYTES = A_BYTES + B_BYTES;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
     const int li = lane & 15, lg = lane >> 4;
 
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int bid = rt_xcd_remap(blockIdx.x, gridDim.x, p.xcd);
+    const int bid = rt_xcd_remap(bx, gx, p.xcd);
     const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
     const int n0 = tile_n * BN, m0 = tile_m * BM;
 
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
     // instead of multiplying zeros for the other 3/4; its rows are the class's pixels in (b, y/2, x/2) order.
     int cy = 0, cx = 0, ny = p.DH, nx = p.DW, kh0 = 0, kw0 = 0, Mloc = p.M;
     if (MODE == 3) {
-        cy = blockIdx.y >> 1; cx = blockIdx.y & 1;
+        cy = by >> 1; cx = by & 1;
         ny = (p.DH - cy + 1) >> 1; nx = (p.DW - cx + 1) >> 1;
         Mloc = p.B * ny * nx;
         kh0 = (cy + p.pad) & 1; kw0 = (cx + p.pad) & 1;
@@ -597,6 +599,26 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* 
     }
 }
 
+template <int BM, int BN, int MODE, int NS, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* __restrict__ src,
+                                                                  const bf16_t* __restrict__ wgt, const GemmArgs p) {
+    gemm_dma_body<BM, BN, MODE, NS>(src, wgt, p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// Several independent dense products in ONE launch (descriptors by value in the kernel arguments: graph-safe, no device
+// tables): the q/k and v projections of an encoder layer, the twelve cross-attention K / V projections of the decoder, pairs
+// of backward-data products.  On the latency-bound transformer chains every launch costs ~4.5 us whatever it computes.
+struct GemmGroup { GemmArgs j[12]; int first[13]; int n; };
+template <int BM, int BN, int NS, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm_dma_grouped_kernel(const GemmGroup g) {
+    int lo = 0;
+    for (int i = 1; i < g.n; ++i) if (g.first[i] <= (int)blockIdx.x) lo = i;
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const int lin = (int)blockIdx.x - g.first[lo];
+    const int gx = g.first[lo + 1] - g.first[lo];
+    gemm_dma_body<BM, BN, 0, NS>(g.j[lo].src, g.j[lo].wgt, g.j[lo], lin, 0, gx);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny path (M <= 16 rows: the decoder / query-encoder / box-head Linears over B*n_q tokens).  No LDS tiles:
 // a workgroup owns 16 output features, its 4 waves split K four ways and stream both operands straight from
@@ -679,12 +701,11 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
+static int fill_gemm_args(const rt_conv_gemm_desc* d, GemmArgs& a) {
     if (!d || !d->src || !d->wgt || (!d->out_bf16 && !d->out_f32)) return RT_ERR_BADARG;
     if (d->SC <= 0 || (d->SC & 63) || (d->N & 3) || d->N <= 0) return RT_ERR_UNSUPPORTED;
     if (d->stride != 1 && d->stride != 2) return RT_ERR_UNSUPPORTED;
     if (d->KH <= 0 || d->KW <= 0 || d->B <= 0 || d->DH <= 0 || d->DW <= 0) return RT_ERR_BADARG;
-    GemmArgs a;
     a.src = (const bf16_t*)d->src; a.wgt = (const bf16_t*)d->wgt;
     a.out_bf16 = (bf16_t*)d->out_bf16; a.out_f32 = d->out_f32; a.out_preact = (bf16_t*)d->out_preact;
     a.bias = d->bias; a.res_f32 = d->res_f32; a.res_bf16 = (const bf16_t*)d->res_bf16;
@@ -705,6 +726,13 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     a.epi_lds = epi_env & 1;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
+    return RT_OK;
+}
+
+extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
+    GemmArgs a;
+    const int frc = fill_gemm_args(d, a);
+    if (frc != RT_OK) return frc;
     hipStream_t s = (hipStream_t)stream;
 
     const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
@@ -756,7 +784,37 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     }
 }
 
-extern "C" int rt_abi_version(void) { return 18; }
+extern "C" int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_stream_t stream) {
+    if (!descs || n <= 0) return RT_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    static const int grp_env = getenv("REFTR_GEMM_GROUP") ? atoi(getenv("REFTR_GEMM_GROUP")) : 1;
+    // groupable: dense products the single-launch heuristic would give the 64x64 / 2-stage / 4-per-CU variant (K < 1024, M > 16)
+    bool ok = grp_env && n >= 2 && n <= 12;
+    GemmGroup g;
+    int blocks = 0;
+    for (int i = 0; i < n && ok; ++i) {
+        const rt_conv_gemm_desc& d = descs[i];
+        GemmArgs a;
+        const int rc = fill_gemm_args(&d, a);
+        if (rc != RT_OK) return rc;
+        const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
+        if (!dense || a.M <= 16 || a.K >= 1024 || d.tile_hint != 0) { ok = false; break; }
+        g.j[i] = a; g.first[i] = blocks;
+        blocks += ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    }
+    if (!ok) {                                   // anything else: the same products as single launches, in order
+        for (int i = 0; i < n; ++i) { const int rc = rt_conv_gemm(descs + i, stream); if (rc != RT_OK) return rc; }
+        return RT_OK;
+    }
+    g.first[n] = blocks; g.n = n;
+    for (int i = n + 1; i < 13; ++i) g.first[i] = blocks;
+    constexpr size_t smem = (size_t)2 * (64 + 64) * 128;
+    hipLaunchKernelGGL((conv_gemm_dma_grouped_kernel<64, 64, 2, 4>), dim3((unsigned)blocks), dim3(256), smem, s, g);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_abi_version(void) { return 19; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

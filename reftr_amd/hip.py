@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -209,6 +209,7 @@ _SIGNATURES = {
     "rt_abi_version": (c_int, []),
     "rt_device_arch": (c_int, [c_int, c_char_p, c_int]),
     "rt_conv_gemm": (c_int, [POINTER(ConvGemmDesc), c_void_p]),
+    "rt_conv_gemm_grouped": (c_int, [c_void_p, c_int, c_void_p]),
     "rt_conv_wgrad": (c_int, [POINTER(ConvWgradDesc), c_void_p]),
     "rt_layernorm_fwd": (c_int, [POINTER(LayerNormDesc), c_void_p]),
     "rt_layernorm_bwd": (c_int, [POINTER(LayerNormBwdDesc), c_void_p]),
@@ -355,7 +356,7 @@ def _req(t, dtype, name):
 # --------------------------------------------------------------------------------------------
 def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=None, gate_scale=1.0,
               preact=None, dtanh=None, res_first=False, act=ACT_NONE, drop_p=0.0, drop_seed=0, transposed=False,
-              out_bf16=True, out_f32=False, out_preact=False, tile_hint=0):
+              out_bf16=True, out_f32=False, out_preact=False, tile_hint=0, group=None):
     """out[B,DH,DW,N] = epilogue(implicit_gemm(src[B,SH,SW,SC], wgt[N,KH,KW,SC])).
 
     geom = (B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad).  Returns (out_bf16 | None, out_f32 | None)
@@ -386,11 +387,38 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
         flops = 2.0 * B * SH * SW * SC * N * KH * KW
     else:
         flops = 2.0 * M * N * KH * KW * SC
-    _timed("conv_gemm", flops, lambda: _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm"),
-           tag=("T" if transposed else "F",) + tuple(geom))
+    if group is not None:      # queued: GemmGroup.run() launches every queued product at once
+        group.add(d, flops, ("T" if transposed else "F",) + tuple(geom), (src, wgt, ob, of, op, bias, res_f32, res_bf16, gate, preact, dtanh))
+    else:
+        _timed("conv_gemm", flops, lambda: _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm"),
+               tag=("T" if transposed else "F",) + tuple(geom))
     if out_preact:
         return ob, of, op
     return ob, of
+
+
+class GemmGroup:
+    """Independent GEMMs queued with `conv_gemm(..., group=g)` / `linear(..., group=g)` (outputs are allocated at queue time)
+    and launched together by `run()` (rt_conv_gemm_grouped: one launch when the products allow it)."""
+
+    def __init__(self):
+        self.descs, self.keep, self.flops, self.nbytes = [], [], 0.0, 0.0
+
+    def add(self, d, flops, tag, keep):
+        self.descs.append(d); self.keep.append(keep); self.flops += flops; self.nbytes += _algo_bytes(tag)
+
+    def run(self):
+        if not self.descs:
+            return
+        n = len(self.descs)
+        for i in range(0, n, 12):
+            chunk = self.descs[i:i + 12]
+            arr = (ConvGemmDesc * len(chunk))(*chunk)
+            share = len(chunk) / n
+            _timed("conv_gemm", self.flops * share,
+                   lambda arr=arr, m=len(chunk): _check(lib().rt_conv_gemm_grouped(arr, m, _stream()), "rt_conv_gemm_grouped"),
+                   nbytes=self.nbytes * share)
+        self.descs, self.keep, self.flops, self.nbytes = [], [], 0.0, 0.0
 
 
 def linear(x, w, bias=None, **kw):

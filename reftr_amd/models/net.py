@@ -303,8 +303,10 @@ class Net:
         E, Hh = cfg.hidden, cfg.nheads
         dh = E // Hh
         r = {"x16": x16, "xp16": xp16}
-        qk, _ = self.lin_fwd(p + "self_attn.qk", xp16)
-        v, _ = self.lin_fwd(p + "self_attn.v", x16)
+        grp = H.GemmGroup()                      # two independent projections, one launch
+        qk, _ = self.lin_fwd(p + "self_attn.qk", xp16, group=grp)
+        v, _ = self.lin_fwd(p + "self_attn.v", x16, group=grp)
+        grp.run()
         r["ad"] = self._drop(cfg.dropout)
         o, lse = H.attn_fwd(qk[:, :E], qk[:, E:], v, kpm, B=B, H=Hh, Sq=S, Sk=S, dh=dh, scale=dh ** -0.5,
                             drop_p=r["ad"][0], drop_seed=r["ad"][1])
@@ -341,13 +343,27 @@ class Net:
         dqk = torch.empty_like(qk)
         _, _, dv = H.attn_bwd(qk[:, :E], qk[:, E:], v, r["o"], do, r["lse"], kpm, B=B, H=Hh, Sq=S, Sk=S, dh=dh,
                               scale=dh ** -0.5, drop_p=r["ad"][0], drop_seed=r["ad"][1], dq=dqk[:, :E], dk=dqk[:, E:])
-        _, dxa = self.lin_bwd(p + "self_attn.v", dv, r["x16"], res_f32=dt, out_bf16=False, out_f32=True)
-        _, dxp = self.lin_bwd(p + "self_attn.qk", dqk, r["xp16"], out_bf16=False, out_f32=True)
+        grp = H.GemmGroup()
+        _, dxa = self.lin_bwd(p + "self_attn.v", dv, r["x16"], res_f32=dt, out_bf16=False, out_f32=True, group=grp)
+        _, dxp = self.lin_bwd(p + "self_attn.qk", dqk, r["xp16"], out_bf16=False, out_f32=True, group=grp)
+        grp.run()
         H.rows_add(M, E, a_f32=dxp, out_f32=dpos_acc, accumulate=True)
         return dxa, dxp          # sum of the two = gradient w.r.t. the layer input
 
     # ------------------------------------------------------------------ decoder layer (transformer.py:231-252)
-    def dec_layer_fwd(self, p, t32, t16, tq16, qpos, mem16, memp16, qmask, kpm, B, T, S):
+    def dec_kv_all(self, prefixes, mem16, memp16):
+        """The cross-attention K / V projections of EVERY decoder layer (they only depend on the encoder memory,
+        transformer.py:231-252): 2 x layers products in one launch, off the decoder's query chain."""
+        grp = H.GemmGroup()
+        out = []
+        for p in prefixes:
+            k2, _ = self.lin_fwd(p + "multihead_attn.k", memp16, group=grp)
+            v2, _ = self.lin_fwd(p + "multihead_attn.v", mem16, group=grp)
+            out.append((k2, v2))
+        grp.run()
+        return out
+
+    def dec_layer_fwd(self, p, t32, t16, tq16, qpos, mem16, memp16, qmask, kpm, B, T, S, kv=None):
         cfg = self.cfg
         E, Hh = cfg.hidden, cfg.nheads
         dh = E // Hh
@@ -374,8 +390,11 @@ class Net:
         t1_32, t1_16, t1q16, m1, r1 = self.ln_fwd(u, p + "norm1.", pos=qpos)
         r.update(u=u, st1=(m1, r1), t1q16=t1q16)
         q2, _ = self.lin_fwd(p + "multihead_attn.q", t1q16)
-        k2, _ = self.lin_fwd(p + "multihead_attn.k", memp16)
-        v2, _ = self.lin_fwd(p + "multihead_attn.v", mem16)
+        if kv is not None:
+            k2, v2 = kv
+        else:
+            k2, _ = self.lin_fwd(p + "multihead_attn.k", memp16)
+            v2, _ = self.lin_fwd(p + "multihead_attn.v", mem16)
         r["ad2"] = self._drop(cfg.dropout)
         o2, lse2 = H.attn_fwd(q2, k2, v2, kpm, B=B, H=Hh, Sq=T, Sk=S, dh=dh, scale=sc, drop_p=r["ad2"][0], drop_seed=r["ad2"][1])
         r.update(q2=q2, k2=k2, v2=v2, o2=o2, lse2=lse2)
@@ -410,8 +429,10 @@ class Net:
         do2, _ = self.lin_bwd(p + "multihead_attn.out_proj.", du2b, r["o2"])
         dq2, dk2, dv2 = H.attn_bwd(r["q2"], r["k2"], r["v2"], r["o2"], do2, r["lse2"], kpm, B=B, H=Hh, Sq=T, Sk=S, dh=dh,
                                    scale=sc, drop_p=r["ad2"][0], drop_seed=r["ad2"][1])
-        self.lin_bwd(p + "multihead_attn.v", dv2, mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc)
-        self.lin_bwd(p + "multihead_attn.k", dk2, memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc)
+        grp = H.GemmGroup()                      # two accumulators, two independent products, one launch
+        self.lin_bwd(p + "multihead_attn.v", dv2, mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
+        self.lin_bwd(p + "multihead_attn.k", dk2, memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
+        grp.run()
         _, dt1q = self.lin_bwd(p + "multihead_attn.q", dq2, r["t1q16"], out_bf16=False, out_f32=True)
         H.rows_add(N, E, a_f32=dt1q, out_f32=dqpos_acc, accumulate=True)
         du, dub = self.ln_bwd(du2, r["u"], p + "norm1.", *r["st1"], dy2=dt1q, drop2_p=r["d1"][0], drop2_seed=r["d1"][1])

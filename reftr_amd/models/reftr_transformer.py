@@ -333,9 +333,10 @@ class RefTR(nn.Module):
         hs16 = torch.empty(NL * N, E, dtype=torch.bfloat16, device=dev)
         dec, hs_stats, t3s = [], [], []
         t32, t16, tq16 = tgt32, tgt16, tgtq16
+        kvs = net.dec_kv_all([f"{vt}decoder.layers.{i}." for i in range(NL)], mem16, memp16) if NL else []
         for i in range(NL):
             t32, t16, tq16, r = net.dec_layer_fwd(f"{vt}decoder.layers.{i}.", t32, t16, tq16, qpos, mem16, memp16,
-                                                  qmask, kpm, B, T, S)
+                                                  qmask, kpm, B, T, S, kv=kvs[i])
             dec.append(r)
             _, _, _, hm, hr = net.ln_fwd(t32, vt + "decoder.norm.", y_bf16=hs16[i * N:(i + 1) * N], want_f32=False)
             hs_stats.append((hm, hr)); t3s.append(t32)

@@ -256,3 +256,39 @@ def test_weight_prep_batched(hip):
     for src, sc, dst, dst_t in keep:
         ref = (src * sc.view(-1, 1, 1) if sc is not None else src).bfloat16()
         assert torch.equal(dst.cpu(), ref) and torch.equal(dst_t.cpu(), ref.permute(2, 1, 0).contiguous())
+
+
+def test_grouped_gemm_equals_single_launches(hip):
+    """rt_conv_gemm_grouped: the same kernel body behind one launch -- bit-identical to n single launches, for every epilogue
+    the grouped call sites use (bias, fp32 in-place accumulation, ragged M / N); mixes it cannot group fall back to singles."""
+    torch.manual_seed(3)
+    jobs = []
+    for M, K, N, acc in ((3520, 256, 512, False), (3520, 256, 256, False), (3333, 512, 256, True), (440, 256, 264, True), (100, 768, 64, False)):
+        x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+        b = torch.randn(N, device="cuda"); r = torch.randn(M, N, device="cuda") if acc else None
+        jobs.append((x, w, b, r))
+
+    def run(group):
+        outs = []
+        for x, w, b, r in jobs:
+            if r is None:
+                ob, of = hip.linear(x, w, bias=b, out_bf16=True, out_f32=True, group=group)
+            else:
+                buf = r.clone()
+                ob, of = hip.linear(x, w, bias=b, res_f32=buf, out_bf16=False, out_f32=buf, group=group)
+            outs.append((ob, of))
+        if group is not None:
+            group.run()
+        torch.cuda.synchronize()
+        return outs
+    single, grouped = run(None), run(hip.GemmGroup())
+    for (a16, a32), (b16, b32) in zip(single, grouped):
+        assert torch.equal(a32, b32) and (a16 is None or torch.equal(a16, b16))
+    # not groupable (a skinny product and a K >= 1024 product in the mix): still the right answers
+    x = torch.randn(8, 256, device="cuda").bfloat16(); w = (torch.randn(256, 256, device="cuda") * 0.05).bfloat16()
+    x2 = torch.randn(512, 2048, device="cuda").bfloat16(); w2 = (torch.randn(256, 2048, device="cuda") * 0.02).bfloat16()
+    g = hip.GemmGroup()
+    _, a = hip.linear(x, w, out_bf16=False, out_f32=True, group=g); _, b = hip.linear(x2, w2, out_bf16=False, out_f32=True, group=g)
+    g.run()
+    _, a0 = hip.linear(x, w, out_bf16=False, out_f32=True); _, b0 = hip.linear(x2, w2, out_bf16=False, out_f32=True)
+    assert torch.equal(a, a0) and torch.equal(b, b0)
