@@ -83,6 +83,10 @@ typedef struct rt_conv_gemm_desc {
     const void* dtanh;      /* bf16 [M, N] or NULL: out *= (1 - dtanh^2)  (backward of a tanh output, BERT pooler) */
     int32_t  res_first;     /* 1: add res_* BEFORE act (bottleneck tail relu(bn(conv) + identity)); 0: after dropout */
     const uint32_t* seed_dev; /* optional DEVICE word: effective dropout seed = hash(*seed_dev, drop_seed) (hipGraph replay) */
+    int32_t drop_shift;       /* dropout granularity: one keep/drop decision per 2^drop_shift consecutive output features of a row
+                                 (hash index = (m * N + n) >> drop_shift).  With drop_shift = log2(head_dim) this is
+                                 nn.MultiheadAttention's probability dropout for a ONE-key softmax (decoder self-attention with one
+                                 query per image, transformer.py:231-236): the attention launch folds into the V projection */
 } rt_conv_gemm_desc;
 int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream);
 /* rt_conv_gemm_grouped — n independent rt_conv_gemm problems (HOST array of descriptors).  Dense products with K < 1024 and

@@ -20,7 +20,7 @@ struct GemmArgs {
     bf16_t* out_bf16; float* out_f32; bf16_t* out_preact;
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
-    float gate_scale, drop_p; uint32_t drop_seed;
+    float gate_scale, drop_p; uint32_t drop_seed; int drop_shift;
     int M, K, sshift, xcd, early, epi_lds;
     unsigned src_bytes, wgt_bytes;
     const uint32_t* seed_dev;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
         const uint32_t seed = rt_site_seed(p.seed_dev, p.drop_seed);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            v[r] = (rt_hash32(seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
+            v[r] = (rt_hash32(seed, (uint32_t)((o + r) >> p.drop_shift)) >= thresh) ? v[r] * keep_scale : 0.f;
     }
     if (!p.res_first) {
         if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, f32x8
         const float keep_scale = 1.0f / (1.0f - p.drop_p);
         const uint32_t seed = rt_site_seed(p.seed_dev, p.drop_seed);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = (rt_hash32(seed, (uint32_t)(o + r)) >= thresh) ? v[r] * keep_scale : 0.f;
+        for (int r = 0; r < 8; ++r) v[r] = (rt_hash32(seed, (uint32_t)((o + r) >> p.drop_shift)) >= thresh) ? v[r] * keep_scale : 0.f;
     }
     if (!p.res_first) add_res();
     if (p.gate) {
@@ -713,6 +713,8 @@ static int fill_gemm_args(const rt_conv_gemm_desc* d, GemmArgs& a) {
     a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed;
     a.act = d->act; a.res_first = d->res_first; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.seed_dev = d->seed_dev;
+    a.drop_shift = d->drop_shift;
+    if (a.drop_shift < 0 || a.drop_shift > 16) return RT_ERR_BADARG;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     // 32-bit element offsets inside the kernel
@@ -814,7 +816,7 @@ extern "C" int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_st
     return RT_OK;
 }
 
-extern "C" int rt_abi_version(void) { return 19; }
+extern "C" int rt_abi_version(void) { return 20; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

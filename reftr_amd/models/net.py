@@ -49,6 +49,7 @@ class Net:
         self.side = H.SideStream(bool(on & 1))
         self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
         self.trivial_sa = os.environ.get("REFTR_TRIVIAL_SA", "1") != "0"
+        self.fold_sa = os.environ.get("REFTR_FOLD_SA", "1") != "0"
         self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "0") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
@@ -363,26 +364,35 @@ class Net:
         grp.run()
         return out
 
-    def dec_layer_fwd(self, p, t32, t16, tq16, qpos, mem16, memp16, qmask, kpm, B, T, S, kv=None):
+    def dec_layer_fwd(self, p, t32, t16, tq16, qpos, mem16, memp16, qmask, kpm, B, T, S, kv=None, t3_out=None, fold_sa=False):
         cfg = self.cfg
         E, Hh = cfg.hidden, cfg.nheads
         dh = E // Hh
         sc = dh ** -0.5
         r = {"t16": t16, "tq16": tq16}
-        v, _ = self.lin_fwd(p + "self_attn.v", t16)
-        r["ad"] = self._drop(cfg.dropout)
         # One query per image and no padded phrase: the self-attention softmax runs over a single key, so it is exactly 1
         # whatever q and k are, and dq = dk = 0 exactly -- the q/k projection, its backward and its (zero) weight gradient
-        # are skipped; the attention kernel still applies the per-head probability dropout and the value path.
+        # are skipped.  What is left of the attention is its per-head probability dropout on the value path: with fold_sa
+        # (single-phrase inputs: the one key is never padding) that is the V projection's own epilogue (one keep/drop decision
+        # per head_dim features, same seed site and hash index b * H + h as the attention kernel), else the attention kernel.
         trivial = T == 1 and self.trivial_sa
-        r["trivial"] = trivial
-        if trivial:
-            qk = None
-            o, lse = H.attn_fwd(v, v, v, qmask, B=B, H=Hh, Sq=1, Sk=1, dh=dh, scale=sc, drop_p=r["ad"][0], drop_seed=r["ad"][1])
+        fold = trivial and fold_sa and self.fold_sa and (dh & (dh - 1)) == 0
+        r["trivial"], r["fold"] = trivial, fold
+        lse = None
+        if fold:
+            r["ad"] = self._drop(cfg.dropout)
+            qk = v = None
+            o, _ = self.lin_fwd(p + "self_attn.v", t16, drop_p=r["ad"][0], drop_seed=r["ad"][1], drop_shift=dh.bit_length() - 1)
         else:
-            qk, _ = self.lin_fwd(p + "self_attn.qk", tq16)
-            o, lse = H.attn_fwd(qk[:, :E], qk[:, E:], v, qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh, scale=sc,
-                                drop_p=r["ad"][0], drop_seed=r["ad"][1])
+            v, _ = self.lin_fwd(p + "self_attn.v", t16)
+            r["ad"] = self._drop(cfg.dropout)
+            if trivial:
+                qk = None
+                o, lse = H.attn_fwd(v, v, v, qmask, B=B, H=Hh, Sq=1, Sk=1, dh=dh, scale=sc, drop_p=r["ad"][0], drop_seed=r["ad"][1])
+            else:
+                qk, _ = self.lin_fwd(p + "self_attn.qk", tq16)
+                o, lse = H.attn_fwd(qk[:, :E], qk[:, E:], v, qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh, scale=sc,
+                                    drop_p=r["ad"][0], drop_seed=r["ad"][1])
         r.update(qk=qk, v=v, o=o, lse=lse)
         r["d1"] = self._drop(cfg.dropout)
         _, u = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=t32,
@@ -409,7 +419,7 @@ class Net:
         r["d3"] = self._drop(cfg.dropout)
         _, u3 = self.lin_fwd(p + "linear2.", hdn, drop_p=r["d3"][0], drop_seed=r["d3"][1], res_f32=t2_32,
                              out_bf16=False, out_f32=True)
-        t3_32, t3_16, t3q16, m3, r3 = self.ln_fwd(u3, p + "norm3.", pos=qpos)
+        t3_32, t3_16, t3q16, m3, r3 = self.ln_fwd(u3, p + "norm3.", pos=qpos, y_f32=t3_out)
         r.update(u3=u3, st3=(m3, r3))
         return t3_32, t3_16, t3q16, r
 
@@ -436,6 +446,11 @@ class Net:
         _, dt1q = self.lin_bwd(p + "multihead_attn.q", dq2, r["t1q16"], out_bf16=False, out_f32=True)
         H.rows_add(N, E, a_f32=dt1q, out_f32=dqpos_acc, accumulate=True)
         du, dub = self.ln_bwd(du2, r["u"], p + "norm1.", *r["st1"], dy2=dt1q, drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
+        if r["fold"]:           # the head-dropout mask of the forward, applied by the backward-data product's epilogue
+            dv, _ = self.lin_bwd(p + "self_attn.out_proj.", dub, r["o"], drop_p=r["ad"][0], drop_seed=r["ad"][1],
+                                 drop_shift=dh.bit_length() - 1)
+            _, dta = self.lin_bwd(p + "self_attn.v", dv, r["t16"], res_f32=du, out_bf16=False, out_f32=True)
+            return dta, None
         do, _ = self.lin_bwd(p + "self_attn.out_proj.", dub, r["o"])
         qk, v = r["qk"], r["v"]
         if r["trivial"]:

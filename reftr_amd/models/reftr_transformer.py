@@ -331,15 +331,20 @@ class RefTR(nn.Module):
         T = Pn * cfg.n_q
         NL = cfg.dec_layers
         hs16 = torch.empty(NL * N, E, dtype=torch.bfloat16, device=dev)
-        dec, hs_stats, t3s = [], [], []
+        dec = []
+        t3_all = torch.empty(NL * N, E, dtype=torch.float32, device=dev)      # every layer's output, for the shared norm
         t32, t16, tq16 = tgt32, tgt16, tgtq16
         kvs = net.dec_kv_all([f"{vt}decoder.layers.{i}." for i in range(NL)], mem16, memp16) if NL else []
         for i in range(NL):
             t32, t16, tq16, r = net.dec_layer_fwd(f"{vt}decoder.layers.{i}.", t32, t16, tq16, qpos, mem16, memp16,
-                                                  qmask, kpm, B, T, S, kv=kvs[i])
+                                                  qmask, kpm, B, T, S, kv=kvs[i], t3_out=t3_all[i * N:(i + 1) * N],
+                                                  fold_sa="phrase" not in samples)
             dec.append(r)
-            _, _, _, hm, hr = net.ln_fwd(t32, vt + "decoder.norm.", y_bf16=hs16[i * N:(i + 1) * N], want_f32=False)
-            hs_stats.append((hm, hr)); t3s.append(t32)
+        # decoder.norm on every layer's output (transformer.py:131-141, return_intermediate): ONE launch over the stack
+        hm = hr = None
+        if NL:
+            _, _, _, hm, hr = net.ln_fwd(t3_all, vt + "decoder.norm.", y_bf16=hs16, want_f32=False)
+        hs_stats, t3s = (hm, hr), t3_all
         y1, _ = net.lin_fwd("bbox_embed.layers.0.", hs16, act=RELU)
         y2, _ = net.lin_fwd("bbox_embed.layers.1.", y1, act=RELU)
         _, logits = net.lin_fwd("bbox_embed.layers.2.", y2, out_bf16=False, out_f32=True)
@@ -426,9 +431,10 @@ class RefTR(nn.Module):
 
         # ---- decoder
         ga = gb = None
+        hm, hr = sv["hs_stats"]
+        dnorm_all, _ = net.ln_bwd(dhs, sv["t3s"], vt + "decoder.norm.", hm, hr, want_bf16=False)     # all layers, one launch
         for i in reversed(range(NL)):
-            hm, hr = sv["hs_stats"][i]
-            dnorm, _ = net.ln_bwd(dhs[i * N:(i + 1) * N], sv["t3s"][i], vt + "decoder.norm.", hm, hr, want_bf16=False)
+            dnorm = dnorm_all[i * N:(i + 1) * N]
             extra = None
             if ga is not None and gb is None:
                 extra = ga

@@ -310,6 +310,40 @@ def test_captured_forward_is_bit_identical_to_eager(hip):
         assert torch.equal(model(s2)["pred_boxes"], b)
 
 
+def test_folded_self_attention_dropout_is_the_attention_kernels(hip, monkeypatch):
+    """Train mode, one query per image: the decoder self-attention's per-head probability dropout folded into the V
+    projection's epilogue (and into the backward-data product of out_proj) draws the same masks as the attention kernel it
+    replaces -- same seed site, hash index b * H + h -- so loss and gradients agree to bf16 rounding of the value path."""
+    res = {}
+    for fold in ("0", "1"):
+        monkeypatch.setenv("REFTR_FOLD_SA", fold)
+        model, crit, P, ocfg = build(small=True)
+        assert model.net.fold_sa == (fold == "1")
+        model.train()
+        s, tg = to_cuda(*make_inputs("e2e_single", B=2, H=96, W=128, L=12))
+        out = model(s)
+        ld = crit(out, tg)
+        total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        model.store.flat_g.zero_()
+        total.backward()
+        torch.cuda.synchronize()
+        G = model.store.G
+        res[fold] = (float(total.detach()), out["pred_logits"].detach().clone(),
+                     {k: G[k].clone() for k in ("vl_transformer.decoder.layers.0.self_attn.out_proj.weight",
+                                                "vl_transformer.decoder.layers.1.self_attn.in_proj_weight",
+                                                "bbox_embed.layers.2.weight")},
+                     [r["fold"] for r in model._saved["dec"]])
+    (l0, y0, g0, f0), (l1, y1, g1, f1) = res["0"], res["1"]
+    assert f0 == [False, False] and f1 == [True, True]
+    # (same masks -- tests/test_ops_gpu.py checks the zero pattern exactly; what is left is one bf16 rounding of the value path)
+    assert abs(l0 - l1) < 5e-3 * abs(l0) and rel(y1, y0) < 2e-2
+    for k in g0:                                 # gradients: the usual flip-limited agreement (DESIGN.md 4)
+        a, b = g1[k].flatten().double(), g0[k].flatten().double()
+        assert rel(g1[k], g0[k]) < 0.2 and float(a @ b / (a.norm() * b.norm())) > 0.98, (k, rel(g1[k], g0[k]))
+    E = 256                                      # the q / k rows of in_proj get no gradient at all in either path
+    assert float(g1["vl_transformer.decoder.layers.1.self_attn.in_proj_weight"][:2 * E].abs().max()) == 0.0
+
+
 def test_dropout_train_mode_runs_and_is_reproducible(hip):
     model, crit, P, ocfg = build(small=True)
     model.train()

@@ -339,3 +339,24 @@ def test_sqnorm_adamw_bf16_gradients_spans_active_and_device_lr(hip):
     dev = run(ranges=wrong, src=gr, lr_dev=lr_dev)
     for a, b in zip(dev[:3], ref[:3]):
         assert rel(a, b) < 1e-6
+
+
+def test_head_granular_epilogue_dropout_equals_one_key_attention_dropout(hip):
+    """rt_conv_gemm's drop_shift = log2(head_dim): one keep/drop decision per head, at the attention kernel's hash index
+    b * H + h -- the zero pattern and the kept values of `attn(v, v, v)` over a single key are reproduced exactly."""
+    torch.manual_seed(0)
+    B, Hh, dh = 8, 8, 32
+    E = Hh * dh
+    x = torch.randn(B, E, device="cuda").bfloat16(); w = (torch.randn(E, E, device="cuda") * 0.06).bfloat16()
+    bias = torch.randn(E, device="cuda") * 0.1
+    qmask = torch.zeros(B, 1, dtype=torch.uint8, device="cuda")
+    p, seed = 0.3, 12345
+    hip.set_seed_dev(None)
+    v, _ = hip.linear(x, w, bias=bias)
+    o_attn, _ = hip.attn_fwd(v, v, v, qmask, B=B, H=Hh, Sq=1, Sk=1, dh=dh, scale=dh ** -0.5, drop_p=p, drop_seed=seed)
+    o_fold, _ = hip.linear(x, w, bias=bias, drop_p=p, drop_seed=seed, drop_shift=5)
+    za, zf = (o_attn.float().view(B, Hh, dh) == 0).all(-1), (o_fold.float().view(B, Hh, dh) == 0).all(-1)
+    assert torch.equal(za, zf) and 0 < int(za.sum()) < B * Hh                 # whole heads are dropped, the same ones
+    kept = ~za[..., None].expand(B, Hh, dh).reshape(B, E)
+    assert rel(o_fold.float()[kept], o_attn.float()[kept]) < 6e-3               # kept values: v / (1 - p), one bf16 rounding apart
+    assert rel(o_attn.float()[kept], (v.float() / (1 - p))[kept]) < 6e-3
