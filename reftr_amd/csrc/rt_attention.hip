@@ -19,6 +19,7 @@
 // Dropout acts on the probabilities with the shared counter hash (index ((b*H+h)*Sq + q)*Sk + key); a fully
 // masked row gives NaN like the reference's softmax over -inf.
 #include "rt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -356,10 +357,194 @@ size_t smem_bytes(int inner, int dh) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// One query per (batch, head): the decoder's cross-attention with a single referring query per image (Sq = 1, Sk = L + h*w).
+// The MFMA kernels above are built for 16-query tiles and spend ~15 us of latency on this case; here a 256-thread workgroup
+// owns one (b, h): each thread takes keys t, t + 256, ... (a 64-B K row and V row per key), the softmax is a block
+// reduction and the output / dq a 32-wide reduction over the block.  Same arithmetic order of the definition, fp32.
+// Backward produces dq, dk and dv in the same launch.
+// ------------------------------------------------------------------------------------------------
+constexpr int Q1_MAXK = 3;            // keys per thread: Sk <= 768
+
+__device__ __forceinline__ void q1_load_row(const bf16_t* row, float* out32) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out32[c * 8 + e] = (float)v[e];
+    }
+}
+
+// block-wide sum of a 32-vector held per thread; result (all 32 values) valid in every thread
+__device__ __forceinline__ void q1_block_sum32(float* v, float (*sm)[32]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) v[d] = rt_wave_sum(v[d]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 32; ++d) sm[wave][d] = v[d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 32; ++d) v[d] = sm[0][d] + sm[1][d] + sm[2][d] + sm[3][d];
+}
+
+struct Q1Row { bf16x8 c[4]; };
+__device__ __forceinline__ Q1Row q1_raw(const bf16_t* row) {
+    Q1Row r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r.c[c] = *reinterpret_cast<const bf16x8*>(row + c * 8);
+    return r;
+}
+__device__ __forceinline__ float q1_dot(const Q1Row& r, const float* x) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)r.c[c][e] * x[c * 8 + e];
+    return a;
+}
+
+__global__ __launch_bounds__(256) void attn_q1_fwd_kernel(const rt_attn_desc p) {
+    __shared__ float sm32[4][32];
+    __shared__ float red[8];
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    // every global load of this thread is issued up front (K and V rows of its <= 3 keys): one memory round trip
+    Q1Row kr[Q1_MAXK], vr[Q1_MAXK];
+    bool ok[Q1_MAXK];
+#pragma unroll
+    for (int i = 0; i < Q1_MAXK; ++i) {
+        const int j = t + i * 256;
+        const int jj = j < p.Sk ? j : 0;
+        ok[i] = j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + jj]);
+        kr[i] = q1_raw((const bf16_t*)p.k + ((size_t)b * p.Sk + jj) * p.ldk + h * 32);
+        vr[i] = q1_raw((const bf16_t*)p.v + ((size_t)b * p.Sk + jj) * p.ldv + h * 32);
+    }
+    float q[32];
+    q1_load_row((const bf16_t*)p.q + (size_t)b * p.ldq + h * 32, q);
+    float sc[Q1_MAXK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < Q1_MAXK; ++i) {
+        sc[i] = ok[i] ? q1_dot(kr[i], q) * p.scale : -INFINITY;
+        m = fmaxf(m, sc[i]);
+    }
+    m = rt_wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < Q1_MAXK; ++i) { sc[i] = __expf(sc[i] - ms); l += sc[i]; }
+    l = rt_wave_sum(l);
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+    const float inv_l = 1.f / l;                 // fully masked row: NaN below, as the reference
+    if (t == 0 && p.lse) p.lse[bh] = ms + __logf(l);
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int i = 0; i < Q1_MAXK; ++i) {
+        const int j = t + i * 256;
+        if (j >= p.Sk) continue;
+        float pr = sc[i] * inv_l;
+        if (do_drop) pr = (rt_hash32(dseed, (uint32_t)((size_t)bh * p.Sk + j)) >= thresh) ? pr * ks : 0.f;
+        if (pr != 0.f || pr != pr) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[c * 8 + e] += pr * (float)vr[i].c[c][e];
+        }
+    }
+    q1_block_sum32(o, sm32);
+    if (t < 32) {
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) mine = (t == d) ? o[d] : mine;
+        ((bf16_t*)p.out)[(size_t)b * p.ldo + h * 32 + t] = (bf16_t)mine;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_q1_bwd_kernel(const rt_attn_bwd_desc p) {
+    __shared__ float sm32[4][32];
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H, t = threadIdx.x;
+    Q1Row kr[Q1_MAXK], vr[Q1_MAXK];
+    bool ok[Q1_MAXK];
+#pragma unroll
+    for (int i = 0; i < Q1_MAXK; ++i) {
+        const int j = t + i * 256;
+        const int jj = j < p.Sk ? j : 0;
+        ok[i] = j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + jj]);
+        kr[i] = q1_raw((const bf16_t*)p.k + ((size_t)b * p.Sk + jj) * p.ldk + h * 32);
+        vr[i] = q1_raw((const bf16_t*)p.v + ((size_t)b * p.Sk + jj) * p.ldv + h * 32);
+    }
+    float q[32], go[32], ov[32];
+    q1_load_row((const bf16_t*)p.q + (size_t)b * p.ldq + h * 32, q);
+    q1_load_row((const bf16_t*)p.dout + (size_t)b * p.ldo + h * 32, go);
+    q1_load_row((const bf16_t*)p.out + (size_t)b * p.ldo + h * 32, ov);
+    float delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) delta += go[d] * ov[d];
+    const float lse = p.lse[bh];
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
+    float dq[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+#pragma unroll
+    for (int i = 0; i < Q1_MAXK; ++i) {
+        const int j = t + i * 256;
+        if (j >= p.Sk) continue;
+        const float pr = ok[i] ? __expf(q1_dot(kr[i], q) * p.scale - lse) : 0.f;
+        float mk = 1.f;
+        if (do_drop) mk = (rt_hash32(dseed, (uint32_t)((size_t)bh * p.Sk + j)) >= thresh) ? ks : 0.f;
+        const float dp = q1_dot(vr[i], go);
+        const float ds = pr * (mk * dp - delta) * p.scale;
+        const float pd = pr * mk;
+        bf16_t* dkr = (bf16_t*)p.dk + ((size_t)b * p.Sk + j) * p.lddk + h * 32;
+        bf16_t* dvr = (bf16_t*)p.dv + ((size_t)b * p.Sk + j) * p.lddv + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 a8, b8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a8[e] = (bf16_t)(ds * q[c * 8 + e]); b8[e] = (bf16_t)(pd * go[c * 8 + e]);
+                dq[c * 8 + e] += ds * (float)kr[i].c[c][e];
+            }
+            *reinterpret_cast<bf16x8*>(dkr + c * 8) = a8;
+            *reinterpret_cast<bf16x8*>(dvr + c * 8) = b8;
+        }
+    }
+    q1_block_sum32(dq, sm32);
+    if (t < 32) {
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) mine = (t == d) ? dq[d] : mine;
+        ((bf16_t*)p.dq)[(size_t)b * p.lddq + h * 32 + t] = (bf16_t)mine;
+    }
+}
+
 extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
     if (!d || !d->q || !d->k || !d->v || !d->out) return RT_ERR_BADARG;
     if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sq <= 0) return RT_ERR_UNSUPPORTED;
     if ((d->ldq | d->ldk | d->ldv | d->ldo) & 7) return RT_ERR_UNSUPPORTED;
+    static const int q1_env = getenv("REFTR_ATTN_Q1") ? atoi(getenv("REFTR_ATTN_Q1")) : 1;
+    if (q1_env && d->Sq == 1 && d->dh == 32 && d->Sk <= 256 * Q1_MAXK) {
+        hipLaunchKernelGGL(attn_q1_fwd_kernel, dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, *d);
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
     const size_t smem = smem_bytes(d->Sk, d->dh);
     const dim3 grid((d->Sq + 127) / 128, d->B * d->H);
     int rc;
@@ -380,6 +565,12 @@ extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
     if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sq <= 0) return RT_ERR_UNSUPPORTED;
     if ((d->ldq | d->ldk | d->ldv | d->ldo | d->lddq | d->lddk | d->lddv) & 7) return RT_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    static const int q1_env = getenv("REFTR_ATTN_Q1") ? atoi(getenv("REFTR_ATTN_Q1")) : 1;
+    if (q1_env && d->Sq == 1 && d->dh == 32 && d->Sk <= 256 * Q1_MAXK) {
+        hipLaunchKernelGGL(attn_q1_bwd_kernel, dim3(d->B * d->H), dim3(256), 0, s, *d);
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
     const size_t smem1 = smem_bytes(d->Sk, d->dh), smem2 = smem_bytes(d->Sq, d->dh);
     const dim3 g1((d->Sq + 127) / 128, d->B * d->H), g2((d->Sk + 127) / 128, d->B * d->H);
     int rc;

@@ -137,6 +137,35 @@ def test_attention_dropout_mask(hip):
     assert rel(o, ref) < 4e-3
 
 
+def test_attention_single_query_kernels_with_dropout_and_mask(hip):
+    """Sq = 1 (the decoder's cross-attention with one query per image) runs on its own fwd / bwd kernels: same definition,
+    same dropout hash index ((b*H + h)*Sq + i)*Sk + j, key-padding mask, dq / dk / dv in one launch."""
+    B, H, Sq, Sk, dh = 3, 8, 1, 440, 32
+    g = torch.Generator().manual_seed(5)
+    E = H * dh
+    q = bf(torch.randn(B * Sq, E, generator=g)).float().requires_grad_(True)
+    k = bf(torch.randn(B * Sk, E, generator=g)).float().requires_grad_(True)
+    v = bf(torch.randn(B * Sk, E, generator=g)).float().requires_grad_(True)
+    kpm = torch.zeros(B, Sk, dtype=torch.uint8); kpm[1, 300:] = 1; kpm[2, ::3] = 1
+    p, seed, scale = 0.2, 4242, dh ** -0.5
+    qh = q.view(B, Sq, H, dh).transpose(1, 2); kh = k.view(B, Sk, H, dh).transpose(1, 2); vh = v.view(B, Sk, H, dh).transpose(1, 2)
+    S = qh @ kh.transpose(-1, -2) * scale
+    S = S.masked_fill(kpm.bool()[:, None, None, :], float("-inf"))
+    keep = torch.from_numpy(hash_keep(seed, np.arange(B * H * Sq * Sk, dtype=np.uint64), p).reshape(B, H, Sq, Sk))
+    out = ((S.softmax(-1) * keep / (1 - np.float32(p))) @ vh).transpose(1, 2).reshape(B * Sq, E)
+    do = bf(torch.randn(B * Sq, E, generator=g))
+    out.backward(do.float())
+    hip.set_seed_dev(None)
+    o, lse = hip.attn_fwd(q.detach().bfloat16().cuda(), k.detach().bfloat16().cuda(), v.detach().bfloat16().cuda(), kpm.cuda(),
+                          B=B, H=H, Sq=Sq, Sk=Sk, dh=dh, scale=scale, drop_p=p, drop_seed=seed)
+    assert rel(o, out) < 4e-3
+    assert rel(lse.view(B, H), torch.logsumexp(S.detach(), -1).view(B, H)) < 1e-5
+    dq, dk, dv = hip.attn_bwd(q.detach().bfloat16().cuda(), k.detach().bfloat16().cuda(), v.detach().bfloat16().cuda(), o, do.cuda(),
+                              lse, kpm.cuda(), B=B, H=H, Sq=Sq, Sk=Sk, dh=dh, scale=scale, drop_p=p, drop_seed=seed)
+    assert rel(dq, q.grad) < 1e-2 and rel(dk, k.grad) < 1e-2 and rel(dv, v.grad) < 1e-2
+    assert float(dk.float().view(B, Sk, E)[1, 300:].abs().max()) == 0.0          # masked keys: exact zeros
+
+
 # ------------------------------------------------------------------ backbone-side
 def test_stem_and_maxpool(hip):
     g = torch.Generator().manual_seed(2)
