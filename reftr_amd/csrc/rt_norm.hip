@@ -452,7 +452,7 @@ extern "C" int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stre
     int blocks = (d->M + 3) / 4;
     if (blocks > lnb) blocks = lnb;
     if (!d->dgamma && !d->dbeta && !d->partials) { blocks = (d->M + 3) / 4; if (blocks > 1024) blocks = 1024; }
-    static const int lnpb = getenv("REFTR_LNPB") ? atoi(getenv("REFTR_LNPB")) : 512;
+    static const int lnpb = getenv("REFTR_LNPB") ? atoi(getenv("REFTR_LNPB")) : 880;
     if (d->partials) { blocks = (d->M + 3) / 4; if (blocks > lnpb) blocks = lnpb; }
     if (d->partials && d->n_blocks_out) *d->n_blocks_out = blocks;
     static const int vec = getenv("REFTR_LNVEC") ? atoi(getenv("REFTR_LNVEC")) : 1;

@@ -50,7 +50,7 @@ class Net:
         self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
         self.trivial_sa = os.environ.get("REFTR_TRIVIAL_SA", "1") != "0"
         self.fold_sa = os.environ.get("REFTR_FOLD_SA", "1") != "0"
-        self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "0") != "0" and str(store.device).startswith("cuda") else None
+        self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
 
