@@ -87,6 +87,9 @@ typedef struct rt_conv_gemm_desc {
                                  (hash index = (m * N + n) >> drop_shift).  With drop_shift = log2(head_dim) this is
                                  nn.MultiheadAttention's probability dropout for a ONE-key softmax (decoder self-attention with one
                                  query per image, transformer.py:231-236): the attention launch folds into the V projection */
+    float* acc2_f32;          /* optional second fp32 destination [M, N] that the result is ADDED to (out_f32 / out_bf16 still receive
+                                 the result itself): the q/k-side input gradient of an attention layer is both passed on and summed into
+                                 the gradient of `pos` / `query_pos`, which every layer re-adds (transformer.py:154-156,168-175) */
 } rt_conv_gemm_desc;
 int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream);
 /* rt_conv_gemm_grouped — n independent rt_conv_gemm problems (HOST array of descriptors).  Dense products with K < 1024 and

@@ -17,7 +17,7 @@ namespace {
 
 struct GemmArgs {
     const bf16_t* src; const bf16_t* wgt;
-    bf16_t* out_bf16; float* out_f32; bf16_t* out_preact;
+    bf16_t* out_bf16; float* out_f32; bf16_t* out_preact; float* acc2_f32;
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed; int drop_shift;
@@ -87,6 +87,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
         for (int r = 0; r < 4; ++r) v[r] *= (1.f - (float)tt[r] * (float)tt[r]);
     }
     if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
+    if (p.acc2_f32) *reinterpret_cast<f32x4*>(p.acc2_f32 + o) += v;          // a second, accumulating destination (one owner per element)
     if (p.out_bf16) {
         bf16x4 ov;
 #pragma unroll
@@ -160,6 +161,10 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, f32x8
     if (p.out_f32) {
         *reinterpret_cast<f32x4*>(p.out_f32 + o) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(p.out_f32 + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    if (p.acc2_f32) {
+        *reinterpret_cast<f32x4*>(p.acc2_f32 + o) += f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p.acc2_f32 + o + 4) += f32x4{v[4], v[5], v[6], v[7]};
     }
     if (p.out_bf16) {
         bf16x8 ov;
@@ -714,6 +719,7 @@ static int fill_gemm_args(const rt_conv_gemm_desc* d, GemmArgs& a) {
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed;
     a.act = d->act; a.res_first = d->res_first; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.seed_dev = d->seed_dev;
     a.drop_shift = d->drop_shift;
+    a.acc2_f32 = d->acc2_f32;
     if (a.drop_shift < 0 || a.drop_shift > 16) return RT_ERR_BADARG;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
@@ -816,7 +822,7 @@ extern "C" int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_st
     return RT_OK;
 }
 
-extern "C" int rt_abi_version(void) { return 20; }
+extern "C" int rt_abi_version(void) { return 21; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

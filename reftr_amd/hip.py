@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -29,7 +29,7 @@ class ConvGemmDesc(Structure):
         ("transposed", c_int32), ("act", c_int32),
         ("gate_scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32), ("tile_hint", c_int32),
         ("out_preact", c_void_p), ("dtanh", c_void_p), ("res_first", c_int32), ("seed_dev", c_void_p),
-        ("drop_shift", c_int32),
+        ("drop_shift", c_int32), ("acc2_f32", c_void_p),
     ]
 
 
@@ -357,7 +357,7 @@ def _req(t, dtype, name):
 # --------------------------------------------------------------------------------------------
 def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=None, gate_scale=1.0,
               preact=None, dtanh=None, res_first=False, act=ACT_NONE, drop_p=0.0, drop_seed=0, transposed=False,
-              out_bf16=True, out_f32=False, out_preact=False, tile_hint=0, group=None, drop_shift=0):
+              out_bf16=True, out_f32=False, out_preact=False, tile_hint=0, group=None, drop_shift=0, acc2_f32=None):
     """out[B,DH,DW,N] = epilogue(implicit_gemm(src[B,SH,SW,SC], wgt[N,KH,KW,SC])).
 
     geom = (B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad).  Returns (out_bf16 | None, out_f32 | None)
@@ -375,12 +375,13 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
     _req(dtanh, torch.bfloat16, "dtanh")
     ob = out_bf16 if torch.is_tensor(out_bf16) else (torch.empty((M, N), dtype=torch.bfloat16, device=src.device) if out_bf16 else None)
     of = out_f32 if torch.is_tensor(out_f32) else (torch.empty((M, N), dtype=torch.float32, device=src.device) if out_f32 else None)
-    _req(ob, torch.bfloat16, "out_bf16"); _req(of, torch.float32, "out_f32")
+    _req(ob, torch.bfloat16, "out_bf16"); _req(of, torch.float32, "out_f32"); _req(acc2_f32, torch.float32, "acc2_f32")
+    assert acc2_f32 is None or acc2_f32.numel() == M * N
     assert (ob is None or ob.numel() == M * N) and (of is None or of.numel() == M * N)
     d = ConvGemmDesc(_p(src), _p(wgt), _p(ob), _p(of), _p(bias), _p(res_f32), _p(res_bf16), _p(gate),
                      _p(preact), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad,
                      1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint, None, _p(dtanh), 1 if res_first else 0, _seedp(drop_p),
-                     drop_shift)
+                     drop_shift, _p(acc2_f32))
     op = None
     if out_preact:
         op = torch.empty((M, N), dtype=torch.bfloat16, device=src.device)

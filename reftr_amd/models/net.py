@@ -346,9 +346,8 @@ class Net:
                               scale=dh ** -0.5, drop_p=r["ad"][0], drop_seed=r["ad"][1], dq=dqk[:, :E], dk=dqk[:, E:])
         grp = H.GemmGroup()
         _, dxa = self.lin_bwd(p + "self_attn.v", dv, r["x16"], res_f32=dt, out_bf16=False, out_f32=True, group=grp)
-        _, dxp = self.lin_bwd(p + "self_attn.qk", dqk, r["xp16"], out_bf16=False, out_f32=True, group=grp)
+        _, dxp = self.lin_bwd(p + "self_attn.qk", dqk, r["xp16"], out_bf16=False, out_f32=True, group=grp, acc2_f32=dpos_acc)
         grp.run()
-        H.rows_add(M, E, a_f32=dxp, out_f32=dpos_acc, accumulate=True)
         return dxa, dxp          # sum of the two = gradient w.r.t. the layer input
 
     # ------------------------------------------------------------------ decoder layer (transformer.py:231-252)
@@ -443,8 +442,7 @@ class Net:
         self.lin_bwd(p + "multihead_attn.v", dv2, mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
         self.lin_bwd(p + "multihead_attn.k", dk2, memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
         grp.run()
-        _, dt1q = self.lin_bwd(p + "multihead_attn.q", dq2, r["t1q16"], out_bf16=False, out_f32=True)
-        H.rows_add(N, E, a_f32=dt1q, out_f32=dqpos_acc, accumulate=True)
+        _, dt1q = self.lin_bwd(p + "multihead_attn.q", dq2, r["t1q16"], out_bf16=False, out_f32=True, acc2_f32=dqpos_acc)
         du, dub = self.ln_bwd(du2, r["u"], p + "norm1.", *r["st1"], dy2=dt1q, drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
         if r["fold"]:           # the head-dropout mask of the forward, applied by the backward-data product's epilogue
             dv, _ = self.lin_bwd(p + "self_attn.out_proj.", dub, r["o"], drop_p=r["ad"][0], drop_seed=r["ad"][1],
@@ -462,6 +460,5 @@ class Net:
         _, _, dv = H.attn_bwd(qk[:, :E], qk[:, E:], v, r["o"], do, r["lse"], qmask, B=B, H=Hh, Sq=T, Sk=T, dh=dh,
                               scale=sc, drop_p=r["ad"][0], drop_seed=r["ad"][1], dq=dqk[:, :E], dk=dqk[:, E:])
         _, dta = self.lin_bwd(p + "self_attn.v", dv, r["t16"], res_f32=du, out_bf16=False, out_f32=True)
-        _, dtq = self.lin_bwd(p + "self_attn.qk", dqk, r["tq16"], out_bf16=False, out_f32=True)
-        H.rows_add(N, E, a_f32=dtq, out_f32=dqpos_acc, accumulate=True)
+        _, dtq = self.lin_bwd(p + "self_attn.qk", dqk, r["tq16"], out_bf16=False, out_f32=True, acc2_f32=dqpos_acc)
         return dta, dtq
