@@ -82,8 +82,8 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* sA, int row0, int
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int DH>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const rt_attn_desc p) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const rt_attn_desc p) {
     constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Skp = (p.Sk + 31) & ~31;
@@ -93,14 +93,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const rt_attn_desc p) {
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 512);
-    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 512);
-    for (int j = threadIdx.x; j < Skp; j += 512)
+    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 64 * NW);
+    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 64 * NW);
+    for (int j = threadIdx.x; j < Skp; j += 64 * NW)
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int q = blockIdx.x * 128 + wave * 16 + li;          // this lane's query
-    if (blockIdx.x * 128 + wave * 16 >= p.Sq) return;
+    const int q = blockIdx.x * (16 * NW) + wave * 16 + li;          // this lane's query
+    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sq) return;
     bf16x8 qf[Geo<DH>::KH];
     load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
     const int nblk = Skp >> 4;
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const rt_attn_desc p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ (+ delta)
-template <int DH>
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const rt_attn_bwd_desc p) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_desc p) {
     constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Skp = (p.Sk + 31) & ~31;
@@ -185,14 +185,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const rt_attn_bwd_desc
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 512);
-    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 512);
-    for (int j = threadIdx.x; j < Skp; j += 512)
+    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 64 * NW);
+    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 64 * NW);
+    for (int j = threadIdx.x; j < Skp; j += 64 * NW)
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int q = blockIdx.x * 128 + wave * 16 + li;
-    if (blockIdx.x * 128 + wave * 16 >= p.Sq) return;
+    const int q = blockIdx.x * (16 * NW) + wave * 16 + li;
+    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sq) return;
     bf16x8 qf[KH], dof[KH], of[KH];
     load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
     load_bfrag<DH>((const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, q, p.Sq, p.ldo, lg, dof);
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const rt_attn_bwd_desc
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int DH>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const rt_attn_bwd_desc p) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd_desc p) {
     constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Sqp = (p.Sq + 31) & ~31;
@@ -265,16 +265,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const rt_attn_bwd_des
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    stage_rows<DH>(sQ, (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, p.Sq, Sqp, p.ldq, threadIdx.x, 512);
-    stage_rows<DH>(sD, (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, p.Sq, Sqp, p.ldo, threadIdx.x, 512);
-    for (int i = threadIdx.x; i < Sqp; i += 512) {
+    stage_rows<DH>(sQ, (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, p.Sq, Sqp, p.ldq, threadIdx.x, 64 * NW);
+    stage_rows<DH>(sD, (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, p.Sq, Sqp, p.ldo, threadIdx.x, 64 * NW);
+    for (int i = threadIdx.x; i < Sqp; i += 64 * NW) {
         sL[i] = (i < p.Sq) ? p.lse[(size_t)bh * p.Sq + i] : INFINITY;       // padded query rows: p = exp(-inf) = 0
         sDel[i] = (i < p.Sq) ? p.delta[(size_t)bh * p.Sq + i] : 0.f;
     }
     __syncthreads();
 
-    const int key = blockIdx.x * 128 + wave * 16 + li;         // this lane's key (MFMA column)
-    if (blockIdx.x * 128 + wave * 16 >= p.Sk) return;
+    const int key = blockIdx.x * (16 * NW) + wave * 16 + li;         // this lane's key (MFMA column)
+    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sk) return;
     bf16x8 kf[KH], vf[KH];
     load_bfrag<DH>((const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, key, p.Sk, p.ldk, lg, kf);
     load_bfrag<DH>((const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, key, p.Sk, p.ldv, lg, vf);
@@ -546,15 +546,15 @@ extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
         return RT_OK;
     }
     const size_t smem = smem_bytes(d->Sk, d->dh);
-    const dim3 grid((d->Sq + 127) / 128, d->B * d->H);
+    static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
+    const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
+    const dim3 grid((d->Sq + 16 * nw - 1) / (16 * nw), d->B * d->H);
     int rc;
-    if (d->dh == 32) {
-        if ((rc = set_smem(attn_fwd_kernel<32>, smem)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(512), smem, (hipStream_t)stream, *d);
-    } else {
-        if ((rc = set_smem(attn_fwd_kernel<64>, smem)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(512), smem, (hipStream_t)stream, *d);
-    }
+#define RT_ATTN_FWD(DHV, NWV) do { if ((rc = set_smem(attn_fwd_kernel<DHV, NWV>, smem)) != RT_OK) return rc; \
+        hipLaunchKernelGGL((attn_fwd_kernel<DHV, NWV>), grid, dim3(64 * NWV), smem, (hipStream_t)stream, *d); } while (0)
+    if (d->dh == 32) { if (nw == 8) RT_ATTN_FWD(32, 8); else if (nw == 4) RT_ATTN_FWD(32, 4); else RT_ATTN_FWD(32, 16); }
+    else             { if (nw == 8) RT_ATTN_FWD(64, 8); else if (nw == 4) RT_ATTN_FWD(64, 4); else RT_ATTN_FWD(64, 16); }
+#undef RT_ATTN_FWD
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
@@ -572,19 +572,17 @@ extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
         return RT_OK;
     }
     const size_t smem1 = smem_bytes(d->Sk, d->dh), smem2 = smem_bytes(d->Sq, d->dh);
-    const dim3 g1((d->Sq + 127) / 128, d->B * d->H), g2((d->Sk + 127) / 128, d->B * d->H);
+    static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
+    const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
+    const dim3 g1((d->Sq + 16 * nw - 1) / (16 * nw), d->B * d->H), g2((d->Sk + 16 * nw - 1) / (16 * nw), d->B * d->H);
     int rc;
-    if (d->dh == 32) {
-        if ((rc = set_smem(attn_bwd_dq_kernel<32>, smem1)) != RT_OK) return rc;
-        if ((rc = set_smem(attn_bwd_dkv_kernel<32>, smem2)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, g1, dim3(512), smem1, s, *d);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, g2, dim3(512), smem2, s, *d);
-    } else {
-        if ((rc = set_smem(attn_bwd_dq_kernel<64>, smem1)) != RT_OK) return rc;
-        if ((rc = set_smem(attn_bwd_dkv_kernel<64>, smem2)) != RT_OK) return rc;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, g1, dim3(512), smem1, s, *d);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, g2, dim3(512), smem2, s, *d);
-    }
+#define RT_ATTN_BWD(DHV, NWV) do { if ((rc = set_smem(attn_bwd_dq_kernel<DHV, NWV>, smem1)) != RT_OK) return rc; \
+        if ((rc = set_smem(attn_bwd_dkv_kernel<DHV, NWV>, smem2)) != RT_OK) return rc; \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, NWV>), g1, dim3(64 * NWV), smem1, s, *d); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, NWV>), g2, dim3(64 * NWV), smem2, s, *d); } while (0)
+    if (d->dh == 32) { if (nw == 8) RT_ATTN_BWD(32, 8); else if (nw == 4) RT_ATTN_BWD(32, 4); else RT_ATTN_BWD(32, 16); }
+    else             { if (nw == 8) RT_ATTN_BWD(64, 8); else if (nw == 4) RT_ATTN_BWD(64, 4); else RT_ATTN_BWD(64, 16); }
+#undef RT_ATTN_BWD
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
