@@ -49,12 +49,55 @@ template <int DH> struct Geo {
 // rows [0, rows) of a [*, ld] bf16 matrix (head slice) -> LDS rows of stride RS; rows [rows, rows_pad) zeroed
 template <int DH>
 __device__ __forceinline__ void stage_rows(unsigned char* dst, const bf16_t* src, int rows, int rows_pad, int ld, int tid, int nthreads) {
-    constexpr int RS = Geo<DH>::RS, CPR = DH / 8;
-    for (int c = tid; c < rows_pad * CPR; c += nthreads) {
-        const int r = c / CPR, cc = c % CPR;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < rows) v = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + cc * 8);
-        *reinterpret_cast<uint4*>(dst + r * RS + cc * 16) = v;
+    constexpr int RS = Geo<DH>::RS, CPR = DH / 8, U = 4;
+    // U independent 16-B loads in flight per thread before the first LDS store: the copy is one or two memory round trips, not
+    // one per 16 B (a load -> store loop serialises on the load latency: 4-8 us for a 28 KB head slice)
+    const int total = rows_pad * CPR;
+    for (int c0 = tid; c0 < total; c0 += nthreads * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nthreads;
+            const int r = c / CPR, cc = c % CPR;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (c < total && r < rows) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)r * ld + cc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nthreads;
+            const int r = c / CPR, cc = c % CPR;
+            if (c < total) *reinterpret_cast<uint4*>(dst + r * RS + cc * 16) = v[u];
+        }
+    }
+}
+
+// two matrices at once (K and V, or Q and dO): both sets of loads are in flight together
+template <int DH>
+__device__ __forceinline__ void stage_rows2(unsigned char* dst0, const bf16_t* src0, int ld0, unsigned char* dst1, const bf16_t* src1, int ld1,
+                                            int rows, int rows_pad, int tid, int nthreads) {
+    constexpr int RS = Geo<DH>::RS, CPR = DH / 8, U = 4;
+    const int total = rows_pad * CPR;
+    for (int c0 = tid; c0 < total; c0 += nthreads * U) {
+        uint4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nthreads;
+            const int r = c / CPR, cc = c % CPR;
+            a[u] = make_uint4(0, 0, 0, 0); b[u] = make_uint4(0, 0, 0, 0);
+            if (c < total && r < rows) {
+                a[u] = *reinterpret_cast<const uint4*>(src0 + (size_t)r * ld0 + cc * 8);
+                b[u] = *reinterpret_cast<const uint4*>(src1 + (size_t)r * ld1 + cc * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * nthreads;
+            const int r = c / CPR, cc = c % CPR;
+            if (c < total) {
+                *reinterpret_cast<uint4*>(dst0 + r * RS + cc * 16) = a[u];
+                *reinterpret_cast<uint4*>(dst1 + r * RS + cc * 16) = b[u];
+            }
+        }
     }
 }
 
@@ -93,8 +136,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const rt_attn_desc p)
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 64 * NW);
-    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 64 * NW);
+    stage_rows2<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.ldk,
+                    sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.ldv, p.Sk, Skp, threadIdx.x, 64 * NW);
     for (int j = threadIdx.x; j < Skp; j += 64 * NW)
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
@@ -173,6 +216,103 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const rt_attn_desc p)
     }
 }
 
+// Forward with the score row kept in registers (NT 16-key tiles, fully unrolled): the NT score MFMAs of a wave are
+// independent and issue back to back, the softmax runs over registers, and the scores are not recomputed for the P V pass.
+// The two-pass kernel above walks 2 x NT dependent [LDS read -> MFMA -> exp] steps per wave and is latency-bound at one
+// workgroup per CU (88 KB of LDS for S = 440).
+template <int DH, int NW, int NT>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_reg_kernel(const rt_attn_desc p) {
+    constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Skp = (p.Sk + 31) & ~31;
+    unsigned char* sK = smem;
+    unsigned char* sV = sK + (size_t)Skp * RS;
+    float* sBias = reinterpret_cast<float*>(sV + (size_t)Skp * RS);
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    stage_rows2<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.ldk,
+                    sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.ldv, p.Sk, Skp, threadIdx.x, 64 * NW);
+    for (int j = threadIdx.x; j < Skp; j += 64 * NW)
+        sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
+    __syncthreads();
+
+    const int q = blockIdx.x * (16 * NW) + wave * 16 + li;
+    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sq) return;
+    bf16x8 qf[Geo<DH>::KH];
+    load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
+    const int nblk = Skp >> 4;                  // <= NT, even
+
+    f32x4 sc[NT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < NT; ++blk) {
+        if (blk < nblk) {
+            const f32x4 acc = tile_dot<DH>(sK, blk * 16, li, lg, qf);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + blk * 16 + lg * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[blk][r] = acc[r] * p.scale + bias[r]; m = fmaxf(m, sc[blk][r]); }
+        } else {
+            sc[blk] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    }
+    float M = fmaxf(m, __shfl_xor(m, 16, 64));
+    M = fmaxf(M, __shfl_xor(M, 32, 64));
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    float l = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NT; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[blk][r] = __expf(sc[blk][r] - Ms); l += sc[blk][r]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.f / l;                 // fully masked row: 0 * inf = NaN below, as the reference
+
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
+    const uint32_t drop_row = (uint32_t)(((size_t)bh * p.Sq + q) * p.Sk);
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tr_r = 4 * lg + (li >> 2), tr_c = (li & 3) * 8;
+#pragma unroll
+    for (int c = 0; c < NT / 2; ++c) {
+        if (2 * c < nblk) {
+            float pv[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int k0 = c * 32 + half * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = sc[2 * c + half][r] * inv_l;
+                    if (do_drop) pr = (rt_hash32(dseed, drop_row + (uint32_t)(k0 + lg * 4 + r)) >= thresh) ? pr * ks : 0.f;
+                    pv[half * 4 + r] = pr;
+                }
+            }
+            const bf16x8 pf = pack8(pv);
+            const unsigned char* v0 = sV + (c * 32 + tr_r) * RS + tr_c;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const bf16x8 vf = tr_pair(v0 + t * 32, v0 + 16 * RS + t * 32);
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
+            }
+        }
+    }
+    if (q < p.Sq) {
+        bf16_t* orow = (bf16_t*)p.out + ((size_t)b * p.Sq + q) * p.ldo + h * DH;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)o[t][r];
+            *reinterpret_cast<bf16x4*>(orow + t * 16 + lg * 4) = ov;
+        }
+        if (lg == 0 && p.lse) p.lse[(size_t)bh * p.Sq + q] = M + __logf(l);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dQ (+ delta)
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_desc p) {
@@ -185,8 +325,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    stage_rows<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.Sk, Skp, p.ldk, threadIdx.x, 64 * NW);
-    stage_rows<DH>(sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.Sk, Skp, p.ldv, threadIdx.x, 64 * NW);
+    stage_rows2<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.ldk,
+                    sV, (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, p.ldv, p.Sk, Skp, threadIdx.x, 64 * NW);
     for (int j = threadIdx.x; j < Skp; j += 64 * NW)
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
@@ -265,8 +405,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    stage_rows<DH>(sQ, (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, p.Sq, Sqp, p.ldq, threadIdx.x, 64 * NW);
-    stage_rows<DH>(sD, (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, p.Sq, Sqp, p.ldo, threadIdx.x, 64 * NW);
+    stage_rows2<DH>(sQ, (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, p.ldq,
+                    sD, (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, p.ldo, p.Sq, Sqp, threadIdx.x, 64 * NW);
     for (int i = threadIdx.x; i < Sqp; i += 64 * NW) {
         sL[i] = (i < p.Sq) ? p.lse[(size_t)bh * p.Sq + i] : INFINITY;       // padded query rows: p = exp(-inf) = 0
         sDel[i] = (i < p.Sq) ? p.delta[(size_t)bh * p.Sq + i] : 0.f;
@@ -552,6 +692,17 @@ extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
     int rc;
 #define RT_ATTN_FWD(DHV, NWV) do { if ((rc = set_smem(attn_fwd_kernel<DHV, NWV>, smem)) != RT_OK) return rc; \
         hipLaunchKernelGGL((attn_fwd_kernel<DHV, NWV>), grid, dim3(64 * NWV), smem, (hipStream_t)stream, *d); } while (0)
+    static const int reg_env = getenv("REFTR_ATTN_REG") ? atoi(getenv("REFTR_ATTN_REG")) : 1;
+    const int tiles = ((d->Sk + 31) & ~31) >> 4;
+    if (reg_env && nw == 8 && tiles <= 28) {          // 28 tiles = 180 VGPRs; 48 would spill: longer rows keep the two-pass kernel
+#define RT_ATTN_FWD_REG(DHV, NTV) do { if ((rc = set_smem(attn_fwd_reg_kernel<DHV, 8, NTV>, smem)) != RT_OK) return rc; \
+        hipLaunchKernelGGL((attn_fwd_reg_kernel<DHV, 8, NTV>), grid, dim3(512), smem, (hipStream_t)stream, *d); } while (0)
+        if (d->dh == 32) { if (tiles <= 8) RT_ATTN_FWD_REG(32, 8); else RT_ATTN_FWD_REG(32, 28); }
+        else             { if (tiles <= 8) RT_ATTN_FWD_REG(64, 8); else RT_ATTN_FWD_REG(64, 28); }
+#undef RT_ATTN_FWD_REG
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
     if (d->dh == 32) { if (nw == 8) RT_ATTN_FWD(32, 8); else if (nw == 4) RT_ATTN_FWD(32, 4); else RT_ATTN_FWD(32, 16); }
     else             { if (nw == 8) RT_ATTN_FWD(64, 8); else if (nw == 4) RT_ATTN_FWD(64, 4); else RT_ATTN_FWD(64, 16); }
 #undef RT_ATTN_FWD
