@@ -42,4 +42,4 @@ for it in range(2):
         a = st.view_of(G0, name); b = st.view_of(G1, name)
         if not torch.isfinite(b).all() or float((a - b).abs().max()) > 1e-5 * (float(a.abs().max()) + 1e-12) + 1e-9:
             bad.append((name, float((a - b).abs().max()) if torch.isfinite(b).all() else float("nan"), float(a.abs().max())))
-    print("step", it, len(bad), "params differ"); [print("   ", x) for x in bad[:30]]
+    print("step", it, len(bad), "params differ"); [print("   ", x) for x in bad]

@@ -182,11 +182,15 @@ __global__ __launch_bounds__(256) void qenc_attn_bwd_kernel(const float* __restr
     __syncthreads();
     for (int l = threadIdx.x; l < L; l += 256) sds[l] = wr[l] * (sds[l] - dot);
     __syncthreads();
-    // blockIdx.y splits the token range of this last (atomic-issue bound) loop four ways
-    const int l0 = (int)blockIdx.y * ((L + (int)gridDim.y - 1) / (int)gridDim.y);
-    const int l1 = min(L, l0 + (L + (int)gridDim.y - 1) / (int)gridDim.y);
-    for (int d = threadIdx.x; d < E; d += 256) {
-        float gk = 0.f;
+    // Last (atomic-issue bound) loop: blockIdx.y owns 64 features, the four waves split the token range; the four partial
+    // dk sums meet in LDS and are added in a fixed order, so dk gets ONE add per (phrase, feature) -- with one phrase per image
+    // every output of this kernel is bit-reproducible (a four-way atomic sum here used to flip bf16 roundings downstream).
+    __shared__ float gks[4][64];
+    const int d = (int)blockIdx.y * 64 + lane;
+    const int per = (L + 3) >> 2;
+    const int l0 = wave * per, l1 = min(L, l0 + per);
+    float gk = 0.f;
+    if (d < E) {
         const float kd = k[(size_t)b * E + d], dcd = dcr[d];
         for (int l = l0; l < l1; ++l) {
             const size_t o = ((size_t)b * L + l) * E + d;
@@ -194,8 +198,10 @@ __global__ __launch_bounds__(256) void qenc_attn_bwd_kernel(const float* __restr
             atomicAdd(dqs + o, sds[l] * kd);
             atomicAdd(dvs + o, wr[l] * dcd);
         }
-        atomicAdd(dk + (size_t)b * E + d, gk);
     }
+    gks[wave][lane] = gk;
+    __syncthreads();
+    if (wave == 0 && d < E) atomicAdd(dk + (size_t)b * E + d, (gks[0][lane] + gks[1][lane]) + (gks[2][lane] + gks[3][lane]));
 }
 
 
@@ -312,7 +318,7 @@ extern "C" int rt_qenc_attn_bwd(const float* k, const float* qs, const float* vs
                                 float* dk, float* dqs, float* dvs, int B, int P, int L, int E, rt_stream_t stream) {
     if (!k || !qs || !vs || !w || !dc || !dk || !dqs || !dvs) return RT_ERR_BADARG;
     if (L > 128 || L <= 0) return RT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(qenc_attn_bwd_kernel, dim3(B * P, 4), dim3(256), 0, (hipStream_t)stream, k, qs, vs, w, dc, dk, dqs, dvs, P, L, E);
+    hipLaunchKernelGGL(qenc_attn_bwd_kernel, dim3(B * P, (E + 63) / 64), dim3(256), 0, (hipStream_t)stream, k, qs, vs, w, dc, dk, dqs, dvs, P, L, E);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
