@@ -117,15 +117,18 @@ __global__ void context_mask_kernel(const uint8_t* smask, const uint8_t* phrase_
 // ---------------------------------------------------------------- QueryEncoder attention
 // models/reftr_transformer.py:48-55: w[b,j,:] = softmax_l(k[b] . qs[b,l] masked by ctx[b,j,l]) (NO 1/sqrt(d)),
 // c[b,j,:] = sum_l w[b,j,l] vs[b,l,:].   One block per (b, j); E <= 256, L <= 128.
-__global__ __launch_bounds__(256) void qenc_attn_fwd_kernel(const float* __restrict__ k, const float* __restrict__ qs,
-                                                            const float* __restrict__ vs, const uint8_t* __restrict__ ctx,
-                                                            float* __restrict__ wout, float* __restrict__ cout,
-                                                            int P, int L, int E) {
+__global__ __launch_bounds__(1024) void qenc_attn_fwd_kernel(const float* __restrict__ k, const float* __restrict__ qs,
+                                                             const float* __restrict__ vs, const uint8_t* __restrict__ ctx,
+                                                             float* __restrict__ wout, float* __restrict__ cout,
+                                                             int P, int L, int E) {
+    // 16 waves: the L score rows go round-robin over the waves (one 1-KB row load + a wave reduction each), the weighted sum
+    // over tokens is split four ways over the waves' quarters and met in LDS -- the 8-workgroup launch is pure latency
     __shared__ float sw[128];
-    __shared__ float red[16];
+    __shared__ float red[32];
+    __shared__ float part[4][256];
     const int b = blockIdx.x / P, j = blockIdx.x % P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int l = wave; l < L; l += 4) {
+    for (int l = wave; l < L; l += 16) {
         float s = 0.f;
         for (int d = lane; d < E; d += 64) s += k[(size_t)b * E + d] * qs[((size_t)b * L + l) * E + d];
         s = rt_wave_sum(s);
@@ -133,40 +136,51 @@ __global__ __launch_bounds__(256) void qenc_attn_fwd_kernel(const float* __restr
     }
     __syncthreads();
     float m = -INFINITY;
-    for (int l = threadIdx.x; l < L; l += 256) m = fmaxf(m, sw[l]);
+    for (int l = threadIdx.x; l < L; l += 1024) m = fmaxf(m, sw[l]);
     m = rt_wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
     __syncthreads();
     float e = 0.f;
-    for (int l = threadIdx.x; l < L; l += 256) { const float x = __expf(sw[l] - m); sw[l] = x; e += x; }
+    for (int l = threadIdx.x; l < L; l += 1024) { const float x = __expf(sw[l] - m); sw[l] = x; e += x; }
     e = rt_wave_sum(e);
-    if (lane == 0) red[wave] = e;
+    if (lane == 0) red[16 + wave] = e;
     __syncthreads();
-    const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
-    for (int l = threadIdx.x; l < L; l += 256) { sw[l] *= inv; wout[((size_t)b * P + j) * L + l] = sw[l]; }
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[16 + w];
+    const float inv = 1.f / tot;
     __syncthreads();
-    for (int d = threadIdx.x; d < E; d += 256) {
-        float a = 0.f;
-        for (int l = 0; l < L; ++l) a += sw[l] * vs[((size_t)b * L + l) * E + d];
-        cout[((size_t)b * P + j) * E + d] = a;
-    }
+    for (int l = threadIdx.x; l < L; l += 1024) { sw[l] *= inv; wout[((size_t)b * P + j) * L + l] = sw[l]; }
+    __syncthreads();
+    // c[d] = sum_l w[l] vs[l][d]: thread (quarter, d) sums its quarter of the tokens, the quarters meet in a fixed order
+    const int qt = threadIdx.x >> 8, d = threadIdx.x & 255;
+    const int per = (L + 3) >> 2, l0 = qt * per, l1 = min(L, l0 + per);
+    float a = 0.f;
+    if (d < E)
+        for (int l = l0; l < l1; ++l) a += sw[l] * vs[((size_t)b * L + l) * E + d];
+    part[qt][d] = a;
+    __syncthreads();
+    if (qt == 0 && d < E) cout[((size_t)b * P + j) * E + d] = (part[0][d] + part[1][d]) + (part[2][d] + part[3][d]);
 }
 
 // backward: dvs[b,l,:] += w[l] dc[:]; dw[l] = dc . vs[l]; ds = w (dw - sum w dw); dk[b,:] += ds[l] qs[l]; dqs[b,l,:] += ds[l] k
-__global__ __launch_bounds__(256) void qenc_attn_bwd_kernel(const float* __restrict__ k, const float* __restrict__ qs,
-                                                            const float* __restrict__ vs, const float* __restrict__ w,
-                                                            const float* __restrict__ dc, float* __restrict__ dk,
-                                                            float* __restrict__ dqs, float* __restrict__ dvs,
-                                                            int P, int L, int E) {
+__global__ __launch_bounds__(1024) void qenc_attn_bwd_kernel(const float* __restrict__ k, const float* __restrict__ qs,
+                                                             const float* __restrict__ vs, const float* __restrict__ w,
+                                                             const float* __restrict__ dc, float* __restrict__ dk,
+                                                             float* __restrict__ dqs, float* __restrict__ dvs,
+                                                             int P, int L, int E) {
     __shared__ float sds[128];
     __shared__ float red[16];
+    __shared__ float gks[16][64];
     const int b = blockIdx.x / P, j = blockIdx.x % P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* wr = w + ((size_t)b * P + j) * L;
     const float* dcr = dc + ((size_t)b * P + j) * E;
-    for (int l = wave; l < L; l += 4) {
+    for (int l = wave; l < L; l += 16) {
         float s = 0.f;
         for (int d = lane; d < E; d += 64) s += dcr[d] * vs[((size_t)b * L + l) * E + d];
         s = rt_wave_sum(s);
@@ -174,20 +188,21 @@ __global__ __launch_bounds__(256) void qenc_attn_bwd_kernel(const float* __restr
     }
     __syncthreads();
     float acc = 0.f;
-    for (int l = threadIdx.x; l < L; l += 256) acc += wr[l] * sds[l];
+    for (int l = threadIdx.x; l < L; l += 1024) acc += wr[l] * sds[l];
     acc = rt_wave_sum(acc);
     if (lane == 0) red[wave] = acc;
     __syncthreads();
-    const float dot = red[0] + red[1] + red[2] + red[3];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dot += red[i];
     __syncthreads();
-    for (int l = threadIdx.x; l < L; l += 256) sds[l] = wr[l] * (sds[l] - dot);
+    for (int l = threadIdx.x; l < L; l += 1024) sds[l] = wr[l] * (sds[l] - dot);
     __syncthreads();
-    // Last (atomic-issue bound) loop: blockIdx.y owns 64 features, the four waves split the token range; the four partial
-    // dk sums meet in LDS and are added in a fixed order, so dk gets ONE add per (phrase, feature) -- with one phrase per image
+    // Last (atomic-issue bound) loop: blockIdx.y owns 64 features, the sixteen waves split the token range; the partial dk
+    // sums meet in LDS and are added in a fixed order, so dk gets ONE add per (phrase, feature) -- with one phrase per image
     // every output of this kernel is bit-reproducible (a four-way atomic sum here used to flip bf16 roundings downstream).
-    __shared__ float gks[4][64];
     const int d = (int)blockIdx.y * 64 + lane;
-    const int per = (L + 3) >> 2;
+    const int per = (L + 15) >> 4;
     const int l0 = wave * per, l1 = min(L, l0 + per);
     float gk = 0.f;
     if (d < E) {
@@ -201,7 +216,12 @@ __global__ __launch_bounds__(256) void qenc_attn_bwd_kernel(const float* __restr
     }
     gks[wave][lane] = gk;
     __syncthreads();
-    if (wave == 0 && d < E) atomicAdd(dk + (size_t)b * E + d, (gks[0][lane] + gks[1][lane]) + (gks[2][lane] + gks[3][lane]));
+    if (wave == 0 && d < E) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += gks[i][lane];
+        atomicAdd(dk + (size_t)b * E + d, t);
+    }
 }
 
 
@@ -309,7 +329,8 @@ extern "C" int rt_qenc_attn_fwd(const float* k, const float* qs, const float* vs
                                 int B, int P, int L, int E, rt_stream_t stream) {
     if (!k || !qs || !vs || !ctx || !w || !c) return RT_ERR_BADARG;
     if (L > 128 || L <= 0) return RT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(qenc_attn_fwd_kernel, dim3(B * P), dim3(256), 0, (hipStream_t)stream, k, qs, vs, ctx, w, c, P, L, E);
+    if (E > 256) return RT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(qenc_attn_fwd_kernel, dim3(B * P), dim3(1024), 0, (hipStream_t)stream, k, qs, vs, ctx, w, c, P, L, E);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
@@ -318,7 +339,7 @@ extern "C" int rt_qenc_attn_bwd(const float* k, const float* qs, const float* vs
                                 float* dk, float* dqs, float* dvs, int B, int P, int L, int E, rt_stream_t stream) {
     if (!k || !qs || !vs || !w || !dc || !dk || !dqs || !dvs) return RT_ERR_BADARG;
     if (L > 128 || L <= 0) return RT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(qenc_attn_bwd_kernel, dim3(B * P, (E + 63) / 64), dim3(256), 0, (hipStream_t)stream, k, qs, vs, w, dc, dk, dqs, dvs, P, L, E);
+    hipLaunchKernelGGL(qenc_attn_bwd_kernel, dim3(B * P, (E + 63) / 64), dim3(1024), 0, (hipStream_t)stream, k, qs, vs, w, dc, dk, dqs, dvs, P, L, E);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
