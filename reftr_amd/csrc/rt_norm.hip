@@ -309,6 +309,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const rt_groupnorm_desc p
     __shared__ float sm[256][2];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpg = p.C / p.G;
+    // 8 threads per group (G <= 32) take the chunks round-robin, then a fixed 3-step butterfly inside each 8-lane group:
+    // one round of loads instead of a serial walk over the groups (this prologue runs in every workgroup)
+    if (p.G <= 32) {
+        const int g = tid >> 3, sub = tid & 7;
+        float s = 0.f, ss = 0.f;
+        if (g < p.G)
+            for (int ch = sub; ch < p.chunks; ch += 8) {
+                const float* q = p.partials + (((size_t)b * p.chunks + ch) * p.G + g) * 2;
+                s += q[0]; ss += q[1];
+            }
+        for (int o = 4; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+        if (g < p.G && sub == 0) {
+            sm[g][0] = s; sm[g][1] = ss;
+            if (blockIdx.x == 0) { p.stats[((size_t)b * p.G + g) * 2] = s; p.stats[((size_t)b * p.G + g) * 2 + 1] = ss; }
+        }
+    } else
     for (int g = wave; g < p.G; g += 4) {
         float s = 0.f, ss = 0.f;
         for (int ch = lane; ch < p.chunks; ch += 64) {
