@@ -217,11 +217,11 @@ def main():
     if roof is not None:
         # HBM bytes per launch from the PMC passes of this same command (benchmarks/pmc_passes.sh -> tools/pmc_traffic.py;
         # FETCH_SIZE and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected inside the timed process)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01m_pmc_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01n_pmc_traffic.json")
         if os.path.exists(pmc) and B == 8 and S_ == 640:
             t = json.load(open(pmc))["gemm_family"]
             roof["traffic"] = t["hbm_bytes_per_step"] / max(len(recs), 1)
-            roof["traffic_unit"] = "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01m_pmc_traffic.json)"
+            roof["traffic_unit"] = "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01n_pmc_traffic.json)"
             roof["algorithmic_bytes_per_launch"] = sum(r["bytes"] for r in recs) / max(len(recs), 1)
     out = {
         "metric": "images/sec training step, RefCOCO R50 640x640 bs=8/GPU", "value": value, "unit": "images/s",
