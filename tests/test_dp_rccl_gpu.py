@@ -76,3 +76,27 @@ def test_dp_schedule_single_rank_rccl_follows_the_eager_loop(hip, single_rank_gr
         # rounding the gradients to bf16 is a larger perturbation of the same kind
         t3 = 8e-2 if dtype == "bf16" else 3e-2
         assert abs(l[1] - le[1]) < 2e-3 * abs(le[1]) and abs(l[2] - le[2]) < t3 * abs(le[2]), (l, le)
+
+
+def test_train_one_epoch_under_the_dp_wrapper(hip, single_rank_group):
+    """The reference's entry point with the data-parallel wrapper: batches replayed from the per-segment graphs, collectives
+    between replays, meters reduced across ranks (util/misc.py:136-160) -- runs and learns on a fixed-shape loader."""
+    from reftr_amd.engine_vg import train_one_epoch
+    from reftr_amd.optim import FusedAdamW
+    from reftr_amd.parallel import DistributedDataParallel
+    from reftr_amd.util.misc import NestedTensor
+    b1 = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    loader = []
+    for samples, targets in [b1] * 4:
+        s = {k: v for k, v in samples.items() if k not in ("img", "img_mask")}
+        s["img"] = NestedTensor(samples["img"], samples["img_mask"])
+        loader.append((s, targets))
+    model, crit, P, ocfg = build(small=True)
+    opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    ddp = DistributedDataParallel(model)
+    stats = train_one_epoch(ddp, crit, loader, opt, None, torch.device("cuda"), 0, max_norm=0.1)
+    caps = model._captured_steps
+    assert len(caps) == 1 and not next(iter(caps.values())).deferred and next(iter(caps.values())).phases == ["main", "bert", "layer4"]
+    assert opt.step_count == 4 and stats["loss"] > 0 and stats["grad_norm"] > 0
+    moved = (model.state_dict()["bbox_embed.layers.1.weight"].float().cpu() - P["bbox_embed.layers.1.weight"]).abs().max()
+    assert 1e-5 < float(moved) < 1e-3
