@@ -719,9 +719,8 @@ def qenc_attn_fwd(k, qs, vs, ctx):
 def qenc_attn_bwd(k, qs, vs, w, dc):
     B, L, E = qs.shape
     P = w.shape[1]
-    dk = torch.zeros((B, E), dtype=torch.float32, device=qs.device)
-    dqs = torch.zeros((B, L, E), dtype=torch.float32, device=qs.device)
-    dvs = torch.zeros((B, L, E), dtype=torch.float32, device=qs.device)
+    zz = torch.zeros(B * E + 2 * B * L * E, dtype=torch.float32, device=qs.device)       # one clear for the three outputs
+    dk, dqs, dvs = zz[:B * E].view(B, E), zz[B * E:B * E + B * L * E].view(B, L, E), zz[B * E + B * L * E:].view(B, L, E)
     _check(lib().rt_qenc_attn_bwd(_p(k), _p(qs), _p(vs), _p(w), _p(dc), _p(dk), _p(dqs), _p(dvs), B, P, L, E, _stream()),
            "rt_qenc_attn_bwd")
     return dk, dqs, dvs

@@ -421,7 +421,8 @@ class RefTR(nn.Module):
         dy2 = H.small_dgrad(dl, l2.w32, gate=sv["y2"])
         dy1, _ = net.lin_bwd("bbox_embed.layers.1.", dy2, sv["y1"], gate=sv["y1"])
         _, dhs = net.lin_bwd("bbox_embed.layers.0.", dy1, sv["hs16"], out_bf16=False, out_f32=True)
-        dmem = f32z(M, E); dmemp = f32z(M, E); dqpos = f32z(N, E)
+        zz = f32z(2 * M + N, E)          # one clear for the three fp32 accumulators of the decoder backward
+        dmem, dmemp, dqpos = zz[:M], zz[M:2 * M], zz[2 * M:]
 
         # ---- RES head (its gradients enter the last decoder output, the encoder memory, input_proj and the ResNet)
         seg_dsrc, seg_extra = None, None
