@@ -15,10 +15,16 @@ Extra objects on the JSON line:
   roofline      MFMA roofline of the dominant kernel family (the implicit-GEMM conv/linear kernels
                 rt_conv_gemm + rt_conv_wgrad): algorithmic 2*MAC FLOPs of their launches in one step divided by
                 the summed launch durations, measured with HIP events on the launch stream in an instrumented
-                pass of the same step right after the timed region; peak = 2.5 PFLOP/s dense bf16.
+                pass of the same step right after the timed region (every rank runs the pass so that the
+                collectives of N > 1 match; rank 0 reports its own events, collectives excluded);
+                peak = 2.5 PFLOP/s dense bf16.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes
+                (FETCH_SIZE / WRITE_SIZE, separate runs: benchmarks/round_artifacts.sh -> profiles/*_pmc_traffic.json);
+                it is only reported when that file was taken on THIS build (build_id) with the same launch count.
   step_roofline the same ratio for the whole step (219.56 GFLOP/img from SURVEY.md §8d x img/s).
   cpu_baseline  the CPU oracle (oracle/reftr_oracle.py, the restatement pinned against the reference) running
                 the same loop body on the host cores for a bounded sample (rank 0, N = 1 only).
+`value` / `ms_per_step` come from the wall time of the K timed steps (the driver's contract); `ms_per_step_median` is the
+median of the K per-step host timings (each step ends in the reference loop's `.item()` sync, engine_vg.py:53).
 """
 import argparse
 import json
@@ -61,7 +67,7 @@ def synth_batch(B, H, W, L, device, seed):
     return samples, targets
 
 
-def cpu_baseline(B, H, W, L, max_seconds=25.0, sample_batch=2, threads=32):
+def cpu_baseline(B, H, W, L, max_seconds=28.0, sample_batch=2, threads=32):
     """Times the oracle's train_step (fp32, dropout on, clip 0.1, AdamW) on the host cores, on a bounded sample:
     `sample_batch` images of the same workload (per-image cost of this path is batch-independent on CPU)."""
     from oracle import reftr_oracle as O
@@ -73,29 +79,28 @@ def cpu_baseline(B, H, W, L, max_seconds=25.0, sample_batch=2, threads=32):
     P = formula_state(param_shapes(cfg))
     samples, targets = synth_batch(sample_batch, H, W, L, "cpu", 1234)
     state = {}
-    t0 = time.time()
-    O.train_step(P, samples, targets, cfg, state, 1, max_norm=0.1, train=True)       # warm-up
-    warm = time.time() - t0
+    t_start = time.time()
+    step = 1
+    for _ in range(2):                                                                # warm-up (2)
+        O.train_step(P, samples, targets, cfg, state, step, max_norm=0.1, train=True)
+        step += 1
     times = []
-    step = 2
-    while sum(times) + warm < max_seconds and len(times) < 3:
+    while len(times) < 10 and (not times or time.time() - t_start + times[-1] < max_seconds):
         t0 = time.time()
         O.train_step(P, samples, targets, cfg, state, step, max_norm=0.1, train=True)
         times.append(time.time() - t0)
         step += 1
-    if not times:
-        times = [warm]
     med = sorted(times)[len(times) // 2]
     return {"value": sample_batch / med, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} timed step(s) after 1 warm-up on {sample_batch} images of the same workload "
+            "sample": f"median of {len(times)} timed step(s) after 2 warm-ups on {sample_batch} images of the same workload "
                       f"({H}x{W}, L={L}, fp32, dropout on, clip 0.1, AdamW), torch CPU threads = {cores}"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,10 +171,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    trace = []
+    trace, per_step = [], []
+    tp = t0
     for _ in range(args.steps):
         loss_value = step()[0]
         trace.append(loss_value)
+        tn = time.perf_counter(); per_step.append(tn - tp); tp = tn
     if os.environ.get("BENCH_TRACE") and rank == 0:
         print("[bench] losses:", " ".join("%.4g" % v for v in trace), file=sys.stderr)
         print("[bench] step_dev", int(opt.step_dev), "seed_dev", int(model.seed_dev), "gnorm", float(opt.grad_norm),
@@ -189,19 +196,28 @@ def main():
     value = B * world * args.steps / el
 
     roof = None
-    if rank == 0 and world == 1 and not force_dist and not args.no_kernel_roofline:   # (collectives need every rank)
+    if not args.no_kernel_roofline:
         recs = []
         # HIP events bracket every rt_conv_gemm / rt_conv_wgrad launch on the launch stream.  The stream is first blocked
         # by a spin kernel while the host enqueues the whole step (no host sync inside), so the kernels then run back to
-        # back as they do under graph replay and the event pairs measure kernel time, not host launch gaps.
+        # back as they do under graph replay and the event pairs measure kernel time, not host launch gaps.  With N > 1
+        # (or the forced single-rank exchange) EVERY rank runs this pass -- the eager loop body, whose collectives match
+        # across ranks -- and rank 0 reports its own events; the all-reduces are not among the timed launches.
         side_was = model.net.side.enabled
         model.net.side.enabled = False          # one stream for this pass: per-launch durations must be additive
-        if mode == "hipgraph":
+        dp = world > 1 or force_dist
+        if mode == "hipgraph" and not dp:
             torch.cuda.synchronize()
             torch.cuda._sleep(int(2.4e9 * 0.12))
             hip.set_launch_timer(recs)
             cap._fwd_bwd(); cap._opt()
         else:
+            if mode == "hipgraph":
+                cap.flush()
+            torch.cuda.synchronize()
+            if dp:
+                dist.barrier()
+            torch.cuda._sleep(int(2.4e9 * 0.12))
             hip.set_launch_timer(recs)
             eager_step()
         torch.cuda.synchronize()
@@ -210,28 +226,49 @@ def main():
         fl = sum(r["flops"] for r in recs)
         tm = sum(r["start"].elapsed_time(r["end"]) for r in recs) * 1e-3
         ach = fl / tm / 1e12
-        roof = {"bound": "mfma", "kernel": "rt_conv_gemm / rt_conv_wgrad(+_grouped) kernels (conv_gemm_dma_kernel, conv_wgrad_dma*_kernel, skinny / small-M)",
-                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
-                "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3}
+        if rank == 0:
+            roof = {"bound": "mfma", "kernel": "rt_conv_gemm / rt_conv_wgrad(+_grouped) kernels (conv_gemm_dma_kernel, conv_wgrad*_kernel, skinny / small-M)",
+                    "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                    "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
+                    "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3,
+                    "algorithmic_bytes_per_launch": sum(r["bytes"] for r in recs) / max(len(recs), 1),
+                    "measured_on": "rank 0, HIP events around every launch of the family on the launch stream"}
+    from reftr_amd._build import build_id
+    bid = build_id()
     if roof is not None:
-        # HBM bytes per launch from the PMC passes of this same command (benchmarks/pmc_passes.sh -> tools/pmc_traffic.py;
-        # FETCH_SIZE and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected inside the timed process)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01n_pmc_traffic.json")
-        if os.path.exists(pmc) and B == 8 and S_ == 640:
-            t = json.load(open(pmc))["gemm_family"]
-            roof["traffic"] = t["hbm_bytes_per_step"] / max(len(recs), 1)
-            roof["traffic_unit"] = "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01n_pmc_traffic.json)"
-            roof["algorithmic_bytes_per_launch"] = sum(r["bytes"] for r in recs) / max(len(recs), 1)
+        # HBM bytes per launch from the PMC passes of this same command (benchmarks/round_artifacts.sh -> tools/pmc_traffic.py;
+        # FETCH_SIZE and WRITE_SIZE need separate rocprofv3 runs, so they cannot be collected inside the timed process).
+        # Only a file taken on THIS build (same sources -> build_id) with the same number of launches per step is quoted.
+        import glob
+        note = "no profiles/*_pmc_traffic.json"
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            t = json.load(open(pmc))
+            if t.get("build_id") != bid:
+                note = f"{os.path.basename(pmc)} was taken on build {t.get('build_id')}, this is {bid}: not quoted"
+                continue
+            if t.get("bench_launches_per_step") != len(recs) or t.get("workload") != [B, S_, world]:
+                note = (f"{os.path.basename(pmc)}: {t.get('bench_launches_per_step')} launches/step for workload {t.get('workload')} "
+                        f"vs {len(recs)} for {[B, S_, world]} here: not quoted")
+                continue
+            fam = t["gemm_family"]
+            roof["traffic"] = fam["hbm_bytes_per_step"] / max(len(recs), 1)
+            roof["traffic_bytes_per_step"] = fam["hbm_bytes_per_step"]
+            roof["traffic_kernel_dispatches_per_step"] = fam["kernel_dispatches_per_step"]
+            note = (f"HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) of the family's kernel dispatches per step / launches_per_step "
+                    f"({os.path.basename(pmc)}, same build; one launch = one rt_conv_gemm / rt_conv_wgrad(_grouped) call, which may "
+                    f"dispatch several kernels: tile kernel + split reduction)")
+            break
+        roof["traffic_note"] = note
     out = {
         "metric": "images/sec training step, RefCOCO R50 640x640 bs=8/GPU", "value": value, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"RefCOCO-shaped REC train step, ResNet-50 + BERT-base + VL transformer 6+6, "
                                f"{S_}x{S_}, batch {B}/GPU, L=40, aux loss, dropout on, clip 0.1, AdamW (configs[1])",
-                   "global_batch": B * world, "parallelism": f"dp{world}", "launch": mode + ("+dp-overlap" if (world > 1 or force_dist) else ""),
+                   "global_batch": B * world, "batch_per_gpu": B, "image_size": S_, "parallelism": f"dp{world}", "launch": mode + ("+dp-overlap" if (world > 1 or force_dist) else ""),
                    **({"grad_exchange": "bf16" if getattr(runner, "bf16", False) else "fp32"} if (world > 1 or force_dist) else {})},
-        "loss": loss_value,
+        "loss": loss_value, "build_id": bid,
+        "ms_per_step_median": sorted(per_step)[len(per_step) // 2] * 1e3,
     }
     if rank == 0:
         step_tf = value * GF_PER_IMG / 1e3

@@ -16,5 +16,5 @@ python tools/step_phases.py $DB1 > $O/${TAG}_phases.txt 2>&1; tail -16 $O/${TAG}
 rm -rf $O/${TAG}_trace1
 bash benchmarks/pmc_passes.sh > $O/${TAG}_pmc.log 2>&1
 F=$(find $O/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find $O/pmc_WRITE_SIZE -name "*.db" | head -1)
-python tools/pmc_traffic.py $F $W --steps 5 --json $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_kernels.txt 2>&1; head -14 $O/${TAG}_pmc_kernels.txt
+python tools/pmc_traffic.py $F $W --steps 5 --bench-json $O/${TAG}_bench.json --json $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_kernels.txt 2>&1; head -14 $O/${TAG}_pmc_kernels.txt
 rm -rf $O/${TAG}_stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE

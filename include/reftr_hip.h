@@ -520,6 +520,39 @@ int rt_resample_u8(const void* src, void* dst, const int32_t* bounds, const int3
 int rt_img_collate_norm(const int64_t* table, float* out, uint8_t* mask, int B, int H, int W, const float* mean3,
                         const float* std3, rt_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Evaluation post-processing, exact decisions / selections.
+ * rt_mask_postprocess — PostProcessSegm.forward (models/reftr_segmentation.py:282-302): pred fp32 [B*Q, h, w] mask logits ->
+ *   masks uint8 [B, Q, max_h, max_w] = sigmoid(bilinear(pred -> max_h x max_w, align_corners=False)) > threshold inside the
+ *   image's own (sizes[b] = {img_h, img_w}) top-left corner, 0 outside it (the reference's crop = the [:img_h, :img_w] view);
+ *   masks_origin (optional) uint8, image b's block at origin_off[b] with shape [Q, orig_h, orig_w] (orig[b] = {orig_h, orig_w}) =
+ *   nearest resize of the cropped mask (torch 'nearest': src = min(floor(dst * in / out), in - 1)); max_origin = max_b orig_h*orig_w.
+ * rt_box_postprocess  — PostProcessVGMultiPhrase.forward (models/post_process.py:45-83): boxes fp32 [B,P,K,4] cxcywh, valid uint8
+ *   [B,P,K] (phrase_mask) -> out fp32 [B,P,4]: row r of image b = xyxy of prediction 0 of its r-th VALID phrase (phrase order
+ *   kept), times {w,h,w,h} when sizes (fp32 [B,2] = {img_h, img_w}) is given; counts int32 [B] = valid phrases per image.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_mask_post_desc {
+    const float*   pred;
+    const int32_t* sizes;
+    const int32_t* orig;
+    const int64_t* origin_off;
+    uint8_t* masks;
+    uint8_t* masks_origin;
+    int32_t B, Q, h, w, max_h, max_w;
+    int64_t max_origin;
+    float   threshold;
+} rt_mask_post_desc;
+int rt_mask_postprocess(const rt_mask_post_desc* d, rt_stream_t stream);
+typedef struct rt_box_post_desc {
+    const float*   boxes;
+    const uint8_t* valid;
+    const float*   sizes;
+    float*   out;
+    int32_t* counts;
+    int32_t B, P, K;
+} rt_box_post_desc;
+int rt_box_postprocess(const rt_box_post_desc* d, rt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

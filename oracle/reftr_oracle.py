@@ -527,6 +527,38 @@ def criterion(out, targets, world_size=1, global_num_boxes=None):
     return losses
 
 
+# ----------------------------------------------------------------------------------------------
+# evaluation post-processing (models/post_process.py:45-83, models/reftr_segmentation.py:282-302)
+# ----------------------------------------------------------------------------------------------
+def postprocess_boxes(pred_boxes, phrase_mask, target_sizes, scale_to_original_shape=False):
+    """PostProcessVGMultiPhrase.forward: per image, the valid phrases' first prediction as xyxy (phrase order kept),
+    optionally times [img_w, img_h, img_w, img_h] (target_sizes [B,2] = (h, w), integer -> promoted to fp32)."""
+    B, n_ph, k, _ = pred_boxes.shape
+    m = phrase_mask.view(B, n_ph, k, -1)
+    out = []
+    for i in range(B):
+        pi = torch.masked_select(pred_boxes[i], m[i]).view(-1, k, 4)
+        b = cxcywh_to_xyxy(pi[:, 0, :])
+        if scale_to_original_shape:
+            ih, iw = target_sizes[i:i + 1].unbind(1)
+            b = b * torch.stack([iw, ih, iw, ih], dim=1)
+        out.append(b)
+    return out
+
+
+def postprocess_segm(pred_masks, orig_target_sizes, max_target_sizes, threshold=0.5):
+    """PostProcessSegm.forward: bilinear (align_corners=False) to the padded frame, sigmoid > threshold, crop to each image's
+    own size, nearest resize to the original size.  Returns [(masks bool [Q,1,h_i,w_i], masks_origin uint8 [Q,1,H_i,W_i])]."""
+    max_h, max_w = max_target_sizes.max(0)[0].tolist()
+    m = F.interpolate(pred_masks.squeeze(2), size=(max_h, max_w), mode="bilinear", align_corners=False)
+    m = m.sigmoid() > threshold
+    out = []
+    for cur, t, tt in zip(m, max_target_sizes, orig_target_sizes):
+        c = cur[:, :int(t[0]), :int(t[1])].unsqueeze(1)
+        out.append((c, F.interpolate(c.float(), size=tuple(tt.tolist()), mode="nearest").byte()))
+    return out
+
+
 def weight_dict(cfg: Cfg):
     """models/reftr_transformer.py:320-329."""
     wd = {"loss_giou": cfg.giou_loss_coef, "loss_bbox": cfg.bbox_loss_coef}

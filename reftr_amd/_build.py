@@ -63,5 +63,22 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_id():
+    """sha256[:16] over the kernel sources, the C-ABI header and the package's Python files: identifies the build a
+    measurement artefact (profiles/*_pmc_traffic.json) was taken on.  (The GPU box has no .git, so the commit cannot be used.)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for d, _, fs in os.walk(_HERE):
+        if os.sep + "build" in d or "__pycache__" in d:
+            continue
+        files += [os.path.join(d, f) for f in fs if f.endswith((".hip", ".h", ".py"))]
+    files += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, os.path.dirname(_HERE)).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)

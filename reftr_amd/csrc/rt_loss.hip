@@ -25,9 +25,19 @@ __global__ __launch_bounds__(256) void box_loss_kernel(const rt_box_loss_desc p)
             layer = l;
             const float wb = p.weights ? p.weights[l * 2] : p.w_bbox;
             const float wg = p.weights ? p.weights[l * 2 + 1] : p.w_giou;
-            int rank = 0;      // masked_select keeps phrase order (criterion.py:126)
-            for (int q = 0; q < ph; ++q) rank += p.valid[(size_t)b * p.P * p.K + q * p.K] ? 1 : 0;
-            const float* tg = p.targets + ((size_t)p.tgt_off[b] + rank) * 4;
+            int rank = 0, nvalid = 0;      // masked_select keeps phrase order (criterion.py:126)
+            for (int q = 0; q < p.P; ++q) {
+                const int v = p.valid[(size_t)b * p.P * p.K + q * p.K] ? 1 : 0;
+                nvalid += v;
+                if (q < ph) rank += v;
+            }
+            // the reference asserts pred_i.shape[0] == target_i.shape[0] per image (criterion.py:127).  A device kernel
+            // cannot raise: a mismatch poisons the losses with NaN (the training loop stops on a non-finite loss,
+            // engine_vg.py:55-58) and never reads outside this image's target rows.
+            const int count = p.tgt_off[b + 1] - p.tgt_off[b];
+            const bool mismatch = nvalid != count;
+            const float* tg = p.targets + ((size_t)p.tgt_off[b] + (mismatch ? 0 : rank)) * 4;
+            if (mismatch) { l1_sum = __builtin_nanf(""); tg = lg; }
             float s[4], t[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) { s[c] = 1.f / (1.f + __expf(-lg[c])); t[c] = tg[c]; }

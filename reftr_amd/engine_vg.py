@@ -288,7 +288,11 @@ class CapturedTrainStep:
         k = []
         for n, v in sorted(samples.items()):
             k.append((n, tuple(v.tensors.shape) if isinstance(v, utils.NestedTensor) else tuple(v.shape)))
-        return tuple(k) + tuple(int(t["boxes"].shape[0]) for t in targets)
+        # every tensor field of the targets is copied into the static batch (_copy_batch) and read by the criterion at its
+        # captured shape: boxes, labels, masks (RefTRSeg), sizes ... all belong to the key
+        for t in targets:
+            k.append(tuple((n, tuple(v.shape)) for n, v in sorted(t.items()) if torch.is_tensor(v)))
+        return tuple(k)
 
     def _fwd_bwd(self, zero=True):
         outputs = self.model(self.s)
@@ -349,6 +353,16 @@ class CapturedTrainStep:
         self.optimizer.step_count = sc
 
 
+def dp_capture_decision(can_replay, can_capture, device):
+    """The collective choice between replaying, capturing and the eager loop body under data parallelism: 'replay' only if
+    EVERY rank can replay its batch, 'capture' only if every rank would capture, else 'eager' on every rank (one MIN all-reduce
+    of two words)."""
+    flags = torch.tensor([int(bool(can_replay)), int(bool(can_capture))], dtype=torch.int32, device=device)
+    torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MIN)
+    all_replay, all_capture = (bool(v) for v in flags.tolist())
+    return "replay" if all_replay else ("capture" if all_capture else "eager")
+
+
 def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4):
     """`train_step` with the same return value, replayed from hipGraphs: the first batch of an input shape captures a
     CapturedTrainStep (kept on the model), later batches of that shape replay it.  Falls back to the eager `train_step` for
@@ -362,7 +376,17 @@ def captured_train_step(model, criterion, samples, targets, optimizer, lr_schedu
     if ok:
         key = (CapturedTrainStep.shape_key(samples, targets), id(criterion), id(optimizer), float(max_norm), model.training)
         ok = key in caps or len(caps) < max_shapes
+    if utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1:
+        # Data parallel: replaying, capturing and the eager loop issue DIFFERENT collective sequences (a capture adds the
+        # num_boxes all-reduce of its constructor and warm-up iterations with real gradient exchanges), and both the shape
+        # key (per-image box counts, image sizes) and the capture budget are rank-local.  The choice is therefore made
+        # collectively: replay only if EVERY rank holds a capture for its batch, capture only if every rank would capture,
+        # otherwise every rank runs the eager step.  One 2-word MIN all-reduce per iteration, issued while the device is
+        # idle behind the previous iteration's loss .item().
+        ok = dp_capture_decision(ok and key in caps, ok and key not in caps, inner.store.device) != "eager"
     if not ok:
+        for other in caps.values():             # a pending (deferred) update must land before the eager forward
+            other.flush()
         return train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm)
     cap = caps.get(key)
     if cap is None:

@@ -135,6 +135,22 @@ class BoxLossDesc(Structure):
     ]
 
 
+class MaskPostDesc(Structure):
+    _fields_ = [
+        ("pred", c_void_p), ("sizes", c_void_p), ("orig", c_void_p), ("origin_off", c_void_p),
+        ("masks", c_void_p), ("masks_origin", c_void_p),
+        ("B", c_int32), ("Q", c_int32), ("h", c_int32), ("w", c_int32), ("max_h", c_int32), ("max_w", c_int32),
+        ("max_origin", c_int64), ("threshold", c_float),
+    ]
+
+
+class BoxPostDesc(Structure):
+    _fields_ = [
+        ("boxes", c_void_p), ("valid", c_void_p), ("sizes", c_void_p), ("out", c_void_p), ("counts", c_void_p),
+        ("B", c_int32), ("P", c_int32), ("K", c_int32),
+    ]
+
+
 class AdamWDesc(Structure):
     _fields_ = [
         ("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64),
@@ -235,6 +251,8 @@ _SIGNATURES = {
     "rt_qenc_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_qenc_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_box_loss": (c_int, [POINTER(BoxLossDesc), c_void_p]),
+    "rt_mask_postprocess": (c_int, [POINTER(MaskPostDesc), c_void_p]),
+    "rt_box_postprocess": (c_int, [POINTER(BoxPostDesc), c_void_p]),
     "rt_small_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rt_pos_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
@@ -737,6 +755,33 @@ def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox=1.0, w_giou=1
                     NL, B, P, K, w_bbox, w_giou, _p(weights))
     _check(lib().rt_box_loss(ctypes.byref(d), _stream()), "rt_box_loss")
     return losses, total, dl
+
+
+def mask_postprocess(pred, sizes_i32, max_hw, threshold=0.5, orig_i32=None, origin_off=None, origin_total=0, max_origin=0):
+    """pred fp32 [B, Q, h, w] mask logits; sizes_i32 / orig_i32 device int32 [B, 2]; origin_off device int64 [B + 1].
+    Returns (masks uint8 [B, Q, max_h, max_w], masks_origin uint8 [origin_total] | None)."""
+    B, Q, h, w = pred.shape
+    _req(pred, torch.float32, "pred"); _req(sizes_i32, torch.int32, "sizes")
+    _req(orig_i32, torch.int32, "orig"); _req(origin_off, torch.int64, "origin_off")
+    max_h, max_w = int(max_hw[0]), int(max_hw[1])
+    masks = _new((B, Q, max_h, max_w), torch.uint8, pred)
+    mo = _new((int(origin_total),), torch.uint8, pred) if orig_i32 is not None else None
+    d = MaskPostDesc(_p(pred), _p(sizes_i32), _p(orig_i32), _p(origin_off), _p(masks), _p(mo), B, Q, h, w, max_h, max_w,
+                     int(max_origin), float(threshold))
+    _check(lib().rt_mask_postprocess(ctypes.byref(d), _stream()), "rt_mask_postprocess")
+    return masks, mo
+
+
+def box_postprocess(boxes, valid_u8, sizes_f32=None):
+    """boxes fp32 [B, P, K, 4] cxcywh, valid uint8 [B, P, K]; sizes fp32 [B, 2] = (img_h, img_w) or None.
+    Returns (xyxy fp32 [B, P, 4] with every image's valid phrases compacted to the front, counts int32 [B])."""
+    B, P, K, _ = boxes.shape
+    _req(boxes, torch.float32, "boxes"); _req(valid_u8, torch.uint8, "valid"); _req(sizes_f32, torch.float32, "sizes")
+    out = torch.zeros(B, P, 4, dtype=torch.float32, device=boxes.device)
+    counts = _new((B,), torch.int32, boxes)
+    d = BoxPostDesc(_p(boxes), _p(valid_u8), _p(sizes_f32), _p(out), _p(counts), B, P, K)
+    _check(lib().rt_box_postprocess(ctypes.byref(d), _stream()), "rt_box_postprocess")
+    return out, counts
 
 
 def sqnorm(g, out):

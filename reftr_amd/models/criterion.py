@@ -51,6 +51,20 @@ class CriterionVGMultiPhrase(nn.Module):
             boxes = torch.zeros(1, 4, dtype=torch.float32, device=device)
         return boxes, self._off_cache[lens]
 
+    def num_boxes(self, targets, device):
+        """criterion.py:176-180: the number of target boxes of the GLOBAL batch averaged over the ranks (one sum all-reduce of
+        a device scalar; the clamp(min=1) is applied by the kernel).  Kept on the device: no host sync."""
+        nb = float(sum(len(t["labels"]) for t in targets))
+        if self.num_boxes_static is not None:
+            return self.num_boxes_static
+        if is_dist_avail_and_initialized():
+            num_boxes = torch.tensor([nb], dtype=torch.float32, device=device)
+            torch.distributed.all_reduce(num_boxes)
+            return num_boxes / get_world_size()
+        if nb not in self._nb_cache:               # cached device scalar: no H2D copy in the steady state / under capture
+            self._nb_cache[nb] = torch.tensor([nb], dtype=torch.float32, device=device)
+        return self._nb_cache[nb]
+
     def forward(self, outputs, targets):
         assert "boxes" in self.losses and "pred_logits" in outputs, \
             "the HIP criterion consumes the model's pre-sigmoid logits (outputs['pred_logits'])"
@@ -59,19 +73,7 @@ class CriterionVGMultiPhrase(nn.Module):
             logits = logits[-1:]
         logits = logits.contiguous()
         device = logits.device
-        # criterion.py:176-180: number of target boxes averaged over ranks, clamp >= 1 (in the kernel); kept on
-        # the device so no host sync is needed
-        nb = float(sum(len(t["labels"]) for t in targets))
-        if self.num_boxes_static is not None:
-            num_boxes = self.num_boxes_static
-        elif is_dist_avail_and_initialized():
-            num_boxes = torch.tensor([nb], dtype=torch.float32, device=device)
-            torch.distributed.all_reduce(num_boxes)
-            num_boxes = num_boxes / get_world_size()
-        else:
-            if nb not in self._nb_cache:           # cached device scalar: no H2D copy in the steady state / under capture
-                self._nb_cache[nb] = torch.tensor([nb], dtype=torch.float32, device=device)
-            num_boxes = self._nb_cache[nb]
+        num_boxes = self.num_boxes(targets, device)
         boxes, off = self._targets(targets, device)
         valid = outputs["phrase_mask"].to(torch.uint8).contiguous()
         losses = _BoxLossFunction.apply(logits, valid, boxes, off, num_boxes)     # [NL, 2]

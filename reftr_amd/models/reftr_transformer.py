@@ -552,6 +552,24 @@ def build_config(args):
         raise NotImplementedError("num_feature_levels > 1: the reference's own forward raises for every such value "
                                   "(models/reftr_transformer.py:171-175 feeds the 1024-channel map to the 512-channel input_proj[0] "
                                   "of :100-108) and every reference config uses 1, so there is no behaviour to match")
+    # Flags the reference's builders read and this build does not implement must fail loudly -- a drop-in that silently
+    # builds a different model is worse than none.  (--freeze_bert, --freeze_backbone and --freeze_reftr are parsed by
+    # main_vg.py but have NO effect in the reference either: freeze_lang_backbone is stored and never used,
+    # reftr_transformer.py:128,152-157; freeze_backbone is never read; build_reftr_seg hard-codes freeze_reftr=False,
+    # reftr_segmentation.py:375.  They are accepted and ignored here for the same behaviour.)
+    if getattr(args, "dilation", False):
+        raise NotImplementedError("--dilation (layer4 stride replaced by dilation, models/modeling/backbone.py:120-125) is not "
+                                  "built: no reference config uses it")
+    pe = getattr(args, "position_embedding", "sine")
+    if pe in ("v3", "learned"):
+        raise NotImplementedError("--position_embedding learned (PositionEmbeddingLearned, models/modeling/"
+                                  "position_encoding.py:59-84) is not built: every reference config uses the sine encoding")
+    if pe not in ("v2", "sine"):
+        raise ValueError(f"not supported {pe}")                     # as position_encoding.py:95
+    if float(getattr(args, "lr_backbone", 1e-5)) <= 0:
+        raise NotImplementedError("lr_backbone <= 0 freezes the whole ResNet in the reference (train_backbone = False, "
+                                  "models/modeling/backbone.py:87-89,150) and drops its parameters from the optimizer and the "
+                                  "clip norm; this build always trains layer2-4")
     # models/reftr_transformer.py:315-318: RobertaModel when args.bert_model starts with 'roberta', BertModel otherwise
     bc = L.roberta_config() if str(getattr(args, "bert_model", "bert-base-uncased")).split("-")[0] == "roberta" else L.BertConfig()
     layers = (3, 4, 23, 3) if getattr(args, "backbone", "resnet50") == "resnet101" else (3, 4, 6, 3)

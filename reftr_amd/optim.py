@@ -113,9 +113,26 @@ class FusedAdamW(torch.optim.Optimizer):
         """Copies the param groups' current learning rates to the device words the kernel reads (stream-ordered: a
         replay enqueued before this call still sees the old values)."""
         lrs = [r[2] for r in self._ranges()]
-        host = torch.tensor(lrs + [0.0] * (8 - len(lrs)), dtype=torch.float32).pin_memory()
+        if lrs == getattr(self, "_lr_last", None):
+            return lrs                # nothing moved since the last copy (StepLR between drops): no traffic at all
+        # two persistent pinned staging buffers, alternated; an event per buffer says its last copy has run, so the
+        # per-iteration schedules (LambdaLR warm-up / cosine, main_vg.py:272-287) cost no host allocation
+        if getattr(self, "_lr_stage", None) is None:
+            self._lr_stage = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._lr_event = [torch.cuda.Event(), torch.cuda.Event()]
+            self._lr_used = [False, False]
+            self._lr_flip = 0
+        i = self._lr_flip
+        self._lr_flip ^= 1
+        if self._lr_used[i]:
+            self._lr_event[i].synchronize()
+        host = self._lr_stage[i]
+        host.zero_()
+        host[:len(lrs)] = torch.tensor(lrs, dtype=torch.float32)
         self.lr_dev.copy_(host, non_blocking=True)
-        self._lr_host = host          # keep the staging buffer alive until the copy has run
+        self._lr_event[i].record()
+        self._lr_used[i] = True
+        self._lr_last = list(lrs)
         return lrs
 
     @torch.no_grad()
@@ -189,6 +206,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
 
 def build_optimizer(model, args):
-    """The optimizer main_vg.py:234-268 builds, on the fused kernels."""
+    """The optimizer main_vg.py:234-268 builds, on the fused kernels (AdamW; --sgd is not built and raises)."""
+    if getattr(args, "sgd", False):
+        raise NotImplementedError("--sgd (torch.optim.SGD, main_vg.py:263-265) is not built: every reference config trains with AdamW")
     return FusedAdamW(model, lr=args.lr, lr_backbone=args.lr_backbone, weight_decay=args.weight_decay,
                       lr_mask_branch_proj=getattr(args, "lr_mask_branch_proj", 1.0))

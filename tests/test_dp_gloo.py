@@ -80,3 +80,54 @@ def test_gradient_allreduce_world2_gloo(dtype):
     for rank, same, covered, ok_sum, gs, nb in res:
         assert same and covered and ok_sum
         assert gs == 0.5 and nb == 3.5
+
+
+def _collectives_worker(rank, world, port, q):
+    """Drives the product's own collective call sites with world > 1: CriterionVGMultiPhrase.num_boxes (C4,
+    models/criterion.py:176-180), util.misc.reduce_dict (C5, util/misc.py:136-160) and the collective capture / replay /
+    eager decision of engine_vg.captured_train_step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reftr_amd.engine_vg import dp_capture_decision
+        from reftr_amd.models.criterion import CriterionVGMultiPhrase
+        from reftr_amd.util import misc as utils
+        crit = CriterionVGMultiPhrase({"loss_bbox": 1.0, "loss_giou": 1.0}, ["boxes"])
+        # rank 0: 3 + 0 boxes, rank 1: 1 + 4 boxes -> global 8 boxes / 2 ranks = 4 per rank (NOT the local 3 or 5)
+        counts = [(3, 0), (1, 4)][rank]
+        targets = [{"labels": torch.zeros(n, dtype=torch.long), "boxes": torch.zeros(n, 4)} for n in counts]
+        nb = crit.num_boxes(targets, torch.device("cpu"))
+        # a static scalar (CapturedTrainStep refreshes it with its own all-reduce) short-cuts the collective
+        crit.num_boxes_static = torch.tensor([7.0])
+        nb_static = float(crit.num_boxes(targets, torch.device("cpu")))
+        crit.num_boxes_static = None
+        # an all-empty global batch: 0 / world (the clamp(min=1) is the kernel's, criterion.py:180)
+        nb0 = crit.num_boxes([{"labels": torch.zeros(0, dtype=torch.long)}], torch.device("cpu"))
+        red = utils.reduce_dict({"loss_giou": torch.tensor(1.0 + rank), "loss_bbox": torch.tensor(10.0 * (rank + 1))})
+        summed = utils.reduce_dict({"a": torch.tensor(2.0 + rank)}, average=False)
+        # rank 0 could replay, rank 1 sees a new shape -> everyone runs the eager body; both new -> capture; both hold one -> replay
+        d1 = dp_capture_decision(rank == 0, rank == 1, torch.device("cpu"))
+        d2 = dp_capture_decision(False, True, torch.device("cpu"))
+        d3 = dp_capture_decision(True, False, torch.device("cpu"))
+        d4 = dp_capture_decision(False, rank == 0, torch.device("cpu"))       # rank 1 is out of capture budget
+        q.put((rank, float(nb), nb_static, float(nb0), float(red["loss_giou"]), float(red["loss_bbox"]), float(summed["a"]),
+               (d1, d2, d3, d4)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_criterion_num_boxes_reduce_dict_and_capture_decision_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_collectives_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nb, nb_static, nb0, giou, bbox, a, dec in res:
+        assert nb == 4.0 and nb_static == 7.0 and nb0 == 0.0
+        assert giou == 1.5 and bbox == 15.0 and a == 5.0           # averaged / summed over the two ranks, same on both
+        assert dec == ("eager", "capture", "replay", "eager")

@@ -100,3 +100,51 @@ def test_train_one_epoch_under_the_dp_wrapper(hip, single_rank_group):
     assert opt.step_count == 4 and stats["loss"] > 0 and stats["grad_norm"] > 0
     moved = (model.state_dict()["bbox_embed.layers.1.weight"].float().cpu() - P["bbox_embed.layers.1.weight"]).abs().max()
     assert 1e-5 < float(moved) < 1e-3
+
+
+def test_bf16_vs_fp32_gradient_exchange_trajectory_of_two_emulated_ranks(hip):
+    """Bounds what the default bf16 gradient exchange (reftr_amd/parallel.py) does to a training trajectory, relative to the
+    reference's fp32 DDP exchange (main_vg.py:290-296), with TWO ranks emulated on the one-GPU box: every step computes
+    the local gradients of two different shards on the same replica, then forms the all-reduced buffer exactly as RCCL
+    would -- fp32: g0 + g1; bf16: bf16(bf16(g0) + bf16(g1)) read by clip + AdamW straight from the bf16 buffer -- with
+    1/world folded into the update.  Same data, same weights at step 0, 6 steps each."""
+    from reftr_amd.optim import FusedAdamW
+    shards = [to_cuda(*make_inputs(f"dp_shard{r}", B=2, H=96, W=128, L=12)) for r in range(2)]
+    res = {}
+    for mode in ("fp32", "bf16"):
+        model, crit, P, ocfg = build(small=True)
+        model.eval()
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        st = model.store
+        model._grad_scale = 0.5
+        if mode == "bf16":
+            st.flat_g16 = torch.zeros_like(st.flat_g, dtype=torch.bfloat16)
+        losses, norms = [], []
+        for it in range(6):
+            gs, lv = [], 0.0
+            for s, tg in shards:
+                out = model(s)
+                ld = crit(out, tg)
+                total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+                st.flat_g.zero_()
+                total.backward()
+                gs.append(st.flat_g.clone()); lv += 0.5 * float(total)
+            if mode == "fp32":
+                st.flat_g.copy_(gs[0] + gs[1])
+            else:
+                st.flat_g16.copy_((gs[0].bfloat16() + gs[1].bfloat16()))
+            gn = opt.clip_grad_norm_(0.1)
+            opt.step()
+            losses.append(lv); norms.append(float(gn))
+        res[mode] = (losses, norms, st.flat_p.clone())
+        if mode == "bf16":
+            del st.flat_g16
+    (l0, n0, p0), (l1, n1, p1) = res["fp32"], res["bf16"]
+    dl = max(abs(a - b) / abs(a) for a, b in zip(l0, l1)); dn = max(abs(a - b) / a for a, b in zip(n0, n1))
+    dp = rel(p1, p0)
+    print(f"\n[bf16 vs fp32 exchange, 2 emulated ranks, 6 steps] loss rel {dl:.2e}  grad-norm rel {dn:.2e}  weights rel {dp:.2e}"
+          f"  losses fp32 {['%.4f' % v for v in l0]}")
+    assert l0[0] == l1[0]                                   # step 0: same weights, the exchange format has not acted yet
+    assert dn < 5e-3                                        # ||bf16 sum|| vs ||fp32 sum||: rounding noise averages out (2^-9 / sqrt(n))
+    assert dl < 2e-2 and dp < 2e-4                          # the fixture's run-to-run trajectory noise (test_model_gpu.py) bounds both
+    assert l0[-1] < l0[0] and l1[-1] < l1[0]

@@ -31,8 +31,10 @@ def compare(samples, targets, tol_box=8e-3, tol_loss=8e-3, backward=True):
     assert np.array_equal(out["phrase_mask"].reshape(-1).cpu().numpy(), valid.numpy())          # bool: exact
     got = boxes.detach().float().cpu().reshape(boxes.shape[0], -1, 4)[:, valid]
     want = ref["logits"].sigmoid().reshape(boxes.shape[0], -1, 4)[:, valid]
-    if valid.any():
-        assert rel(got, want) < tol_box, rel(got, want)
+    rb = rel(got, want) if valid.any() else 0.0
+    rl_max = max(abs(float(v) - float(rl[k])) / max(1.0, abs(float(rl[k]))) for k, v in ld.items())
+    print(f"\n[edge case] boxes rel {rb:.2e} (tol {tol_box:.1e})  worst loss rel {rl_max:.2e} (tol {tol_loss:.1e})")
+    assert rb < tol_box, rb
     for k, v in ld.items():
         assert abs(float(v) - float(rl[k])) < tol_loss * max(1.0, abs(float(rl[k]))), (k, float(v), float(rl[k]))
     if backward:
@@ -73,6 +75,21 @@ def test_batch_without_any_box(hip):
     targets = [{"boxes": torch.zeros(0, 4), "labels": torch.zeros(0, dtype=torch.long)} for _ in range(2)]
     model, ld = compare(samples, targets, backward=False)      # (every query masked: the same out-of-domain NaN as above)
     assert all(float(v) == 0.0 for v in ld.values())
+
+
+def test_box_count_mismatch_poisons_the_loss(hip):
+    """The reference asserts that every image has as many valid phrases as target boxes (criterion.py:127).  The device
+    criterion cannot raise without a host sync: it must not read another image's targets and must make the mismatch loud
+    -- the losses come back NaN, which stops the training loop exactly like the assert would (engine_vg.py:55-58)."""
+    from reftr_amd import hip as H
+    logits = torch.zeros(2, 2, 3, 1, 4, device="cuda")
+    valid = torch.tensor([[1, 1, 0], [1, 0, 0]], dtype=torch.uint8, device="cuda")
+    boxes = torch.tensor([[0.5, 0.5, 0.2, 0.2]] * 3, device="cuda")
+    nb = torch.tensor([3.0], device="cuda")
+    ok, _, _ = H.box_loss(logits, valid, boxes, torch.tensor([0, 2, 3], dtype=torch.int32, device="cuda"), nb, want_grad=False)
+    assert torch.isfinite(ok).all()
+    bad, _, _ = H.box_loss(logits, valid, boxes, torch.tensor([0, 1, 3], dtype=torch.int32, device="cuda"), nb, want_grad=False)
+    assert torch.isnan(bad[:, 0]).all()                                # image 0: 2 valid phrases, 1 box; image 1: 1 phrase, 2 boxes
 
 
 @pytest.mark.parametrize("B,H,W,L", [(1, 75, 101, 6), (3, 64, 130, 9)])

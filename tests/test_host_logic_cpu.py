@@ -96,14 +96,25 @@ def test_unsupported_options_raise():
     assert build_reftr(ref_args(bert_model="roberta-base"))[0].cfg.bert.pad_idx == 1
 
 
-def test_post_process_segm_matches_reference_golden_exactly():
-    from reftr_amd.models.post_process import PostProcessSegm
+def test_oracle_post_process_segm_matches_reference_golden_exactly():
+    """The oracle's restatement of PostProcessSegm is pinned to the reference's outputs (tests/golden/seg_single.npz); the
+    product's HIP post-processor is checked against the same vectors in tests/test_post_gpu.py."""
+    from oracle import reftr_oracle as O
     g = np.load(os.path.join(ROOT, "tests", "golden", "seg_single.npz"))
-    res = PostProcessSegm()([{} for _ in range(2)], {"pred_masks": torch.from_numpy(g["pred_masks"])},
-                            torch.from_numpy(g["post_orig"]), torch.from_numpy(g["post_sizes"]))
+    res = O.postprocess_segm(torch.from_numpy(g["pred_masks"])[:, :, None], torch.from_numpy(g["post_orig"]), torch.from_numpy(g["post_sizes"]))
     for i in range(2):
-        assert torch.equal(res[i]["masks"], torch.from_numpy(g[f"post_masks{i}"]))
-        assert torch.equal(res[i]["masks_origin"], torch.from_numpy(g[f"post_masks_origin{i}"]))
+        assert torch.equal(res[i][0], torch.from_numpy(g[f"post_masks{i}"]))
+        assert torch.equal(res[i][1], torch.from_numpy(g[f"post_masks_origin{i}"]))
+
+
+def test_post_processors_reject_host_tensors():
+    from reftr_amd.models.post_process import PostProcessSegm, PostProcessVGMultiPhrase
+    g = np.load(os.path.join(GOLD, "postprocess.npz"))
+    with pytest.raises(RuntimeError):
+        PostProcessVGMultiPhrase()({"pred_boxes": torch.from_numpy(g["pred"]), "phrase_mask": torch.from_numpy(g["mask"])},
+                                   torch.from_numpy(g["sizes"]))
+    with pytest.raises(RuntimeError):
+        PostProcessSegm()([{}], {"pred_masks": torch.zeros(1, 1, 4, 4)}, torch.tensor([[8, 8]]), torch.tensor([[8, 8]]))
 
 
 def test_no_cpu_fallback_exists():
@@ -125,13 +136,12 @@ def test_product_never_imports_oracle():
     assert not pat.search(open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0])
 
 
-def test_postprocess_matches_reference_golden_exactly():
-    from reftr_amd.models.post_process import PostProcessVGMultiPhrase
+def test_oracle_postprocess_matches_reference_golden_exactly():
+    from oracle import reftr_oracle as O
     g = np.load(os.path.join(GOLD, "postprocess.npz"))
-    res = PostProcessVGMultiPhrase()({"pred_boxes": torch.from_numpy(g["pred"]), "phrase_mask": torch.from_numpy(g["mask"])},
-                                     torch.from_numpy(g["sizes"]), scale_to_original_shape=True)
+    res = O.postprocess_boxes(torch.from_numpy(g["pred"]), torch.from_numpy(g["mask"]), torch.from_numpy(g["sizes"]), True)
     for i, r in enumerate(res):
-        assert torch.equal(r["boxes"], torch.from_numpy(g[f"boxes{i}"]))
+        assert torch.equal(r, torch.from_numpy(g[f"boxes{i}"]))
 
 
 def test_nested_tensor_padding():

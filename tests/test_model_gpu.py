@@ -2,8 +2,8 @@
   (1) the golden vectors minted from the imported reference (tests/golden/e2e_*.npz, steps_single.npz) and
   (2) the CPU oracle on the same seeded inputs and formula weights.
 
-Tolerances (bf16 GEMM operands / bf16 backbone activations vs the reference's fp32):
-  boxes (sigmoid outputs)  rel-L2 <= 5e-3      logits rel-L2 <= 2e-2      losses rel <= 5e-3
+Tolerances (bf16 GEMM operands / bf16 backbone activations vs the reference's fp32): every
+assert sits at <= 1.5 x the value measured on MI355X (the `TOL` table below; the measured values are printed by each run).
   gradients: noise-limited by ReLU-mask / L1-sign flips that a 0.5 % forward perturbation triggers, so they are
   checked globally (rel-L2 <= 0.25, cosine >= 0.97) and for the head tensors tightly (<= 2e-2).
 Integer / bool outputs (phrase_mask) must be exact.
@@ -20,6 +20,10 @@ from oracle.synth import make_inputs
 from oracle.weights import formula_state
 
 pytestmark = pytest.mark.gpu
+# <= 1.5 x the values measured on MI355X for the reduced-depth fixture (printed by every run): boxes 1.1e-3, single loss
+# terms <= 1.0e-3, total 4e-4, raw logits vs the q=True oracle 4.6e-3 (bf16 rounding-flip floor, see
+# tests/test_parity_fullsize_gpu.py)
+TOL = {"boxes": 1.7e-3, "loss": 1.5e-3, "total": 8e-4, "logits_q": 7e-3}
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -60,14 +64,15 @@ def test_forward_backward_vs_reference_golden(hip, tag, n_phrase):
     s, tg = to_cuda(samples, targets)
     out = model(s)
     boxes = torch.cat([torch.stack([a["pred_boxes"] for a in out["aux_outputs"]]), out["pred_boxes"][None]])
-    assert rel(boxes, g["boxes"]) < 5e-3
+    rb = rel(boxes, g["boxes"])
     assert np.array_equal(out["phrase_mask"].cpu().numpy(), g["phrase_mask"])            # exact
     ld = crit(out, tg)
-    for k, v in ld.items():
-        ref = float(g["loss." + k])
-        assert abs(float(v) - ref) < 5e-3 * max(1.0, abs(ref)), k
+    rl = max(abs(float(v) - float(g["loss." + k])) / max(1.0, abs(float(g["loss." + k]))) for k, v in ld.items())
     total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
-    assert abs(float(total) - float(g["total_loss"])) < 5e-3 * float(g["total_loss"])
+    rt = abs(float(total) - float(g["total_loss"])) / float(g["total_loss"])
+    print(f"\n[{tag} vs reference golden] boxes {rb:.2e}  worst loss {rl:.2e}  total {rt:.2e}")
+    assert rb < TOL["boxes"], rb
+    assert rl < TOL["loss"] and rt < TOL["total"], (rl, rt)
     model.store.flat_g.zero_()
     total.backward()
     G = model.store.G
@@ -99,7 +104,9 @@ def test_gradients_vs_oracle_global(hip):
     ref = dict(zip(names, torch.autograd.grad(tot, [leaves[k] for k in names])))
     s, tg = to_cuda(samples, targets)
     out = model(s)
-    assert rel(out["pred_logits"], o["logits"]) < 2e-2
+    rlq = rel(out["pred_logits"], o["logits"])
+    print(f"\n[small fixture] logits vs q=True oracle {rlq:.2e}")
+    assert rlq < TOL["logits_q"], rlq
     ld = crit(out, tg)
     total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
     model.store.flat_g.zero_()
@@ -132,8 +139,9 @@ def test_three_training_steps(hip):
         _, ref_loss, ref_gn, _ = O.train_step(Pq, samples, targets, ocfg, state, it + 1, max_norm=0.1, train=False, q=True)
         loss_value, _, _, gnorm = train_step(model, crit, s, tg, opt, None, max_norm=0.1)
         if it == 0:
-            assert abs(loss_value - float(g["loss"][0])) < 5e-3 * float(g["loss"][0])
-            assert abs(float(gnorm) - float(g["gnorm"][0])) < 0.05 * float(g["gnorm"][0])
+            e_l = abs(loss_value - float(g["loss"][0])) / float(g["loss"][0]); e_g = abs(float(gnorm) - float(g["gnorm"][0])) / float(g["gnorm"][0])
+            print(f"\n[step 0 vs reference golden] loss rel {e_l:.2e}  grad-norm rel {e_g:.2e}")
+            assert e_l < TOL["total"] * 2 and e_g < 0.05, (e_l, e_g)
         # the two bf16-point trajectories drift apart (zero-true-gradient biases take sign-of-noise Adam steps)
         assert abs(loss_value - ref_loss) < (2e-2 if it < 2 else 6e-2) * ref_loss, (it, loss_value, ref_loss)
         assert abs(float(gnorm) - ref_gn) < 0.25 * ref_gn, (it, float(gnorm), ref_gn)

@@ -1,0 +1,299 @@
+"""GPU parity at FULL depth (BERT 12 + encoder 6 + decoder 6 layers) against the CPU oracle, element-wise:
+
+  * configs[0] of BASELINE.json -- RefCOCO-shaped, ResNet-50, 320x320, batch 2, L = 40 -- single- and multi-phrase;
+  * configs[3] -- the REC+RES multitask model (RefTRSeg) -- at 320x320 / batch 2 against the oracle, and at its full size
+    (640x640, batch 8) through size-independent properties (the oracle needs minutes per step there).
+
+Two oracle modes (oracle/reftr_oracle.py): q=False is the reference's fp32 arithmetic, q=True applies the HIP path's bf16
+rounding points (GEMM operands, stored backbone activations).  What is gated and why (measured values are printed by every
+test; `MEASURED` holds the values of the build these thresholds were set on, the asserts sit at <= 1.5 x them):
+
+  boxes / losses vs q=False   the north star's quantities: 1.2-1.3e-3 rel-L2 on the boxes, <= 2.4e-3 on single loss terms.
+  logits vs q=True            5.9-6.9e-3.  This is NOT 1e-3 and cannot be for ANY implementation that stores bf16
+                              activations: two valid fp32 summation orders of the same dot product differ in the last bit,
+                              which flips the bf16 rounding (2^-9 relative) of a few per cent of the stored activations of
+                              every one of the ~70 GEMM layers; the flips accumulate to 8e-3 on c5 and 6e-3 on the logits
+                              between the oracle's own torch-CPU order and the MFMA order (the oracle's q=True and q=False
+                              outputs differ from each other by the same amount).  The per-kernel tests (test_gemm_gpu.py,
+                              test_ops_gpu.py) feed IDENTICAL bf16 inputs to both sides and are tight (fp32 outputs 2e-5).
+  gradients                   compared for a LINEAR functional of the logits (same upstream gradient on both sides: no L1-sign
+                              / GIoU kink of the criterion can flip), at d_logits, d_hs, d_memory, d_c5 and globally.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reftr_oracle as O
+from oracle.shapes import param_shapes
+from oracle.synth import make_inputs
+from oracle.weights import formula_state, formula_tensor
+from test_model_gpu import rel, to_cuda
+
+pytestmark = pytest.mark.gpu
+
+# values measured on the build the thresholds were set on (MI355X, ROCm 7.2; printed again by every run)
+MEASURED = {
+    "single": dict(boxes=1.29e-3, logits_q=5.9e-3, c5_q=8.7e-3, memory_q=4.3e-3, loss=2.4e-3, total=2.1e-4),
+    "multi": dict(boxes=1.22e-3, logits_q=6.9e-3, c5_q=8.7e-3, memory_q=4.3e-3, loss=2.4e-3, total=2.1e-4),
+}
+
+
+def build_full(masks=False):
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase, CriterionVGOnePhraseSeg
+    from reftr_amd.models.reftr_transformer import RefTR
+    ocfg = O.Cfg(masks=True, aux_loss=False) if masks else O.Cfg()
+    cfg = L.ModelConfig(masks=True) if masks else L.ModelConfig()
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda", aux_loss=not masks)
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    if masks:
+        crit = CriterionVGOnePhraseSeg(O.weight_dict(ocfg), ["masks", "boxes"])
+    else:
+        crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    return model, crit, P, ocfg
+
+
+def oracle_run(P, samples, targets, ocfg, q, functional=None):
+    """Oracle forward + backward.  `functional`: fixed tensor W -> the scalar is sum(logits * W) instead of the criterion's
+    total loss.  Returns (outputs, losses, total, parameter gradients, gradients w.r.t. logits / hs / memory / c5)."""
+    names = [k for k in P if O.is_trainable(k) and torch.is_floating_point(P[k])]
+    Pq = {k: v.clone() for k, v in P.items()}
+    leaves = {k: Pq[k].requires_grad_(True) for k in names}
+    o = O.reftr_forward(Pq, samples, ocfg, q=q)
+    losses = O.criterion(o, targets)
+    tot = O.total_loss(losses, O.weight_dict(ocfg))
+    scalar = tot if functional is None else (o["logits"] * functional).sum()
+    inter = [o["logits"], o["hs"], o["memory"], o["c5"]]
+    allg = torch.autograd.grad(scalar, [leaves[k] for k in names] + inter, allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(P[k])) for k, g in zip(names, allg[:len(names)])}
+    return o, losses, tot, grads, allg[len(names):], names
+
+
+def hip_scalar_backward(model, scalar):
+    model.store.flat_g.zero_()
+    scalar.backward()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kind", ["single", "multi"])
+def test_cfg1_full_depth_forward_and_losses_vs_oracle(hip, kind):
+    """configs[0]: 320x320, batch 2, L = 40, 12 + 6 + 6 layers (reftr_transformer.py:159-297, criterion.py:113-202)."""
+    n_phrase = 3 if kind == "multi" else 0
+    samples, targets = make_inputs("e2e_" + kind, B=2, H=320, W=320, L=40, n_phrase=n_phrase)
+    model, crit, P, ocfg = build_full()
+    s, tg = to_cuda(samples, targets)
+    with torch.no_grad():
+        out = model(s)
+        ld = crit(out, tg)
+        total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    sv = model._saved
+    got = {}
+    with torch.no_grad():
+        for q in (False, True):
+            o = O.reftr_forward(P, samples, ocfg, q=q)
+            losses = O.criterion(o, targets)
+            tot = O.total_loss(losses, O.weight_dict(ocfg))
+            Bn, C, h, w = o["c5"].shape
+            tag = "_q" if q else ""
+            got["c5" + tag] = rel(sv["c5"].view(Bn, h, w, C).permute(0, 3, 1, 2), o["c5"])
+            got["memory" + tag] = rel(sv["memory"].view(Bn, -1, 256).transpose(0, 1), o["memory"])
+            got["logits" + tag] = rel(out["pred_logits"], o["logits"])
+            got["boxes" + tag] = rel(out["pred_logits"].sigmoid(), o["logits"].sigmoid())
+            got["loss" + tag] = max(abs(float(ld[k]) - float(losses[k])) / max(abs(float(losses[k])), 1e-6) for k in losses)
+            got["total" + tag] = abs(float(total) - float(tot)) / float(tot)
+            if not q:
+                assert np.array_equal(out["phrase_mask"].cpu().numpy(), o["phrase_mask"].numpy())       # exact
+    print(f"\n[cfg1 {kind}] " + "  ".join(f"{k}={v:.2e}" for k, v in got.items()))
+    m = MEASURED[kind]
+    assert got["boxes"] < 1.5 * m["boxes"], got                 # the north star's output quantity: ~1e-3 relative
+    assert got["loss"] < 1.5 * m["loss"] and got["total"] < 1e-3, got
+    assert got["logits_q"] < 1.5 * m["logits_q"], got           # bf16-flip noise floor (module docstring)
+    assert got["c5_q"] < 1.5 * m["c5_q"] and got["memory_q"] < 1.5 * m["memory_q"], got
+    # both oracle modes are equally far away: the distance is rounding-flip noise, not a systematic difference
+    assert 0.6 < got["logits"] / got["logits_q"] < 1.6, got
+
+
+# measured: d_logits exact (the functional's own gradient), d_hs / d_memory / d_c5 and the global parameter gradient
+MEASURED_GRAD = {"single": dict(d_hs=5e-3, d_memory=6e-2, d_c5=8e-2, glob=6e-2, cos=0.998),
+                 "multi": dict(d_hs=5e-3, d_memory=6e-2, d_c5=8e-2, glob=6e-2, cos=0.998)}
+
+
+@pytest.mark.parametrize("kind", ["single", "multi"])
+def test_cfg1_full_depth_backward_of_a_linear_functional_vs_oracle(hip, kind):
+    """Mid-network gradients at full depth against the q=True oracle, with the SAME upstream gradient on both sides
+    (scalar = sum(logits * W), W fixed): d_hs (head), d_memory (decoder + query encoder), d_c5 (encoder + input_proj +
+    GroupNorm) and every parameter gradient.  What is left is the bf16 noise of the backward GEMM operands and the
+    ReLU-mask flips of the forward noise."""
+    n_phrase = 3 if kind == "multi" else 0
+    samples, targets = make_inputs("e2e_" + kind, B=2, H=320, W=320, L=40, n_phrase=n_phrase)
+    model, crit, P, ocfg = build_full()
+    model._debug = True
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    W = formula_tensor("functional.w", tuple(out["pred_logits"].shape), 1.0, bf16=False)
+    if n_phrase:            # padded phrase slots carry no loss in the reference either: keep them out of the functional
+        W = W * out["phrase_mask"].view(1, *out["phrase_mask"].shape, 1, 1).cpu().float()
+    hip_scalar_backward(model, (out["pred_logits"] * W.cuda()).sum())
+    o, _, _, grads, ig, names = oracle_run(P, samples, targets, ocfg, q=True, functional=W)
+    d = model._dbg
+    Bn, C, h, w = o["c5"].shape
+    got = {
+        "d_logits": rel(d["dlogits"], ig[0]),
+        "d_hs": rel(d["dhs"].view(ig[1].shape), ig[1]),
+        "d_memory": rel(d["dmem"].view(Bn, -1, 256).transpose(0, 1), ig[2]),
+        "d_c5": rel(d["g_c5"].view(Bn, h, w, C).permute(0, 3, 1, 2), ig[3] * (o["c5"] > 0)),
+    }
+    a = torch.cat([model.store.G[k].detach().float().cpu().reshape(-1) for k in names])
+    b = torch.cat([grads[k].reshape(-1) for k in names])
+    got["glob"] = float((a - b).norm() / b.norm())
+    got["cos"] = float((a * b).sum() / (a.norm() * b.norm()))
+    per = sorted(rel(model.store.G[k], grads[k]) for k in names if float(grads[k].norm()) > 1e-6 * float(b.norm()))
+    got["median_tensor"] = per[len(per) // 2]
+    print(f"\n[cfg1 {kind} functional backward] " + "  ".join(f"{k}={v:.3e}" for k, v in got.items()))
+    m = MEASURED_GRAD[kind]
+    assert got["d_logits"] < 1e-6, got
+    assert got["d_hs"] < 1.5 * m["d_hs"], got
+    assert got["d_memory"] < 1.5 * m["d_memory"] and got["d_c5"] < 1.5 * m["d_c5"], got
+    assert got["glob"] < 1.5 * m["glob"] and got["cos"] > 1 - 1.5 * (1 - m["cos"]), got
+
+
+# ---------------------------------------------------------------------------------------------- configs[3]: RefTRSeg
+def box_masks(targets, sizes):
+    """Deterministic bool masks [1, h, w]: the pixels inside the image's first target box."""
+    out = []
+    for t, (h, w) in zip(targets, sizes):
+        cx, cy, bw, bh = [float(v) for v in t["boxes"][0]]
+        ys = torch.arange(h)[:, None].float() / h; xs = torch.arange(w)[None, :].float() / w
+        m = (xs >= cx - bw / 2) & (xs < cx + bw / 2) & (ys >= cy - bh / 2) & (ys < cy + bh / 2)
+        out.append(dict(t, masks=m[None]))
+    return out
+
+
+MEASURED_SEG = dict(boxes=1.3e-3, pred_masks=1.5e-2, mask_att=1.0e-2, loss=5e-3)
+
+
+def test_cfg4_seg_full_depth_vs_oracle(hip):
+    """RefTRSeg at full depth, 320x320, batch 2 (reftr_segmentation.py:76-175, 314-337) against the fp32 oracle."""
+    samples, targets = make_inputs("seg_full", B=2, H=320, W=320, L=40)
+    targets = box_masks(targets, [(320, 320), (240, 213)])          # make_inputs: image 1 is valid on 3/4 x 2/3 of the frame
+    model, crit, P, ocfg = build_full(masks=True)
+    s, tg = to_cuda(samples, targets)
+    with torch.no_grad():
+        out = model(s)
+        ld = crit(out, tg)
+        o = O.reftr_forward(P, samples, ocfg, q=False)
+        losses = O.criterion(o, targets)
+    got = {
+        "boxes": rel(out["pred_boxes"], o["pred_boxes"]),
+        "pred_masks": rel(out["pred_masks"], o["pred_masks"]),
+        "mask_att": rel(out["mask_att"], o["mask_att"]),
+        "loss": max(abs(float(ld[k]) - float(losses[k])) / max(abs(float(losses[k])), 0.1) for k in losses),
+    }
+    print("\n[cfg4 320x320 full depth] " + "  ".join(f"{k}={v:.2e}" for k, v in got.items())
+          + "  losses " + " ".join(f"{k}={float(ld[k]):.5f}/{float(losses[k]):.5f}" for k in losses))
+    assert out["pred_masks"].shape == o["pred_masks"].shape == (2, 1, 80, 80)
+    for k, v in MEASURED_SEG.items():
+        assert got[k] < 1.5 * v, (k, got)
+
+
+@pytest.fixture(scope="module")
+def cfg4():
+    """configs[3] at its full size: RefTRSeg, ResNet-50, 640x640, batch 8, L = 40 (no aux loss, reftr_segmentation.py:52)."""
+    import bench
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGOnePhraseSeg
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.util.misc import NestedTensor
+    cfg = L.ModelConfig(masks=True)
+    model = RefTR(cfg, device="cuda", aux_loss=False)
+    wd = {"loss_giou": 1.0, "loss_bbox": 1.0, "loss_dice": 1.0, "loss_mask": 1.0}
+    crit = CriterionVGOnePhraseSeg(wd, ["masks", "boxes"])
+    samples, targets = bench.synth_batch(8, 640, 640, 40, "cuda", 1234)
+    g = torch.Generator().manual_seed(99)
+    for b, t in enumerate(targets):                      # Bernoulli(0.3) masks [1, H, W] on the valid region
+        wv = 480 if b % 2 == 0 else 640
+        t["masks"] = torch.rand(1, 640, wv, generator=g) < 0.3
+    s = {k: v.cuda() for k, v in samples.items() if k not in ("img", "img_mask")}
+    s["img"] = NestedTensor(samples["img"].cuda(), samples["img_mask"].cuda())
+    tg = [{k: v.cuda() for k, v in t.items()} for t in targets]
+    return model, crit, s, tg, cfg
+
+
+def _seg_init(model):
+    model.reset_parameters(seed=0)
+    torch.manual_seed(11)
+    model.store.P["bbox_embed.layers.2.weight"].normal_(0, 0.05)
+    model.mark_dirty()
+    model.eval()
+
+
+def test_cfg4_fullsize_known_answer_determinism_and_batch_equivariance(cfg4):
+    from test_fullsize_gpu import closed_form_losses, take
+    model, crit, s, tg, cfg = cfg4
+    model.reset_parameters(seed=0)                       # the reference's init: last bbox layer zero (reftr_transformer.py:131-132)
+    model.eval()
+    with torch.no_grad():
+        out = model(s)
+        ld = crit(out, tg)
+    assert out["pred_boxes"].shape == (8, 1, 1, 4) and "aux_outputs" not in out
+    assert out["pred_masks"].shape == (8, 1, 160, 160) and out["mask_att"].shape == (8, 8, 20, 20)
+    assert bool((out["pred_boxes"] == 0.5).all())
+    lb, lg = closed_form_losses(tg)
+    assert abs(float(ld["loss_bbox"]) - lb) < 2e-6 * max(1.0, lb) and abs(float(ld["loss_giou"]) - lg) < 2e-6 * max(1.0, lg)
+    # the attention map is a joint softmax over heads x h x w of each query (reftr_segmentation.py:205): sums to 1, zero on padding
+    att = out["mask_att"].float()
+    assert float((att.flatten(1).sum(1) - 1).abs().max()) < 1e-3
+    pad = s["img"].mask[:, ::32, ::32][:, :20, :20]
+    assert float((att * pad[:, None].float()).abs().max()) == 0.0
+    assert np.isfinite(float(ld["loss_mask"])) and 0 < float(ld["loss_dice"]) < 1
+    # determinism + batch equivariance of the eval forward (no atomics; samples independent)
+    _seg_init(model)
+    with torch.no_grad():
+        a = model(s); a = {k: a[k].clone() for k in ("pred_logits", "pred_masks", "mask_att")}
+        b = model(s)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        perm = [3, 0, 7, 1, 6, 2, 5, 4]
+        sp, _ = take(s, tg, perm)
+        c = model(sp)
+    assert float(a["pred_masks"].std()) > 1e-3
+    assert float((c["pred_masks"] - a["pred_masks"][perm]).abs().max()) <= 1e-4 * float(a["pred_masks"].abs().max())
+    assert float((c["pred_logits"] - a["pred_logits"][:, perm]).abs().max()) <= 1e-5 * float(a["pred_logits"].abs().max())
+
+
+def test_cfg4_fullsize_shard_additivity_and_train_step(cfg4):
+    """The data-parallel contract for the multitask loss: all four losses are normalised by the GLOBAL number of boxes
+    (reftr_segmentation.py:316-337, criterion.py:176-180), so grad(batch of 8) = (grad(first 4) + grad(last 4)) / 2."""
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.models import layout as L
+    from reftr_amd.optim import FusedAdamW
+    from test_fullsize_gpu import _grads, take
+    model, crit, s, tg, cfg = cfg4
+    _seg_init(model)
+    g_full, l_full = _grads(model, crit, s, tg)
+    s0, t0 = take(s, tg, [0, 1, 2, 3]); s1, t1 = take(s, tg, [4, 5, 6, 7])
+    g0, l0 = _grads(model, crit, s0, t0)
+    g1, l1 = _grads(model, crit, s1, t1)
+    assert torch.isfinite(g_full).all() and float(g_full.norm()) > 0
+    assert abs(l_full - 0.5 * (l0 + l1)) < 2e-5 * abs(l_full)
+    want = 0.5 * (g0 + g1)
+    st = model.store
+    for grp in (L.GROUP_MAIN, L.GROUP_MASK, L.GROUP_BACKBONE, L.GROUP_BERT):
+        b, e = st.group_range[grp]
+        if e <= b:
+            continue
+        x, y = g_full[b:e].double(), want[b:e].double()
+        relerr = float((x - y).norm() / y.norm()); cos = float((x @ y) / (x.norm() * y.norm()))
+        print(f"[cfg4 shard additivity] group {grp}: rel {relerr:.2e} cos {cos:.7f}")
+        assert relerr < 3e-3 and cos > 0.99999, (grp, relerr, cos)
+    # one REC+RES training step at full size (dropout on, clip 0.1, AdamW): finite, weights move by at most lr
+    opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    model.train()
+    before = model.store.flat_p.clone()
+    lv, _, _, gn = train_step(model, crit, s, tg, opt, None, 0.1)
+    torch.cuda.synchronize()
+    assert np.isfinite(lv) and torch.isfinite(model.store.flat_g).all() and torch.isfinite(model.store.flat_p).all()
+    step = (model.store.flat_p - before).abs().max()
+    assert float(gn) > 0 and 0 < float(step) <= 1.01e-4 + 1e-8 * float(before.abs().max()) + 1e-7

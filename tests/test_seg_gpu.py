@@ -99,10 +99,10 @@ def test_refer_segmentation_vs_reference_golden(hip):
     assert float(ph[:, :, 520:].abs().max()) == 0.0 and float(ph[520:].abs().max()) == 0.0
     # post-processing decisions
     from reftr_amd.models.post_process import PostProcessSegm
-    res = PostProcessSegm()([{} for _ in range(2)], {"pred_masks": out["pred_masks"].detach().cpu()},
+    res = PostProcessSegm()([{} for _ in range(2)], {"pred_masks": out["pred_masks"].detach()},
                             torch.from_numpy(g["post_orig"]), torch.from_numpy(g["post_sizes"]))
     for i in range(2):
-        same = (res[i]["masks"] == torch.from_numpy(g[f"post_masks{i}"])).float().mean()
+        same = (res[i]["masks"].cpu() == torch.from_numpy(g[f"post_masks{i}"])).float().mean()
         assert float(same) > 0.99
 
 

@@ -1,7 +1,12 @@
 """HBM traffic of the GEMM-family kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes: the two do not fit one pass).
 
-    python tools/pmc_traffic.py <fetch.db> <write.db> --steps 5 [--json profiles/rNN_pmc_traffic.json]
+    python tools/pmc_traffic.py <fetch.db> <write.db> --steps 5 --bench-json gpurun_out/rNN_bench.json [--json profiles/rNN_pmc_traffic.json]
+
+--bench-json: the JSON line of the same build's `python bench.py` run; its build_id (hash of the sources), its
+launches_per_step (one launch = one rt_conv_gemm / rt_conv_wgrad(_grouped) call; a call may dispatch several kernels, e.g.
+tile kernel + split reduction, so kernel_dispatches_per_step below is larger) and its workload are written into the output,
+and bench.py only quotes a traffic file whose three values match the running build.
 
 Units / corrections (same guide, "HBM [CDNA4]"): both counters are kilobytes; on gfx950 FETCH_SIZE reports half of the
 bytes of wide coalesced reads (128-B requests tallied at 64 B), so fetch bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE
@@ -24,6 +29,7 @@ def main():
     ap.add_argument("fetch_db"); ap.add_argument("write_db")
     ap.add_argument("--steps", type=int, required=True, help="training steps the profiled command ran (warm-up included)")
     ap.add_argument("--json", default="")
+    ap.add_argument("--bench-json", default="", help="bench.py's JSON line of the same build (build_id, launches_per_step)")
     a = ap.parse_args()
     f, w = per_kernel(a.fetch_db), per_kernel(a.write_db)
     rows, fam = [], dict(launches=0, fetch=0.0, write=0.0)
@@ -39,14 +45,20 @@ def main():
     tot_f, tot_w = sum(r[2] for r in rows), sum(r[3] for r in rows)
     res = {
         "steps": a.steps,
-        "gemm_family": {"launches_per_step": fam["launches"] / a.steps,
+        "gemm_family": {"kernel_dispatches_per_step": fam["launches"] / a.steps,
                         "hbm_bytes_per_step": (fam["fetch"] + fam["write"]) / a.steps,
-                        "hbm_bytes_per_launch": (fam["fetch"] + fam["write"]) / max(1, fam["launches"]),
                         "fetch_bytes_per_step": fam["fetch"] / a.steps, "write_bytes_per_step": fam["write"] / a.steps},
         "whole_step": {"hbm_bytes_per_step": (tot_f + tot_w) / a.steps, "fetch_bytes_per_step": tot_f / a.steps,
                        "write_bytes_per_step": tot_w / a.steps},
         "corrections": "fetch = 2 x FETCH_SIZE KB (gfx950 128-B requests tallied at 64 B); write = WRITE_SIZE KB",
     }
+    if a.bench_json:
+        import os
+        b = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
+        res["build_id"] = b.get("build_id")
+        res["bench_launches_per_step"] = b["roofline"]["launches_per_step"]
+        res["workload"] = [b["config"]["batch_per_gpu"], b["config"]["image_size"], b["n_gpus"]]
+        res["gemm_family"]["hbm_bytes_per_launch"] = res["gemm_family"]["hbm_bytes_per_step"] / res["bench_launches_per_step"]
     print(json.dumps(res, indent=1))
     if a.json:
         json.dump(res, open(a.json, "w"), indent=1)
