@@ -91,7 +91,8 @@ class RefTR(nn.Module):
     def reset_parameters(self, seed=0):
         """Random init with the reference's distributions (models/reftr.py:45-49 xavier on every VLTransformer
         matrix, level_embed ~ N(0,1); reftr_transformer.py:131-135 zero last bbox layer, xavier input_proj;
-        BERT-style N(0, 0.02); kaiming for convs; identity FrozenBN)."""
+        BERT-style N(0, 0.02); kaiming for convs; identity FrozenBN; RES head: xavier projections, kaiming_uniform(a=1)
+        convolutions with zero bias, unit GroupNorm, reftr_segmentation.py:190-193,238-241)."""
         g = torch.Generator(device="cpu").manual_seed(seed)
         for name, shape, kind in self.store.table:
             t = self.store.P[name]
@@ -100,6 +101,7 @@ class RefTR(nn.Module):
                 t.fill_(1.0 if leaf in ("weight", "running_var") else 0.0)
                 continue
             is_norm = ("LayerNorm" in name or ".norm" in name or name.startswith("input_proj.0.1")
+                       or (name.startswith("mask_head.gn"))       # GroupNorm of MaskHeadSmallConv: weight 1, bias 0 (torch default)
                        or (len(shape) == 1 and name.split(".")[-2] in ("1", "5") and leaf in ("weight", "bias")
                            and any(s in name for s in ("map_sentence", "map_phrase", "fuse_encoder_query", "context_out"))))
             if is_norm:
@@ -120,8 +122,11 @@ class RefTR(nn.Module):
                     v.normal_(0.0, math.sqrt(2.0 / (fan_out * rf)), generator=g)
                 elif name == "vl_transformer.level_embed":
                     v.normal_(0.0, 1.0, generator=g)
-                elif name.startswith("vl_transformer.") or name.startswith("input_proj.0.0"):
-                    a = math.sqrt(6.0 / (fan_in + fan_out * rf))
+                elif name.startswith("vl_transformer.") or name.startswith("input_proj.0.0") or name.startswith("bbox_attention."):
+                    a = math.sqrt(6.0 / (fan_in + fan_out * rf))          # xavier_uniform (also reftr_segmentation.py:190-193)
+                    v.uniform_(-a, a, generator=g)
+                elif name.startswith("mask_head."):
+                    a = math.sqrt(3.0 / fan_in)                           # kaiming_uniform_(a=1), reftr_segmentation.py:238-241
                     v.uniform_(-a, a, generator=g)
                 else:
                     a = 1.0 / math.sqrt(fan_in)

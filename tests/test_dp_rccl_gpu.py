@@ -102,49 +102,56 @@ def test_train_one_epoch_under_the_dp_wrapper(hip, single_rank_group):
     assert 1e-5 < float(moved) < 1e-3
 
 
-def test_bf16_vs_fp32_gradient_exchange_trajectory_of_two_emulated_ranks(hip):
-    """Bounds what the default bf16 gradient exchange (reftr_amd/parallel.py) does to a training trajectory, relative to the
-    reference's fp32 DDP exchange (main_vg.py:290-296), with TWO ranks emulated on the one-GPU box: every step computes
-    the local gradients of two different shards on the same replica, then forms the all-reduced buffer exactly as RCCL
-    would -- fp32: g0 + g1; bf16: bf16(bf16(g0) + bf16(g1)) read by clip + AdamW straight from the bf16 buffer -- with
-    1/world folded into the update.  Same data, same weights at step 0, 6 steps each."""
+def test_bf16_vs_fp32_gradient_exchange_of_two_emulated_ranks_along_a_trajectory(hip):
+    """Bounds what the default bf16 gradient exchange (reftr_amd/parallel.py) does to training, relative to the reference's
+    fp32 DDP exchange (main_vg.py:290-296), with TWO ranks emulated on the one-GPU box.  Along a 6-step trajectory (driven by
+    the fp32 exchange) every step computes the local gradients g0, g1 of two different shards on the same replica and forms
+    the all-reduced buffer both ways, exactly as RCCL would -- fp32: g0 + g1; bf16: bf16(bf16(g0) + bf16(g1)), read by clip +
+    AdamW straight from the bf16 buffer -- then applies clip(0.1) + AdamW (1/world folded in) from the SAME weights and
+    optimizer state and compares the two updates: total gradient norm and the direction / size of the weight update.
+    (Whole trajectories are not compared: on this fixture two fp32 runs already drift apart by 1e-2 in the loss after three
+    steps through atomics-order noise, tests/test_model_gpu.py, and Adam's first steps are sign-like.)"""
     from reftr_amd.optim import FusedAdamW
     shards = [to_cuda(*make_inputs(f"dp_shard{r}", B=2, H=96, W=128, L=12)) for r in range(2)]
-    res = {}
-    for mode in ("fp32", "bf16"):
-        model, crit, P, ocfg = build(small=True)
-        model.eval()
-        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
-        st = model.store
-        model._grad_scale = 0.5
-        if mode == "bf16":
-            st.flat_g16 = torch.zeros_like(st.flat_g, dtype=torch.bfloat16)
-        losses, norms = [], []
-        for it in range(6):
-            gs, lv = [], 0.0
-            for s, tg in shards:
-                out = model(s)
-                ld = crit(out, tg)
-                total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
-                st.flat_g.zero_()
-                total.backward()
-                gs.append(st.flat_g.clone()); lv += 0.5 * float(total)
-            if mode == "fp32":
-                st.flat_g.copy_(gs[0] + gs[1])
+    model, crit, P, ocfg = build(small=True)
+    model.eval()
+    opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    st = model.store
+    model._grad_scale = 0.5
+    g16 = torch.zeros_like(st.flat_g, dtype=torch.bfloat16)
+    rows, losses = [], []
+    for it in range(6):
+        gs, lv = [], 0.0
+        for s, tg in shards:
+            out = model(s)
+            ld = crit(out, tg)
+            total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+            st.flat_g.zero_()
+            total.backward()
+            gs.append(st.flat_g.clone()); lv += 0.5 * float(total)
+        losses.append(lv)
+        state = (st.flat_p.clone(), opt.m.clone(), opt.v.clone(), opt.step_dev.clone(), opt.step_count)
+
+        def update(bf16):
+            st.flat_p.copy_(state[0]); opt.m.copy_(state[1]); opt.v.copy_(state[2]); opt.step_dev.copy_(state[3]); opt.step_count = state[4]
+            if bf16:
+                g16.copy_(gs[0].bfloat16() + gs[1].bfloat16()); st.flat_g16 = g16
             else:
-                st.flat_g16.copy_((gs[0].bfloat16() + gs[1].bfloat16()))
-            gn = opt.clip_grad_norm_(0.1)
-            opt.step()
-            losses.append(lv); norms.append(float(gn))
-        res[mode] = (losses, norms, st.flat_p.clone())
-        if mode == "bf16":
-            del st.flat_g16
-    (l0, n0, p0), (l1, n1, p1) = res["fp32"], res["bf16"]
-    dl = max(abs(a - b) / abs(a) for a, b in zip(l0, l1)); dn = max(abs(a - b) / a for a, b in zip(n0, n1))
-    dp = rel(p1, p0)
-    print(f"\n[bf16 vs fp32 exchange, 2 emulated ranks, 6 steps] loss rel {dl:.2e}  grad-norm rel {dn:.2e}  weights rel {dp:.2e}"
-          f"  losses fp32 {['%.4f' % v for v in l0]}")
-    assert l0[0] == l1[0]                                   # step 0: same weights, the exchange format has not acted yet
-    assert dn < 5e-3                                        # ||bf16 sum|| vs ||fp32 sum||: rounding noise averages out (2^-9 / sqrt(n))
-    assert dl < 2e-2 and dp < 2e-4                          # the fixture's run-to-run trajectory noise (test_model_gpu.py) bounds both
-    assert l0[-1] < l0[0] and l1[-1] < l1[0]
+                st.flat_g.copy_(gs[0] + gs[1])
+            try:
+                gn = opt.clip_grad_norm_(0.1)
+                opt.step()
+                torch.cuda.synchronize()
+                return float(gn), (st.flat_p - state[0]).double()
+            finally:
+                if bf16:
+                    del st.flat_g16
+        n16, d16 = update(True)
+        n32, d32 = update(False)                 # the trajectory continues from the fp32 update
+        rows.append((abs(n16 - n32) / n32, float((d16 * d32).sum() / (d16.norm() * d32.norm())), float((d16 - d32).norm() / d32.norm())))
+    print("\n[bf16 vs fp32 exchange, 2 emulated ranks] per step (grad-norm rel, cos of the weight update, rel diff of the update): "
+          + "  ".join(f"({a:.1e}, {b:.5f}, {c:.1e})" for a, b, c in rows) + f"  losses {['%.4f' % v for v in losses]}")
+    assert losses[-1] < losses[0]
+    for a, b, c in rows:
+        assert a < 2e-3           # ||sum|| : the 2^-9 rounding errors average out over 10^8 elements
+        assert b > 0.995 and c < 0.1

@@ -18,7 +18,7 @@ from test_model_gpu import build, rel, to_cuda
 pytestmark = pytest.mark.gpu
 
 
-def compare(samples, targets, tol_box=8e-3, tol_loss=8e-3, backward=True):
+def compare(samples, targets, tol_box=3.1e-3, tol_loss=3.4e-3, backward=True):      # 1.5 x the worst measured (2.05e-3 / 2.22e-3)
     model, crit, P, ocfg = build(small=True)
     model.eval()
     s, tg = to_cuda(samples, targets)

@@ -115,9 +115,12 @@ def test_cfg1_full_depth_forward_and_losses_vs_oracle(hip, kind):
     assert 0.6 < got["logits"] / got["logits_q"] < 1.6, got
 
 
-# measured: d_logits exact (the functional's own gradient), d_hs / d_memory / d_c5 and the global parameter gradient
-MEASURED_GRAD = {"single": dict(d_hs=5e-3, d_memory=6e-2, d_c5=8e-2, glob=6e-2, cos=0.998),
-                 "multi": dict(d_hs=5e-3, d_memory=6e-2, d_c5=8e-2, glob=6e-2, cos=0.998)}
+# measured: d_logits exact (the functional's own gradient); d_hs / d_memory / d_c5 and the global parameter gradient sit on the
+# ReLU-mask-flip floor: the 0.5 % forward noise flips ~1 % of the ReLU decisions of the 3-layer box head / FFNs / bottlenecks,
+# and a flipped unit contributes its whole gradient -> sqrt(1 %) = 10 % in L2 already at d_hs, one ReLU MLP below the logits.
+# The sharp statement about the backward pass is the directional-derivative test below.
+MEASURED_GRAD = {"single": dict(d_hs=9.1e-2, d_memory=1.16e-1, d_c5=9.5e-2, glob=8.0e-2, cos=0.9968),
+                 "multi": dict(d_hs=9.3e-2, d_memory=1.9e-1, d_c5=1.8e-1, glob=1.47e-1, cos=0.9896)}
 
 
 @pytest.mark.parametrize("kind", ["single", "multi"])
@@ -145,8 +148,8 @@ def test_cfg1_full_depth_backward_of_a_linear_functional_vs_oracle(hip, kind):
         "d_memory": rel(d["dmem"].view(Bn, -1, 256).transpose(0, 1), ig[2]),
         "d_c5": rel(d["g_c5"].view(Bn, h, w, C).permute(0, 3, 1, 2), ig[3] * (o["c5"] > 0)),
     }
-    a = torch.cat([model.store.G[k].detach().float().cpu().reshape(-1) for k in names])
-    b = torch.cat([grads[k].reshape(-1) for k in names])
+    a = torch.cat([model.store.G[k].detach().double().cpu().reshape(-1) for k in names])
+    b = torch.cat([grads[k].double().reshape(-1) for k in names])
     got["glob"] = float((a - b).norm() / b.norm())
     got["cos"] = float((a * b).sum() / (a.norm() * b.norm()))
     per = sorted(rel(model.store.G[k], grads[k]) for k in names if float(grads[k].norm()) > 1e-6 * float(b.norm()))
@@ -157,6 +160,53 @@ def test_cfg1_full_depth_backward_of_a_linear_functional_vs_oracle(hip, kind):
     assert got["d_hs"] < 1.5 * m["d_hs"], got
     assert got["d_memory"] < 1.5 * m["d_memory"] and got["d_c5"] < 1.5 * m["d_c5"], got
     assert got["glob"] < 1.5 * m["glob"] and got["cos"] > 1 - 1.5 * (1 - m["cos"]), got
+
+
+def test_cfg1_full_depth_backward_is_the_derivative_of_the_forward(hip):
+    """Self-consistency at full depth, free of any oracle noise: the eval-mode forward is bit-deterministic, so central
+    differences of the scalar s(theta) = sum(logits * W) along a direction v measure the directional derivative of the function
+    the kernels compute; it must equal <flat_g, v> from the hand-written backward.  v = the normalised gradient of each
+    learning-rate group (main | ResNet | BERT), step sized for a 2 % change of s (far above the bf16 staircase of the forward).
+    Together with the forward parity above this pins the gradients: a wrong-but-consistent layer would show up in the forward,
+    a wrong backward formula shows up here."""
+    from reftr_amd.models import layout as L
+    samples, targets = make_inputs("e2e_single", B=2, H=320, W=320, L=40)
+    model, crit, P, ocfg = build_full()
+    # The formula weights sit exactly ON the bf16 grid: a perturbation below half an ulp would never reach the bf16 GEMM
+    # operands (the forward would not move at all for the Linear weights).  Dither the fp32 masters uniformly over their
+    # rounding interval (+-2^-8 relative), so that operand rounding acts as unbiased stochastic rounding of the perturbation
+    # (expected noise of the difference quotient over ~10^8 weights: < 1 %).
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    st = model.store
+    st.flat_p.mul_(1.0 + (torch.rand(st.flat_p.shape, generator=gen, device="cuda") - 0.5) * 2.0 ** -7)
+    model.mark_dirty()
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    W = formula_tensor("functional.w", tuple(out["pred_logits"].shape), 1.0, bf16=False).cuda()
+    scale = float((out["pred_logits"].detach() * W).abs().sum())
+    hip_scalar_backward(model, (out["pred_logits"] * W).sum())
+    g, p0 = st.flat_g.clone(), st.flat_p.clone()
+    res = {}
+    for name, grp in (("main", L.GROUP_MAIN), ("resnet", L.GROUP_BACKBONE), ("bert", L.GROUP_BERT)):
+        a, b = st.group_range[grp]
+        gn = float(g[a:b].double().norm())
+        v = torch.zeros_like(g); v[a:b] = g[a:b] / gn
+        eps = 0.02 * scale / gn
+        vals = []
+        for sign in (1.0, -1.0):
+            st.flat_p.copy_(p0 + sign * eps * v)
+            model.mark_dirty()
+            with torch.no_grad():
+                vals.append(float((model(s)["pred_logits"].double() * W.double()).sum()))
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        res[name] = (fd, gn, abs(fd - gn) / gn)
+    st.flat_p.copy_(p0); model.mark_dirty()
+    print("\n[cfg1 directional derivative] " + "  ".join(f"{k}: fd={v[0]:.4e} <g,v>={v[1]:.4e} rel={v[2]:.2e}" for k, v in res.items()))
+    for k, v in res.items():
+        assert v[2] < MEASURED_FD[k] * 1.5, (k, v)
+
+
+MEASURED_FD = {"main": 2e-2, "resnet": 3e-2, "bert": 3e-2}
 
 
 # ---------------------------------------------------------------------------------------------- configs[3]: RefTRSeg
@@ -171,7 +221,7 @@ def box_masks(targets, sizes):
     return out
 
 
-MEASURED_SEG = dict(boxes=1.3e-3, pred_masks=1.5e-2, mask_att=1.0e-2, loss=5e-3)
+MEASURED_SEG = dict(boxes=2.45e-3, pred_masks=1.65e-2, mask_att=4.4e-3, loss=1.7e-3)
 
 
 def test_cfg4_seg_full_depth_vs_oracle(hip):
