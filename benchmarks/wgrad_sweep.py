@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reftr_amd import hip
 from tile_sweep import graph_time
-VARS = [int(v) for v in os.environ.get('VARS', '9,0,1,2,3,5').split(',')]      # 9 = register-staged kernel, 0 = default LDS-DMA choice
+VARS = [int(v) for v in os.environ.get('VARS', '0,8,2').split(',')]      # 0 = library default (v2 kernels), 8 = first-generation default (128x128, 32-row chunks, 3 stages), 9 = register-staged
 WS = os.environ.get('WS', '1') == '1'
 # (name, B, H, Cin, Cout, k, stride)
 CONVS = [("l1 1x1 64->256 @160", 8, 160, 64, 256, 1, 1), ("l1 1x1 256->64 @160", 8, 160, 256, 64, 1, 1), ("l1 3x3 64 @160", 8, 160, 64, 64, 3, 1),

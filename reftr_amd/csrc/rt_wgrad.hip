@@ -695,6 +695,14 @@ int launch_wgrad_dma(WgradArgs a, int msplit, float* ws, long long ws_bytes, hip
 
 static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a);
 
+// second-generation kernels (rt_wgrad2.hip)
+bool rt_w2_eligible(const rt_conv_wgrad_desc& d);
+int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* workspace, long long workspace_bytes, hipStream_t s);
+static int w2_enabled() {
+    static const int e = getenv("REFTR_WG2") ? atoi(getenv("REFTR_WG2")) : 1;
+    return e;
+}
+
 // The Linear weight gradients a grouped launch accepts: plain [M,N]^T [M,K] products on the 128x128 DMA kernel.
 static bool groupable(const rt_conv_wgrad_desc& d) {
     const long long M = (long long)d.B * d.DH * d.DW;
@@ -702,9 +710,34 @@ static bool groupable(const rt_conv_wgrad_desc& d) {
            d.variant == 0 && d.msplit <= 0;
 }
 
+static int wgrad_grouped_v1(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes, rt_stream_t stream);
+
 extern "C" int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes,
                                      rt_stream_t stream) {
     if (!descs || n <= 0) return RT_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (w2_enabled()) {
+        // second generation: every eligible problem of the group (1x1 / 3x3 convolutions and Linears alike) shares the grouped
+        // v2 launches and their group-level split policy; the rest (ragged channel counts, pinned variants) goes on below
+        static int idx[4096];
+        static rt_conv_wgrad_desc rest[4096];
+        int m = 0, nr = 0;
+        for (int i = 0; i < n && i < 4096; ++i) {
+            if (!descs[i].dy || !descs[i].x || !descs[i].dw) return RT_ERR_BADARG;
+            if (rt_w2_eligible(descs[i])) idx[m++] = i; else rest[nr++] = descs[i];
+        }
+        if (n > 4096) return RT_ERR_UNSUPPORTED;
+        if (m > 0) {
+            const int rc = rt_w2_run(descs, idx, m, workspace, workspace ? (long long)workspace_bytes : 0, s);
+            if (rc != RT_OK) return rc;
+        }
+        // (the v2 launches above have consumed the workspace; the first-generation group below re-uses it -- same stream, in order)
+        return nr > 0 ? wgrad_grouped_v1(rest, nr, workspace, workspace_bytes, stream) : RT_OK;
+    }
+    return wgrad_grouped_v1(descs, n, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_grouped_v1(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes, rt_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     constexpr int BN = 128, BC = 128, CR = 32, NS = 3, MINB = 2;
     static WgradGroup g; static ReduceGroup r;            // host-side staging (single caller thread per device, see header)
@@ -803,6 +836,10 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
         hipLaunchKernelGGL(small_m_wgrad_kernel, dim3(blocks), dim3(256), 0, s, a.dy, a.x, a.dw, a.scale, a.dbias, a.M, a.N, a.SC);
         RT_CHECK_LAUNCH();
         return RT_OK;
+    }
+    if (w2_enabled() && rt_w2_eligible(*d) && !getenv("REFTR_WGV")) {       // a group of one
+        const int zero = 0;
+        return rt_w2_run(d, &zero, 1, d->workspace, d->workspace ? (long long)d->workspace_bytes : 0, s);
     }
     // variant: 0 = LDS-DMA kernels (default), 9 = register-staged kernel, 1..5 = pinned 128x128 DMA staging shapes
     static const int wgv_env = getenv("REFTR_WGV") ? atoi(getenv("REFTR_WGV")) : 0;

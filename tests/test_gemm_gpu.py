@@ -292,3 +292,47 @@ def test_grouped_gemm_equals_single_launches(hip):
     g.run()
     _, a0 = hip.linear(x, w, out_bf16=False, out_f32=True); _, b0 = hip.linear(x2, w2, out_bf16=False, out_f32=True)
     assert torch.equal(a, a0) and torch.equal(b, b0)
+
+
+def test_wgrad_v2_grouped_policy_matches_torch(hip):
+    """Second-generation weight gradients (csrc/rt_wgrad2.hip) as the training step uses them: ONE rt_conv_wgrad_grouped call
+    over a stage-like mix -- 1x1 / 3x3 / stride-2 convolutions with a FrozenBN scale, Linears with a fused bias gradient, every
+    tile configuration (256x256, 128x256, 256x128, 128x128), ragged channel counts and row counts, a group small enough that
+    the m axis is split (workspace + reduction) -- against torch fp32; dw is accumulated into a non-zero buffer."""
+    g = torch.Generator().manual_seed(21)
+    batch = hip.WgradBatch(workspace_mb=256)
+    checks = []
+    convs = [(2, 40, 40, 256, 1024, 1, 1, 0), (2, 40, 40, 1024, 256, 1, 1, 0), (2, 40, 40, 256, 256, 3, 1, 1), (2, 41, 39, 128, 128, 3, 2, 1),
+             (2, 40, 40, 512, 1024, 1, 2, 0), (1, 80, 80, 128, 512, 1, 1, 0), (1, 80, 80, 512, 128, 1, 1, 0), (2, 23, 19, 192, 320, 3, 1, 1)]
+    for B, H, W, Ci, Co, k, s, p in convs:
+        x = bf(torch.randn(B, Ci, H, W, generator=g)).float()
+        w = torch.zeros(Co, Ci, k, k, requires_grad=True)
+        y = F.conv2d(x, w, None, stride=s, padding=p)
+        dy = bf(torch.randn(y.shape, generator=g))
+        y.backward(dy.float())
+        Ho, Wo = y.shape[-2:]
+        scale = torch.rand(Co, generator=g) + 0.5
+        dw = torch.full((Co, k, k, Ci), 0.25, device="cuda")
+        batch.add_conv(nhwc(dy).cuda(), nhwc(x).bfloat16().cuda(), dw, (B, H, W, Ci, Ho, Wo, Co, k, k, s, p), scale=scale.cuda())
+        checks.append((dw, w.grad.permute(0, 2, 3, 1) * scale.view(-1, 1, 1, 1), None, None))
+    for M, K, N in [(320, 768, 2304), (3520, 2048, 256), (3520, 256, 512), (333, 64, 72), (20000, 256, 256)]:
+        x = bf(torch.randn(M, K, generator=g)); dy = bf(torch.randn(M, N, generator=g))
+        dw = torch.full((N, K), 0.25, device="cuda"); db = torch.full((N,), 2.0, device="cuda")
+        batch.add(dy.cuda(), x.cuda(), dw, db)
+        checks.append((dw, dy.float().T @ x.float(), db, dy.float().sum(0)))
+    batch.run()
+    for dw, ref, db, ref_b in checks:
+        assert rel(dw - 0.25, ref) < TOL_F32, (tuple(dw.shape), rel(dw - 0.25, ref))
+        if db is not None:
+            assert rel(db - 2.0, ref_b) < 1e-5
+
+
+def test_wgrad_v2_single_problem_splits_the_row_axis(hip):
+    """A group of one: few tiles, many rows -> the row axis is cut into ~256 workgroups whose partial tiles meet in the reduction."""
+    g = torch.Generator().manual_seed(22)
+    for M, K, N in [(51200, 128, 128), (12800, 256, 1024), (100000, 64, 64)]:
+        x = bf(torch.randn(M, K, generator=g)); dy = bf(torch.randn(M, N, generator=g))
+        dw = torch.full((N, K), -1.0, device="cuda"); db = torch.zeros(N, device="cuda")
+        hip.linear_wgrad(dy.cuda(), x.cuda(), dw, dbias=db)
+        assert rel(dw + 1.0, dy.float().T @ x.float()) < TOL_F32
+        assert rel(db, dy.float().sum(0)) < 1e-5
