@@ -35,7 +35,7 @@ struct W2Prob {
     int SH, SW, SC, DH, DW, N, KH, KW, stride, pad, M;
     int n_tiles, c_tiles, tiles, splits, chunks_per_split, out_elems;
     unsigned dy_bytes, x_bytes;
-    int simple, accumulate, xrot;
+    int simple, accumulate, xrot, cfg;
 };
 constexpr int W2_MAXP = 20;
 // cum[x][i]: workgroups of problems 0 .. i-1 that run on XCD x (block id b -> XCD b & 7, position b >> 3 in its order)
@@ -345,7 +345,10 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
     }
 }
 
-template <int BN, int BC, int WN, int WC, int CR, int NS>
+// One launch for a whole group: every problem carries its tile configuration (0: 256x256, 1: 128x256, 2: 256x128, 3: 128x128),
+// so that the small-output problems of a stage (layer2: 128-channel sides) do not serialise into four chip-wide launches
+// with four tails and four reductions.
+template <int CR, int NS>
 __global__ __launch_bounds__(512, 1) void w2_grouped_kernel(const W2Group g) {
     // block id -> XCD x = id & 7 (hardware round-robin), position q = id >> 3 in that XCD's order -> (problem, split, tile):
     // problem i owns positions [cum[x][i], cum[x][i+1]); inside, its row splits s with (s + xrot) % 8 == x follow each other,
@@ -372,8 +375,17 @@ __global__ __launch_bounds__(512, 1) void w2_grouped_kernel(const W2Group g) {
         split = local / p.tiles; tile = local - split * p.tiles;
     }
     split = __builtin_amdgcn_readfirstlane(split); tile = __builtin_amdgcn_readfirstlane(tile);
-    if (p.simple) w2_body<BN, BC, WN, WC, CR, NS, true>(p, split, tile, g.abl, g.pf);
-    else          w2_body<BN, BC, WN, WC, CR, NS, false>(p, split, tile, g.abl, g.pf);
+    const int sel = __builtin_amdgcn_readfirstlane(p.cfg * 2 + (p.simple ? 1 : 0));
+    switch (sel) {
+        case 0: w2_body<256, 256, 4, 2, CR, NS, false>(p, split, tile, g.abl, g.pf); break;
+        case 1: w2_body<256, 256, 4, 2, CR, NS, true>(p, split, tile, g.abl, g.pf); break;
+        case 2: w2_body<128, 256, 2, 4, CR, NS, false>(p, split, tile, g.abl, g.pf); break;
+        case 3: w2_body<128, 256, 2, 4, CR, NS, true>(p, split, tile, g.abl, g.pf); break;
+        case 4: w2_body<256, 128, 4, 2, CR, NS, false>(p, split, tile, g.abl, g.pf); break;
+        case 5: w2_body<256, 128, 4, 2, CR, NS, true>(p, split, tile, g.abl, g.pf); break;
+        case 6: w2_body<128, 128, 2, 4, CR, NS, false>(p, split, tile, g.abl, g.pf); break;
+        default: w2_body<128, 128, 2, 4, CR, NS, true>(p, split, tile, g.abl, g.pf); break;
+    }
 }
 
 // dw[i] (+)= scale[i / row_elems] * sum_s part[s][i] for every split problem of a group (one launch)
@@ -402,15 +414,15 @@ __global__ __launch_bounds__(256) void w2_reduce_kernel(const W2Reduce g) {
     *o = g.accumulate[lo] ? *o + a : a;
 }
 
-template <int BN, int BC, int WN, int WC, int CR, int NS>
+template <int CR, int NS>
 int w2_launch(const W2Group& g, int blocks, hipStream_t s) {
-    constexpr size_t smem = (size_t)NS * CR * (BN + BC) * 2 + 4 * 256;      // stages + the prefetch scratch words
+    constexpr size_t smem = (size_t)NS * CR * (256 + 256) * 2 + 4 * 256;      // the largest configuration's stages + the prefetch scratch words
     static bool attr_done = false;
     if (!attr_done) {
-        if (smem > 65536) (void)hipFuncSetAttribute((const void*)w2_grouped_kernel<BN, BC, WN, WC, CR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)w2_grouped_kernel<CR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((w2_grouped_kernel<BN, BC, WN, WC, CR, NS>), dim3((unsigned)blocks), dim3(512), smem, s, g);
+    hipLaunchKernelGGL((w2_grouped_kernel<CR, NS>), dim3((unsigned)blocks), dim3(512), smem, s, g);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
@@ -443,20 +455,19 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
     constexpr int CR = 32;
     static const int BNs[4] = {256, 128, 256, 128}, BCs[4] = {256, 256, 128, 128};
     static const int slots[4] = {256, 256, 256, 512};         // resident workgroups on the chip (LDS: 130 / 98 / 98 / 66 KB each)
-    for (int cfg = 0; cfg < 4; ++cfg) {
-        // ---- collect this configuration's problems
-        int list[1024]; int m = 0;
-        for (int i = 0; i < n && m < 1024; ++i) if (w2_cfg_of(descs[idx[i]]) == cfg) list[m++] = idx[i];
-        if (!m) continue;
-        const int BN = BNs[cfg], BC = BCs[cfg];
-        // ---- group-level split policy: cut the m axis only while the group has fewer tile tasks than resident slots
+    for (int base = 0; base < n; base += W2_MAXP) {         // one launch (and one split policy) per W2_MAXP problems
+        // ---- group-level split policy: cut the m axis only while the group has fewer tile tasks than resident slots; work is
+        // counted in 128x128-tile chunk units so that problems of different tile configurations end up with equally long workgroups
+        const int* list = idx + base; const int m = n - base < W2_MAXP ? n - base : W2_MAXP;
         long long tiles_total = 0; double work = 0;
         for (int k = 0; k < m; ++k) {
             const rt_conv_wgrad_desc& d = descs[list[k]];
+            const int cfg = w2_cfg_of(d); const int BN = BNs[cfg], BC = BCs[cfg];
             const long long M = (long long)d.B * d.DH * d.DW;
             const long long tl = (long long)((d.N + BN - 1) / BN) * ((d.SC + BC - 1) / BC) * d.KH * d.KW;
-            tiles_total += tl; work += (double)tl * (double)((M + CR - 1) / CR);
+            tiles_total += tl; work += (double)tl * (double)((M + CR - 1) / CR) * (double)(BN / 128 * (BC / 128));
         }
+        const int cfg = 0;
         const int target = target_env > 0 ? target_env : slots[cfg];
         const double per_wg = work / (double)target;          // chunks a workgroup should own so that ~`target` workgroups cover the group
         W2Group g; W2Reduce r; g.n = 0; r.n = 0; g.xcd = xcd_env; g.abl = abl_env; g.pf = pf_env;
@@ -469,13 +480,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
                 int blocks;
                 if (xcd_env) { int mx = 0; for (int x = 0; x < 8; ++x) if (xcount[x] > mx) mx = xcount[x]; blocks = mx * 8; }
                 else blocks = lin_total;
-                int rc;
-                switch (cfg) {
-                    case 0: rc = w2_launch<256, 256, 4, 2, CR, 4>(g, blocks, s); break;
-                    case 1: rc = w2_launch<128, 256, 2, 4, CR, 4>(g, blocks, s); break;
-                    case 2: rc = w2_launch<256, 128, 4, 2, CR, 4>(g, blocks, s); break;
-                    default: rc = w2_launch<128, 128, 2, 4, CR, 4>(g, blocks, s); break;
-                }
+                const int rc = w2_launch<CR, 4>(g, blocks, s);
                 if (rc != RT_OK) return rc;
             }
             if (r.n > 0) {
@@ -490,6 +495,8 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
         for (int k = 0; k < m; ++k) {
             const rt_conv_wgrad_desc& d = descs[list[k]];
             W2Prob p;
+            p.cfg = w2_cfg_of(d);
+            const int BN = BNs[p.cfg], BC = BCs[p.cfg];
             p.dy = (const bf16_t*)d.dy; p.x = (const bf16_t*)d.x; p.dw = d.dw; p.scale = d.scale; p.dbias = d.dbias; p.part = nullptr;
             p.SH = d.SH; p.SW = d.SW; p.SC = d.SC; p.DH = d.DH; p.DW = d.DW; p.N = d.N; p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
             const long long M = (long long)d.B * d.DH * d.DW;
@@ -502,7 +509,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             const int total_chunks = (int)((M + CR - 1) / CR);
             int splits = 1;
             if (tiles_total < target) {
-                splits = (int)((double)total_chunks / per_wg + 0.5);
+                splits = (int)((double)total_chunks * (double)(BN / 128 * (BC / 128)) / per_wg + 0.5);
                 const int maxs = (int)(M / minrows_env);
                 if (splits > maxs) splits = maxs;
                 if (splits < 1) splits = 1;
