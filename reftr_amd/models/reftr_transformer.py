@@ -52,7 +52,8 @@ class _RefTRSegFunction(torch.autograd.Function):
 class RefTR(nn.Module):
     def __init__(self, cfg: L.ModelConfig, device="cuda", aux_loss=True):
         super().__init__()
-        assert cfg.n_q == 1, "num_queries_per_phrase = 1 (every reference config); n_q > 1 is not wired yet"
+        assert cfg.n_q >= 1
+        assert cfg.n_q == 1 or not cfg.masks, "RefTRSeg predicts one mask per image (n_ph = n_q = 1, reftr_segmentation.py:101-103)"
         self.cfg = cfg
         self.aux_loss = aux_loss and not cfg.masks       # RefTRSeg is built with aux_loss=False (reftr_segmentation.py:52)
         self.num_queries_per_phrase = cfg.n_q
@@ -325,11 +326,22 @@ class RefTR(nn.Module):
         cn32, _, _, cm, cr = net.ln_fwd(co, qe + "context_out.1.", want_bf16=False)
         H.rows_add(N, E, a_f32=cn32, b_f32=mem32, b_map=(-Pn, S, 0), out_bf16=cat_rows, o_map=(1, 2, 0))
         (f32, _, _, _, _), fq_ctx = net.mlp_fwd(cat16, qe + "fuse_encoder_query.", want_bf16=False)
-        emb = st.P[qe + "query_embed.weight"].view(2, E)                   # n_q = 1: rows [tgt part | query_pos part]
+        # phrase_queries = fused.repeat(1, 1, 1, 2) + query_embed.view(1, 1, n_q, -1), phrase-major (:60-64): query row
+        # (b * Pn + ph) * n_q + q = fused[b, ph] + query_embed[q], first half -> tgt, second half -> query_pos
+        nq = cfg.n_q
+        Nf, N = N, N * nq                                                  # fused phrase rows / query rows
         tgt32 = torch.empty(N, E, dtype=torch.float32, device=dev); tgt16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
         qpos = torch.empty(N, E, dtype=torch.float32, device=dev); tgtq16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
-        H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 0), out_f32=tgt32, out_bf16=tgt16)
-        H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 1), out_f32=qpos)
+        if nq == 1:
+            emb = st.P[qe + "query_embed.weight"].view(2, E)               # rows [tgt part | query_pos part]
+            H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 0), out_f32=tgt32, out_bf16=tgt16)
+            H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 1), out_f32=qpos)
+        else:
+            emb2 = st.P[qe + "query_embed.weight"].view(nq, 2, E)
+            emb_t, emb_p = emb2[:, 0].contiguous(), emb2[:, 1].contiguous()       # [n_q, E] each (n_q x 1 KB of glue)
+            H.rows_add(N, E, a_f32=f32, a_map=(-nq, 1, 0), b_f32=emb_t, b_map=(nq, 0, 0), out_f32=tgt32, out_bf16=tgt16)
+            H.rows_add(N, E, a_f32=f32, a_map=(-nq, 1, 0), b_f32=emb_p, b_map=(nq, 0, 0), out_f32=qpos)
+            qmask = qmask.view(B, Pn, 1).expand(B, Pn, nq).reshape(B, Pn * nq).contiguous()      # :237-238
         H.rows_add(N, E, a_f32=tgt32, b_f32=qpos, out_bf16=tgtq16)
 
         # ---- decoder (models/modeling/transformer.py:105-143) + shared norm on every layer's output
@@ -343,7 +355,7 @@ class RefTR(nn.Module):
         for i in range(NL):
             t32, t16, tq16, r = net.dec_layer_fwd(f"{vt}decoder.layers.{i}.", t32, t16, tq16, qpos, mem16, memp16,
                                                   qmask, kpm, B, T, S, kv=kvs[i], t3_out=t3_all[i * N:(i + 1) * N],
-                                                  fold_sa="phrase" not in samples)
+                                                  fold_sa="phrase" not in samples and nq == 1)
             dec.append(r)
         # decoder.norm on every layer's output (transformer.py:131-141, return_intermediate): ONE launch over the stack
         hm = hr = None
@@ -355,7 +367,7 @@ class RefTR(nn.Module):
         _, logits = net.lin_fwd("bbox_embed.layers.2.", y2, out_bf16=False, out_f32=True)
 
         self._saved = dict(
-            B=B, S=S, Lq=Lq, HW=HW, Pn=Pn, N=N, T=T, NL=NL, bb_saved=bb_saved, c5=c5, bctx=bctx, pctx=pctx, ms_ctx=ms_ctx,
+            B=B, S=S, Lq=Lq, HW=HW, Pn=Pn, N=N, Nf=Nf, T=T, NL=NL, bb_saved=bb_saved, c5=c5, bctx=bctx, pctx=pctx, ms_ctx=ms_ctx,
             mp_ctx=mp_ctx, ip=ip, gn_stats=gn_stats, kpm=kpm, qmask=qmask, ctxmask=ctxmask, enc=enc, mem16=mem16,
             memp16=memp16, mem32=mem32, cls16=cls16, lang16=lang16, kq=kq, qs=qs, vs=vs, qw=qw, c16=c16, co=co,
             cst=(cm, cr), fq_ctx=fq_ctx, dec=dec, hs_stats=hs_stats, t3s=t3s, hs16=hs16, y1=y1, y2=y2, pooled16=pooled16,
@@ -451,15 +463,25 @@ class RefTR(nn.Module):
                                        sv["qmask"], sv["kpm"], B, T, S, dmem, dmemp, dqpos)
 
         # ---- QueryEncoder backward
-        gqe = st.G[qe + "query_embed.weight"].view(2, E)
-        H.colsum(ga, gqe[0]); H.colsum(dqpos, gqe[1])
+        nq, Nf = cfg.n_q, sv["Nf"]
         df = torch.empty(N, E, dtype=torch.float32, device=dev)
+        if nq == 1:
+            gqe = st.G[qe + "query_embed.weight"].view(2, E)
+            H.colsum(ga, gqe[0]); H.colsum(dqpos, gqe[1])
         if gb is None:                  # trivial self-attention (one query per image): no gradient through t + query_pos
             H.rows_add(N, E, a_f32=ga, b_f32=dqpos, out_f32=df)
         else:
-            H.colsum(gb, gqe[0])
+            if nq == 1:
+                H.colsum(gb, gqe[0])
             H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=df)
             H.rows_add(N, E, a_f32=dqpos, out_f32=df, accumulate=True)
+        if nq > 1:
+            # query row (phrase, q): d query_embed[q] = sum over phrases, d fused[phrase] = sum over q (rows of a few KB: glue)
+            dt = (ga if gb is None else ga + gb).view(Nf, nq, E)
+            g2 = st.G[qe + "query_embed.weight"].view(nq, 2, E)
+            g2[:, 0] += dt.sum(0); g2[:, 1] += dqpos.view(Nf, nq, E).sum(0)
+            df = df.view(Nf, nq, E).sum(1).contiguous()
+        N = Nf                          # from here on: one row per phrase
         dcat = net.mlp_bwd(sv["fq_ctx"], df, qe + "fuse_encoder_query.")            # fp32 [N, 2E]
         dcat_rows = dcat.view(2 * N, E)
         _, dcob = net.ln_bwd(dcat_rows, sv["co"], qe + "context_out.1.", *sv["cst"], rowmap=(1, 2, 0), want_f32=False)

@@ -442,3 +442,49 @@ def test_roberta_backbone_vs_reference_golden(hip):
     ref = torch.from_numpy(g["grad_pos_emb"])
     assert float((gp * ref).sum() / (gp.norm() * ref.norm())) > 0.97
     assert rel(model.store.G["bbox_embed.layers.2.weight"], g["grad_bbox2_w"]) < 3e-2
+
+
+@pytest.mark.parametrize("n_phrase", [0, 3])
+def test_two_queries_per_phrase_vs_oracle(hip, n_phrase):
+    """num_queries_per_phrase = 2 (reftr_transformer.py:60-66, 235-238, 276-280): query rows are phrase-major
+    (phrase, q), both queries of a phrase share its validity, the box loss averages over k = n_q predictions per target
+    (criterion.py:131-153).  Single-phrase inputs with n_q > 1 crash in the reference (its [B, 1] query mask does not match
+    the n_q decoder keys); here the mask is expanded like in the multi-phrase branch -- compared with the oracle, which
+    expands it the same way."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), n_q=2)
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), n_q=2)
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda")
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    samples, targets = make_inputs("e2e_nq2", B=2, H=96, W=128, L=12, n_phrase=n_phrase)
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    Pn = max(n_phrase, 1)
+    assert out["pred_boxes"].shape == (2, Pn, 2, 4) and out["phrase_mask"].shape == (2, 2 * Pn)
+    names = [k for k in P if O.is_trainable(k)]
+    Pq = {k: v.clone() for k, v in P.items()}
+    leaves = {k: Pq[k].requires_grad_(True) for k in names}
+    o = O.reftr_forward(Pq, samples, ocfg, q=False)
+    ol = O.criterion(o, targets)
+    tot = O.total_loss(ol, O.weight_dict(ocfg))
+    ref = dict(zip(names, torch.autograd.grad(tot, [leaves[k] for k in names])))
+    assert np.array_equal(out["phrase_mask"].cpu().numpy(), o["phrase_mask"].numpy())
+    valid = o["phrase_mask"].view(2, Pn, 2)
+    rb = rel(out["pred_logits"].sigmoid()[:, valid.cuda()], o["logits"].sigmoid()[:, valid])
+    ld = crit(out, tg)
+    rl = max(abs(float(ld[k]) - float(ol[k])) / max(1.0, abs(float(ol[k]))) for k in ol)
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    model.store.flat_g.zero_()
+    total.backward()
+    a = torch.cat([model.store.G[k].detach().double().cpu().reshape(-1) for k in names])
+    b = torch.cat([ref[k].double().reshape(-1) for k in names])
+    rg, cos = float((a - b).norm() / b.norm()), float((a * b).sum() / (a.norm() * b.norm()))
+    gq = rel(model.store.G["query_encoder.query_embed.weight"], ref["query_encoder.query_embed.weight"])
+    print(f"\n[n_q = 2, {Pn} phrase(s)] boxes {rb:.2e}  worst loss {rl:.2e}  global grad rel {rg:.2e} cos {cos:.4f}  d query_embed rel {gq:.2e}")
+    assert rb < TOL["boxes"] * 1.5 and rl < TOL["loss"] * 1.5
+    assert rg < 0.25 and cos > 0.97 and gq < 0.1
