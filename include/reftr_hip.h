@@ -104,7 +104,7 @@ int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_stream_t stre
  *   dw[n][kh][kw][c] += scale[n] * sum_m dy[m, n] * gather(x)[m, (kh,kw,c)]
  * Replaces the conv_backward(weight) / addmm(grad^T, input) calls autograd issues for every trainable
  * Conv2d (layer2-4, backbone.py:87-89; input_proj) and nn.Linear on the path.
- * dy  bf16 [B, DH, DW, N]     x  bf16 [B, SH, SW, SC]     dw  fp32 [N][KH][KW][SC] (accumulated, atomics)
+ * dy  bf16 [B, DH, DW, N]     x  bf16 [B, SH, SW, SC]     dw  fp32 [N][KH][KW][SC] (accumulated; `overwrite`: assigned)
  * Both operands are staged in their natural row-major layout and turned into MFMA fragments with the
  * gfx950 LDS transpose read (ds_read_b64_tr_b16).  The M axis is split over blocks (`msplit`, 0=auto).
  * constraints: SC % 16 == 0, N % 4 == 0
@@ -123,6 +123,10 @@ typedef struct rt_conv_wgrad_desc {
     float*  workspace;    /* optional scratch for the split-M partial tiles (plain stores + one reduction pass instead of
                              fp32 atomics); must not be shared by launches on concurrent streams.  NULL: atomics */
     int64_t workspace_bytes;
+    int32_t overwrite;    /* 1: dw = result instead of dw += result (the caller guarantees this is the first contribution to dw since
+                             the gradient buffer was last consumed: no pre-zeroed memory is needed and the epilogue skips the read of
+                             dw).  dbias always accumulates. */
+    int32_t reserved;
 } rt_conv_wgrad_desc;
 int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
 
@@ -131,7 +135,7 @@ int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
  * launch per 64 problems; `jobs` is a HOST array, copied into the kernel arguments. */
 typedef struct rt_small_wgrad_job {
     const void* dy; const void* x; float* dw; float* dbias;
-    int32_t M, N, K, reserved;
+    int32_t M, N, K, overwrite;      /* overwrite: as in rt_conv_wgrad_desc (dbias accumulates) */
 } rt_small_wgrad_job;
 int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream);
 
@@ -502,6 +506,10 @@ typedef struct rt_adamw_desc {
     const void* g16;          /* optional bf16 gradient buffer read INSTEAD of g (the exchanged gradients of a data-parallel run) */
 } rt_adamw_desc;
 int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream);
+/* rt_zero_chunks — clears `n` chunks of an fp32 buffer in one launch: table (DEVICE, static) = n x {int64 element offset, int64
+ * element count (<= 16384)}.  Used for the gradient tensors that are accumulated with atomics (biases, norm parameters,
+ * embeddings) when the weight matrices are produced in overwrite mode and the full clear of the gradient buffer is skipped. */
+int rt_zero_chunks(float* base, const int64_t* table, int n, rt_stream_t stream);
 /* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */
 int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream);
 

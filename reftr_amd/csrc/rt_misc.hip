@@ -361,3 +361,27 @@ extern "C" int rt_pos_grad(const float* dpos, float* d_lang_pos, float* d_type, 
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
+
+
+// rt_zero_chunks: see include/reftr_hip.h.  One workgroup per chunk (<= 16384 floats); 16-B stores where the chunk is aligned.
+namespace {
+__global__ __launch_bounds__(256) void zero_chunks_kernel(float* __restrict__ base, const int64_t* __restrict__ table) {
+    const int64_t off = table[2 * blockIdx.x], cnt = table[2 * blockIdx.x + 1];
+    float* p = base + off;
+    int64_t i = threadIdx.x;
+    const int64_t head = (4 - (off & 3)) & 3;                    // elements in front of the first 16-B boundary
+    if (i < head && i < cnt) p[i] = 0.f;
+    const int64_t n4 = cnt > head ? (cnt - head) >> 2 : 0;
+    f32x4* p4 = reinterpret_cast<f32x4*>(p + head);
+    for (int64_t j = threadIdx.x; j < n4; j += 256) p4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t tail0 = head + (n4 << 2);
+    if (tail0 + i < cnt) p[tail0 + i] = 0.f;
+}
+}  // namespace
+
+extern "C" int rt_zero_chunks(float* base, const int64_t* table, int n, rt_stream_t stream) {
+    if (!base || !table || n <= 0) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(zero_chunks_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, base, table);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}

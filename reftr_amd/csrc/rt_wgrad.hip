@@ -21,6 +21,7 @@ struct WgradArgs {
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
     int M, chunks_per_block, c_tiles;
     float* part; int out_elems; int xcd, early, epi_lds;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
+    int overwrite;            // single-writer launches (one split, no workspace) store instead of accumulating
     unsigned dy_bytes, x_bytes;
 };
 
@@ -475,7 +476,7 @@ __device__ __forceinline__ void wgrad_dma_body(const bf16_t* __restrict__ dyp, c
                 float* o = dst + ((size_t)n * taps + tap) * p.SC + c;
                 if (mode == 0) { *o = v; continue; }
                 if (p.scale) v *= p.scale[n];
-                atomicAdd(o, v);
+                if (p.overwrite) *o = v; else atomicAdd(o, v);
             }
         }
     }
@@ -502,12 +503,12 @@ __global__ __launch_bounds__(256, MINB) void conv_wgrad_dma_grouped_kernel(const
     wgrad_dma_body<BN, BC, true, CR, NS>(g.j[lo].dy, g.j[lo].x, g.j[lo], lin, g.gx[lo], g.gy[lo]);
 }
 
-struct ReduceGroup { const float* part[24]; float* dw[24]; const float* scale[24]; int out_elems[24], row_elems[24], nsplit[24], first[25]; int n; };
+struct ReduceGroup { const float* part[24]; float* dw[24]; const float* scale[24]; int out_elems[24], row_elems[24], nsplit[24], overwrite[24], first[25]; int n; };
 
 // dw[i] += scale[i / row_elems] * sum_s part[s][i].  A workgroup owns 64 float4 columns; its 4 thread rows take the
 // splits round-robin (4 independent loads in flight each) and meet in LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           const float* __restrict__ scale, int out_elems, int row_elems, int nsplit) {
+                                                           const float* __restrict__ scale, int out_elems, int row_elems, int nsplit, int overwrite) {
     __shared__ f32x4 red[3][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = (blockIdx.x * 64 + tx) * 4;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     a += red[0][tx] + red[1][tx] + red[2][tx];
     if (scale) a *= scale[i / row_elems];
     f32x4* o = reinterpret_cast<f32x4*>(dw + i);
-    *o = *o + a;
+    *o = overwrite ? a : *o + a;
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const ReduceGroup g) {
@@ -552,13 +553,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const ReduceG
     a += red[0][tx] + red[1][tx] + red[2][tx];
     if (scale) a *= scale[i / row_elems];
     f32x4* o = reinterpret_cast<f32x4*>(dw + i);
-    *o = *o + a;
+    *o = g.overwrite[lo] ? a : *o + a;
 }
 
 // M <= 16 rows (decoder-side Linears): plain outer-product accumulation, one thread per (n, 4 k's)
 __global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             float* __restrict__ dw, const float* __restrict__ scale,
-                                                            float* __restrict__ dbias, int M, int N, int K) {
+                                                            float* __restrict__ dbias, int M, int N, int K, int overwrite) {
     const int k4 = K >> 2;
     const size_t total = (size_t)N * k4;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __rest
         }
         if (scale) a *= scale[n];
         f32x4* o = reinterpret_cast<f32x4*>(dw + (size_t)n * K + kk);
-        *o = *o + a;
+        *o = overwrite ? a : *o + a;
         if (dbias && kk == 0) dbias[n] += gs;
     }
 }
@@ -604,12 +605,22 @@ __global__ __launch_bounds__(256) void small_m_wgrad_grouped_kernel(const SmallJ
         for (int r = 0; r < 4; ++r) a[r] += g * (float)xv[r];
     }
     f32x4* o = reinterpret_cast<f32x4*>(q.dw + (size_t)n * q.K + kk);
-    *o = *o + a;
+    *o = q.overwrite ? a : *o + a;
     if (q.dbias && kk == 0) q.dbias[n] += gs;
+}
+
+// overwrite semantics for launches whose tiles are accumulated with atomics by several workgroups: clear dw, then accumulate
+static int wg_clear_for_atomics(WgradArgs& a, hipStream_t s) {
+    if (!a.overwrite) return RT_OK;
+    const size_t n = (size_t)a.N * a.KH * a.KW * a.SC;
+    const hipError_t e = rt_zero_f32(a.dw, n, s);
+    a.overwrite = 0;
+    return e == hipSuccess ? RT_OK : (int)e;
 }
 
 template <int BN, int BC>
 int launch_wgrad(WgradArgs a, int msplit, hipStream_t s) {
+    { const int zrc = wg_clear_for_atomics(a, s); if (zrc != RT_OK) return zrc; }
     const int nt = (a.N + BN - 1) / BN;
     a.c_tiles = (a.SC + BC - 1) / BC;
     const int taps = a.KH * a.KW;
@@ -672,6 +683,7 @@ int launch_wgrad_dma(WgradArgs a, int msplit, float* ws, long long ws_bytes, hip
     const int gy = (total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
     const bool use_ws = ws && gy > 1 && (long long)gy * out_elems * 4 <= ws_bytes && (out_elems & 3) == 0;
     a.part = use_ws ? ws : nullptr; a.out_elems = (int)out_elems;
+    if (!use_ws && gy > 1) { const int zrc = wg_clear_for_atomics(a, s); if (zrc != RT_OK) return zrc; }
     constexpr size_t smem = (size_t)NS * CR * (BN * 2 + BC * 2);
     const dim3 grid((unsigned)base_blocks, (unsigned)gy), block(256);
     const bool simple = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0);
@@ -685,7 +697,7 @@ int launch_wgrad_dma(WgradArgs a, int msplit, float* ws, long long ws_bytes, hip
     RT_CHECK_LAUNCH();
     if (use_ws) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((out_elems / 4 + 63) / 64)), dim3(256), 0, s, ws, a.dw, a.scale,
-                           (int)out_elems, taps * a.SC, gy);
+                           (int)out_elems, taps * a.SC, gy, a.overwrite);
         RT_CHECK_LAUNCH();
     }
     return RT_OK;
@@ -791,11 +803,12 @@ static int wgrad_grouped_v1(const rt_conv_wgrad_desc* descs, int n, float* works
         }
         const bool use_ws = gy > 1 && workspace && ws_off + need <= workspace_bytes;
         a.part = use_ws ? workspace + ws_off / 4 : nullptr; a.out_elems = (int)out_elems;
+        if (!use_ws && gy > 1) { const int zrc = wg_clear_for_atomics(a, s); if (zrc != RT_OK) return zrc; }
         g.j[g.n] = a; g.first[g.n] = blocks; g.gx[g.n] = (int)base_blocks; g.gy[g.n] = gy; ++g.n;
         blocks += (int)((base_blocks * gy + 7) / 8 * 8);
         if (use_ws) {
             r.part[r.n] = a.part; r.dw[r.n] = a.dw; r.scale[r.n] = a.scale; r.out_elems[r.n] = (int)out_elems; r.row_elems[r.n] = a.SC;
-            r.nsplit[r.n] = gy; r.first[r.n] = rblocks; ++r.n;
+            r.nsplit[r.n] = gy; r.overwrite[r.n] = a.overwrite; r.first[r.n] = rblocks; ++r.n;
             rblocks += (int)((out_elems / 4 + 63) / 64);
             ws_off += (need + 255) / 256 * 256;
         }
@@ -813,7 +826,7 @@ static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a) {
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     if (M * d->N >= 0x3fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
-    a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0; a.part = nullptr; a.out_elems = 0;
+    a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0; a.part = nullptr; a.out_elems = 0; a.overwrite = d->overwrite ? 1 : 0;
     static const int xcd_env = getenv("REFTR_XCD") ? atoi(getenv("REFTR_XCD")) : 1;
     a.xcd = xcd_env;
     static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
@@ -833,7 +846,7 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (a.M <= 16 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && (a.SC & 3) == 0) {
         const size_t total = (size_t)a.N * (a.SC >> 2);
         int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(small_m_wgrad_kernel, dim3(blocks), dim3(256), 0, s, a.dy, a.x, a.dw, a.scale, a.dbias, a.M, a.N, a.SC);
+        hipLaunchKernelGGL(small_m_wgrad_kernel, dim3(blocks), dim3(256), 0, s, a.dy, a.x, a.dw, a.scale, a.dbias, a.M, a.N, a.SC, a.overwrite);
         RT_CHECK_LAUNCH();
         return RT_OK;
     }

@@ -505,7 +505,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             p.out_elems = d.N * d.KH * d.KW * d.SC;
             p.dy_bytes = (unsigned)(M * d.N * 2); p.x_bytes = (unsigned)((long long)d.B * d.SH * d.SW * d.SC * 2);
             p.simple = (d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
-            p.accumulate = 1;
+            p.accumulate = d.overwrite ? 0 : 1;
             const int total_chunks = (int)((M + CR - 1) / CR);
             int splits = 1;
             if (tiles_total < target) {
@@ -530,7 +530,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             if (p.splits > 1 && workspace) {
                 p.part = workspace + ws_off / 4;
                 r.part[r.n] = p.part; r.dw[r.n] = p.dw; r.scale[r.n] = p.scale; r.out_elems[r.n] = p.out_elems;
-                r.row_elems[r.n] = d.KH * d.KW * d.SC; r.nsplit[r.n] = p.splits; r.accumulate[r.n] = 1; r.first[r.n] = rblocks; ++r.n;
+                r.row_elems[r.n] = d.KH * d.KW * d.SC; r.nsplit[r.n] = p.splits; r.accumulate[r.n] = p.accumulate; r.first[r.n] = rblocks; ++r.n;
                 rblocks += (p.out_elems / 4 + 255) / 256;
                 ws_off += ((long long)p.splits * p.out_elems * 4 + 255) / 256 * 256;
             } else if (p.splits > 1) {                    // no scratch: do not split

@@ -71,6 +71,15 @@ def _total(criterion, loss_dict):
     return sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
 
 
+def _zero_grad(optimizer):
+    """engine_vg.py:60.  The fused optimizer clears only what backward accumulates with atomics (the weight matrices are
+    overwritten by their producers); any other optimizer: the plain zero_grad()."""
+    if isinstance(getattr(optimizer, "model", None), torch.nn.Module) and hasattr(optimizer, "apply_pending"):
+        optimizer.zero_grad(fast=True)
+    else:
+        optimizer.zero_grad()
+
+
 def train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0):
     """The loop body, engine_vg.py:40-72.  Returns (loss_value, reduced scaled dict, reduced unscaled dict,
     grad_norm tensor)."""
@@ -86,7 +95,7 @@ def train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None,
         print("Loss is {}, stopping training".format(loss_value))
         print(loss_dict_reduced)
         sys.exit(1)
-    optimizer.zero_grad()
+    _zero_grad(optimizer)
     losses.backward()
     if hasattr(optimizer, "clip_grad_norm_"):
         grad_total_norm = optimizer.clip_grad_norm_(max_norm)
@@ -299,7 +308,7 @@ class CapturedTrainStep:
         loss_dict = self.criterion(outputs, self.t)
         losses = _total(self.criterion, loss_dict)
         if zero:
-            self.optimizer.zero_grad()
+            _zero_grad(self.optimizer)
         losses.backward()
         return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}
 

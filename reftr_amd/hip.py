@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -40,7 +40,7 @@ class ConvWgradDesc(Structure):
         ("DH", c_int32), ("DW", c_int32), ("N", c_int32),
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
         ("msplit", c_int32), ("dbias", c_void_p), ("variant", c_int32),
-        ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64),
+        ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64), ("overwrite", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -167,7 +167,7 @@ class AdamWDesc(Structure):
 # (tests/test_abi.py cross-checks this table against the header).
 class SmallWgradJob(Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
-                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("reserved", c_int32)]
+                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("overwrite", c_int32)]
 
 
 class GnNhwcDesc(Structure):
@@ -258,6 +258,7 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_sqnorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
+    "rt_zero_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
     "rt_ln_param_grad_grouped": (c_int, [POINTER(LnPgJob), c_int, c_void_p]),
     "rt_conv_wgrad_grouped": (c_int, [POINTER(ConvWgradDesc), c_int, c_void_p, ctypes.c_int64, c_void_p]),
@@ -463,8 +464,8 @@ def _wgrad_workspace(dev):
     return ws
 
 
-def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, workspace=True):
-    """dw[N,KH,KW,SC] (fp32, accumulated) += scale[n] * sum_m dy[m,n] * gather(x)[m,(kh,kw,c)]."""
+def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, workspace=True, overwrite=False):
+    """dw[N,KH,KW,SC] (fp32) += (overwrite: =) scale[n] * sum_m dy[m,n] * gather(x)[m,(kh,kw,c)]."""
     B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw")
     _req(scale, torch.float32, "scale")
@@ -472,7 +473,7 @@ def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, 
     _req(dbias, torch.float32, "dbias")
     ws = _wgrad_workspace(dy.device) if workspace else None
     d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit, _p(dbias), variant,
-                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0)
+                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0, int(bool(overwrite)), 0)
     _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
            lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"), tag=("W",) + tuple(geom))
     return dw
@@ -784,6 +785,12 @@ def box_postprocess(boxes, valid_u8, sizes_f32=None):
     return out, counts
 
 
+def zero_chunks(base, table, n):
+    """Clears n chunks {element offset, count} (static device int64 table) of the fp32 buffer `base` in one launch."""
+    _req(base, torch.float32, "base"); _req(table, torch.int64, "table")
+    _check(lib().rt_zero_chunks(_p(base), _p(table), int(n), _stream()), "rt_zero_chunks")
+
+
 def sqnorm(g, out):
     if g.dtype == torch.bfloat16:
         _check(lib().rt_sqnorm_bf16(_p(g), g.numel(), _p(out), _stream()), "rt_sqnorm_bf16")
@@ -840,21 +847,22 @@ class WgradBatch:
         self.flops += 2.0 * geom[0] * geom[4] * geom[5] * geom[6] * geom[7] * geom[8] * geom[3]
         self.nbytes += _algo_bytes(("W",) + tuple(geom))
 
-    def add(self, dy, x, dw, dbias=None):
+    def add(self, dy, x, dw, dbias=None, overwrite=False):
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(dbias, torch.float32, "dbias")
         M, N = dy.shape
         K = x.shape[1]
         assert x.shape[0] == M and dw.numel() == N * K
-        self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), None, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, _p(dbias), 0, None, 0))
+        self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), None, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, _p(dbias), 0, None, 0,
+                                        int(bool(overwrite)), 0))
         self.keep.append((dy, x))
         self._account((M, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
 
-    def add_conv(self, dy, x, dw, geom, scale=None):
+    def add_conv(self, dy, x, dw, geom, scale=None, overwrite=False):
         """A convolution weight gradient (any geometry: the non-groupable ones are forwarded to rt_conv_wgrad at run())."""
         B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(scale, torch.float32, "scale")
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, 0, None, 0,
-                                        None, 0))
+                                        None, 0, int(bool(overwrite)), 0))
         self.keep.append((dy, x, scale))
         self._account(geom)
 
@@ -886,12 +894,12 @@ class SmallWgradBatch:
         self.jobs, self.keep = [], []
         self.flops = self.nbytes = 0.0
 
-    def add(self, dy, x, dw, dbias=None):
+    def add(self, dy, x, dw, dbias=None, overwrite=False):
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(dbias, torch.float32, "dbias")
         M, N = dy.shape
         K = x.shape[1]
         assert M <= 16 and x.shape[0] == M and dw.numel() == N * K and K % 4 == 0
-        self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, 0))
+        self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, int(bool(overwrite))))
         self.keep.append((dy, x))
         self.flops += 2.0 * M * N * K; self.nbytes += 2.0 * M * (N + K) + 4.0 * N * K
 

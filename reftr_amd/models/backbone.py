@@ -60,6 +60,9 @@ class ResNetBody:
         self.W = {}      # bf16 operands: name -> [N][T][C]; name + '.t' -> [C][T][N]
         self.bn = {}     # bn prefix -> (scale, shift) fp32
         self.all_convs = [c for st in self.blocks for b in st for c in (b.conv1, b.conv2, b.conv3, b.down) if c is not None]
+        for c in self.all_convs:
+            if c.trainable:
+                store.register_overwritable(store.phys(c.name, grad=True))
 
     # ------------------------------------------------------------------ operands
     def refresh(self, full):
@@ -135,10 +138,11 @@ class ResNetBody:
     # ------------------------------------------------------------------ backward
     def _wgrad(self, g, x, c, geom):
         dw, sc = self.store.phys(c.name, grad=True), self.bn[c.bn][0]
+        ow = self.store.claim(dw)
         if self.batch is not None:
-            self.batch.add_conv(g, x, dw, geom, scale=sc)
+            self.batch.add_conv(g, x, dw, geom, scale=sc, overwrite=ow)
         else:
-            self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc), g, x)
+            self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc, overwrite=ow), g, x)
 
     def _dgrad(self, g, c, geom, res=None, gate=None, res_f32=None):
         B, SH, SW, SC, DH, DW, N, KH, KW, s, p = geom

@@ -101,6 +101,8 @@ class Net:
         w = st.phys("input_proj.0.0.weight").view(E, 2048)
         gw = st.phys("input_proj.0.0.weight", grad=True).view(E, 2048)
         self.lins["input_proj.0.0."] = Lin(w, st.P["input_proj.0.0.bias"], gw, st.G["input_proj.0.0.bias"], st.device)
+        for l in self.lins.values():             # every weight gradient of these goes through lin_bwd (which claims first writes)
+            st.register_overwritable(l.gw)
 
     def _mha(self, p, split_qk):
         E = self.cfg.hidden
@@ -138,12 +140,13 @@ class Net:
     def lin_bwd(self, key, dy, x, need_dx=True, **kw):
         """weight + bias gradient of a Linear (accumulated) and, if asked, its input gradient."""
         l = self.lins[key]
+        ow = self.store.claim(l.gw)                                # training loop: the first contribution overwrites
         if self.small_wg is not None and dy.shape[0] <= 16:       # decoder-side rows: queued, launched as one group
-            self.small_wg.add(dy, x, l.gw, l.gb)
+            self.small_wg.add(dy, x, l.gw, l.gb, overwrite=ow)
         elif self.big_wg is not None and dy.shape[0] > 16:
-            self.big_wg.add(dy, x, l.gw, l.gb)                     # flushed per section (flush_wgrads)
+            self.big_wg.add(dy, x, l.gw, l.gb, overwrite=ow)       # flushed per section (flush_wgrads)
         else:
-            self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb), dy, x)
+            self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb, overwrite=ow), dy, x)
         if need_dx:
             return H.linear(dy, l.WT, **kw)
         return None

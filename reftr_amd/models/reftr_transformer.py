@@ -407,6 +407,7 @@ class RefTR(nn.Module):
                 return name
         self._bwd_gen = None
         H.set_seed_dev(None)
+        self.store.finish_overwrite()
         for hook in self._post_backward_hooks:
             hook()
         return None
@@ -433,7 +434,7 @@ class RefTR(nn.Module):
         dl16 = torch.empty(NL * N, 4, dtype=torch.bfloat16, device=dev)
         H.rows_add(NL * N, 4, a_f32=dl, out_bf16=dl16)
         l2 = net.lins["bbox_embed.layers.2."]
-        H.linear_wgrad(dl16, sv["y2"], l2.gw)
+        H.linear_wgrad(dl16, sv["y2"], l2.gw, overwrite=st.claim(l2.gw))
         H.colsum(dl, l2.gb)
         dy2 = H.small_dgrad(dl, l2.w32, gate=sv["y2"])
         dy1, _ = net.lin_bwd("bbox_embed.layers.1.", dy2, sv["y1"], gate=sv["y1"])

@@ -3,7 +3,10 @@
 All trainable tensors are views of ONE fp32 buffer (`flat_p`), their gradients views of `flat_g`:
   * the optimizer is a single streaming kernel over the buffer (rt_adamw_flat), gradient clipping a single
     reduction (rt_sqnorm), the data-parallel exchange a handful of large all-reduces over `flat_g`;
-  * weight-gradient kernels accumulate straight into `flat_g` views (zeroed once per step by one memset).
+  * weight-gradient kernels write straight into `flat_g` views: accumulated onto a buffer cleared by one memset, or -- in
+    the training loop (`arm_overwrite`) -- the FIRST contribution to a weight matrix overwrites it, so that only the small
+    atomically-accumulated tensors (biases, norm parameters, embeddings: the complement of the registered matrices) are
+    cleared per step and the matrices' epilogues skip the read of their old value.
 Conv weights are stored channels-last ([Cout][kh][kw][Cin], the implicit-GEMM operand order) but exposed
 with the reference's logical shape [Cout, Cin, kh, kw] through strides, so state_dict()/load_state_dict()
 keep working against reference checkpoints.
@@ -77,6 +80,58 @@ class ParamStore:
         self.flat_g = torch.zeros(self.n_train, dtype=torch.float32, device=device)
         self.P = {n: self._view(self.flat[b], n, o) for n, (b, o) in self.offset.items()}
         self.G = {n: self._view(self.flat_g, n, o) for n, (b, o) in self.offset.items() if b == "p"}
+        # overwrite-mode bookkeeping (see the module docstring): registered matrices {data_ptr: (offset, numel)}
+        self._ow, self._ow_table, self._armed, self._written, self._ever = {}, None, False, set(), set()
+
+    # ------------------------------------------------------------------ overwrite-mode gradient production
+    def register_overwritable(self, gw):
+        """`gw`: a contiguous piece of flat_g (a weight matrix's gradient) whose every producer asks `claim` first."""
+        assert gw.is_contiguous() and gw.dtype == torch.float32
+        off = (gw.data_ptr() - self.flat_g.data_ptr()) // 4
+        assert 0 <= off and off + gw.numel() <= self.flat_g.numel()
+        self._ow[gw.data_ptr()] = (off, gw.numel())
+        self._ow_table = None
+
+    def _complement_table(self):
+        """Static device table of <= 16384-element chunks covering everything that is NOT a registered matrix."""
+        if self._ow_table is None:
+            chunks, pos = [], 0
+            for off, n in sorted(self._ow.values()) + [(self.flat_g.numel(), 0)]:
+                a = pos
+                while a < off:
+                    c = min(16384, off - a)
+                    chunks += [a, c]; a += c
+                pos = max(pos, off + n)
+            self._ow_table = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
+        return self._ow_table
+
+    def arm_overwrite(self):
+        """Start of a training backward: clear the atomically-accumulated tensors only; until `finish_overwrite` the first
+        `claim` of every registered matrix answers True (its producer overwrites)."""
+        from .. import hip as H
+        table, n = self._complement_table()
+        if n:
+            H.zero_chunks(self.flat_g, table, n)
+        self._armed, self._written = True, set()
+
+    def claim(self, gw):
+        if not self._armed:
+            return False
+        key = gw.data_ptr()
+        if key not in self._ow or key in self._written:
+            return False
+        self._written.add(key)
+        return True
+
+    def finish_overwrite(self):
+        """End of backward: a registered matrix that was written in an earlier step but not in this one (another input kind:
+        single- vs multi-phrase) still holds that step's gradient -- clear it once."""
+        if not self._armed:
+            return
+        for key in self._ever - self._written:
+            off, n = self._ow[key]
+            self.flat_g[off:off + n].zero_()
+        self._ever, self._armed = set(self._written), False
 
     def _view(self, buf, name, off):
         shape = self.shapes[name]

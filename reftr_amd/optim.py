@@ -44,9 +44,16 @@ class FusedAdamW(torch.optim.Optimizer):
         self.lr_dev = None            # device learning rates (one per non-empty param group) read by the kernel
         self._flush_pending = None    # set by the engine: applies a pending update before anyone reads weights / state
 
-    def zero_grad(self, set_to_none=False):
-        """One memset of the flat gradient buffer (param.grad views are kept)."""
-        self.model.store.flat_g.zero_()
+    def zero_grad(self, set_to_none=False, fast=False):
+        """One memset of the flat gradient buffer (param.grad views are kept).  fast=True (the training loops of
+        reftr_amd.engine_vg, right in front of backward): only the atomically-accumulated tensors are cleared and the weight
+        matrices -- 96 % of the 607 MB -- are overwritten by their first weight-gradient launch (ParamStore.arm_overwrite);
+        REFTR_OVERWRITE=0 keeps the full clear."""
+        import os
+        if fast and os.environ.get("REFTR_OVERWRITE", "1") != "0" and self.model.store.flat_g.is_cuda:
+            self.model.store.arm_overwrite()
+        else:
+            self.model.store.flat_g.zero_()
 
     def _grad_buffer(self):
         """The buffer the update reads: the fp32 gradients, or -- in a data-parallel run that exchanges bf16 -- the bf16 copy
