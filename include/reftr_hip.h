@@ -529,6 +529,32 @@ int rt_img_collate_norm(const int64_t* table, float* out, uint8_t* mask, int B, 
                         const float* std3, rt_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * rt_cem_fwd / rt_cem_bwd — the CEM block of RefTRSeg (--ablation cem_loss, models/reftr_segmentation.py:16-41) for the one
+ * query per image of RES: u_b = c3(hs_b) (hs bf16 [B, E] = last decoder output, w3 [16, E], b3 [16]), res bf16 [B*HW, ld] =
+ * MaskHeadSmallConv's last feature map (16 channels in front of the padding), a_p = res_p . w2 + b2,
+ *   energy_b = sum_p softmax_p(a)_p * clamp((cos(u_b, res_p) + 1) / 2, 1e-6, 1 - 1e-6),  loss = -sum_b log(energy_b + 1e-6) / B
+ * (the softmax over the single query, c1, is the constant 1).  One workgroup per image, online softmax (one pass over the pixels).
+ * Backward (g = d loss): dres fp32 [B*HW, lddr] += d res, dhs [B, E] = d hs, dw3 / db3 / dw2 += (d c2.bias = d c1 = 0 exactly).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_cem_desc {
+    const void*  hs;        /* bf16 [B, E] */
+    const float* w3;        /* [16, E] */
+    const float* b3;        /* [16] */
+    const void*  res;
+    const float* w2;        /* [16] */
+    const float* b2;        /* [1] */
+    float* u;               /* [B, 16]: written by the forward, read by the backward */
+    float* energy;          /* [B] */
+    float* stats;           /* [B, 2] = {max_p a_p, sum_p exp(a_p - max)} */
+    float* loss;            /* [1] */
+    const float* g;         /* backward: device scalar d loss */
+    float* dres; float* dhs; float* dw3; float* db3; float* dw2;
+    int32_t B, HW, ld, lddr, E, reserved;
+} rt_cem_desc;
+int rt_cem_fwd(const rt_cem_desc* d, rt_stream_t stream);
+int rt_cem_bwd(const rt_cem_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * Evaluation post-processing, exact decisions / selections.
  * rt_mask_postprocess — PostProcessSegm.forward (models/reftr_segmentation.py:282-302): pred fp32 [B*Q, h, w] mask logits ->
  *   masks uint8 [B, Q, max_h, max_w] = sigmoid(bilinear(pred -> max_h x max_w, align_corners=False)) > threshold inside the

@@ -57,6 +57,7 @@ class Cfg:
     resnet_layers: tuple = (3, 4, 6, 3)
     bert: BertCfg = field(default_factory=BertCfg)
     masks: bool = False           # RefTRSeg (reftr_segmentation.py): RES head on top of the single-phrase REC model
+    cem: bool = False             # --ablation cem_loss: the CEM block + loss_cem (reftr_segmentation.py:16-41, 62-64, 146-147)
     mask_loss_coef: float = 1.0   # main_vg.py (default 1)
     dice_loss_coef: float = 1.0
     bbox_loss_coef: float = 1.0   # main_vg.py:134 (default 1)
@@ -431,7 +432,27 @@ def seg_forward(P, out, samples, cfg: Cfg, q=False):
     bbox_mask = mh_attention_map(P, hs_last.reshape(B, -1, cfg.hidden), mem_vis, m5, cfg.nheads, q=q)
     feats = out["feats"]
     seg, res_feat = mask_head(P, torch.cat([src, mem_vis], 1), bbox_mask, [feats[2], feats[1], feats[0]], q=q)
-    return {"pred_masks": seg.view(B, -1, seg.shape[-2], seg.shape[-1]), "mask_att": bbox_mask[:, 0], "res_feat": res_feat}
+    res = {"pred_masks": seg.view(B, -1, seg.shape[-2], seg.shape[-1]), "mask_att": bbox_mask[:, 0], "res_feat": res_feat}
+    if cfg.cem:
+        res["cem_loss"] = cem_forward(P, hs_last, res_feat, q=q)
+    return res
+
+
+def cem_forward(P, rec_feat, res_feat, pfx="cem_block.", q=False):
+    """CEM.forward (reftr_segmentation.py:25-41).  rec_feat [B, n_ph, n_q, c] (last decoder layer), res_feat [B, c/16, H, W]
+    (MaskHeadSmallConv's last feature map).  es = softmax over the n_ph*n_q axis (= 1 for the single query of RES); ec =
+    softmax over the pixels of c2(res); tsc = clamp((cos(c3(rec), res) + 1) / 2, 1e-6, 1 - 1e-6);
+    loss = -sum_b log(es^T tsc ec + 1e-6) / B."""
+    B, n_ph, n_q, c = rec_feat.shape
+    rec = rec_feat.reshape(B, -1, c)
+    res = res_feat.reshape(B, c // 16, -1).transpose(1, 2)
+    es = F.softmax(linear(rec, P, pfx + "c1.", q), dim=-2)
+    ec = F.softmax(linear(res, P, pfx + "c2.", q=False), dim=-2)
+    r = F.normalize(linear(rec, P, pfx + "c3.", q), dim=-1)
+    s = F.normalize(res, dim=-1).transpose(-1, -2)
+    tsc = torch.clamp((torch.bmm(r, s) + 1.0) / 2.0, 1e-6, 1.0 - 1e-6)
+    energy = torch.bmm(torch.bmm(es.transpose(-1, -2), tsc), ec)
+    return -1.0 * torch.sum(torch.log(energy + 1e-6)) * 1.0 / B
 
 
 def dice_loss(inputs, targets, num_boxes):
@@ -521,6 +542,8 @@ def criterion(out, targets, world_size=1, global_num_boxes=None):
     losses = dict(loss_boxes(out["pred_boxes"], out["phrase_mask"], targets, nb))
     if "pred_masks" in out:       # CriterionVGOnePhraseSeg: losses = ['masks', 'boxes'] (reftr_segmentation.py:388)
         losses.update(loss_masks(out["pred_masks"], targets))
+        if "cem_loss" in out:     # reftr_segmentation.py:335-336
+            losses["loss_cem"] = out["cem_loss"]
     for i, aux in enumerate(out.get("aux_outputs", [])):
         for k_, v in loss_boxes(aux["pred_boxes"], aux["phrase_mask"], targets, nb).items():
             losses[f"{k_}_{i}"] = v

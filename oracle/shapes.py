@@ -108,4 +108,6 @@ def param_shapes(cfg):
         s[mh + "out_lay.weight"] = (1, inter[4], 3, 3); s[mh + "out_lay.bias"] = (1,)
         for i, (fd, co) in enumerate(((1024, inter[1]), (512, inter[2]), (256, inter[3]))):
             s[f"{mh}adapter{i + 1}.weight"] = (co, fd, 1, 1); s[f"{mh}adapter{i + 1}.bias"] = (co,)
+        if getattr(cfg, "cem", False):    # CEM block (reftr_segmentation.py:16-23, 62-64)
+            lin("cem_block.c1.", 1, E); lin("cem_block.c2.", 1, E // 16); lin("cem_block.c3.", E // 16, E)
     return s

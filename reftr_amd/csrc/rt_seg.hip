@@ -447,3 +447,176 @@ extern "C" int rt_mask_loss(const rt_mask_loss_desc* d, rt_stream_t stream) {
     }
     return RT_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ CEM block
+namespace {
+
+struct CemPix { float a, t, cosv, nrm; };
+__device__ __forceinline__ CemPix cem_pixel(const float (&x)[16], const float (&w2)[16], float b2, const float (&r)[16]) {
+    float a = b2, dot = 0.f, n2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { a += x[c] * w2[c]; dot += r[c] * x[c]; n2 += x[c] * x[c]; }
+    CemPix o;
+    o.a = a; o.nrm = fmaxf(sqrtf(n2), 1e-12f); o.cosv = dot / o.nrm;
+    o.t = fminf(fmaxf((o.cosv + 1.f) * 0.5f, 1e-6f), 1.f - 1e-6f);
+    return o;
+}
+__device__ __forceinline__ void cem_load(const bf16_t* row, float (&x)[16]) {
+    const bf16x8 lo = *reinterpret_cast<const bf16x8*>(row), hi = *reinterpret_cast<const bf16x8*>(row + 8);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { x[c] = (float)lo[c]; x[8 + c] = (float)hi[c]; }
+}
+__device__ __forceinline__ void cem_unit(const float* u, float (&r)[16], float& un) {
+    float n2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) n2 += u[c] * u[c];
+    un = fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r[c] = u[c] / un;
+}
+
+__global__ __launch_bounds__(1024) void cem_fwd_kernel(const rt_cem_desc p) {
+    __shared__ float sm[3][16];
+    __shared__ float su[16];
+    const int b = blockIdx.x;
+    {   // u = c3(hs_b): wave w computes output w
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const bf16_t* h = (const bf16_t*)p.hs + (size_t)b * p.E;
+        float a = 0.f;
+        for (int k = lane; k < p.E; k += 64) a += (float)h[k] * p.w3[(size_t)wave * p.E + k];
+        a = rt_wave_sum(a);
+        if (lane == 0) { su[wave] = a + p.b3[wave]; p.u[b * 16 + wave] = su[wave]; }
+    }
+    __syncthreads();
+    float w2[16], r[16], un;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) w2[c] = p.w2[c];
+    cem_unit(su, r, un);
+    const float b2 = p.b2[0];
+    const bf16_t* res = (const bf16_t*)p.res + (size_t)b * p.HW * p.ld;
+    float m = -INFINITY, s = 0.f, e = 0.f;                       // online softmax: s = sum exp(a - m), e = sum t exp(a - m)
+    for (int i = threadIdx.x; i < p.HW; i += 1024) {
+        float x[16];
+        cem_load(res + (size_t)i * p.ld, x);
+        const CemPix q = cem_pixel(x, w2, b2, r);
+        const float mn = fmaxf(m, q.a), sc = __expf(m - mn), w = __expf(q.a - mn);
+        s = s * sc + w; e = e * sc + q.t * w; m = mn;
+    }
+    // combine (m, s, e) over the block: wave shuffle, then the 16 waves through LDS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64), e2 = __shfl_xor(e, o, 64);
+        const float mn = fmaxf(m, m2), c1 = (m == -INFINITY) ? 0.f : __expf(m - mn), c2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+        s = s * c1 + s2 * c2; e = e * c1 + e2 * c2; m = mn;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sm[0][wave] = m; sm[1][wave] = s; sm[2][wave] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float M = -INFINITY;
+        for (int w = 0; w < 16; ++w) M = fmaxf(M, sm[0][w]);
+        float S = 0.f, E = 0.f;
+        for (int w = 0; w < 16; ++w) { const float c = (sm[0][w] == -INFINITY) ? 0.f : __expf(sm[0][w] - M); S += sm[1][w] * c; E += sm[2][w] * c; }
+        const float energy = E / S;
+        p.energy[b] = energy; p.stats[2 * b] = M; p.stats[2 * b + 1] = S;
+        atomicAdd(p.loss, -__logf(energy + 1e-6f) / (float)p.B);
+    }
+}
+
+__global__ __launch_bounds__(1024) void cem_bwd_kernel(const rt_cem_desc p) {
+    __shared__ float sm[16][32];
+    const int b = blockIdx.x;
+    float w2[16], r[16], un;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) w2[c] = p.w2[c];
+    cem_unit(p.u + b * 16, r, un);
+    const float b2 = p.b2[0];
+    const float E = p.energy[b], M = p.stats[2 * b], S = p.stats[2 * b + 1];
+    const float dE = -p.g[0] / ((float)p.B * (E + 1e-6f));
+    const bf16_t* res = (const bf16_t*)p.res + (size_t)b * p.HW * p.ld;
+    float* dres = p.dres + (size_t)b * p.HW * p.lddr;
+    float dr[16], dw[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { dr[c] = 0.f; dw[c] = 0.f; }
+    for (int i = threadIdx.x; i < p.HW; i += 1024) {
+        float x[16];
+        cem_load(res + (size_t)i * p.ld, x);
+        const CemPix q = cem_pixel(x, w2, b2, r);
+        const float ec = __expf(q.a - M) / S;
+        const float da = ec * dE * (q.t - E);                    // through the softmax over the pixels
+        const float tt = (q.cosv + 1.f) * 0.5f;
+        const float dcos = (tt > 1e-6f && tt < 1.f - 1e-6f) ? 0.5f * dE * ec : 0.f;
+        const float k1 = dcos / q.nrm, k2 = dcos * q.cosv / (q.nrm * q.nrm);
+        float* o = dres + (size_t)i * p.lddr;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            f32x4 v = *reinterpret_cast<f32x4*>(o + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c4 * 4 + e;
+                v[e] += w2[c] * da + k1 * r[c] - k2 * x[c];
+                dr[c] += k1 * x[c]; dw[c] += da * x[c];
+            }
+            *reinterpret_cast<f32x4*>(o + c4 * 4) = v;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float a = rt_wave_sum(dr[c]), d2 = rt_wave_sum(dw[c]);
+        if (lane == 0) { sm[wave][c] = a; sm[wave][16 + c] = d2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += sm[w][threadIdx.x];
+        sm[0][threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        // r = u / |u|: du = (dr - (dr . r) r) / |u|
+        float dot = 0.f;
+        for (int c = 0; c < 16; ++c) dot += sm[0][c] * r[c];
+        const float du = (sm[0][threadIdx.x] - dot * r[threadIdx.x]) / un;
+        sm[1][threadIdx.x] = du;
+        atomicAdd(p.db3 + threadIdx.x, du);
+        atomicAdd(p.dw2 + threadIdx.x, sm[0][16 + threadIdx.x]);
+    }
+    __syncthreads();
+    // c3 backward: dhs_b = du @ w3, dw3 += du (x) hs_b
+    const bf16_t* h = (const bf16_t*)p.hs + (size_t)b * p.E;
+    for (int k = threadIdx.x; k < p.E; k += 1024) {
+        const float hk = (float)h[k];
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float du = sm[1][c];
+            a += du * p.w3[(size_t)c * p.E + k];
+            atomicAdd(p.dw3 + (size_t)c * p.E + k, du * hk);
+        }
+        p.dhs[(size_t)b * p.E + k] = a;
+    }
+}
+
+}  // namespace
+
+extern "C" int rt_cem_fwd(const rt_cem_desc* d, rt_stream_t stream) {
+    if (!d || !d->hs || !d->w3 || !d->b3 || !d->u || !d->res || !d->w2 || !d->b2 || !d->energy || !d->stats || !d->loss) return RT_ERR_BADARG;
+    if (d->B <= 0 || d->HW <= 0 || d->E <= 0 || d->ld < 16 || (d->ld & 7)) return RT_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const hipError_t e = rt_zero_f32(d->loss, 1, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cem_fwd_kernel, dim3((unsigned)d->B), dim3(1024), 0, s, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_cem_bwd(const rt_cem_desc* d, rt_stream_t stream) {
+    if (!d || !d->hs || !d->w3 || !d->u || !d->res || !d->w2 || !d->b2 || !d->energy || !d->stats || !d->g || !d->dres || !d->dhs ||
+        !d->dw3 || !d->db3 || !d->dw2) return RT_ERR_BADARG;
+    if (d->B <= 0 || d->HW <= 0 || d->E <= 0 || d->ld < 16 || (d->ld & 7) || d->lddr < 16 || (d->lddr & 3)) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(cem_bwd_kernel, dim3((unsigned)d->B), dim3(1024), 0, (hipStream_t)stream, *d);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}

@@ -151,6 +151,13 @@ class BoxPostDesc(Structure):
     ]
 
 
+class CemDesc(Structure):
+    _fields_ = [("hs", c_void_p), ("w3", c_void_p), ("b3", c_void_p), ("res", c_void_p), ("w2", c_void_p), ("b2", c_void_p),
+                ("u", c_void_p), ("energy", c_void_p), ("stats", c_void_p), ("loss", c_void_p), ("g", c_void_p),
+                ("dres", c_void_p), ("dhs", c_void_p), ("dw3", c_void_p), ("db3", c_void_p), ("dw2", c_void_p),
+                ("B", c_int32), ("HW", c_int32), ("ld", c_int32), ("lddr", c_int32), ("E", c_int32), ("reserved", c_int32)]
+
+
 class AdamWDesc(Structure):
     _fields_ = [
         ("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64),
@@ -251,6 +258,8 @@ _SIGNATURES = {
     "rt_qenc_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_qenc_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_box_loss": (c_int, [POINTER(BoxLossDesc), c_void_p]),
+    "rt_cem_fwd": (c_int, [POINTER(CemDesc), c_void_p]),
+    "rt_cem_bwd": (c_int, [POINTER(CemDesc), c_void_p]),
     "rt_mask_postprocess": (c_int, [POINTER(MaskPostDesc), c_void_p]),
     "rt_box_postprocess": (c_int, [POINTER(BoxPostDesc), c_void_p]),
     "rt_small_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -756,6 +765,34 @@ def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox=1.0, w_giou=1
                     NL, B, P, K, w_bbox, w_giou, _p(weights))
     _check(lib().rt_box_loss(ctypes.byref(d), _stream()), "rt_box_loss")
     return losses, total, dl
+
+
+def cem_fwd(hs16, w3, b3, res16, w2, b2, B, HW):
+    """CEM block forward (rt_cem_fwd): returns (loss [1], saved = (u [B,16], energy [B], stats [B,2]))."""
+    _req(hs16, torch.bfloat16, "hs"); _req(res16, torch.bfloat16, "res")
+    for t, n in ((w3, "w3"), (b3, "b3"), (w2, "w2"), (b2, "b2")):
+        _req(t, torch.float32, n)
+    E = hs16.shape[-1]
+    u = _new((B, 16), torch.float32, w3); energy = _new((B,), torch.float32, w3); stats = _new((B, 2), torch.float32, w3)
+    loss = _new((1,), torch.float32, w3)
+    d = CemDesc(_p(hs16), _p(w3), _p(b3), _p(res16), _p(w2), _p(b2), _p(u), _p(energy), _p(stats), _p(loss), None,
+                None, None, None, None, None, B, HW, res16.shape[-1], 0, E, 0)
+    _check(lib().rt_cem_fwd(ctypes.byref(d), _stream()), "rt_cem_fwd")
+    return loss, (u, energy, stats)
+
+
+def cem_bwd(hs16, w3, b3, res16, w2, b2, saved, g, dres, dw3, db3, dw2, B, HW):
+    """CEM block backward: dres (fp32 [B*HW, ld]) += d res; dw3 / db3 / dw2 accumulate; returns d hs fp32 [B, E]."""
+    _req(g, torch.float32, "g"); _req(dres, torch.float32, "dres")
+    for t, n in ((dw3, "dw3"), (db3, "db3"), (dw2, "dw2")):
+        _req(t, torch.float32, n)
+    u, energy, stats = saved
+    E = hs16.shape[-1]
+    dhs = _new((B, E), torch.float32, w3)
+    d = CemDesc(_p(hs16), _p(w3), _p(b3), _p(res16), _p(w2), _p(b2), _p(u), _p(energy), _p(stats), None, _p(g),
+                _p(dres), _p(dhs), _p(dw3), _p(db3), _p(dw2), B, HW, res16.shape[-1], dres.shape[-1], E, 0)
+    _check(lib().rt_cem_bwd(ctypes.byref(d), _stream()), "rt_cem_bwd")
+    return dhs
 
 
 def mask_postprocess(pred, sizes_i32, max_hw, threshold=0.5, orig_i32=None, origin_off=None, origin_total=0, max_origin=0):

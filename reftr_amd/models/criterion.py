@@ -104,6 +104,8 @@ def _weighted_total(crit, loss_dict):
     total = (box * crit._wbox).sum()
     if getattr(crit, "_last_mask", None) is not None and "loss_mask" in loss_dict:
         total = total + (crit._last_mask * crit._wmask).sum()
+    if "loss_cem" in loss_dict and "loss_cem" in crit.weight_dict:
+        total = total + loss_dict["loss_cem"] * crit.weight_dict["loss_cem"]
     return total
 
 
@@ -158,5 +160,7 @@ class CriterionVGOnePhraseSeg(CriterionVGMultiPhrase):
             lm = _MaskLossFunction.apply(pm, tgt, float(bs * nq))
             self._last_mask = lm
             losses["loss_mask"], losses["loss_dice"] = lm[0], lm[1]
+        if "cem_loss" in outputs:                                       # reftr_segmentation.py:237-238
+            losses["loss_cem"] = outputs["cem_loss"]
         losses.update(super().forward(outputs, targets))
         return losses

@@ -44,6 +44,7 @@ class ModelConfig:
     aux_loss: bool = True
     resnet_layers: tuple = (3, 4, 6, 3)   # resnet50; resnet101 = (3, 4, 23, 3)
     masks: bool = False                   # RefTRSeg: RES head (bbox_attention + mask_head), single phrase, no aux loss
+    cem: bool = False                     # --ablation cem_loss: CEM block + loss_cem (reftr_segmentation.py:16-41, 62-64)
     bert: BertConfig = field(default_factory=BertConfig)
 
 
@@ -189,6 +190,14 @@ def seg_table(cfg: ModelConfig):
     return t
 
 
+def cem_table(cfg: ModelConfig):
+    """CEM block (reftr_segmentation.py:16-23): c1 Linear(E, 1), c2 Linear(E/16, 1), c3 Linear(E, E/16)."""
+    E = cfg.hidden
+    return [("cem_block.c1.weight", (1, E), "param"), ("cem_block.c1.bias", (1,), "param"),
+            ("cem_block.c2.weight", (1, E // 16), "param"), ("cem_block.c2.bias", (1,), "param"),
+            ("cem_block.c3.weight", (E // 16, E), "param"), ("cem_block.c3.bias", (E // 16,), "param")]
+
+
 def phys_dims(cfg: ModelConfig):
     """Physical (stored) shapes of tensors whose channel counts are padded to multiples of 64 so that they are legal
     implicit-GEMM operands: conv weight [Cout_pad][kh][kw][Cin_pad], bias [Cout_pad]; the padding stays zero (zero
@@ -198,13 +207,15 @@ def phys_dims(cfg: ModelConfig):
         for name, ci, co, k in seg_convs(cfg):
             d[name + ".weight"] = (pad64(co), k, k, pad64(ci))
             d[name + ".bias"] = (pad64(co),)
+    if cfg.masks and cfg.cem:              # one-element biases: stored in 4-element (16-B) slots like every tensor of the flat buffers
+        d["cem_block.c1.bias"] = (4,); d["cem_block.c2.bias"] = (4,)
     return d
 
 
 def full_table(cfg: ModelConfig):
     """All tensors of the model.  Trainable ones are listed group by group (main, backbone, bert) in the
     order they are laid out in the flat parameter buffer."""
-    return main_table(cfg) + (seg_table(cfg) if cfg.masks else []) + resnet_table("img_backbone.0.body.", cfg.resnet_layers) + bert_table("lang_backbone.", cfg.bert)
+    return main_table(cfg) + (seg_table(cfg) if cfg.masks else []) + (cem_table(cfg) if cfg.masks and cfg.cem else []) + resnet_table("img_backbone.0.body.", cfg.resnet_layers) + bert_table("lang_backbone.", cfg.bert)
 
 
 def reference_param_order(cfg: ModelConfig):
@@ -270,4 +281,6 @@ def reference_param_order(cfg: ModelConfig):
         wb(mh + "out_lay.")
         for i in range(1, 4):
             wb(f"{mh}adapter{i}.")
+        if cfg.cem:                       # registered last (reftr_segmentation.py:62-64)
+            wb("cem_block.c1."); wb("cem_block.c2."); wb("cem_block.c3.")
     return names

@@ -41,11 +41,13 @@ class _RefTRSegFunction(torch.autograd.Function):
     def forward(ctx, anchor, model, samples):
         ctx.model = model
         logits = model._forward_impl(samples)
+        if model.cfg.cem:
+            return logits, model._saved["pred_masks"], model._saved["seg"]["cem_loss"]
         return logits, model._saved["pred_masks"]
 
     @staticmethod
-    def backward(ctx, dlogits, dmasks):
-        ctx.model._backward_impl(dlogits.contiguous(), dmasks.contiguous())
+    def backward(ctx, dlogits, dmasks, dcem=None):
+        ctx.model._backward_impl(dlogits.contiguous(), dmasks.contiguous(), None if dcem is None else dcem.contiguous())
         return None, None, None
 
 
@@ -207,7 +209,9 @@ class RefTR(nn.Module):
         pred_masks = None
         if self.seg is not None:
             assert "phrase" not in samples, "RefTRSeg is single-phrase (reftr_segmentation.py:101-103)"
-            logits, pred_masks = _RefTRSegFunction.apply(self._anchor, self, samples)
+            res = _RefTRSegFunction.apply(self._anchor, self, samples)
+            logits, pred_masks = res[0], res[1]
+            cem_loss = res[2] if self.cfg.cem else None
         else:
             logits = _RefTRFunction.apply(self._anchor, self, samples)      # [NL, B, P, K, 4]
         boxes = logits.sigmoid()
@@ -216,6 +220,8 @@ class RefTR(nn.Module):
         if pred_masks is not None:                                          # reftr_segmentation.py:147-148
             out["pred_masks"] = pred_masks
             out["mask_att"] = self._saved["mask_att"]
+            if cem_loss is not None:                                        # reftr_segmentation.py:145-146
+                out["cem_loss"] = cem_loss[0]
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_boxes": b, "phrase_mask": phrase_mask} for b in boxes[:-1]]
         return out
@@ -390,8 +396,8 @@ class RefTR(nn.Module):
     def dp_mode(self):
         return bool(self._stops) or any(self._phase_hooks.values())
 
-    def _backward_impl(self, dlogits, dmasks=None):
-        self._bwd_gen = self._backward_phases(dlogits, dmasks)
+    def _backward_impl(self, dlogits, dmasks=None, dcem=None):
+        self._bwd_gen = self._backward_phases(dlogits, dmasks, dcem)
         self.continue_backward()
 
     def continue_backward(self):
@@ -417,7 +423,7 @@ class RefTR(nn.Module):
         while self.continue_backward() is not None:
             pass
 
-    def _backward_phases(self, dlogits, dmasks=None):
+    def _backward_phases(self, dlogits, dmasks=None, dcem=None):
         cfg, net, st, sv = self.cfg, self.net, self.store, self._saved
         E = cfg.hidden
         dev = st.device
@@ -445,7 +451,7 @@ class RefTR(nn.Module):
         # ---- RES head (its gradients enter the last decoder output, the encoder memory, input_proj and the ResNet)
         seg_dsrc, seg_extra = None, None
         if dmasks is not None:
-            d_hs, seg_dsrc, seg_extra = self.seg.backward(sv["seg"], dmasks, dmem)
+            d_hs, seg_dsrc, seg_extra = self.seg.backward(sv["seg"], dmasks, dmem, dcem)
             dhs[(NL - 1) * N:] += d_hs
 
         # ---- decoder
@@ -608,7 +614,8 @@ def build_config(args):
                          dec_layers=0 if getattr(args, "no_decoder", False) else args.dec_layers,
                          ffn=args.dim_feedforward, dropout=args.dropout, max_lang_seq=args.max_lang_seq,
                          n_q=args.num_queries_per_phrase, aux_loss=args.aux_loss, resnet_layers=layers, bert=bc,
-                         masks=bool(getattr(args, "masks", False)))
+                         masks=bool(getattr(args, "masks", False)),
+                         cem=bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss")
 
 
 def build_reftr(args):
@@ -637,8 +644,6 @@ def build_reftr_seg(args):
     from .post_process import PostProcessSegm, PostProcessVGMultiPhrase
     if args.reftr_type != "transformer_single_phrase":
         raise NotImplementedError                                   # as the reference (:389-390)
-    if getattr(args, "ablation", "none") == "cem_loss":
-        raise NotImplementedError("--ablation cem_loss (CEM block, reftr_segmentation.py:16-41) is not built")
     device = torch.device(args.device)
     cfg = build_config(args)
     assert cfg.masks

@@ -93,11 +93,15 @@ class SegHead:
         po, gout = self._conv(cv["out_lay"], a, B, ph, pw)
         sv["gout"] = gout
         pred = po[:, 0].reshape(B, 1, ph, pw).contiguous()
+        if cfg.cem:                        # CEM block on (last decoder output, res_feat) (reftr_segmentation.py:139-146)
+            P = self.store.P
+            sv["cem_loss"], sv["cem"] = H.cem_fwd(hs_last16, P["cem_block.c3.weight"], P["cem_block.c3.bias"], a,
+                                                  P["cem_block.c2.weight"], P["cem_block.c2.bias"], B, ph * pw)
         return pred, Pm.view(B, nh, h, w), sv
 
     # ------------------------------------------------------------------ backward
-    def backward(self, sv, dpred, dmem):
-        """dpred [B,1,H1,W1] fp32.  Accumulates the encoder-memory gradient into dmem ([B*S,E] fp32) and returns
+    def backward(self, sv, dpred, dmem, dcem=None):
+        """dpred [B,1,H1,W1] fp32, dcem [1] fp32 = d loss_cem (cfg.cem).  Accumulates the encoder-memory gradient into dmem ([B*S,E] fp32) and returns
         (d_hs_last fp32 [B,E], d_src fp32 [B*hw,E] (gradient of the input_proj+GN rows), extra = {stage index: ungated
         fp32 gradient w.r.t. that ResNet stage output})."""
         cfg, net = self.cfg, self.net
@@ -110,6 +114,12 @@ class SegHead:
         d16 = torch.zeros(M5, cv["out_lay"].cop, dtype=torch.bfloat16, device=dpred.device)
         d16[:, 0] = dpred.reshape(-1)
         da = self._conv_bwd(cv["out_lay"], d16, sv["a5"], sv["gout"])
+        d_hs_cem = None
+        if cfg.cem:
+            P, G = self.store.P, self.store.G
+            d_hs_cem = H.cem_bwd(sv["hs_last16"], P["cem_block.c3.weight"], P["cem_block.c3.bias"], sv["a5"],
+                                 P["cem_block.c2.weight"], P["cem_block.c2.bias"], sv["cem"], dcem, da,
+                                 G["cem_block.c3.weight"], G["cem_block.c3.bias"], G["cem_block.c2.weight"], B, st5["fh"] * st5["fw"])
         extra = {}
         for j in (2, 1, 0):
             stg = sv["stages"][j]
@@ -130,6 +140,8 @@ class SegHead:
         dq, dk = H.attn_map_bwd(sv["q"], sv["kall"], sv["P"], dX0, B, HW, E, nh, S, Lq, 2 * E)
         dq16 = dq.to(torch.bfloat16); dk16 = dk.to(torch.bfloat16)
         _, d_hs = net.lin_bwd("bbox_attention.q_linear.", dq16, sv["hs_last16"], out_bf16=False, out_f32=True)
+        if d_hs_cem is not None:
+            d_hs += d_hs_cem
         net.lin_bwd("bbox_attention.k_linear.", dk16, sv["mem16"], res_f32=dmem, out_bf16=False, out_f32=dmem)
         d_src = dX0[:, :E].contiguous()
         d_memvis = dX0[:, E:2 * E].contiguous()

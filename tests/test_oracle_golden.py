@@ -137,6 +137,36 @@ def test_refer_segmentation_golden():
             assert rel(mine, ref) < 1e-4, k
 
 
+def test_cem_block_golden():
+    """RefTRSeg with the CEM block (--ablation cem_loss, reftr_segmentation.py:16-41): loss_cem, the other losses and the
+    gradients (incl. the exact zeros of c1 and c2.bias) vs the imported reference (oracle/gen_golden_cem.py)."""
+    g = gold("seg_cem")
+    cfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False, cem=True)
+    P = formula_state(param_shapes(cfg))
+    samples, targets = seg_batch(g)
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(names) == sorted(k for k in P if O.is_trainable(k))
+    leaves = {k: P[k].requires_grad_(True) for k in names}
+    out = O.reftr_forward(P, samples, cfg)
+    losses = O.criterion(out, targets)
+    for k in ("loss_cem", "loss_mask", "loss_dice", "loss_bbox", "loss_giou"):
+        assert abs(float(losses[k]) - float(g["loss." + k])) < 1e-5 * max(1.0, abs(float(g["loss." + k]))), k
+    total = O.total_loss(losses, O.weight_dict(cfg))
+    assert abs(float(total) - float(g["total_loss"])) < 1e-5 * float(g["total_loss"])
+    grads = torch.autograd.grad(total, [leaves[k] for k in names], allow_unused=True)
+    grads = {k: (v if v is not None else torch.zeros_like(P[k])) for k, v in zip(names, grads)}
+    gn = {str(n): float(v) for n, v in zip(g["grad_names"], g["grad_norms"])}
+    for k in names:
+        assert abs(float(grads[k].norm()) - gn[k]) < 1e-4 * max(gn[k], 1e-6) + 1e-6, k
+    # c2.bias: zero by the softmax's shift invariance, 2.8e-7 of fp32 rounding left in the reference's autograd
+    assert gn["cem_block.c1.weight"] == 0.0 and gn["cem_block.c1.bias"] == 0.0 and gn["cem_block.c2.bias"] < 1e-6
+    for key in g.files:
+        if key.startswith("grad."):
+            k = key[5:]
+            mine = grads[k][:8] if grads[k].dim() > 1 and grads[k].shape[0] > 8 else grads[k]
+            assert rel(mine, torch.from_numpy(g[key])) < 1e-4, k
+
+
 def test_roberta_backbone_golden():
     """RefTR with a HF RobertaModel language backbone (configs/flickr30k/RefTR_flickr_roberta.sh): position ids from the
     padding index, one token type, eps 1e-5."""
