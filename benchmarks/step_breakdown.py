@@ -39,6 +39,15 @@ for r in recs:
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for v in agg.values())
 print("total GEMM-family time %.2f ms, %d launches" % (tot / 1e3, len(recs)))
-print("%-4s %-44s %5s %9s %8s %8s" % ("kind", "B,SH,SW,SC,DH,DW,N,KH,KW,s,p", "n", "total us", "avg us", "TF"))
-for tag, (n, t, f) in rows[:60]:
-    print("%-4s %-44s %5d %9.1f %8.1f %8.1f" % (tag[0], ",".join(map(str, tag[1:])), n, t, t / n, f / t / 1e6))
+def hbm_us(tag):
+    """the launch's algorithmic bytes (operands once, bf16 in / bf16 out, fp32 dw) at 5 TB/s"""
+    if tag is None or len(tag) != 12:
+        return float("nan")
+    B, SH, SW, SC, DH, DW, N, KH, KW, st, pd = tag[1:]
+    a, o, w = B * SH * SW * SC * 2, B * DH * DW * N * 2, N * KH * KW * SC
+    return (a + o + w * (4 if tag[0] == "W" else 2)) / 5e12 * 1e6
+print("%-4s %-44s %5s %9s %8s %8s %8s %6s" % ("kind", "B,SH,SW,SC,DH,DW,N,KH,KW,s,p", "n", "total us", "avg us", "TF", "hbm us", "x hbm"))
+for tag, (n, t, f) in rows[:int(os.environ.get("ROWS", "70"))]:
+    h = hbm_us(tag)
+    tag = tag or ("grouped",)
+    print("%-4s %-44s %5d %9.1f %8.1f %8.1f %8.1f %6.1f" % (tag[0], ",".join(map(str, tag[1:])), n, t, t / n, f / t / 1e6, h, t / n / h))

@@ -3,7 +3,7 @@ variants (hints 11-33), timed as 20 back-to-back launches inside one hipGraph.""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reftr_amd import hip
-HINTS = [1, 2, 3, 11, 12, 13, 21, 22, 31, 32, 33]
+HINTS = [int(h) for h in os.environ["HINTS"].split(",")] if os.environ.get("HINTS") else [1, 2, 3, 11, 12, 13, 21, 22, 31, 32, 33]
 SHAPES = [("l1 64->256 @160", 204800, 64, 256), ("l1 256->64 @160", 204800, 256, 64), ("l1 64->64", 204800, 64, 64),
           ("l2 256->128 @160", 204800, 256, 128), ("l2 128->512 @80", 51200, 128, 512), ("l2 512->128 @80", 51200, 512, 128),
           ("l3 256->1024 @40", 12800, 256, 1024), ("l3 1024->256 @40", 12800, 1024, 256), ("l3 512->256 @80", 51200, 512, 256),
@@ -26,6 +26,8 @@ def graph_time(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 if __name__ != "__main__":
     CONVS = SHAPES = []
+elif os.environ.get("ONLY") == "lin":
+    CONVS = []
 else:
   CONVS = [("l1 3x3 64 @160", 8, 160, 64, 64, 1), ("l2 3x3 128 @80", 8, 80, 128, 128, 1), ("l2 3x3s2 128 @160", 8, 160, 128, 128, 2),
            ("l3 3x3 256 @40", 8, 40, 256, 256, 1), ("l4 3x3 512 @20", 8, 20, 512, 512, 1), ("l4 3x3s2 512 @40", 8, 40, 512, 512, 2)]

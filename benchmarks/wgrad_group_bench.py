@@ -1,6 +1,7 @@
 """Weight gradients the way the step launches them: one rt_conv_wgrad_grouped call per ResNet stage (all of its 1x1 / 3x3
 convolutions) and per transformer section, timed inside a hipGraph.  REFTR_WG2=0 gives the first-generation kernels."""
 import os, sys, torch
+OW = os.environ.get("OVERWRITE", "1") == "1"      # the training loop's mode: first writer assigns
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reftr_amd import hip
 from tile_sweep import graph_time
@@ -25,18 +26,21 @@ def stage(planes, H, blocks, inpl):
     return out
 
 GROUPS = {"layer2": stage(128, 160, 4, 256), "layer3": stage(256, 80, 6, 512), "layer4": stage(512, 40, 3, 1024)}
+if os.environ.get("SYN"):          # balanced synthetic groups: the effect of XCD-local placement without the imbalance of a real stage
+    GROUPS = {"16 x layer3 3x3": [(8, 40, 256, 256, 3, 1)] * 16, "16 x layer4 1x1 2048->512": [(8, 20, 2048, 512, 1, 1)] * 16,
+              "16 x layer2 3x3": [(8, 80, 128, 128, 3, 1)] * 16, "8 x layer4 3x3": [(8, 20, 512, 512, 3, 1)] * 8}
 LIN = {"bert x12": [(320, 768, 2304), (320, 768, 768), (320, 768, 3072), (320, 3072, 768)] * 12,
        "encoder x6": [(3520, 256, 512), (3520, 256, 256), (3520, 256, 256), (3520, 256, 2048), (3520, 2048, 256)] * 6,
        "decoder kv x6 + input_proj": [(3520, 256, 256)] * 12 + [(3200, 2048, 256)]}
 tot_t = tot_f = 0.0
-for name, convs in GROUPS.items():
+for name, convs in (GROUPS.items() if os.environ.get("ONLY") != "lin" else []):
     keep = []; fl = 0.0
     for c in convs:
         fl += conv(None, keep, *c)
     def run():
         b = hip.WgradBatch(workspace_mb=1024)
         for x, dy, dw, sc, geom in keep:
-            b.add_conv(dy, x, dw, geom, scale=sc)
+            b.add_conv(dy, x, dw, geom, scale=sc, overwrite=OW)
         b.run()
     t = graph_time(run, iters=5)
     tot_t += t; tot_f += fl
@@ -49,7 +53,7 @@ for name, lins in (LIN.items() if os.environ.get("ONLY") != "conv" else []):
     def run():
         b = hip.WgradBatch(workspace_mb=512)
         for x, dy, dw, db in keep:
-            b.add(dy, x, dw, db)
+            b.add(dy, x, dw, db, overwrite=OW)
         b.run()
     t = graph_time(run, iters=5)
     tot_t += t; tot_f += fl

@@ -53,13 +53,14 @@ def build(force=False, verbose=False):
         results = list(ex.map(lambda s: _compile_one(s, hdr_mtime, force), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(ch for _, ch in results)
-    if rebuilt or not os.path.exists(LIB_PATH) or force:
+    stale = os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs)   # interrupted link
+    if rebuilt or stale or not os.path.exists(LIB_PATH) or force:
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", LIB_PATH] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"[reftr_amd] {LIB_PATH} ({'rebuilt' if rebuilt else 'up to date'}, {len(objs)} objects)")
+        print(f"[reftr_amd] {LIB_PATH} ({'rebuilt' if rebuilt or stale else 'up to date'}, {len(objs)} objects)")
     return LIB_PATH
 
 

@@ -21,7 +21,7 @@ struct GemmArgs {
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed; int drop_shift;
-    int M, K, sshift, xcd, early, epi_lds;
+    int M, K, sshift, xcd, early, epi_lds, abl, prefetch;
     unsigned src_bytes, wgt_bytes;
     const uint32_t* seed_dev;
 };
@@ -99,7 +99,9 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4
 // Same epilogue on 8 consecutive output features of row m (the LDS-staged, row-coalesced path of the DMA kernel):
 // every global access is a full 16-B (bf16) / 32-B (fp32) contiguous piece of one output row.
 typedef __attribute__((ext_vector_type(8))) float f32x8;
-__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, f32x8 v) {
+// `pre` (compile-time): the bf16 residual / gate pieces of this row piece were fetched at the start of the workgroup (pres, pgate).
+template <bool PRE = false>
+__device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, f32x8 v, const bf16x8 pres = bf16x8{}, const bf16x8 pgate = bf16x8{}) {
     const size_t o = (size_t)m * p.N + n;
     if (p.bias) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
@@ -119,7 +121,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, f32x8
             for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
         }
         if (p.res_bf16) {
-            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.res_bf16 + o);
+            const bf16x8 rr = PRE ? pres : *reinterpret_cast<const bf16x8*>(p.res_bf16 + o);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += (float)rr[r];
         }
@@ -144,7 +146,7 @@ __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n, f32x8
     }
     if (!p.res_first) add_res();
     if (p.gate) {
-        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(p.gate + o);
+        const bf16x8 gg = PRE ? pgate : *reinterpret_cast<const bf16x8*>(p.gate + o);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = ((float)gg[r] > 0.f) ? v[r] * p.gate_scale : 0.f;
     }
@@ -520,18 +522,53 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
         }
     };
 
+    // Epilogue operands first: the bf16 residual / ReLU-gate pieces this thread will need in the row-coalesced epilogue are
+    // requested BEFORE the first operand tile, so that their HBM latency runs under the K loop instead of in front of the
+    // stores (measured with REFTR_GEMM_ABL: the epilogue alone is as long as loads + MFMAs on the wide-output products, and
+    // at <= 2 workgroups per CU in their epilogue at a time its reads are latency-, not bandwidth-bound).  They are the
+    // oldest entries of this wave's vmcnt queue: the counted waits below stay conservative-exact.
+    constexpr int EP_LD = BN + 4;                                  // padded fp32 row (bank spread)
+    constexpr int HALVES = ((size_t)BM * EP_LD * 4 > (size_t)NS * BUF_BYTES) ? 2 : 1;    // 128x128 / 2 stages: two m-halves
+    constexpr int ROWS = BM / HALVES;
+    constexpr int CPR = BN / 8;                                    // 8-channel pieces per row
+    constexpr int PIECES = ROWS * CPR / 256;
+    constexpr bool CAN_PRE = HALVES == 1 && PIECES <= 4;
+    const bool epi_lds = p.epi_lds && (p.N & 7) == 0;
+    const bool pre = CAN_PRE && epi_lds && p.prefetch && (p.res_bf16 || p.gate);
+    bf16x8 pre_res[CAN_PRE ? PIECES : 1], pre_gate[CAN_PRE ? PIECES : 1];
+    auto out_piece = [&](int idx, int& m, int& n) __attribute__((always_inline)) -> bool {
+        const int rl = idx / CPR, cl = (idx - rl * CPR) * 8;
+        m = m0 + rl; n = n0 + cl;
+        if (m >= Mloc || n >= p.N) return false;
+        if (MODE == 3) {
+            const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
+            m = (bb * p.DH + 2 * yy + cy) * p.DW + 2 * xx + cx;
+        }
+        return true;
+    };
+    if (CAN_PRE && pre) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            int m, n;
+            const bool ok = out_piece(i * 256 + t, m, n);
+            const size_t o = ok ? (size_t)m * p.N + n : 0;
+            pre_res[i] = p.res_bf16 ? *reinterpret_cast<const bf16x8*>(p.res_bf16 + o) : bf16x8{};
+            pre_gate[i] = p.gate ? *reinterpret_cast<const bf16x8*>(p.gate + o) : bf16x8{};
+        }
+    }
+
     // prologue: tiles 0 .. NS-2 in flight (past the end the last tile is re-fetched into a free stage)
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_tile(s);
+    for (int s = 0; s < NS - 1; ++s) if (!(p.abl & 1)) issue_tile(s);
     int cbuf = 0, lbuf = NS - 1;
     if (p.early) {
         // issue-before-wait schedule: tile kt+NS-1 is requested BEFORE the wait for tile kt, so NS-1 tiles (not NS-2) are
         // in flight while the workgroup is parked; the price is a second barrier per K tile (stage release).
         for (int kt = 0; kt < nk; ++kt) {
-            issue_tile(lbuf);                          // its stage was released by the barrier that ended iteration kt-1
+            if (!(p.abl & 1)) issue_tile(lbuf);        // its stage was released by the barrier that ended iteration kt-1
             rt_wait_vmcnt<(NS - 1) * LPT>();           // tile kt has landed (this thread's part)
             __syncthreads();
-            compute(cbuf);
+            if (!(p.abl & 2)) compute(cbuf);
             __syncthreads();                           // everyone is done reading stage cbuf
             cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
             lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
@@ -547,15 +584,19 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
         }
     }
     rt_wait_vmcnt<0>();                            // drain the over-fetched tail before the workgroup's LDS is released
+    if (p.abl & 4) {                               // ablation probe (REFTR_GEMM_ABL, wrong results): no epilogue
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) asm volatile("" ::"v"(acc[a][b]));
+        return;
+    }
 
     // Row-coalesced epilogue: the MFMA C/D layout gives a lane 4 channels of one pixel, i.e. 8-B (bf16) pieces on 16
     // different rows per store instruction.  Staging the fp32 tile through LDS (the operand stages are dead now) turns every
     // residual / gate read and every store into 16-B pieces of ONE row per lane, 128+ contiguous bytes per row.
-    constexpr int EP_LD = BN + 4;                                  // padded fp32 row (bank spread)
-    constexpr int HALVES = ((size_t)BM * EP_LD * 4 > (size_t)NS * BUF_BYTES) ? 2 : 1;    // 128x128 / 2 stages: two m-halves
-    constexpr int ROWS = BM / HALVES;
     static_assert((size_t)ROWS * EP_LD * 4 <= (size_t)NS * BUF_BYTES, "epilogue tile does not fit the LDS stages");
-    if (p.epi_lds && (p.N & 7) == 0) {
+    if (epi_lds) {
         float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
@@ -568,20 +609,16 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
                         *reinterpret_cast<f32x4*>(tile + ((HALVES == 1 ? wm * (BM / 2) : 0) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4) = acc[a][b];
             }
             __syncthreads();
-            constexpr int CPR = BN / 8;                            // 8-channel pieces per row
 #pragma unroll
-            for (int i = 0; i < ROWS * CPR / 256; ++i) {
+            for (int i = 0; i < PIECES; ++i) {
                 const int idx = i * 256 + t;
                 const int rl = idx / CPR, cl = (idx - rl * CPR) * 8;
-                int m = m0 + h * ROWS + rl;
-                const int n = n0 + cl;
-                if (m >= Mloc || n >= p.N) continue;
-                if (MODE == 3) {
-                    const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
-                    m = (bb * p.DH + 2 * yy + cy) * p.DW + 2 * xx + cx;
-                }
+                int m, n;
+                if (!out_piece(h * ROWS * CPR + idx, m, n)) continue;
                 const f32x4 lo4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl), hi4 = *reinterpret_cast<const f32x4*>(tile + rl * EP_LD + cl + 4);
-                epilogue8(p, m, n, f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]});
+                const f32x8 v8 = f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                if (CAN_PRE && pre) epilogue8<true>(p, m, n, v8, pre_res[CAN_PRE ? i : 0], pre_gate[CAN_PRE ? i : 0]);
+                else epilogue8(p, m, n, v8);
             }
         }
         return;
@@ -732,6 +769,10 @@ static int fill_gemm_args(const rt_conv_gemm_desc* d, GemmArgs& a) {
     a.early = early_env & 1;
     static const int epi_env = getenv("REFTR_EPI") ? atoi(getenv("REFTR_EPI")) : 3;
     a.epi_lds = epi_env & 1;
+    static const int abl_env = getenv("REFTR_GEMM_ABL") ? atoi(getenv("REFTR_GEMM_ABL")) : 0;   // 1 no loads, 2 no MFMA, 4 no epilogue
+    a.abl = abl_env;
+    static const int pre_env = getenv("REFTR_EPI_PREFETCH") ? atoi(getenv("REFTR_EPI_PREFETCH")) : 1;
+    a.prefetch = pre_env;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
     return RT_OK;

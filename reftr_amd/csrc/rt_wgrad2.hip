@@ -431,7 +431,7 @@ int w2_launch(const W2Group& g, int blocks, hipStream_t s) {
 
 // Eligibility: channel counts the DMA path can address in 16-B pieces, enough rows for the pipeline to matter.
 bool rt_w2_eligible(const rt_conv_wgrad_desc& d) {
-    static const int minm_env = getenv("REFTR_W2_MINM") ? atoi(getenv("REFTR_W2_MINM")) : 1024;
+    static const int minm_env = getenv("REFTR_W2_MINM") ? atoi(getenv("REFTR_W2_MINM")) : 256;
     const long long M = (long long)d.B * d.DH * d.DW;
     if (M < minm_env || (d.N & 7) || (d.SC & 7) || d.N < 64 || d.SC < 64) return false;
     if (d.variant != 0 || d.msplit > 0) return false;
