@@ -242,7 +242,9 @@ def test_wgrad_fused_bias_grad(hip, M, K, N):
 
 def test_weight_prep_batched(hip):
     g = torch.Generator().manual_seed(12)
-    jobs = [(24, 9, 16, True), (100, 1, 70, False), (4, 1, 256, False), (33, 4, 33, True)]
+    # 16-B path (C and N multiples of 8), mixed (one of them), element-wise path, several tiles per job, ragged tiles
+    jobs = [(24, 9, 16, True), (100, 1, 70, False), (4, 1, 256, False), (33, 4, 33, True), (768, 1, 3072, False),
+            (136, 9, 72, True), (72, 1, 100, True), (100, 1, 72, False)]
     batch = hip.WeightPrepBatch("cuda")
     keep = []
     for N, T, C, scaled in jobs:
