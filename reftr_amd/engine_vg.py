@@ -118,6 +118,8 @@ def _clone_batch(samples, targets):
 
 
 def _copy_batch(dst_s, dst_t, samples, targets):
+    if samples is dst_s and targets is dst_t:        # the caller filled the static buffers in place (CapturedTrainStep.batch)
+        return
     for k, v in samples.items():
         if isinstance(v, utils.NestedTensor):
             dst_s[k].tensors.copy_(v.tensors, non_blocking=True); dst_s[k].mask.copy_(v.mask, non_blocking=True)
@@ -321,8 +323,16 @@ class CapturedTrainStep:
         self.grad_norm = self.optimizer.clip_grad_norm_(self.max_norm)
         self.optimizer.step()
 
+    @property
+    def batch(self):
+        """The static input buffers the graphs read: (samples, targets).  An input pipeline that writes the next batch INTO
+        them (reftr_amd.data's device kernels take an output tensor) and calls `step(*step.batch)` pays no staging copy;
+        any other batch of the captured shape is copied in (one small copy per field) before the replay."""
+        return self.s, self.t
+
     def __call__(self, samples, targets):
-        assert self.shape_key(samples, targets) == self.key, "captured for another input shape; use train_step"
+        assert (samples is self.s and targets is self.t) or self.shape_key(samples, targets) == self.key, \
+            "captured for another input shape; use train_step"
         if self.deferred:
             _copy_batch(self.s, self.t, samples, targets)
             self.g_fb.replay()                # applies iteration i-1's update with the rates synced at iteration i-1
