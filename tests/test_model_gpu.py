@@ -488,3 +488,40 @@ def test_two_queries_per_phrase_vs_oracle(hip, n_phrase):
     print(f"\n[n_q = 2, {Pn} phrase(s)] boxes {rb:.2e}  worst loss {rl:.2e}  global grad rel {rg:.2e} cos {cos:.4f}  d query_embed rel {gq:.2e}")
     assert rb < TOL["boxes"] * 1.5 and rl < TOL["loss"] * 1.5
     assert rg < 0.25 and cos > 0.97 and gq < 0.1
+
+
+def test_captured_step_static_batch_filled_in_place(hip):
+    """CapturedTrainStep.batch: a batch written INTO the static input buffers and replayed gives the step of the same batch
+    handed over as separate tensors (which are copied in); the copy path itself is skipped by identity, not by value."""
+    from reftr_amd.engine_vg import CapturedTrainStep, _copy_batch
+    from reftr_amd.optim import FusedAdamW
+    sa, ta = to_cuda(*make_inputs("e2e_single", B=2, H=96, W=128, L=12))
+    sb, tb = to_cuda(*make_inputs("other_batch", B=2, H=96, W=128, L=12))
+    model, crit, P, ocfg = build(small=True)
+    model.eval()
+    opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+    cap = CapturedTrainStep(model, crit, opt, 0.1, sa, ta, warmup=1)
+    snap = (model.store.flat_p.clone(), opt.m.clone(), opt.v.clone())
+
+    def restore():
+        cap.reset_pending()
+        model.store.flat_p.copy_(snap[0]); opt.m.copy_(snap[1]); opt.v.copy_(snap[2]); opt.step_dev.zero_(); opt.step_count = 0
+        model.mark_dirty(full=True)
+    restore()
+    l_copy = [float(cap(sb, tb)[0]) for _ in range(2)]
+    restore()
+    s_static, t_static = cap.batch
+    assert s_static is cap.s and t_static is cap.t
+    _copy_batch(s_static, t_static, sa, ta)                 # stale content first: the replay must read what is written next
+    s_static["img"].tensors.copy_(sb["img"].tensors); s_static["img"].mask.copy_(sb["img"].mask)
+    for k, v in sb.items():
+        if torch.is_tensor(v):
+            s_static[k].copy_(v)
+    for d, t in zip(t_static, tb):
+        for k, v in t.items():
+            d[k].copy_(v)
+    l_static = [float(cap(s_static, t_static)[0]) for _ in range(2)]
+    la = float(cap(sa, ta)[0])
+    print("static-batch losses", l_copy, l_static, la)
+    assert abs(l_copy[0] - l_static[0]) < 1e-6 * abs(l_copy[0]) and abs(l_copy[1] - l_static[1]) < 2e-3 * abs(l_copy[1])
+    assert abs(la - l_copy[0]) > 1e-3 * abs(la)             # the two batches are different problems
