@@ -42,7 +42,10 @@ def main():
     print("%-90s %7s %12s %12s" % ("kernel", "calls", "fetch MB/call", "write MB/call"))
     for k, n, fb, wb in rows[:25]:
         print("%-90s %7d %12.2f %12.2f" % (k[:90], n, fb / n / 1e6, wb / n / 1e6))
-    tot_f, tot_w = sum(r[2] for r in rows), sum(r[3] for r in rows)
+    # model construction (parameter init: ~500 torch fill / RNG kernels, once per process) is not part of a step
+    init = re.compile(r"FillFunctor|distribution_|uniform_|normal_")
+    step_rows = [r for r in rows if not init.search(r[0])]
+    tot_f, tot_w = sum(r[2] for r in step_rows), sum(r[3] for r in step_rows)
     res = {
         "steps": a.steps,
         "gemm_family": {"kernel_dispatches_per_step": fam["launches"] / a.steps,
@@ -50,6 +53,7 @@ def main():
                         "fetch_bytes_per_step": fam["fetch"] / a.steps, "write_bytes_per_step": fam["write"] / a.steps},
         "whole_step": {"hbm_bytes_per_step": (tot_f + tot_w) / a.steps, "fetch_bytes_per_step": tot_f / a.steps,
                        "write_bytes_per_step": tot_w / a.steps},
+        "excluded_init_bytes": sum(r[2] + r[3] for r in rows if init.search(r[0])),
         "corrections": "fetch = 2 x FETCH_SIZE KB (gfx950 128-B requests tallied at 64 B); write = WRITE_SIZE KB",
     }
     if a.bench_json:
