@@ -1,0 +1,2 @@
+cd benchmarks
+for a in 0 1 2 4 3 5 6; do echo "== REFTR_GEMM_ABL=$a"; REFTR_GEMM_ABL=$a ONLY=conv HINTS=0 python tile_sweep.py 2>&1 | grep -v "^hints\|amdgpu" | cut -c1-36 | tr '\n' ';'; echo; done

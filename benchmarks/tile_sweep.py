@@ -44,7 +44,7 @@ for name, B, Hh, ci, co, st in CONVS:
     fl = 2.0 * B * ho * ho * co * ci * 9
     print("%-20s fwd   " % name + " ".join("%6.1f" % v for v in rf) + "  best %d (%4.0f TF)" % (HINTS[rf.index(min(rf))], fl / min(rf) / 1e6), flush=True)
     print("%-20s dgrad " % name + " ".join("%6.1f" % v for v in rd) + "  best %d (%4.0f TF)" % (HINTS[rd.index(min(rd))], fl / min(rd) / 1e6), flush=True)
-for name, M, K, N in SHAPES:
+for name, M, K, N in (SHAPES if os.environ.get("ONLY") != "conv" else []):
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
     res = torch.randn(M, N, device="cuda").bfloat16()
     ob = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)

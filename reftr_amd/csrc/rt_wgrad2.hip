@@ -24,6 +24,7 @@
 // 32-lane half of the transpose read touches land on four different 64-B bank groups) is applied to the SOURCE address.
 #include "rt_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -72,14 +73,24 @@ __device__ __forceinline__ bf16x8 w2_frag2(const unsigned char* base, int off0, 
 }
 
 // BN x BC output tile, WN x WC waves (WN * WC == 8), CR contraction rows per stage, NS stages.
-template <int BN, int BC, int WN, int WC, int CR, int NS, bool SIMPLE>
+// TAPS = 3 (3x3, stride 1, pad 1 only): a workgroup accumulates the three kw taps of ONE kernel row kh of its output tile.  For a
+// chunk of 32 output pixels m0 .. m0+31 the source pixel of (m, kw) is the flat pixel index m + (kh-1) W + (kw-1) whenever it lies
+// inside the image row / image, so the x operand of all three taps is ONE contiguous slab of 34 rows (staged once, as plainly as a
+// 1x1 problem's rows) and tap kw reads it shifted by kw rows; the dy fragments are shared by the three taps.  Where the source
+// would fall outside (first / last column, first / last image row) the flat index names some other pixel: those (m, kw) terms are
+// removed by AND-ing the x fragments with a row mask (ballot of the validity of the chunk's 32 rows per tap, expanded through a
+// 256-entry LDS table: byte of 8 row bits -> 8 x 16-bit lanes).  3x the flop per staged byte and per dy fragment read.
+template <int BN, int BC, int WN, int WC, int CR, int NS, bool SIMPLE, int TAPS = 1>
 __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const int tile, const int abl, const int pf) {
     static_assert(WN * WC == 8, "8 waves");
+    constexpr bool FUSED = TAPS == 3;
+    static_assert(TAPS == 1 || (TAPS == 3 && !SIMPLE), "taps");
+    constexpr int BROWS = FUSED ? 48 : CR;               // staged x rows: the 34-row window rounded up to whole 4-KB DMA rounds
     constexpr int WTN = BN / WN, WTC = BC / WC;          // wave tile
     constexpr int TN = WTN / 32, TC = WTC / 32;          // 32x32 MFMA blocks per wave
     static_assert(TN >= 1 && TC >= 1, "wave tile too small");
     constexpr int RBA = BN * 2, RBB = BC * 2;            // LDS row bytes
-    constexpr int A_BYTES = CR * RBA, B_BYTES = CR * RBB, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = CR * RBA, B_BYTES = BROWS * RBB, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int AJ = A_BYTES / 4096, BJ = B_BYTES / 4096;      // DMA instructions per thread of waves 0-3 per stage (4 waves x 1 KB)
     static_assert(AJ >= 1 && BJ >= 1 && A_BYTES % 4096 == 0 && B_BYTES % 4096 == 0, "stage must be whole 4-KB rounds");
     constexpr int LPT = AJ + BJ;
@@ -125,6 +136,7 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
         const int c = c0 + sl * 8;
         b_r[j] = r;
         if (SIMPLE) { voff_b[j] = c < p.SC ? (r * p.SC + c) * 2 : OOB; gb[j] = gy[j] = gx[j] = 0; }
+        else if (FUSED) { voff_b[j] = (c < p.SC && r < CR + 4) ? (r * p.SC + c) * 2 : OOB; gb[j] = gy[j] = gx[j] = 0; }
         else {
             voff_b[j] = c < p.SC ? c * 2 : OOB;
             const int m = chunk_begin * CR + r;
@@ -149,15 +161,45 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
     }
     const int pf_shift = SIMPLE ? 0 : ((kh - p.pad) * p.SW + (kw - p.pad)) * p.SC * 2;       // bytes
 
-    f32x16 acc[TN][TC];
+    f32x16 acc[TAPS][TN][TC];
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+    for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int b = 0; b < TC; ++b)
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int b = 0; b < TC; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tp][a][b][r] = 0.f;
 
-    const bool do_bias = p.dbias && tile_c == 0 && tap == 0;
+    const bool do_bias = p.dbias && tile_c == 0 && tap == 0;      // fused: tap = kh, kernel row 0 holds tap 0
+
+    // ---- fused taps: row-mask table (byte of 8 row bits -> eight 16-bit lanes) and the (h, w) of this lane's row of the chunk
+    // whose fragments are read next
+    uint4* const mtab = reinterpret_cast<uint4*>(smem + NS * BUF_BYTES);
+    int mw = 0, mh = 0;
+    unsigned mbits[3] = {0u, 0u, 0u};
+    if (FUSED) {
+        if (t < 256) {
+            uint4 e;
+            e.x = ((t & 1) ? 0xFFFFu : 0u) | ((t & 2) ? 0xFFFF0000u : 0u);
+            e.y = ((t & 4) ? 0xFFFFu : 0u) | ((t & 8) ? 0xFFFF0000u : 0u);
+            e.z = ((t & 16) ? 0xFFFFu : 0u) | ((t & 32) ? 0xFFFF0000u : 0u);
+            e.w = ((t & 64) ? 0xFFFFu : 0u) | ((t & 128) ? 0xFFFF0000u : 0u);
+            mtab[t] = e;
+        }
+        const int m = (split * p.chunks_per_split) * CR + (lane & 31);
+        mw = m % p.DW; mh = (m / p.DW) % p.DH;
+    }
+    auto row_masks = [&]() __attribute__((always_inline)) {       // validity of (row, kw) for the 32 rows of the chunk at (mh, mw)
+        const bool vrow = (unsigned)(mh + tap - 1) < (unsigned)p.DH;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            mbits[q] = (unsigned)__ballot(vrow && (unsigned)(mw + q - 1) < (unsigned)p.DW);
+    };
+    auto next_rows = [&]() __attribute__((always_inline)) {
+        mw += CR;
+        while (mw >= p.DW) { mw -= p.DW; if (++mh >= p.DH) mh = 0; }
+    };
     float bsum = 0.f;
 
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)(wave & 3) * 1024u;
@@ -172,7 +214,16 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
 #pragma unroll
         for (int j = 0; j < AJ; ++j) w2_dma16(rs_dy, bA + j * 4096, voff_a[j]);
         const bool last = (lc + 1 >= chunk_end);
-        if (SIMPLE) {
+        if (FUSED) {
+            // rows g0 .. g0 + 33 of x (flat pixel index, may start before the tensor / end behind it: those rows read as zero)
+            const int base = (lc * CR + (tap - 1) * p.DW - 1) * p.SC * 2;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                int off = voff_b[j] == OOB ? OOB : base + voff_b[j];
+                if (off < 0) off = OOB;
+                w2_dma16(rs_x_abs, bB + j * 4096, off);
+            }
+        } else if (SIMPLE) {
             const unsigned xoff = (unsigned)lc * (unsigned)(CR * 2) * (unsigned)p.SC;
             const w2_i32x4 rs_x = w2_rsrc(reinterpret_cast<const unsigned char*>(p.x) + xoff, p.x_bytes - xoff);
 #pragma unroll
@@ -238,20 +289,51 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
             addr_b[b][h] = r * RBB + ((((cb >> 4) ^ w2_swz(r)) << 4) | (cb & 15));
         }
     }
-    auto load_frags = [&](int stage, int kk, bf16x8 (&af)[TN], bf16x8 (&bfr)[TC]) __attribute__((always_inline)) {
+    int addr_b3[FUSED ? 3 : 1][TC][2];               // fused: tap kw reads the window kw rows further down (the swizzle follows the row)
+    if (FUSED) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int b = 0; b < TC; ++b) {
+                const int cb = (wc * WTC + b * 32) * 2 + colb;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = row0 + 4 * h + q;
+                    addr_b3[q][b][h] = r * RBB + ((((cb >> 4) ^ w2_swz(r)) << 4) | (cb & 15));
+                }
+            }
+    }
+    auto load_frags = [&](int stage, int kk, bf16x8 (&af)[TN], bf16x8 (&bfr)[TAPS][TC]) __attribute__((always_inline)) {
         const unsigned char* bA = smem + stage * BUF_BYTES;
         const unsigned char* bB = bA + A_BYTES;
 #pragma unroll
         for (int a = 0; a < TN; ++a) af[a] = w2_frag2(bA, addr_a[a][0] + kk * 16 * RBA, addr_a[a][1] + kk * 16 * RBA);
+        if (FUSED) {
 #pragma unroll
-        for (int b = 0; b < TC; ++b) bfr[b] = w2_frag2(bB, addr_b[b][0] + kk * 16 * RBB, addr_b[b][1] + kk * 16 * RBB);
+            for (int q = 0; q < TAPS; ++q) {
+                const unsigned byte = (mbits[q] >> (kk * 16 + (lane >> 5) * 8)) & 0xFFu;
+                const uint4 mk = mtab[byte];
+#pragma unroll
+                for (int b = 0; b < TC; ++b) {
+                    union { bf16x8 v; uint4 u; } f;
+                    f.v = w2_frag2(bB, addr_b3[q][b][0] + kk * 16 * RBB, addr_b3[q][b][1] + kk * 16 * RBB);
+                    f.u.x &= mk.x; f.u.y &= mk.y; f.u.z &= mk.z; f.u.w &= mk.w;
+                    bfr[q][b] = f.v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < TC; ++b) bfr[0][b] = w2_frag2(bB, addr_b[b][0] + kk * 16 * RBB, addr_b[b][1] + kk * 16 * RBB);
+        }
     };
-    auto mma = [&](const bf16x8 (&af)[TN], const bf16x8 (&bfr)[TC]) __attribute__((always_inline)) {
+    auto mma = [&](const bf16x8 (&af)[TN], const bf16x8 (&bfr)[TAPS][TC]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+        for (int q = 0; q < TAPS; ++q)
 #pragma unroll
-            for (int b = 0; b < TC; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TC; ++b)
+                    acc[q][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[q][b], acc[q][a][b], 0, 0, 0);
     };
     auto bias_rows = [&](int stage) __attribute__((always_inline)) {
         // fused bias gradient: column sums of the dy tile that is in LDS (512 threads: BN columns x 512 / BN row groups)
@@ -273,9 +355,10 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
     // the split's end re-fetch its last chunk and are never multiplied.)
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0) issue(s0);
-    bf16x8 fa0[TN], fb0[TC], fa1[TN], fb1[TC];
+    bf16x8 fa0[TN], fb0[TAPS][TC], fa1[TN], fb1[TAPS][TC];
     if (dma_wave) w2_wait_vmcnt<(NS - 1) * LPT>();
     __syncthreads();
+    if (FUSED) row_masks();
     load_frags(0, 0, fa0, fb0);
     int cbuf = 0;
     for (int c = 0; c < nch; ++c) {
@@ -288,6 +371,7 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
         if (dma_wave && !(abl & 1)) w2_wait_vmcnt<(NS - 2) * LPT>();      // this thread's pieces of chunk c+1 have landed
         __syncthreads();
         if (!(abl & 1)) issue(cbuf);                           // chunk c + NS
+        if (FUSED) { next_rows(); row_masks(); }               // masks of chunk c + 1
         if (!(abl & 2)) {
             load_frags(nbuf, 0, fa0, fb0);
             mma(fa1, fb1);
@@ -313,12 +397,15 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
     __syncthreads();                 // every wave is done reading the stages; the DMA tail is drained (vmcnt 0 above)
     const int er = lane / LPR, ec = (lane % LPR) * 4;
 #pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+    const int otap = FUSED ? tap * 3 + tp : tap;
+#pragma unroll
     for (int a = 0; a < TN; ++a) {
 #pragma unroll
         for (int b = 0; b < TC; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WTC + b * 32 + (lane & 31)] = acc[a][b][r];
+                ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * WTC + b * 32 + (lane & 31)] = acc[tp][a][b][r];
         constexpr int NB = NI > 8 ? 8 : NI;                          // 16-B pieces per lane in flight at a time
 #pragma unroll
         for (int i0 = 0; i0 < NI; i0 += NB) {
@@ -330,7 +417,7 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
                 v[i] = *reinterpret_cast<const f32x4*>(ep + row * WTC + ec);
                 const int n = n0 + wn * WTN + a * 32 + row, c = c0 + wc * WTC + ec;
                 ok[i] = n < p.N && c < p.SC;
-                o[i] = dst + ((size_t)(ok[i] ? n : 0) * taps + tap) * p.SC + (ok[i] ? c : 0);
+                o[i] = dst + ((size_t)(ok[i] ? n : 0) * taps + otap) * p.SC + (ok[i] ? c : 0);
                 if (direct && p.scale) v[i] *= p.scale[ok[i] ? n : 0];
             }
             if (direct && p.accumulate) {
@@ -342,6 +429,7 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
 #pragma unroll
             for (int i = 0; i < NB; ++i) if (ok[i]) *reinterpret_cast<f32x4*>(o[i]) = v[i];
         }
+    }
     }
 }
 
@@ -384,7 +472,8 @@ __global__ __launch_bounds__(512, 1) void w2_grouped_kernel(const W2Group g) {
         case 4: w2_body<256, 128, 4, 2, CR, NS, false>(p, split, tile, g.abl, g.pf); break;
         case 5: w2_body<256, 128, 4, 2, CR, NS, true>(p, split, tile, g.abl, g.pf); break;
         case 6: w2_body<128, 128, 2, 4, CR, NS, false>(p, split, tile, g.abl, g.pf); break;
-        default: w2_body<128, 128, 2, 4, CR, NS, true>(p, split, tile, g.abl, g.pf); break;
+        case 7: w2_body<128, 128, 2, 4, CR, NS, true>(p, split, tile, g.abl, g.pf); break;
+        default: w2_body<128, 128, 2, 4, CR, NS, false, 3>(p, split, tile, g.abl, 0); break;      // cfg 4: three taps per workgroup
     }
 }
 
@@ -417,6 +506,7 @@ __global__ __launch_bounds__(256) void w2_reduce_kernel(const W2Reduce g) {
 template <int CR, int NS>
 int w2_launch(const W2Group& g, int blocks, hipStream_t s) {
     constexpr size_t smem = (size_t)NS * CR * (256 + 256) * 2 + 4 * 256;      // the largest configuration's stages + the prefetch scratch words
+    static_assert((size_t)NS * (CR * 256 + 48 * 256) + 4096 <= smem, "fused-tap stages + mask table");
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)w2_grouped_kernel<CR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -440,7 +530,15 @@ bool rt_w2_eligible(const rt_conv_wgrad_desc& d) {
     return true;
 }
 
-static int w2_cfg_of(const rt_conv_wgrad_desc& d) {       // 0: 256x256, 1: 128x256, 2: 256x128, 3: 128x128
+static int w2_cfg_of(const rt_conv_wgrad_desc& d) {       // 0: 256x256, 1: 128x256, 2: 256x128, 3: 128x128, 4: 128x128 x 3 taps
+    static const int fuse_env = getenv("REFTR_W2_FUSE3") ? atoi(getenv("REFTR_W2_FUSE3")) : 1;
+    static const int fuse_minw = getenv("REFTR_W2_FUSE3_MINW") ? atoi(getenv("REFTR_W2_FUSE3_MINW")) : 8;
+    static const int fuse_maxc = getenv("REFTR_W2_FUSE3_MAXC") ? atoi(getenv("REFTR_W2_FUSE3_MAXC")) : 128;
+    // fused taps where the per-tap tile could not be wider than 128 x 128 anyway (layer2, the RES head): 2.3x on those; with 256
+    // channels a side the per-tap 256 x 256 tile is as good (layer3: equal), and at W = 20 the row masks cost more than the taps
+    // save (layer4: 150 -> 169 us) -- REFTR_W2_FUSE3_MAXC / _MINW widen the choice
+    if (fuse_env && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.SH == d.DH && d.SW == d.DW && d.DW >= fuse_minw &&
+        d.N <= fuse_maxc && d.SC <= fuse_maxc && (long long)d.B * d.SH * d.SW * d.SC * 2 < 0x3fffffffLL) return 4;
     const bool n_big = d.N > 128, c_big = d.SC > 128;
     return n_big ? (c_big ? 0 : 2) : (c_big ? 1 : 3);
 }
@@ -453,7 +551,13 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
     static const int abl_env = getenv("REFTR_W2_ABL") ? atoi(getenv("REFTR_W2_ABL")) : 0;      // ablation probes (wrong results)
     static const int pf_env = getenv("REFTR_W2_PF") ? atoi(getenv("REFTR_W2_PF")) : 0;
     constexpr int CR = 32;
-    static const int BNs[4] = {256, 128, 256, 128}, BCs[4] = {256, 256, 128, 128};
+    static const int BNs[5] = {256, 128, 256, 128, 128}, BCs[5] = {256, 256, 128, 128, 128};
+    static double wts[5] = {4, 2, 2, 1, 3};                   // cost of one chunk of a tile task, in 128x128-tile units (REFTR_W2_WTS="a,b,c,d,e")
+    static bool wts_done = false;
+    if (!wts_done) {
+        if (const char* e = getenv("REFTR_W2_WTS")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &wts[0], &wts[1], &wts[2], &wts[3], &wts[4]);
+        wts_done = true;
+    }
     static const int slots[4] = {256, 256, 256, 512};         // resident workgroups on the chip (LDS: 130 / 98 / 98 / 66 KB each)
     for (int base = 0; base < n; base += W2_MAXP) {         // one launch (and one split policy) per W2_MAXP problems
         // ---- group-level split policy: cut the m axis only while the group has fewer tile tasks than resident slots; work is
@@ -464,12 +568,36 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             const rt_conv_wgrad_desc& d = descs[list[k]];
             const int cfg = w2_cfg_of(d); const int BN = BNs[cfg], BC = BCs[cfg];
             const long long M = (long long)d.B * d.DH * d.DW;
-            const long long tl = (long long)((d.N + BN - 1) / BN) * ((d.SC + BC - 1) / BC) * d.KH * d.KW;
-            tiles_total += tl; work += (double)tl * (double)((M + CR - 1) / CR) * (double)(BN / 128 * (BC / 128));
+            const long long tl = (long long)((d.N + BN - 1) / BN) * ((d.SC + BC - 1) / BC) * (cfg == 4 ? 3 : d.KH * d.KW);
+            tiles_total += tl; work += (double)tl * (double)((M + CR - 1) / CR) * (double)wts[cfg];
         }
         const int cfg = 0;
         const int target = target_env > 0 ? target_env : slots[cfg];
-        const double per_wg = work / (double)target;          // chunks a workgroup should own so that ~`target` workgroups cover the group
+        double per_wg = work / (double)target;                // chunks a workgroup should own so that ~`target` workgroups cover the group
+        // The per-problem rounding of the split counts must not push the launch over the resident slots: a 257th workgroup of
+        // a long task is a whole extra task time for everybody (measured: a layer3 stage went from 288 to 352 us).  Coarsen
+        // per_wg until the rounded counts fit.
+        static const int fit_env = getenv("REFTR_W2_FIT") ? atoi(getenv("REFTR_W2_FIT")) : 1;
+        if (fit_env && tiles_total < target) {
+            for (int it = 0; it < 24; ++it) {
+                long long total = 0;
+                for (int k = 0; k < m; ++k) {
+                    const rt_conv_wgrad_desc& d = descs[list[k]];
+                    const int cfg = w2_cfg_of(d); const int BN = BNs[cfg], BC = BCs[cfg];
+                    const long long M = (long long)d.B * d.DH * d.DW;
+                    const long long tl = (long long)((d.N + BN - 1) / BN) * ((d.SC + BC - 1) / BC) * (cfg == 4 ? 3 : d.KH * d.KW);
+                    const int total_chunks = (int)((M + CR - 1) / CR);
+                    int sp = (int)((double)total_chunks * (double)wts[cfg] / per_wg + 0.5);
+                    const int maxs = (int)(M / minrows_env);
+                    if (sp > maxs) sp = maxs;
+                    if (sp < 1) sp = 1;
+                    const int cps = (total_chunks + sp - 1) / sp;
+                    total += tl * ((total_chunks + cps - 1) / cps);
+                }
+                if (total <= target) break;
+                per_wg *= 1.03;
+            }
+        }
         W2Group g; W2Reduce r; g.n = 0; r.n = 0; g.xcd = xcd_env; g.abl = abl_env; g.pf = pf_env;
         int rblocks = 0; long long ws_off = 0;
         double xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -501,7 +629,8 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             p.SH = d.SH; p.SW = d.SW; p.SC = d.SC; p.DH = d.DH; p.DW = d.DW; p.N = d.N; p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
             const long long M = (long long)d.B * d.DH * d.DW;
             p.M = (int)M;
-            p.n_tiles = (d.N + BN - 1) / BN; p.c_tiles = (d.SC + BC - 1) / BC; p.tiles = p.n_tiles * p.c_tiles * d.KH * d.KW;
+            p.n_tiles = (d.N + BN - 1) / BN; p.c_tiles = (d.SC + BC - 1) / BC;
+            p.tiles = p.n_tiles * p.c_tiles * (p.cfg == 4 ? 3 : d.KH * d.KW);
             p.out_elems = d.N * d.KH * d.KW * d.SC;
             p.dy_bytes = (unsigned)(M * d.N * 2); p.x_bytes = (unsigned)((long long)d.B * d.SH * d.SW * d.SC * 2);
             p.simple = (d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0) ? 1 : 0;
@@ -509,7 +638,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             const int total_chunks = (int)((M + CR - 1) / CR);
             int splits = 1;
             if (tiles_total < target) {
-                splits = (int)((double)total_chunks * (double)(BN / 128 * (BC / 128)) / per_wg + 0.5);
+                splits = (int)((double)total_chunks * (double)wts[p.cfg] / per_wg + 0.5);
                 const int maxs = (int)(M / minrows_env);
                 if (splits > maxs) splits = maxs;
                 if (splits < 1) splits = 1;
@@ -546,6 +675,9 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
                 xcount[x] += cnt * p.tiles; xload[x] += (double)cnt * p.tiles * p.chunks_per_split;
                 g.cum[x][g.n + 1] = xcount[x];
             }
+            static const int dbg_env = getenv("REFTR_W2_DEBUG") ? atoi(getenv("REFTR_W2_DEBUG")) : 0;
+            if (dbg_env) fprintf(stderr, "[w2] M=%d N=%d C=%d k=%d s=%d cfg=%d tiles=%d splits=%d chunks/split=%d  (group tiles %lld, per_wg %.0f)\n",
+                                 p.M, p.N, p.SC, p.KH, p.stride, p.cfg, p.tiles, p.splits, p.chunks_per_split, tiles_total, per_wg);
             lin_total += p.tiles * p.splits;
             if (!xcd_env) g.cum[0][g.n + 1] = lin_total;
             g.p[g.n] = p; ++g.n;

@@ -338,3 +338,45 @@ def test_wgrad_v2_single_problem_splits_the_row_axis(hip):
         hip.linear_wgrad(dy.cuda(), x.cuda(), dw, dbias=db)
         assert rel(dw + 1.0, dy.float().T @ x.float()) < TOL_F32
         assert rel(db, dy.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [
+    (2, 40, 40, 256, 256),       # layer3: two channel tiles each side
+    (1, 80, 80, 128, 128),       # layer2: rows of 80 (a 32-row chunk crosses an image row 2 times out of 5)
+    (2, 20, 20, 512, 512),       # layer4: every chunk holds one or two row ends
+    (3, 13, 9, 64, 72),          # W < 32: several image rows per chunk; odd sizes; chunks cross IMAGE boundaries; ragged channels
+    (2, 23, 19, 192, 320),       # ragged tiles on both sides
+    (1, 8, 100, 128, 64),        # W > 32 with few rows: the first / last image row masks cover whole chunks
+])
+@pytest.mark.parametrize("overwrite", [False, True])
+def test_wgrad_v2_fused_taps_3x3(hip, B, H, W, Ci, Co, overwrite):
+    """3x3 / stride 1 / pad 1 weight gradients on the tap-fused tile (three kw taps of a kernel row per workgroup, x staged as one
+    34-row window, border terms removed by row masks) against torch fp32, alone (row axis split) and inside a group (unsplit)."""
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    x = bf(torch.randn(B, Ci, H, W, generator=g)).float()
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=1, padding=1)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy.float())
+    ref = w.grad.permute(0, 2, 3, 1)
+    geom = (B, H, W, Ci, H, W, Co, 3, 3, 1, 1)
+    dyc, xc = nhwc(dy).cuda(), nhwc(x).bfloat16().cuda()
+    base = 0.0 if overwrite else 0.5
+    dw = torch.full((Co, 3, 3, Ci), 7.0 if overwrite else base, device="cuda")
+    hip.conv_wgrad(dyc, xc, dw, geom=geom, overwrite=overwrite)
+    e1 = rel(dw - base, ref)
+    # inside a group with enough other tile tasks that nothing is split
+    batch = hip.WgradBatch(workspace_mb=256)
+    dw2 = torch.full((Co, 3, 3, Ci), 7.0 if overwrite else base, device="cuda")
+    batch.add_conv(dyc, xc, dw2, geom, overwrite=overwrite)
+    keep = []
+    for _ in range(3):
+        xa = torch.randn(2048, 1024, device="cuda").bfloat16(); da = torch.randn(2048, 1024, device="cuda").bfloat16()
+        dwa = torch.zeros(1024, 1024, device="cuda"); keep.append((xa, da, dwa))
+        batch.add(da, xa, dwa, None)
+    batch.run()
+    e2 = rel(dw2 - base, ref)
+    print("fused taps", (B, H, W, Ci, Co), "single", e1, "grouped", e2)
+    assert e1 < TOL_F32 and e2 < TOL_F32
+    for xa, da, dwa in keep:
+        assert rel(dwa, da.float().T @ xa.float()) < TOL_F32
