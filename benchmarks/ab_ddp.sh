@@ -1,10 +1,6 @@
-P='import sys,json
-for l in sys.stdin:
-    if l.startswith("{\"metric\""):
-        d=json.loads(l); print(round(d["ms_per_step"],3), round(d["value"],1), d["config"]["launch"], d["loss"])
-    elif "bench]" in l: print(l.strip()[:300])'
-echo "plain:"; timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-roofline 2>&1 | python -c "$P"
-for ph in "bert" "main,bert" "main,bert,layer4" "main,bert_hi,bert_mid,bert,layer4"; do
-echo "single-rank RCCL, graphs, exchange at: $ph"; REFTR_DDP_PHASES=$ph REFTR_DDP_FORCE=1 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-roofline 2>&1 | python -c "$P"
+# the data-parallel schedules on the one-GPU box (single-rank RCCL): compute cost of each exchange schedule vs the N = 1 step
+for r in 1 2; do
+echo -n "N=1 schedule                      "; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), d['config'].get('launch'))"
+echo -n "REFTR_DDP_FORCE=1 interleave      "; REFTR_DDP_FORCE=1 REFTR_DDP_SCHEDULE=interleave python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), d['config'].get('launch'))"
+echo -n "REFTR_DDP_FORCE=1 serial          "; REFTR_DDP_FORCE=1 REFTR_DDP_SCHEDULE=serial python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), d['config'].get('launch'))"
 done
-echo "single-rank RCCL, eager, all boundaries:"; REFTR_DDP_FORCE=1 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-roofline --no-graph 2>&1 | python -c "$P"

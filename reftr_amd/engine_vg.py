@@ -180,7 +180,8 @@ class CapturedTrainStep:
         if force_phases is not None:
             self.phases = [b for b in inner.active_boundaries() if b in force_phases]
         elif force_two_phase and not self.phases:
-            self.phases = ["bert"]                   # [everything but the ResNet | the ResNet]
+            # serial schedule: [everything but the ResNet | the ResNet]; interleaved: [... transformer backward | BERT || ResNet]
+            self.phases = ["bert"] if inner.dp_schedule == "serial" else ["main"]
         self.two_phase = bool(self.phases)
         inner._stops = frozenset(self.phases)
         self.deferred = (not self.two_phase and not self._post and hasattr(optimizer, "enable_deferred")

@@ -76,6 +76,11 @@ class RefTR(nn.Module):
         # `_stops` makes backward return there instead (CapturedTrainStep captures one graph per segment and issues the
         # collectives between replays; `continue_backward()` resumes).
         self._phase_hooks = {}
+        # REFTR_DDP_SCHEDULE: "interleave" (default) -- BERT's backward stays on the language stream, one third beside each
+        # ResNet stage, the two slices of a pair exchanged together; "serial" -- BERT's backward on the main stream in front of
+        # the ResNet's (every BERT byte is exchanged under the ResNet backward, at the price of 1.6 ms of serialised compute)
+        self.dp_schedule = os.environ.get("REFTR_DDP_SCHEDULE", "interleave")
+        assert self.dp_schedule in ("interleave", "serial")
         self._stops = frozenset()
         self._bwd_gen = None
         self._post_backward_hooks = []
@@ -386,10 +391,15 @@ class RefTR(nn.Module):
         return logits.view(NL, B, Pn, cfg.n_q, 4)
 
     # ------------------------------------------------------------------ backward
-    BOUNDARIES = ("main", "bert_hi", "bert_mid", "bert", "layer4")
+    BOUNDARIES_SERIAL = ("main", "bert_hi", "bert_mid", "bert", "layer4")
+    BOUNDARIES_INTERLEAVE = ("main", "pair4", "pair3")     # pair4 = BERT layers 11-8 + ResNet layer4, pair3 = BERT 7-4 + layer3
+
+    @property
+    def BOUNDARIES(self):
+        return self.BOUNDARIES_SERIAL if self.dp_schedule == "serial" else self.BOUNDARIES_INTERLEAVE
 
     def active_boundaries(self):
-        """The boundaries this model's backward actually passes (BERT is cut in thirds only from 3 layers up)."""
+        """The boundaries this model's backward actually passes (serial schedule: BERT is cut in thirds only from 3 layers up)."""
         return tuple(b for b in self.BOUNDARIES if self.cfg.bert.layers >= 3 or b not in ("bert_hi", "bert_mid"))
 
     @property
@@ -543,6 +553,42 @@ class RefTR(nn.Module):
         # concurrently with the ResNet backward.  Data parallel: on the main stream BEFORE the ResNet backward, so that every
         # non-ResNet gradient (> 80 % of the bytes) is exchanged under the ResNet backward; the exchange of a slice starts as
         # soon as it is final: the main group before BERT, BERT in thirds (layers 11-8 + pooler | 7-4 | 3-0 + embeddings).
+        if dp and self.dp_schedule == "interleave":
+            # [main slice final] | BERT 11-8 (language stream) || ResNet layer4 | BERT 7-4 || layer3 | BERT 3-0 + embeddings || layer2
+            net.flush_wgrads()
+            net.side.join(); net.wg.join()
+            yield "main"
+            nl = cfg.bert.layers
+            cuts = {(2 * nl) // 3: "pair4", nl // 3: "pair3"} if nl >= 3 else {}
+            if sv["pctx"] is None:
+                passes = [(sv["bctx"], d_seq, dpool)]
+            else:
+                passes = [(sv["bctx"], d_seq, None), (sv["pctx"], None, dpool)]
+
+            def _bert_thirds():
+                for n, (ctx, a, b_) in enumerate(passes):
+                    last = n == len(passes) - 1          # a layer's gradient is final after the LAST pass through it
+                    for layer in net.bert_bwd_layers(ctx, a, b_, stops=tuple(cuts) if last else ()):
+                        yield cuts[layer]
+            bg = _bert_thirds()
+            rg = self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra)
+
+            def _advance_bert():
+                for _ in bg:
+                    return                               # stopped at a cut: this third's gradients are launched
+            for name in ("pair4", "pair3", None):
+                net.side.run(_advance_bert, d_seq, dpool)
+                for _ in rg:
+                    break                                # one ResNet stage (4, 3, then 2 + what is left)
+                if name is None:
+                    for _ in rg:
+                        pass
+                net.flush_wgrads()
+                net.side.join()
+                net.wg.join()
+                if name is not None:
+                    yield name
+            return
         if dp:
             net.flush_wgrads()       # encoder / map_sentence / input_proj weight gradients
             net.side.join(); net.wg.join()

@@ -19,6 +19,12 @@ class DistributedDataParallel(nn.Module):
     parallel mode backward finishes the slices in this order (RefTR.BOUNDARIES) and the asynchronous all-reduce of a slice is
     launched the moment it is final, on RCCL's stream, under the backward that is still running:
 
+      REFTR_DDP_SCHEDULE=interleave (default): BERT's backward stays on the language stream, a third beside each ResNet stage
+        main   decoder / encoder / heads / input_proj (+ mask head)        under everything that follows
+        pair4  BERT layers 11-8 + pooler and ResNet layer4                  under BERT 7-0 / layer3-2
+        pair3  BERT layers 7-4 and ResNet layer3                            under BERT 3-0 / layer2
+        (end)  BERT layers 3-0 + embeddings and ResNet layer2, then everything is waited for (exposed: ~120 MB in bf16)
+      REFTR_DDP_SCHEDULE=serial: BERT's backward on the main stream in front of the ResNet's (+1.6 ms of serialised compute)
         main   decoder / encoder / heads / input_proj (+ mask head)        under the BERT backward
         bert_hi, bert_mid, bert   BERT layers 11-8 + pooler | 7-4 | 3-0 + embeddings (the layers' flat order is 0..11,
                                   backward walks 11..0)                    under the rest of BERT and the ResNet backward
@@ -84,7 +90,8 @@ class DistributedDataParallel(nn.Module):
         return [(a, min(a + step, n)) for a in range(0, n, step)]
 
     def slice_bounds(self):
-        """{boundary or 'end': (a, b)} -- the contiguous piece of flat_g that becomes final at each boundary."""
+        """{boundary or 'end': (a, b) or [(a, b), (c, d)]} -- the piece(s) of flat_g that become final at each boundary (the
+        interleaved schedule pairs a BERT third with a ResNet stage)."""
         from .models import layout as L
         st = self.module.store
         cfg = self.module.cfg
@@ -99,6 +106,10 @@ class DistributedDataParallel(nn.Module):
         hi, mid = (lay((2 * nl) // 3), lay(nl // 3)) if nl >= 3 else (ba, ba)
         l4 = off("img_backbone.0.body.layer4.0.conv1.weight")
         assert ba <= mid <= hi <= bb and ra <= l4 <= rb
+        if self.module.dp_schedule == "interleave":
+            l3 = off("img_backbone.0.body.layer3.0.conv1.weight")
+            assert ra <= l3 <= l4
+            return {"main": (ma, kb), "pair4": [(l4, rb), (hi, bb)], "pair3": [(l3, l4), (mid, hi)], "end": [(ra, l3), (ba, mid)]}
         return {"main": (ma, kb), "bert_hi": (hi, bb), "bert_mid": (mid, hi), "bert": (ba, mid),
                 "layer4": (l4, rb), "end": (ra, l4)}
 
@@ -110,7 +121,7 @@ class DistributedDataParallel(nn.Module):
         per = max(1, -(-total // self.n_chunks))
         out, carry = {}, []
         for name in list(self.module.BOUNDARIES) + ["end"]:
-            carry.append(sl[name])
+            carry += sl[name] if isinstance(sl[name], list) else [sl[name]]
             if name in self.phases or name == "end":
                 out[name] = [c for a, b in carry for c in self._split(a, b, per)]
                 carry = []

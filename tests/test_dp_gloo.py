@@ -17,6 +17,7 @@ def _free_port():
 
 def _worker(rank, world, port, q, dtype):
     os.environ["REFTR_DDP_DTYPE"] = dtype
+    os.environ["REFTR_DDP_SCHEDULE"] = "serial" if dtype == "fp32" else "interleave"      # both exchange schedules get a run
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -36,15 +37,22 @@ def _worker(rank, world, port, q, dtype):
         local = torch.randn(m.store.flat_g.numel(), generator=g)
         m.store.flat_g.copy_(local)
         pb = ddp.phase_bounds()                                  # boundary -> chunks of the slice that is final there
-        assert list(pb) == list(m.active_boundaries()) + ["end"] == ["main", "bert", "layer4", "end"]   # 1 BERT layer: no thirds
+        serial = m.dp_schedule == "serial"
+        assert list(pb) == list(m.active_boundaries()) + ["end"] == (["main", "bert", "layer4", "end"] if serial else ["main", "pair4", "pair3", "end"])   # 1 BERT layer: no thirds
         spans = sorted(c for v in pb.values() for c in v)
         covered = covered and spans[0][0] == 0 and spans[-1][1] == m.store.flat_g.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         from reftr_amd.models import layout as Lm
         bb = m.store.group_range[Lm.GROUP_BACKBONE]
         be = m.store.group_range[Lm.GROUP_BERT]
         l4 = m.store.offset["img_backbone.0.body.layer4.0.conv1.weight"][1]
-        covered = covered and pb["end"][0][0] == bb[0] and pb["end"][-1][1] == l4 and pb["layer4"][0][0] == l4 and pb["layer4"][-1][1] == bb[1]
-        covered = covered and pb["bert"][0][0] == be[0] and pb["bert"][-1][1] == be[1] and pb["main"][0][0] == 0
+        if serial:
+            covered = covered and pb["end"][0][0] == bb[0] and pb["end"][-1][1] == l4 and pb["layer4"][0][0] == l4 and pb["layer4"][-1][1] == bb[1]
+            covered = covered and pb["bert"][0][0] == be[0] and pb["bert"][-1][1] == be[1] and pb["main"][0][0] == 0
+        else:       # pair4 = ResNet layer4 + (1 BERT layer: no thirds) the whole BERT slice; pair3 = layer3; end = layer2
+            l3 = m.store.offset["img_backbone.0.body.layer3.0.conv1.weight"][1]
+            p4 = sorted(pb["pair4"]); p3 = sorted(pb["pair3"])
+            covered = covered and p4[0][0] == l4 and p4[-1][1] == be[1] and any(c[0] == be[0] for c in p4) and p3[0][0] == l3 and p3[-1][1] == l4
+            covered = covered and sorted(pb["end"])[0][0] == bb[0] and sorted(pb["end"])[-1][1] == l3 and pb["main"][0][0] == 0
         for name in m.active_boundaries():                       # backward passes the boundaries in this order
             for hook in m._phase_hooks[name]:
                 hook()

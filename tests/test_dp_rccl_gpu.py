@@ -30,12 +30,14 @@ def single_rank_group(monkeypatch):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_dp_schedule_single_rank_rccl_follows_the_eager_loop(hip, single_rank_group, monkeypatch, dtype):
+@pytest.mark.parametrize("dtype,schedule", [("bf16", "interleave"), ("fp32", "interleave"), ("bf16", "serial"), ("fp32", "serial")])
+def test_dp_schedule_single_rank_rccl_follows_the_eager_loop(hip, single_rank_group, monkeypatch, dtype, schedule):
     from reftr_amd.engine_vg import CapturedTrainStep, train_step
     from reftr_amd.optim import FusedAdamW
     from reftr_amd.parallel import DistributedDataParallel
     monkeypatch.setenv("REFTR_DDP_DTYPE", dtype)
+    monkeypatch.setenv("REFTR_DDP_SCHEDULE", schedule)
+    names = ["main", "bert", "layer4"] if schedule == "serial" else ["main", "pair4", "pair3"]     # 2 BERT layers: no thirds
     samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
     s, tg = to_cuda(samples, targets)
     out = {}
@@ -47,11 +49,11 @@ def test_dp_schedule_single_rank_rccl_follows_the_eager_loop(hip, single_rank_gr
         if mode != "eager":
             runner = DistributedDataParallel(model)
             assert runner.active and runner.bf16 == (dtype == "bf16") and model.dp_mode
-            assert list(runner.phase_bounds()) == ["main", "bert", "layer4", "end"]
+            assert list(runner.phase_bounds()) == names + ["end"]
         if mode == "dp-graph":
             p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
             cap = CapturedTrainStep(runner, crit, opt, 0.1, s, tg, warmup=1)
-            assert not cap.deferred and cap.phases == ["main", "bert", "layer4"] and len(cap.g_seg) == 3
+            assert not cap.deferred and cap.phases == names and len(cap.g_seg) == 3
             model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
             model.mark_dirty(full=True)
         losses, first = [], None
@@ -96,7 +98,7 @@ def test_train_one_epoch_under_the_dp_wrapper(hip, single_rank_group):
     ddp = DistributedDataParallel(model)
     stats = train_one_epoch(ddp, crit, loader, opt, None, torch.device("cuda"), 0, max_norm=0.1)
     caps = model._captured_steps
-    assert len(caps) == 1 and not next(iter(caps.values())).deferred and next(iter(caps.values())).phases == ["main", "bert", "layer4"]
+    assert len(caps) == 1 and not next(iter(caps.values())).deferred and next(iter(caps.values())).phases == ["main", "pair4", "pair3"]
     assert opt.step_count == 4 and stats["loss"] > 0 and stats["grad_norm"] > 0
     moved = (model.state_dict()["bbox_embed.layers.1.weight"].float().cpu() - P["bbox_embed.layers.1.weight"]).abs().max()
     assert 1e-5 < float(moved) < 1e-3

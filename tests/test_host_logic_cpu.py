@@ -225,12 +225,42 @@ def test_optimizer_state_roundtrip_with_torch_adamw(masks):
     assert [g_["lr"] for g_ in back.param_groups] == [1e-4, 1e-5, 1e-5, 1e-4] and back.param_groups[0]["weight_decay"] == 1e-4
 
 
-def test_dp_exchange_slices_follow_the_backward_order():
+def test_dp_interleaved_schedule_pairs_bert_thirds_with_resnet_stages(monkeypatch):
+    """REFTR_DDP_SCHEDULE=interleave (default): BERT's backward keeps its own stream; the slices that are final together -- a BERT
+    third and the ResNet stage that ran beside it -- are exchanged at one boundary; disjoint and covering."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.parallel import DistributedDataParallel
+    monkeypatch.delenv("REFTR_DDP_SCHEDULE", raising=False)
+    cfg = L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=6))
+    m = RefTR(cfg, device="cpu")
+    ddp = DistributedDataParallel(m, n_chunks=7)
+    assert m.dp_schedule == "interleave" and m.active_boundaries() == ("main", "pair4", "pair3")
+    sl = ddp.slice_bounds()
+    st = m.store
+    spans = sorted(r for v in sl.values() for r in (v if isinstance(v, list) else [v]))
+    assert spans[0][0] == 0 and spans[-1][1] == st.flat_g.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    off = lambda n: st.offset[n][1]                                       # noqa: E731
+    q = "lang_backbone.encoder.layer.%d.attention.self.query.weight"
+    assert sl["pair4"] == [(off("img_backbone.0.body.layer4.0.conv1.weight"), st.group_range[L.GROUP_BACKBONE][1]),
+                           (off(q % 4), st.group_range[L.GROUP_BERT][1])]
+    assert sl["pair3"] == [(off("img_backbone.0.body.layer3.0.conv1.weight"), off("img_backbone.0.body.layer4.0.conv1.weight")),
+                           (off(q % 2), off(q % 4))]
+    assert sl["end"] == [(st.group_range[L.GROUP_BACKBONE][0], off("img_backbone.0.body.layer3.0.conv1.weight")),
+                         (st.group_range[L.GROUP_BERT][0], off(q % 2))]
+    pb = ddp.phase_bounds()
+    assert list(pb) == ["main", "pair4", "pair3", "end"]
+    chunks = sorted(c for v in pb.values() for c in v)
+    assert chunks[0][0] == 0 and chunks[-1][1] == st.flat_g.numel() and all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+
+
+def test_dp_exchange_slices_follow_the_backward_order(monkeypatch):
     """reftr_amd.parallel: the slice that is final at each backward boundary (main | BERT thirds, walked 11..0 | layer4 |
     rest of the ResNet) -- contiguous, disjoint, covering the flat gradient buffer, cut at parameter boundaries."""
     from reftr_amd.models import layout as L
     from reftr_amd.models.reftr_transformer import RefTR
     from reftr_amd.parallel import DistributedDataParallel
+    monkeypatch.setenv("REFTR_DDP_SCHEDULE", "serial")
     cfg = L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=6))
     m = RefTR(cfg, device="cpu")
     ddp = DistributedDataParallel(m, n_chunks=7)

@@ -25,3 +25,13 @@ for n, (label, i) in enumerate(idx):
     seg = step[i:j]
     print("  %-40s %4d kernels  %7.3f ms  (busy %7.3f)" % (label, len(seg), (seg[-1][2] - seg[0][1]) / 1e6, sum(r[2] - r[1] for r in seg) / 1e6))
 print("  %-40s %4d kernels  %7.3f ms" % ("(before first marker: zero-fill, prep)", idx[0][1], (step[idx[0][1]][1] - t0) / 1e6))
+if len(sys.argv) > 2:               # dump the kernel sequence of the phases whose label contains argv[2]: start offset, duration, gap, name
+    for n, (label, i) in enumerate(idx):
+        if sys.argv[2] not in label:
+            continue
+        j = idx[n + 1][1] if n + 1 < len(idx) else len(step)
+        print("--", label)
+        for k in range(i, j):
+            nm, st, en = step[k]
+            gap = (st - step[k - 1][2]) / 1e3 if k > 0 else 0.0
+            print("  %9.1f us  %6.1f us  gap %5.1f  %s" % ((st - t0) / 1e3, (en - st) / 1e3, gap, nm.replace("(anonymous namespace)::", "").replace("void ", "")[:100]))
