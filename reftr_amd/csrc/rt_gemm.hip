@@ -379,11 +379,14 @@ __device__ __forceinline__ void rt_dma16(const i32x4 rsrc, unsigned lds_base, in
 
 // The body is a device function: it runs as a kernel of its own (conv_gemm_dma_kernel) or as one of up to 12 independent
 // problems of a grouped launch (conv_gemm_dma_grouped_kernel); bx / by / gx stand for blockIdx.x / blockIdx.y / gridDim.x.
-template <int BM, int BN, int MODE, int NS>
+// NW = 4 waves arranged 2(n) x 2(m), or 8 waves 2(n) x 4(m): the same tile with smaller wave tiles and twice the waves per CU
+template <int BM, int BN, int MODE, int NS, int NW = 4>
 __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, const GemmArgs& p,
                                               const int bx, const int by, const int gx) {
-    constexpr int TM = BM / 32, TN = BN / 32;
-    constexpr int AJ = BN / 32, BJ = BM / 32;
+    constexpr int NT = 64 * NW, WM = NW / 2, RPP = NT / 8;        // threads, waves along m, rows one DMA pass covers
+    constexpr int TM = BM / (16 * WM), TN = BN / 32;
+    constexpr int AJ = BN / RPP, BJ = BM / RPP;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves"); static_assert(AJ >= 1 && BJ >= 1 && TM >= 1, "tile too small for the wave count");
     constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int LPT = AJ + BJ;                   // DMA instructions per thread per K tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -418,13 +421,13 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     int a_off[AJ];
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        const int n = n0 + srow + 32 * j;
+        const int n = n0 + srow + RPP * j;
         a_off[j] = n < p.N ? (n * p.K + chunk * 8) * 2 : OOB;
     }
     int b_off[BJ], b_y[BJ], b_x[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int m = m0 + srow + 32 * j;
+        const int m = m0 + srow + RPP * j;
         const bool ok = m < Mloc;
         const int mm = ok ? m : 0;
         if (MODE == 0) {
@@ -462,11 +465,11 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
         const unsigned bB = bA + A_BYTES;
         const int k0b = MODE == 3 ? ((kh * p.KW + kw) * p.SC + c0) * 2 : lk << 7;
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) rt_dma16(rs_w, bA + j * 4096, a_off[j], k0b);
+        for (int j = 0; j < AJ; ++j) rt_dma16(rs_w, bA + j * (RPP * 128), a_off[j], k0b);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             if (MODE == 0) {
-                rt_dma16(rs_x, bB + j * 4096, b_off[j], k0b);
+                rt_dma16(rs_x, bB + j * (RPP * 128), b_off[j], k0b);
             } else {
                 bool ok;
                 int sy, sx;
@@ -483,7 +486,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
                 }
                 ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
                 const int off = (b_off[j] + (sy * p.SW + sx) * p.SC) * 2;
-                rt_dma16(rs_x, bB + j * 4096, ok ? off : OOB, c0 * 2);
+                rt_dma16(rs_x, bB + j * (RPP * 128), ok ? off : OOB, c0 * 2);
             }
         }
         if (lk + 1 < nk) {
@@ -511,7 +514,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
             }
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                const int row = wm * (BM / 2) + b * 16 + li;
+                const int row = wm * (BM / WM) + b * 16 + li;
                 bfr[b] = *reinterpret_cast<const bf16x8*>(bB + row * 128 + slot);
             }
 #pragma unroll
@@ -531,7 +534,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     constexpr int HALVES = ((size_t)BM * EP_LD * 4 > (size_t)NS * BUF_BYTES) ? 2 : 1;    // 128x128 / 2 stages: two m-halves
     constexpr int ROWS = BM / HALVES;
     constexpr int CPR = BN / 8;                                    // 8-channel pieces per row
-    constexpr int PIECES = ROWS * CPR / 256;
+    constexpr int PIECES = ROWS * CPR / NT;
     constexpr bool CAN_PRE = HALVES == 1 && PIECES <= 4;
     const bool epi_lds = p.epi_lds && (p.N & 7) == 0;
     const bool pre = CAN_PRE && epi_lds && p.prefetch && (p.res_bf16 || p.gate);
@@ -550,7 +553,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             int m, n;
-            const bool ok = out_piece(i * 256 + t, m, n);
+            const bool ok = out_piece(i * NT + t, m, n);
             const size_t o = ok ? (size_t)m * p.N + n : 0;
             pre_res[i] = p.res_bf16 ? *reinterpret_cast<const bf16x8*>(p.res_bf16 + o) : bf16x8{};
             pre_gate[i] = p.gate ? *reinterpret_cast<const bf16x8*>(p.gate + o) : bf16x8{};
@@ -601,17 +604,17 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
             __syncthreads();    // every wave has drained its own DMA tail (vmcnt 0 above) and finished reading the stages / tile
-            if (HALVES == 1 || wm == h) {
+            if (HALVES == 1 || wm / (WM / 2) == h) {
 #pragma unroll
                 for (int a = 0; a < TN; ++a)
 #pragma unroll
                     for (int b = 0; b < TM; ++b)
-                        *reinterpret_cast<f32x4*>(tile + ((HALVES == 1 ? wm * (BM / 2) : 0) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4) = acc[a][b];
+                        *reinterpret_cast<f32x4*>(tile + ((HALVES == 1 ? wm : wm % (WM / 2)) * (BM / WM) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4) = acc[a][b];
             }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
-                const int idx = i * 256 + t;
+                const int idx = i * NT + t;
                 const int rl = idx / CPR, cl = (idx - rl * CPR) * 8;
                 int m, n;
                 if (!out_piece(h * ROWS * CPR + idx, m, n)) continue;
@@ -630,7 +633,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
         if (n >= p.N) continue;
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
-            int m = m0 + wm * (BM / 2) + b * 16 + li;
+            int m = m0 + wm * (BM / WM) + b * 16 + li;
             if (m >= Mloc) continue;
             if (MODE == 3) {            // class-local row -> pixel row of the NHWC output
                 const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
@@ -641,10 +644,10 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     }
 }
 
-template <int BM, int BN, int MODE, int NS, int MINB>
-__global__ __launch_bounds__(256, MINB) void conv_gemm_dma_kernel(const bf16_t* __restrict__ src,
-                                                                  const bf16_t* __restrict__ wgt, const GemmArgs p) {
-    gemm_dma_body<BM, BN, MODE, NS>(src, wgt, p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+template <int BM, int BN, int MODE, int NS, int MINB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, MINB) void conv_gemm_dma_kernel(const bf16_t* __restrict__ src,
+                                                                      const bf16_t* __restrict__ wgt, const GemmArgs p) {
+    gemm_dma_body<BM, BN, MODE, NS, NW>(src, wgt, p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 // Several independent dense products in ONE launch (descriptors by value in the kernel arguments: graph-safe, no device
@@ -712,30 +715,30 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     return RT_OK;
 }
 
-template <int BM, int BN, int NS, int MINB>
+template <int BM, int BN, int NS, int MINB, int NW = 4>
 int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const size_t smem = (size_t)NS * (BM + BN) * 128;
-    const dim3 grid((unsigned)(mt * nt)), block(256);
+    const dim3 grid((unsigned)(mt * nt)), block(64 * NW);
     const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
     static const int par_env = getenv("REFTR_S2PARITY") ? atoi(getenv("REFTR_S2PARITY")) : 1;
     auto set_smem = [&](const void* f) {
         if (smem > 65536) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     };
     if (dense) {
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 0, NS, MINB>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 0, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW>), grid, block, smem, s, a.src, a.wgt, a);
     } else if (!a.transposed) {
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 1, NS, MINB>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW>), grid, block, smem, s, a.src, a.wgt, a);
     } else if (a.stride == 2 && par_env) {
         const int m_cls = a.B * ((a.DH + 1) / 2) * ((a.DW + 1) / 2);           // largest parity class
         const dim3 grid3((unsigned)(((m_cls + BM - 1) / BM) * nt), 4);
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 3, NS, MINB>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 3, NS, MINB>), grid3, block, smem, s, a.src, a.wgt, a);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW>), grid3, block, smem, s, a.src, a.wgt, a);
     } else {
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 2, NS, MINB>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, NS, MINB>), grid, block, smem, s, a.src, a.wgt, a);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 2, NS, MINB, NW>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, NS, MINB, NW>), grid, block, smem, s, a.src, a.wgt, a);
     }
     RT_CHECK_LAUNCH();
     return RT_OK;
@@ -802,8 +805,16 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         else if (a.N > 64 && t128 >= 384) hint = 1;
         else if (t12864 >= 256) hint = 2;
         else hint = 3;
-        static const int tilev = getenv("REFTR_TILEV") ? atoi(getenv("REFTR_TILEV")) : 1;
-        if (dma && tilev) {
+        static const int tilev = getenv("REFTR_TILEV") ? atoi(getenv("REFTR_TILEV")) : 2;
+        if (dma && tilev >= 2) {
+            // round 2 (profiles/r02_tile_sweep_8wave.txt): the 128x128 tile runs on 8-wave workgroups (2 x 4 waves, 16 waves per CU
+            // at two workgroups: beats the 4-wave form on every shape); it takes over the long reductions with >= 1.5 rounds of
+            // tiles (or >= 0.75 rounds from K = 2048 up) and the short ones whose tiles fill exactly one round of 2 per CU
+            if (a.K < 1024) hint = (a.N >= 128 && t128 >= 384 && t128 <= 512) ? 51 : 31;
+            else if (a.N > 64 && (t128 >= 384 || (a.K >= 2048 && t128 >= 192))) hint = 51;
+            else if (t12864 >= 256) hint = 21;
+            else hint = 33;
+        } else if (dma && tilev) {
             // with the issue-before-wait schedule (profiles/r01g_tile_sweep_early.txt): short K streams best through
             // 64x64 workgroups; 128x128 pays off from K >= 1024 with >= 1.5 waves of tiles; 128x64 in between
             if (a.K < 1024) hint = 31;
@@ -829,6 +840,11 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         case 31: return launch_gemm_dma<64, 64, 2, 4>(a, s);
         case 32: return launch_gemm_dma<64, 64, 4, 2>(a, s);
         case 33: return launch_gemm_dma<64, 64, 3, 3>(a, s);
+        // 8-wave workgroups (2 x 4 waves) on the 128-row tiles
+        case 51: return launch_gemm_dma<128, 128, 2, 2, 8>(a, s);
+        case 52: return launch_gemm_dma<128, 128, 3, 1, 8>(a, s);
+        case 53: return launch_gemm_dma<128, 64, 2, 2, 8>(a, s);
+        case 54: return launch_gemm_dma<128, 64, 3, 2, 8>(a, s);
         default: return RT_ERR_BADARG;
     }
 }
