@@ -228,9 +228,12 @@ def test_cem_training_steps_captured(hip):
         seqs.append(ls)
     print("cem step losses", seqs)
     assert all(np.isfinite(v) for ls in seqs for t in ls for v in t)
-    for a, b in zip(*seqs):
-        # measured at step 4: total 3.9e-3, loss_cem 4.8e-3 (bf16 rounding flips amplified by three updates; step 1 is equal)
-        assert abs(a[0] - b[0]) < 1e-2 * abs(a[0]) and abs(a[1] - b[1]) < 1e-2 * abs(a[1])
+    # step 1 is identical; afterwards the fixture amplifies 1-ulp weight differences (atomics order in the LayerNorm / bias
+    # gradients): two EAGER runs differ from each other by up to 1e-3 at step 2, 2e-3 at step 3 and 3.6e-2 at step 4 (measured over
+    # five runs), so the later steps are bounded like tests/test_model_gpu.py::test_captured_step_matches_eager bounds them
+    for it, (a, b) in enumerate(zip(*seqs)):
+        tol = (1e-6, 3e-3, 1e-2, 8e-2)[it]
+        assert abs(a[0] - b[0]) < tol * abs(a[0]) and abs(a[1] - b[1]) < tol * abs(a[1]), (it, a, b)
     assert seqs[0][0] == seqs[1][0]
     assert seqs[0][-1][0] < seqs[0][0][0]
 
