@@ -810,7 +810,9 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
             // round 2 (profiles/r02_tile_sweep_8wave.txt): the 128x128 tile runs on 8-wave workgroups (2 x 4 waves, 16 waves per CU
             // at two workgroups: beats the 4-wave form on every shape); it takes over the long reductions with >= 1.5 rounds of
             // tiles (or >= 0.75 rounds from K = 2048 up) and the short ones whose tiles fill exactly one round of 2 per CU
+            const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
             if (a.K < 1024) hint = (a.N >= 128 && t128 >= 384 && t128 <= 512) ? 51 : 31;
+            else if (a.K >= 2048 && a.N >= 128 && t256 >= 512) hint = 62;     // big products only (4096^3: 898 TF/s); none in the step
             else if (a.N > 64 && (t128 >= 384 || (a.K >= 2048 && t128 >= 192))) hint = 51;
             else if (t12864 >= 256) hint = 21;
             else hint = 33;
@@ -845,6 +847,9 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         case 52: return launch_gemm_dma<128, 128, 3, 1, 8>(a, s);
         case 53: return launch_gemm_dma<128, 64, 2, 2, 8>(a, s);
         case 54: return launch_gemm_dma<128, 64, 3, 2, 8>(a, s);
+        case 61: return launch_gemm_dma<256, 128, 2, 1, 8>(a, s);
+        case 62: return launch_gemm_dma<256, 128, 3, 1, 8>(a, s);
+        case 63: return launch_gemm_dma<128, 256, 2, 1, 8>(a, s);
         default: return RT_ERR_BADARG;
     }
 }

@@ -46,6 +46,7 @@ def hash_keep(seed, idx, p):
     (129, 64, 68, 31), (3520, 2048, 256, 32), (320, 768, 3072, 33), (3520, 256, 2048, 13),
     # 8-wave workgroups
     (200, 256, 256, 51), (3520, 2048, 256, 52), (333, 192, 72, 53), (12800, 256, 1024, 54), (129, 64, 68, 51),
+    (700, 256, 264, 61), (3520, 2048, 256, 62), (333, 192, 328, 63),
 ])
 def test_linear_fwd(hip, M, K, N, hint):
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -99,7 +100,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54])
+@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54, 61, 62, 63])
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", [CONV_CASES[1], CONV_CASES[4], CONV_CASES[2]])
 def test_conv_dma_variants(hip, hint, B, H, W, Ci, Co, k, s, p):
     """The LDS-DMA tile variants against torch fp32: forward gather and transposed (backward-data) gather."""
