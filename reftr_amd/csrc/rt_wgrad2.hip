@@ -10,8 +10,12 @@
 //     launch and ONE split policy: the m axis is only cut when the group has fewer tile tasks than the chip has workgroup
 //     slots.  Unsplit tiles accumulate straight into dw (one owner per element: plain read-modify-write, no atomics, no
 //     partial tiles through memory, no reduction launch); split tiles go through the workspace and one grouped reduction;
-//   * XCD placement by table: all tiles of one row split (they read the same dy / x rows; each XCD has its own L2) run on ONE
-//     XCD, next to each other in its dispatch order -- the shared rows cross the fabric once;
+//   * XCD placement: the linear task order (problem, row split, tile / tap -- the tasks that read the same dy / x rows are
+//     adjacent) is dealt to the 8 XCDs in contiguous runs of gridDim.x / 8 tasks (block id -> rt_xcd_remap) instead of the
+//     hardware's round-robin: the same number of tasks per XCD as the plain map (an XCD is 32 CUs: one task more than its
+//     share is a whole extra round), but a split's tiles and taps share one XCD's L2 -- fabric fetches 3.39 -> 1.89 GB over
+//     the ResNet groups at equal time, the transformer groups 15 % faster.  (A table that put whole units on XCDs round-robin,
+//     REFTR_W2_XCD=1, cut the fetches as much and lost 30 % to that imbalance.)
 //   * software pipeline: one barrier per 32-row chunk, NS-1 chunks of LDS-DMA in flight, and the fragment reads of the next
 //     16-row step (including the first step of the NEXT chunk) are issued before the MFMAs of the current one;
 //   * wave-specialised L2 prefetch: waves 0-3 issue the stage DMAs; waves 4-7 touch every 128-B line of the chunk `pf`
@@ -40,7 +44,7 @@ struct W2Prob {
 };
 constexpr int W2_MAXP = 20;
 // cum[x][i]: workgroups of problems 0 .. i-1 that run on XCD x (block id b -> XCD b & 7, position b >> 3 in its order)
-struct W2Group { W2Prob p[W2_MAXP]; int cum[8][W2_MAXP + 1]; int n; int xcd; int abl; int pf; };
+struct W2Group { W2Prob p[W2_MAXP]; int cum[8][W2_MAXP + 1]; int n; int xcd; int abl; int pf; int remap; };
 
 template <int N> __device__ __forceinline__ void w2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ w2_i32x4 w2_rsrc(const void* ptr, unsigned bytes) {
@@ -442,12 +446,15 @@ __global__ __launch_bounds__(512, 1) void w2_grouped_kernel(const W2Group g) {
     // problem i owns positions [cum[x][i], cum[x][i+1]); inside, its row splits s with (s + xrot) % 8 == x follow each other,
     // each with all of its tiles adjacent (they read the same dy / x rows: one trip over the fabric per XCD-resident split).
     const int x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+    // remap (REFTR_W2_XCD=2): the linear task order (problem, row split, tile -- the tasks that read the same rows are adjacent) is
+    // dealt to the XCDs in CONTIGUOUS runs of gridDim.x / 8 instead of round-robin: same task count per XCD as the linear map
+    // (no balance cost), but a split's tiles / taps share one XCD's L2
+    const int b = g.remap ? rt_xcd_remap((int)blockIdx.x, (int)gridDim.x, 1) : (int)blockIdx.x;
     int lo = 0, hi = g.n;
     if (g.xcd) {
         if (q >= g.cum[x][g.n]) return;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (g.cum[x][mid] <= q) lo = mid; else hi = mid; }
     } else {
-        const int b = (int)blockIdx.x;
         if (b >= g.cum[0][g.n]) return;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (g.cum[0][mid] <= b) lo = mid; else hi = mid; }
     }
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(512, 1) void w2_grouped_kernel(const W2Group g) {
         tile = local % p.tiles;
         split = ((x - p.xrot) & 7) + 8 * (local / p.tiles);
     } else {
-        const int local = (int)blockIdx.x - g.cum[0][lo];
+        const int local = b - g.cum[0][lo];
         split = local / p.tiles; tile = local - split * p.tiles;
     }
     split = __builtin_amdgcn_readfirstlane(split); tile = __builtin_amdgcn_readfirstlane(tile);
@@ -546,7 +553,7 @@ static int w2_cfg_of(const rt_conv_wgrad_desc& d) {       // 0: 256x256, 1: 128x
 // Launches every descriptor of `idx` (all eligible) as grouped v2 launches.  Split policy: see the file header.
 int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* workspace, long long workspace_bytes, hipStream_t s) {
     static const int target_env = getenv("REFTR_W2_TARGET") ? atoi(getenv("REFTR_W2_TARGET")) : 0;
-    static const int xcd_env = getenv("REFTR_W2_XCD") ? atoi(getenv("REFTR_W2_XCD")) : 0;
+    static const int xcd_env = getenv("REFTR_W2_XCD") ? atoi(getenv("REFTR_W2_XCD")) : 2;      // 0 linear, 1 per-XCD table (round-robin units), 2 contiguous runs
     static const int minrows_env = getenv("REFTR_W2_MINROWS") ? atoi(getenv("REFTR_W2_MINROWS")) : 256;
     static const int abl_env = getenv("REFTR_W2_ABL") ? atoi(getenv("REFTR_W2_ABL")) : 0;      // ablation probes (wrong results)
     static const int pf_env = getenv("REFTR_W2_PF") ? atoi(getenv("REFTR_W2_PF")) : 0;
@@ -598,7 +605,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
                 per_wg *= 1.03;
             }
         }
-        W2Group g; W2Reduce r; g.n = 0; r.n = 0; g.xcd = xcd_env; g.abl = abl_env; g.pf = pf_env;
+        W2Group g; W2Reduce r; g.n = 0; r.n = 0; g.xcd = xcd_env == 1; g.remap = xcd_env == 2; g.abl = abl_env; g.pf = pf_env;
         int rblocks = 0; long long ws_off = 0;
         double xload[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int xcount[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lin_total = 0;
@@ -606,7 +613,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
         auto flush = [&]() -> int {
             if (g.n > 0) {
                 int blocks;
-                if (xcd_env) { int mx = 0; for (int x = 0; x < 8; ++x) if (xcount[x] > mx) mx = xcount[x]; blocks = mx * 8; }
+                if (xcd_env == 1) { int mx = 0; for (int x = 0; x < 8; ++x) if (xcount[x] > mx) mx = xcount[x]; blocks = mx * 8; }
                 else blocks = lin_total;
                 const int rc = w2_launch<CR, 4>(g, blocks, s);
                 if (rc != RT_OK) return rc;
@@ -668,7 +675,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             // XCD placement: split s -> XCD (s + xrot) % 8; xrot = the XCD with the least work so far in this launch
             int best = 0;
             for (int x = 1; x < 8; ++x) if (xload[x] < xload[best]) best = x;
-            p.xrot = xcd_env ? best : 0;
+            p.xrot = xcd_env == 1 ? best : 0;
             for (int x = 0; x < 8; ++x) {
                 const int j0 = (x - p.xrot) & 7;                                  // first split of this problem on XCD x
                 const int cnt = j0 < p.splits ? (p.splits - j0 + 7) / 8 : 0;      // splits j0, j0 + 8, ...
@@ -679,7 +686,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             if (dbg_env) fprintf(stderr, "[w2] M=%d N=%d C=%d k=%d s=%d cfg=%d tiles=%d splits=%d chunks/split=%d  (group tiles %lld, per_wg %.0f)\n",
                                  p.M, p.N, p.SC, p.KH, p.stride, p.cfg, p.tiles, p.splits, p.chunks_per_split, tiles_total, per_wg);
             lin_total += p.tiles * p.splits;
-            if (!xcd_env) g.cum[0][g.n + 1] = lin_total;
+            if (xcd_env != 1) g.cum[0][g.n + 1] = lin_total;
             g.p[g.n] = p; ++g.n;
         }
         const int frc = flush();
