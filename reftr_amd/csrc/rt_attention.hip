@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const rt_attn_desc p)
     unsigned char* sK = smem;
     unsigned char* sV = sK + (size_t)Skp * RS;
     float* sBias = reinterpret_cast<float*>(sV + (size_t)Skp * RS);
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     stage_rows2<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.ldk,
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const rt_attn_desc p)
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int q = blockIdx.x * (16 * NW) + wave * 16 + li;          // this lane's query
-    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sq) return;
+    const int q = blockIdx.y * (16 * NW) + wave * 16 + li;          // this lane's query
+    if (blockIdx.y * (16 * NW) + wave * 16 >= p.Sq) return;
     bf16x8 qf[Geo<DH>::KH];
     load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
     const int nblk = Skp >> 4;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_reg_kernel(const rt_attn_des
     unsigned char* sK = smem;
     unsigned char* sV = sK + (size_t)Skp * RS;
     float* sBias = reinterpret_cast<float*>(sV + (size_t)Skp * RS);
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     stage_rows2<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.ldk,
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_reg_kernel(const rt_attn_des
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int q = blockIdx.x * (16 * NW) + wave * 16 + li;
-    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sq) return;
+    const int q = blockIdx.y * (16 * NW) + wave * 16 + li;
+    if (blockIdx.y * (16 * NW) + wave * 16 >= p.Sq) return;
     bf16x8 qf[Geo<DH>::KH];
     load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
     const int nblk = Skp >> 4;                  // <= NT, even
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_
     unsigned char* sK = smem;
     unsigned char* sV = sK + (size_t)Skp * RS;
     float* sBias = reinterpret_cast<float*>(sV + (size_t)Skp * RS);
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     stage_rows2<DH>(sK, (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, p.ldk,
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int q = blockIdx.x * (16 * NW) + wave * 16 + li;
-    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sq) return;
+    const int q = blockIdx.y * (16 * NW) + wave * 16 + li;
+    if (blockIdx.y * (16 * NW) + wave * 16 >= p.Sq) return;
     bf16x8 qf[KH], dof[KH], of[KH];
     load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
     load_bfrag<DH>((const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, q, p.Sq, p.ldo, lg, dof);
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd
     unsigned char* sD = sQ + (size_t)Sqp * RS;
     float* sL = reinterpret_cast<float*>(sD + (size_t)Sqp * RS);
     float* sDel = sL + Sqp;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
     stage_rows2<DH>(sQ, (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, p.ldq,
@@ -413,8 +413,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd
     }
     __syncthreads();
 
-    const int key = blockIdx.x * (16 * NW) + wave * 16 + li;         // this lane's key (MFMA column)
-    if (blockIdx.x * (16 * NW) + wave * 16 >= p.Sk) return;
+    const int key = blockIdx.y * (16 * NW) + wave * 16 + li;         // this lane's key (MFMA column)
+    if (blockIdx.y * (16 * NW) + wave * 16 >= p.Sk) return;
     bf16x8 kf[KH], vf[KH];
     load_bfrag<DH>((const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, key, p.Sk, p.ldk, lg, kf);
     load_bfrag<DH>((const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, key, p.Sk, p.ldv, lg, vf);
@@ -688,7 +688,9 @@ extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
     const size_t smem = smem_bytes(d->Sk, d->dh);
     static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
     const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
-    const dim3 grid((d->Sq + 16 * nw - 1) / (16 * nw), d->B * d->H);
+    // (b, h) on grid.x: the row blocks of one head get ids bh, bh + B*H, ... -> the same XCD whenever B*H is a multiple of 8, so the
+    // head's K / V rows cross the fabric once per XCD instead of once per block
+    const dim3 grid(d->B * d->H, (d->Sq + 16 * nw - 1) / (16 * nw));
     int rc;
 #define RT_ATTN_FWD(DHV, NWV) do { if ((rc = set_smem(attn_fwd_kernel<DHV, NWV>, smem)) != RT_OK) return rc; \
         hipLaunchKernelGGL((attn_fwd_kernel<DHV, NWV>), grid, dim3(64 * NWV), smem, (hipStream_t)stream, *d); } while (0)
@@ -725,7 +727,7 @@ extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
     const size_t smem1 = smem_bytes(d->Sk, d->dh), smem2 = smem_bytes(d->Sq, d->dh);
     static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
     const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
-    const dim3 g1((d->Sq + 16 * nw - 1) / (16 * nw), d->B * d->H), g2((d->Sk + 16 * nw - 1) / (16 * nw), d->B * d->H);
+    const dim3 g1(d->B * d->H, (d->Sq + 16 * nw - 1) / (16 * nw)), g2(d->B * d->H, (d->Sk + 16 * nw - 1) / (16 * nw));
     int rc;
 #define RT_ATTN_BWD(DHV, NWV) do { if ((rc = set_smem(attn_bwd_dq_kernel<DHV, NWV>, smem1)) != RT_OK) return rc; \
         if ((rc = set_smem(attn_bwd_dkv_kernel<DHV, NWV>, smem2)) != RT_OK) return rc; \
