@@ -733,7 +733,9 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW>), grid, block, smem, s, a.src, a.wgt, a);
     } else if (a.stride == 2 && par_env) {
         const int m_cls = a.B * ((a.DH + 1) / 2) * ((a.DW + 1) / 2);           // largest parity class
-        const dim3 grid3((unsigned)(((m_cls + BM - 1) / BM) * nt), 4);
+        // grid.x padded to a multiple of 8: block (x, y) has linear id y * gridDim.x + x, so only then do the four parity classes
+        // of a tile range (they gather from the same dy rows) sit on the same XCD as the tile map assumes (surplus blocks exit)
+        const dim3 grid3((unsigned)(((((m_cls + BM - 1) / BM) * nt) + 7) / 8 * 8), 4);
         set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW>);
         hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW>), grid3, block, smem, s, a.src, a.wgt, a);
     } else {
