@@ -234,8 +234,7 @@ def test_cem_training_steps_captured(hip):
     for it, (a, b) in enumerate(zip(*seqs)):
         tol = (1e-6, 3e-3, 1e-2, 8e-2)[it]
         assert abs(a[0] - b[0]) < tol * abs(a[0]) and abs(a[1] - b[1]) < tol * abs(a[1]), (it, a, b)
-    assert seqs[0][0] == seqs[1][0]
-    assert seqs[0][-1][0] < seqs[0][0][0]
+    assert seqs[0][-1][0] < seqs[0][0][0]         # (step 1 is compared to 1e-6 above: the mask loss is summed with atomics)
 
 
 def test_seg_training_steps_run(hip):
