@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* __restrict
                                                         int B, int Hp, int Wp, int Ho, int Wo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int row = blockIdx.x * 4 + wave;          // (b, oh)
+    // neighbouring output rows read overlapping input rows (7-row window, stride 2): contiguous runs of blocks per XCD
+    const int row = rt_xcd_remap((int)blockIdx.x, (int)gridDim.x, 1) * 4 + wave;          // (b, oh)
     if (row >= B * Ho) return;
     const int b = row / Ho, oh = row % Ho;
     bf16x8 wf[7][4];
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__
                                                       int B, int H, int W, int C, int Ho, int Wo) {
     const int cch = C / 8;
     const size_t total = (size_t)B * Ho * Wo * cch;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    // output rows oy and oy + 1 share an input row: contiguous runs of blocks per XCD keep those re-reads in one L2
+    for (size_t i = rt_xcd_remap((int)blockIdx.x, (int)gridDim.x, 1) * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int cc = (int)(i % cch);
         size_t t = i / cch;
         const int ox = (int)(t % Wo); t /= Wo;
