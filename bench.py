@@ -236,6 +236,10 @@ def main():
                     "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
                     "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3,
                     "algorithmic_bytes_per_launch": sum(r["bytes"] for r in recs) / max(len(recs), 1),
+                    # the elementwise operations fused into the GEMM epilogues move bytes of their own (residual / ReLU-gate /
+                    # GELU' reads, second outputs): the reference runs them as separate kernels; `traffic` should be read
+                    # against algorithmic + epilogue bytes
+                    "epilogue_bytes_per_launch": sum(r.get("epi_bytes", 0.0) for r in recs) / max(len(recs), 1),
                     "measured_on": "rank 0, HIP events around every launch of the family on the launch stream"}
     from reftr_amd._build import build_id
     bid = build_id()

@@ -357,7 +357,7 @@ def _algo_bytes(tag):
     return 2.0 * (B * SH * SW * SC + N * KH * KW * SC + M * N)
 
 
-def _timed(kind, flops, fn, tag=None, nbytes=None):
+def _timed(kind, flops, fn, tag=None, nbytes=None, epi_bytes=0.0):
     if _TIMER is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -365,7 +365,8 @@ def _timed(kind, flops, fn, tag=None, nbytes=None):
     r = fn()
     e1.record()
     _TIMER.append({"kind": kind, "flops": float(flops), "start": e0, "end": e1, "tag": tag,
-                   "bytes": nbytes if nbytes is not None else (_algo_bytes(tag) if tag is not None else 0.0)})
+                   "bytes": nbytes if nbytes is not None else (_algo_bytes(tag) if tag is not None else 0.0),
+                   "epi_bytes": float(epi_bytes)})
     return r
 
 
@@ -418,11 +419,17 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
         flops = 2.0 * B * SH * SW * SC * N * KH * KW
     else:
         flops = 2.0 * M * N * KH * KW * SC
+    # bytes of the elementwise operations fused into the epilogue (NOT part of the operand-only "algorithmic" figure): bf16
+    # residual / gate / GELU-pre-activation / tanh reads, fp32 residual read, read-modify-write of the second destination, and
+    # every output beyond the first bf16 one
+    epi = M * N * (2.0 * sum(t is not None for t in (res_bf16, gate, preact, dtanh)) + 4.0 * (res_f32 is not None)
+                   + 8.0 * (acc2_f32 is not None) + (4.0 if of is not None else 0.0) + (2.0 if ob is not None else 0.0) - 2.0
+                   + (2.0 if out_preact else 0.0))
     if group is not None:      # queued: GemmGroup.run() launches every queued product at once
-        group.add(d, flops, ("T" if transposed else "F",) + tuple(geom), (src, wgt, ob, of, op, bias, res_f32, res_bf16, gate, preact, dtanh))
+        group.add(d, flops, ("T" if transposed else "F",) + tuple(geom), (src, wgt, ob, of, op, bias, res_f32, res_bf16, gate, preact, dtanh), epi)
     else:
         _timed("conv_gemm", flops, lambda: _check(lib().rt_conv_gemm(ctypes.byref(d), _stream()), "rt_conv_gemm"),
-               tag=("T" if transposed else "F",) + tuple(geom))
+               tag=("T" if transposed else "F",) + tuple(geom), epi_bytes=epi)
     if out_preact:
         return ob, of, op
     return ob, of
@@ -433,10 +440,10 @@ class GemmGroup:
     and launched together by `run()` (rt_conv_gemm_grouped: one launch when the products allow it)."""
 
     def __init__(self):
-        self.descs, self.keep, self.flops, self.nbytes = [], [], 0.0, 0.0
+        self.descs, self.keep, self.flops, self.nbytes, self.epi = [], [], 0.0, 0.0, 0.0
 
-    def add(self, d, flops, tag, keep):
-        self.descs.append(d); self.keep.append(keep); self.flops += flops; self.nbytes += _algo_bytes(tag)
+    def add(self, d, flops, tag, keep, epi=0.0):
+        self.descs.append(d); self.keep.append(keep); self.flops += flops; self.nbytes += _algo_bytes(tag); self.epi += epi
 
     def run(self):
         if not self.descs:
@@ -448,8 +455,8 @@ class GemmGroup:
             share = len(chunk) / n
             _timed("conv_gemm", self.flops * share,
                    lambda arr=arr, m=len(chunk): _check(lib().rt_conv_gemm_grouped(arr, m, _stream()), "rt_conv_gemm_grouped"),
-                   nbytes=self.nbytes * share)
-        self.descs, self.keep, self.flops, self.nbytes = [], [], 0.0, 0.0
+                   nbytes=self.nbytes * share, epi_bytes=self.epi * share)
+        self.descs, self.keep, self.flops, self.nbytes, self.epi = [], [], 0.0, 0.0, 0.0
 
 
 def linear(x, w, bias=None, **kw):
