@@ -21,7 +21,7 @@ struct GemmArgs {
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed; int drop_shift;
-    int M, K, sshift, xcd, early, epi_lds, abl, prefetch;
+    int M, K, sshift, xcd, early, epi_lds, abl, prefetch, mfast;
     unsigned src_bytes, wgt_bytes;
     const uint32_t* seed_dev;
 };
@@ -399,7 +399,10 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
 
     const int n_tiles = (p.N + BN - 1) / BN;
     const int bid = rt_xcd_remap(bx, gx, p.xcd);
-    const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+    // tile order inside an XCD's contiguous run: n fastest shares the activation rows of an m tile across its n tiles; m fastest
+    // (dense products with few rows and many output features: the BERT Linears) shares a weight slab across the m tiles instead
+    int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+    if (MODE == 0 && p.mfast) { const int m_tiles = (p.M + BM - 1) / BM; tile_m = bid % m_tiles; tile_n = bid / m_tiles; }
     const int n0 = tile_n * BN, m0 = tile_m * BM;
 
     // MODE 3 (stride-2 backward-data): blockIdx.y is the output parity class (y&1, x&1).  Only taps with
@@ -727,7 +730,13 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
     };
     if (dense) {
         set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW>), grid, block, smem, s, a.src, a.wgt, a);
+        // distinct operand slabs an XCD's run of R tiles touches: R / n_tiles + min(R, n_tiles) (n fastest) vs the same with m_tiles
+        static const int mfast_env = getenv("REFTR_MFAST") ? atoi(getenv("REFTR_MFAST")) : 1;
+        GemmArgs am = a;
+        const double R = (double)(mt * nt) / 8.0;
+        const double cn = R / nt + (R < nt ? R : nt), cm = R / mt + (R < mt ? R : mt);
+        am.mfast = (mfast_env && a.xcd && mt * nt >= 16 && cm < cn) ? 1 : 0;
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW>), grid, block, smem, s, a.src, a.wgt, am);
     } else if (!a.transposed) {
         set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW>);
         hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW>), grid, block, smem, s, a.src, a.wgt, a);
@@ -778,6 +787,7 @@ static int fill_gemm_args(const rt_conv_gemm_desc* d, GemmArgs& a) {
     a.abl = abl_env;
     static const int pre_env = getenv("REFTR_EPI_PREFETCH") ? atoi(getenv("REFTR_EPI_PREFETCH")) : 1;
     a.prefetch = pre_env;
+    a.mfast = 0;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
     a.wgt_bytes = (unsigned)((long long)d->N * d->KH * d->KW * d->SC * 2);
     return RT_OK;
