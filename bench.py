@@ -96,6 +96,39 @@ def cpu_baseline(B, H, W, L, max_seconds=28.0, sample_batch=2, threads=32):
                       f"({H}x{W}, L={L}, fp32, dropout on, clip 0.1, AdamW), torch CPU threads = {cores}"}
 
 
+def launch_decision(gpus, environ):
+    """What `bench.py --gpus N` does with the environment it finds (host logic, covered on CPU by tests/test_host_logic_cpu.py):
+      ("run", world)        this process is one rank of a `world`-rank job (or the single-GPU run);
+      ("spawn", gpus)       --gpus N > 1 without a launcher: re-execute through torch.distributed.run, one rank per GPU
+                            (the reference's launch: one process per GPU, main_vg.py:290-296, util/misc.py:392-431);
+      ("refuse", message)   launcher and flag disagree -- never time a different number of GPUs than the one asked for."""
+    if gpus < 1:
+        return ("refuse", f"--gpus must be >= 1 (got {gpus})")
+    ws = environ.get("WORLD_SIZE")
+    if ws is None:
+        return ("run", 1) if gpus == 1 else ("spawn", gpus)
+    world = int(ws)
+    if world != gpus:
+        return ("refuse", f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks: pass --gpus {world} "
+                          f"(or start {gpus} ranks)")
+    return ("run", world)
+
+
+def spawn_ranks(gpus, argv):
+    """Re-execute this script as `gpus` ranks on 127.0.0.1 (one per GPU, RCCL) and return the launcher's exit code; rank 0 of
+    the child job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on these hosts (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,10 +141,17 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     args = ap.parse_args()
 
+    what, arg = launch_decision(args.gpus, os.environ)
+    if what == "refuse":
+        print(f"[bench] {arg}", file=sys.stderr)
+        sys.exit(2)
+    if what == "spawn":
+        sys.exit(spawn_ranks(arg, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    world = arg
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists for the product)"
+    assert torch.cuda.device_count() > local, f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible"
     torch.cuda.set_device(local)
     force_dist = os.environ.get("REFTR_DDP_FORCE") == "1"        # one-GPU exercise of the data-parallel schedule
     if world > 1 or force_dist:
@@ -171,6 +211,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    dp = world > 1 or force_dist
+    if dp:
+        runner.timing = []                 # (event, event) around the end-of-backward waits: the exposed part of the exchange
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -193,6 +236,14 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
+    rccl = None
+    if dp:
+        exposed = [a.elapsed_time(b) for a, b in runner.timing]
+        runner.timing = None
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "exchange_dtype": "bf16" if runner.bf16 else "fp32",
+                "bytes_per_rank_per_step": runner.exchange_bytes(), "schedule": model.dp_schedule, "boundaries": list(runner.phases),
+                "exposed_exchange_ms": (sum(exposed) / len(exposed)) if exposed else None,
+                "note": "exposed = time the compute stream waits for outstanding all-reduces after backward (HIP events, rank 0, mean over the timed steps)"}
 
     import math
     assert math.isfinite(loss_value) and abs(loss_value) < 1e3, f"training step produced a non-finite / absurd loss ({loss_value})"
@@ -209,7 +260,6 @@ def main():
         # across ranks -- and rank 0 reports its own events; the all-reduces are not among the timed launches.
         side_was = model.net.side.enabled
         model.net.side.enabled = False          # one stream for this pass: per-launch durations must be additive
-        dp = world > 1 or force_dist
         if mode == "hipgraph" and not dp:
             torch.cuda.synchronize()
             torch.cuda._sleep(int(2.4e9 * 0.12))
@@ -284,6 +334,8 @@ def main():
                                 "frac": step_tf / (PEAK_BF16_TFLOPS * world), "gflop_per_img": GF_PER_IMG}
         if roof is not None:
             out["roofline"] = roof
+        if rccl is not None:
+            out["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, S_, S_, Lq)
     if dist.is_initialized():

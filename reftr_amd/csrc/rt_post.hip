@@ -71,30 +71,32 @@ __global__ __launch_bounds__(256) void mask_postprocess_kernel(const rt_mask_pos
 
 __global__ __launch_bounds__(64) void box_postprocess_kernel(const rt_box_post_desc p) {
     const int b = blockIdx.x;
-    const int ph = threadIdx.x;
-    // phrase_mask is [B, P, K]; the reference selects rows of [P, K, 4] whose mask is set and keeps prediction 0 of each
-    // selected phrase (post_process.py:62-70): a phrase is selected iff its K mask entries are set (they are equal by
-    // construction, reftr_transformer.py:237-238); rank = number of selected phrases before it.
-    int rank = 0, n = 0;
-    bool mine = false;
-    for (int j = 0; j < p.P; ++j) {
-        const bool v = p.valid[((size_t)b * p.P + j) * p.K] != 0;
-        if (j < ph && v) ++rank;
-        if (j == ph) mine = v;
-        n += v ? 1 : 0;
+    const int lane = threadIdx.x;
+    // phrase_mask is [B, P, K]; the reference masked_selects the (p, k) entries of [P, K, 4] whose mask is set and keeps
+    // prediction 0 of each selected phrase (post_process.py:62-70).  The K entries of a phrase are equal by construction
+    // (reftr_transformer.py:237-238), so a phrase is selected iff its entry 0 is set; rank = number of selected phrases in
+    // front of it.  Any P: the wave walks the phrases 64 at a time, ranks inside a pass come from a ballot + population count
+    // of the lower lanes (ordered, exact), `base` carries the count of the passes before.
+    int base = 0;
+    for (int j0 = 0; j0 < p.P; j0 += 64) {
+        const int ph = j0 + lane;
+        const bool mine = ph < p.P && p.valid[((size_t)b * p.P + ph) * p.K] != 0;
+        const unsigned long long bal = __ballot(mine);
+        const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+        base += __popcll(bal);
+        if (!mine) continue;
+        const float* s = p.boxes + ((size_t)(b * p.P + ph) * p.K) * 4;
+        const float cx = s[0], cy = s[1], w = s[2], h = s[3];
+        float x0 = __fsub_rn(cx, __fmul_rn(0.5f, w)), y0 = __fsub_rn(cy, __fmul_rn(0.5f, h));
+        float x1 = __fadd_rn(cx, __fmul_rn(0.5f, w)), y1 = __fadd_rn(cy, __fmul_rn(0.5f, h));
+        if (p.sizes) {                                  // scale_to_original_shape: boxes * [img_w, img_h, img_w, img_h]
+            const float ih = p.sizes[b * 2], iw = p.sizes[b * 2 + 1];
+            x0 = __fmul_rn(x0, iw); y0 = __fmul_rn(y0, ih); x1 = __fmul_rn(x1, iw); y1 = __fmul_rn(y1, ih);
+        }
+        float* o = p.out + ((size_t)b * p.P + rank) * 4;
+        o[0] = x0; o[1] = y0; o[2] = x1; o[3] = y1;
     }
-    if (ph == 0) p.counts[b] = n;
-    if (ph >= p.P || !mine) return;
-    const float* s = p.boxes + ((size_t)(b * p.P + ph) * p.K) * 4;
-    const float cx = s[0], cy = s[1], w = s[2], h = s[3];
-    float x0 = __fsub_rn(cx, __fmul_rn(0.5f, w)), y0 = __fsub_rn(cy, __fmul_rn(0.5f, h));
-    float x1 = __fadd_rn(cx, __fmul_rn(0.5f, w)), y1 = __fadd_rn(cy, __fmul_rn(0.5f, h));
-    if (p.sizes) {                                  // scale_to_original_shape: boxes * [img_w, img_h, img_w, img_h]
-        const float ih = p.sizes[b * 2], iw = p.sizes[b * 2 + 1];
-        x0 = __fmul_rn(x0, iw); y0 = __fmul_rn(y0, ih); x1 = __fmul_rn(x1, iw); y1 = __fmul_rn(y1, ih);
-    }
-    float* o = p.out + ((size_t)b * p.P + rank) * 4;
-    o[0] = x0; o[1] = y0; o[2] = x1; o[3] = y1;
+    if (lane == 0) p.counts[b] = base;
 }
 
 }  // namespace
@@ -114,7 +116,6 @@ extern "C" int rt_mask_postprocess(const rt_mask_post_desc* d, rt_stream_t strea
 extern "C" int rt_box_postprocess(const rt_box_post_desc* d, rt_stream_t stream) {
     if (!d || !d->boxes || !d->valid || !d->out || !d->counts) return RT_ERR_BADARG;
     if (d->B <= 0 || d->P <= 0 || d->K <= 0) return RT_ERR_BADARG;
-    if (d->P > 64) return RT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(box_postprocess_kernel, dim3((unsigned)d->B), dim3(64), 0, (hipStream_t)stream, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;

@@ -604,6 +604,7 @@ __global__ __launch_bounds__(1024) void cem_bwd_kernel(const rt_cem_desc p) {
 extern "C" int rt_cem_fwd(const rt_cem_desc* d, rt_stream_t stream) {
     if (!d || !d->hs || !d->w3 || !d->b3 || !d->u || !d->res || !d->w2 || !d->b2 || !d->energy || !d->stats || !d->loss) return RT_ERR_BADARG;
     if (d->B <= 0 || d->HW <= 0 || d->E <= 0 || d->ld < 16 || (d->ld & 7)) return RT_ERR_BADARG;
+    if (d->E != 256) return RT_ERR_UNSUPPORTED;      // the kernels hold hidden/16 == 16 channels per image in 16 waves / fixed arrays
     hipStream_t s = (hipStream_t)stream;
     const hipError_t e = rt_zero_f32(d->loss, 1, s);
     if (e != hipSuccess) return (int)e;
@@ -616,6 +617,7 @@ extern "C" int rt_cem_bwd(const rt_cem_desc* d, rt_stream_t stream) {
     if (!d || !d->hs || !d->w3 || !d->u || !d->res || !d->w2 || !d->b2 || !d->energy || !d->stats || !d->g || !d->dres || !d->dhs ||
         !d->dw3 || !d->db3 || !d->dw2) return RT_ERR_BADARG;
     if (d->B <= 0 || d->HW <= 0 || d->E <= 0 || d->ld < 16 || (d->ld & 7) || d->lddr < 16 || (d->lddr & 3)) return RT_ERR_BADARG;
+    if (d->E != 256) return RT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cem_bwd_kernel, dim3((unsigned)d->B), dim3(1024), 0, (hipStream_t)stream, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;

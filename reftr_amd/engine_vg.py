@@ -187,6 +187,7 @@ class CapturedTrainStep:
         self.deferred = (not self.two_phase and not self._post and hasattr(optimizer, "enable_deferred")
                          and os.environ.get("REFTR_DEFER_OPT", "1") == "1")
         self._pending = False
+        self._staged = None
         if self.deferred:
             self._init_deferred(warmup)
             return
@@ -268,7 +269,8 @@ class CapturedTrainStep:
         finally:
             inner._pre_update = None
             inner._zero_grad_side = False
-        opt.finish_step(self.max_norm)
+        self.grad_norm = opt.finish_step(self.max_norm)
+        self._pack_stats()
         return out
 
     def flush(self):
@@ -313,7 +315,16 @@ class CapturedTrainStep:
         if zero:
             _zero_grad(self.optimizer)
         losses.backward()
-        return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}
+        self._last = (losses.detach(), {k: v.detach() for k, v in loss_dict.items()})
+        return self._last
+
+    def _pack_stats(self):
+        """Every scalar the loop reads from an iteration -- the unweighted losses (sorted by name) and the gradient norm -- in
+        ONE static device vector (a single small kernel at the end of the graph): the engine fetches it with one device -> host
+        copy per iteration instead of one .item() per meter (the reference: engine_vg.py:46-53,69-72, util/misc.py:156-160)."""
+        ld = self._last[1]
+        self.stat_names = tuple(sorted(ld))
+        self.stats = torch.stack([ld[k].reshape(()).float() for k in self.stat_names] + [self.grad_norm.reshape(()).float()])
 
     @staticmethod
     def _run(hooks):
@@ -323,6 +334,7 @@ class CapturedTrainStep:
     def _opt(self):
         self.grad_norm = self.optimizer.clip_grad_norm_(self.max_norm)
         self.optimizer.step()
+        self._pack_stats()
 
     @property
     def batch(self):
@@ -331,11 +343,27 @@ class CapturedTrainStep:
         any other batch of the captured shape is copied in (one small copy per field) before the replay."""
         return self.s, self.t
 
+    def stage(self, samples, targets):
+        """Copies the NEXT batch into the static input buffers now -- stream-ordered behind the replay that is still running,
+        while the host would otherwise idle in front of the iteration's device -> host copy -- so that the next call only has to
+        launch the graph.  Returns False (and does nothing) for a batch of another shape."""
+        if samples is None or self.shape_key(samples, targets) != self.key:
+            return False
+        _copy_batch(self.s, self.t, samples, targets)
+        self._staged = (samples, targets)
+        return True
+
+    def _stage_in(self, samples, targets):
+        staged, self._staged = self._staged, None
+        if staged is None or staged[0] is not samples or staged[1] is not targets:
+            _copy_batch(self.s, self.t, samples, targets)
+
     def __call__(self, samples, targets):
-        assert (samples is self.s and targets is self.t) or self.shape_key(samples, targets) == self.key, \
+        staged = self._staged is not None and self._staged[0] is samples and self._staged[1] is targets
+        assert staged or (samples is self.s and targets is self.t) or self.shape_key(samples, targets) == self.key, \
             "captured for another input shape; use train_step"
         if self.deferred:
-            _copy_batch(self.s, self.t, samples, targets)
+            self._stage_in(samples, targets)
             self.g_fb.replay()                # applies iteration i-1's update with the rates synced at iteration i-1
             lrs = [g["lr"] for g in self.optimizer.param_groups]
             if lrs != self._lrs:              # this iteration's rates, for the update the NEXT replay (or flush) applies
@@ -352,7 +380,7 @@ class CapturedTrainStep:
                 self.optimizer.sync_lr()          # stream-ordered, in front of this iteration's optimizer graph
             else:
                 self.refresh_lr()
-        _copy_batch(self.s, self.t, samples, targets)
+        self._stage_in(samples, targets)
         self._refresh_num_boxes(targets)
         self.g_fb.replay()
         for name, g in zip(self.phases, self.g_seg):
@@ -383,10 +411,25 @@ def dp_capture_decision(can_replay, can_capture, device):
     return "replay" if all_replay else ("capture" if all_capture else "eager")
 
 
-def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4):
+class Lookahead:
+    """The next batch of a loop, fetched at most once: by the step while the device is busy with the current batch (the
+    captured path calls it between the graph launch and the iteration's host sync), else by the loop itself."""
+
+    def __init__(self, fn):
+        self.fn, self.batch, self.done = fn, None, False
+
+    def __call__(self):
+        if not self.done:
+            self.batch, self.done = self.fn(), True
+        return self.batch
+
+
+def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4, lookahead=None):
     """`train_step` with the same return value, replayed from hipGraphs: the first batch of an input shape captures a
     CapturedTrainStep (kept on the model), later batches of that shape replay it.  Falls back to the eager `train_step` for
-    CPU tensors, foreign optimizers and once more than `max_shapes` different shapes have been seen (variable-size data)."""
+    CPU tensors, foreign optimizers and once more than `max_shapes` different shapes have been seen (variable-size data).
+    `lookahead` (a Lookahead) is called while the replay runs: the next batch is fetched and staged into the graph's input
+    buffers under the current step instead of in front of the next one."""
     inner = getattr(model, "module", model)
     caps = inner.__dict__.setdefault("_captured_steps", {})
     img = samples.get("img")
@@ -403,7 +446,17 @@ def captured_train_step(model, criterion, samples, targets, optimizer, lr_schedu
         # collectively: replay only if EVERY rank holds a capture for its batch, capture only if every rank would capture,
         # otherwise every rank runs the eager step.  One 2-word MIN all-reduce per iteration, issued while the device is
         # idle behind the previous iteration's loss .item().
+        mine = ok
         ok = dp_capture_decision(ok and key in caps, ok and key not in caps, inner.store.device) != "eager"
+        if mine and not ok:
+            # this rank could have replayed / captured, another one could not (its capture budget is spent, or its batch has a
+            # shape this rank already holds while the other must still capture): the whole job runs this iteration eagerly.
+            # Said once per shape -- a run that quietly degrades to eager launches is 2-3x slower.
+            seen = inner.__dict__.setdefault("_dp_eager_logged", set())
+            if key not in seen:
+                seen.add(key)
+                print(f"[reftr_amd] rank {utils.get_rank()}: data-parallel step runs eagerly (ranks disagree on replay/capture for this "
+                      f"input shape; {len(caps)} of {max_shapes} captures in use)", file=sys.stderr)
     if not ok:
         for other in caps.values():             # a pending (deferred) update must land before the eager forward
             other.flush()
@@ -428,40 +481,51 @@ def captured_train_step(model, criterion, samples, targets, optimizer, lr_schedu
         for other in caps.values():
             if other is not cap:
                 other.flush()
-    losses, loss_dict, grad_total_norm = cap(samples, targets)
+    cap(samples, targets)
+    if lookahead is not None:                 # host work under the replay: next batch's H2D hand-over + staging copies
+        nxt = lookahead()
+        if nxt is not None and nxt[0] is not None:
+            cap.stage(*nxt)
+    # ONE device -> host copy for everything the loop looks at (losses for the meters and the finite check, gradient norm);
+    # under data parallelism the loss entries are first averaged over the ranks in one all-reduce (util/misc.py:136-160)
+    stats = cap.stats
+    k = len(cap.stat_names)
+    if utils.get_world_size() > 1:
+        stats = stats.clone()
+        torch.distributed.all_reduce(stats[:k])
+        stats[:k] /= utils.get_world_size()
+    host = stats.tolist()
     weight_dict = criterion.weight_dict
-    loss_dict_reduced = utils.reduce_dict(loss_dict)
-    unscaled = {f"{k}_unscaled": v for k, v in loss_dict_reduced.items()}
-    scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
-    loss_value = sum(scaled.values()).item()
+    unscaled = {f"{n}_unscaled": v for n, v in zip(cap.stat_names, host)}
+    scaled = {n: v * weight_dict[n] for n, v in zip(cap.stat_names, host) if n in weight_dict}
+    loss_value = sum(scaled.values())
     if not math.isfinite(loss_value):
         print("Loss is {}, stopping training".format(loss_value))
-        print(loss_dict_reduced)
+        print(unscaled)
         sys.exit(1)
     if lr_scheduler is not None:
         lr_scheduler.step()
-    return loss_value, scaled, unscaled, grad_total_norm
+    return loss_value, scaled, unscaled, host[k]
 
 
 def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, device, epoch, max_norm=0):
     model.train()
     criterion.train()
-    metric_logger = utils.MetricLogger(delimiter="  ")
-    metric_logger.add_meter("lr", utils.SmoothedValue(window_size=1, fmt="{value:.6f}"))
-    metric_logger.add_meter("grad_norm", utils.SmoothedValue(window_size=1, fmt="{value:.2f}"))
+    board = utils.StatBoard()
     header = "Epoch: [{}]".format(epoch)
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
-    for _ in metric_logger.log_every(range(len(data_loader)), 50, header):
-        # the loop body of engine_vg.py:40-72 -- replayed from hipGraphs for fixed-shape data (RefCOCO: 640 x 640, L = 40)
-        loss_value, scaled, unscaled, gnorm = captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm)
-        metric_logger.update(loss=loss_value, **scaled, **unscaled)
-        metric_logger.update(lr=optimizer.param_groups[0]["lr"])
-        metric_logger.update(grad_norm=gnorm)
-        samples, targets = prefetcher.next()
-    metric_logger.synchronize_between_processes()
-    print("Averaged stats:", metric_logger)
-    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+    for _ in board.log_every(range(len(data_loader)), 50, header):
+        # the loop body of engine_vg.py:40-72 -- replayed from hipGraphs for fixed-shape data (RefCOCO: 640 x 640, L = 40);
+        # the replayed path hands back host numbers (one stacked copy per iteration), the eager one device scalars
+        ahead = Lookahead(prefetcher.next)
+        loss_value, scaled, unscaled, gnorm = captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm,
+                                                                  lookahead=ahead)
+        board.add(loss=loss_value, **scaled, **unscaled, lr=optimizer.param_groups[0]["lr"], grad_norm=gnorm)
+        samples, targets = ahead()
+    board.synchronize_between_processes()
+    print("Averaged stats:", board)
+    return board.global_avg()
 
 
 class CapturedForward:
@@ -519,7 +583,7 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
     from .util.box_ops import mask_iou
     model.eval()
     criterion.eval()
-    metric_logger = utils.MetricLogger(delimiter="  ")
+    board = utils.StatBoard()
     sum_accu = torch.zeros((), device=device); sum_iou = torch.zeros((), device=device); cnt = torch.zeros((), device=device)
     seg_iou = torch.zeros((), device=device); cnt_seg = 0.0
     results_dict = {}
@@ -528,13 +592,20 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
     # the forward is replayed from a hipGraph per input shape (fixed-size evaluation sets; bit-identical outputs; up to four
     # shapes, then eager launches); REFTR_EVAL_GRAPH=0: always eager
     fwd = CapturedForward(model) if (os.environ.get("REFTR_EVAL_GRAPH", "1") == "1" and torch.device(device).type == "cuda") else model
-    for _ in metric_logger.log_every(range(len(data_loader)), 50, "Test:"):
+    wvec = None
+    for _ in board.log_every(range(len(data_loader)), 50, "Test:"):
         outputs = fwd(samples)
         loss_dict = criterion(outputs, targets)
         weight_dict = criterion.weight_dict
         red = utils.reduce_dict(loss_dict)
-        scaled = {k: v * weight_dict[k] for k, v in red.items() if k in weight_dict}
-        metric_logger.update(loss=sum(scaled.values()), **scaled, **{f"{k}_unscaled": v for k, v in red.items()})
+        # meters stay on the device (no .item() per loss): [unscaled..., scaled..., total] of this iteration in one vector
+        names = sorted(red)
+        wn = [k for k in names if k in weight_dict]
+        if wvec is None or wvec[0] != names:
+            wvec = (names, torch.tensor([weight_dict[k] for k in wn], dtype=torch.float32, device=red[names[0]].device))
+        un = torch.stack([red[k].reshape(()).float() for k in names])
+        sc = torch.stack([red[k].reshape(()).float() for k in wn]) * wvec[1]
+        board.add_device([f"{k}_unscaled" for k in names] + wn + ["loss"], torch.cat([un, sc, sc.sum().reshape(1)]))
         key = "orig_size" if "orig_size" in targets[0] else "size"
         orig_sizes = torch.stack([t[key] for t in targets], dim=0)
         results = postprocessors["bbox"](outputs, orig_sizes)
@@ -554,8 +625,8 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
             if "image_id" in tg:
                 results_dict[int(tg["image_id"])] = res["boxes"].cpu().numpy().tolist()
         samples, targets = prefetcher.next()
-    metric_logger.synchronize_between_processes()
-    stats = {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+    board.synchronize_between_processes()
+    stats = board.global_avg()
     if utils.is_dist_avail_and_initialized():
         for t in (sum_accu, sum_iou, cnt):
             torch.distributed.all_reduce(t)

@@ -407,6 +407,12 @@ class RefTR(nn.Module):
         return bool(self._stops) or any(self._phase_hooks.values())
 
     def _backward_impl(self, dlogits, dmasks=None, dcem=None):
+        if self._bwd_gen is not None:
+            # the previous backward stopped at a data-parallel boundary and was never resumed (an exception in the loop): its
+            # half-written gradient set is void.  A backward armed for THIS step by zero_grad(fast=True) keeps its state (the
+            # written set was reset when it was armed); anything else was fully cleared by the caller.
+            self._bwd_gen.close()
+            self._bwd_gen = None
         self._bwd_gen = self._backward_phases(dlogits, dmasks, dcem)
         self.continue_backward()
 
@@ -650,6 +656,9 @@ def build_config(args):
         raise NotImplementedError("lr_backbone <= 0 freezes the whole ResNet in the reference (train_backbone = False, "
                                   "models/modeling/backbone.py:87-89,150) and drops its parameters from the optimizer and the "
                                   "clip norm; this build always trains layer2-4")
+    if bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss" and int(args.hidden_dim) != 256:
+        raise NotImplementedError("--ablation cem_loss with hidden_dim != 256: the CEM kernels (rt_cem_fwd / rt_cem_bwd) are built for "
+                                  "hidden_dim // 16 == 16 channels (every reference config uses hidden_dim 256)")
     # models/reftr_transformer.py:315-318: RobertaModel when args.bert_model starts with 'roberta', BertModel otherwise
     bc = L.roberta_config() if str(getattr(args, "bert_model", "bert-base-uncased")).split("-")[0] == "roberta" else L.BertConfig()
     layers = (3, 4, 23, 3) if getattr(args, "backbone", "resnet50") == "resnet101" else (3, 4, 6, 3)

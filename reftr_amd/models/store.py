@@ -81,7 +81,7 @@ class ParamStore:
         self.P = {n: self._view(self.flat[b], n, o) for n, (b, o) in self.offset.items()}
         self.G = {n: self._view(self.flat_g, n, o) for n, (b, o) in self.offset.items() if b == "p"}
         # overwrite-mode bookkeeping (see the module docstring): registered matrices {data_ptr: (offset, numel)}
-        self._ow, self._ow_table, self._armed, self._written, self._ever = {}, None, False, set(), set()
+        self._ow, self._ow_table, self._armed, self._written, self._stale_tables = {}, None, False, set(), {}
 
     # ------------------------------------------------------------------ overwrite-mode gradient production
     def register_overwritable(self, gw):
@@ -90,7 +90,7 @@ class ParamStore:
         off = (gw.data_ptr() - self.flat_g.data_ptr()) // 4
         assert 0 <= off and off + gw.numel() <= self.flat_g.numel()
         self._ow[gw.data_ptr()] = (off, gw.numel())
-        self._ow_table = None
+        self._ow_table, self._stale_tables = None, {}
 
     def _complement_table(self):
         """Static device table of <= 16384-element chunks covering everything that is NOT a registered matrix."""
@@ -123,15 +123,34 @@ class ParamStore:
         self._written.add(key)
         return True
 
+    def disarm(self):
+        """Forget a backward that never reached `finish_overwrite` (an exception, an abandoned data-parallel phase generator):
+        the caller clears the whole buffer, nothing may stay in overwrite mode."""
+        self._armed, self._written = False, set()
+
     def finish_overwrite(self):
-        """End of backward: a registered matrix that was written in an earlier step but not in this one (another input kind:
-        single- vs multi-phrase) still holds that step's gradient -- clear it once."""
+        """End of backward: EVERY registered matrix that no producer wrote in this step is cleared -- unconditionally, by one
+        launch that depends on this step's written set only, never on what earlier steps did.  (A matrix that an input kind
+        never produces -- the decoder's self-attention q/k projections with one query per image, map_phrase's second pass --
+        would otherwise keep the gradient of whichever step last wrote it; a captured graph bakes its host-side decisions in,
+        so the clear must be part of every step's own launches: a T == 1 graph replayed after a T > 1 graph clears what the
+        T > 1 step left behind.)"""
         if not self._armed:
             return
-        for key in self._ever - self._written:
-            off, n = self._ow[key]
-            self.flat_g[off:off + n].zero_()
-        self._ever, self._armed = set(self._written), False
+        missing = frozenset(self._ow) - self._written
+        if missing:
+            ent = self._stale_tables.get(missing)
+            if ent is None:
+                chunks = []
+                for off, n in sorted(self._ow[k] for k in missing):
+                    a = off
+                    while a < off + n:
+                        c = min(16384, off + n - a)
+                        chunks += [a, c]; a += c
+                ent = self._stale_tables[missing] = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
+            from .. import hip as H
+            H.zero_chunks(self.flat_g, ent[0], ent[1])
+        self._armed, self._written = False, set()
 
     def _view(self, buf, name, off):
         shape = self.shapes[name]

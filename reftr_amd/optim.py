@@ -53,6 +53,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if fast and os.environ.get("REFTR_OVERWRITE", "1") != "0" and self.model.store.flat_g.is_cuda:
             self.model.store.arm_overwrite()
         else:
+            self.model.store.disarm()         # a backward that was abandoned half-way must not leave overwrite mode armed
             self.model.store.flat_g.zero_()
 
     def _grad_buffer(self):

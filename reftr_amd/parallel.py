@@ -44,6 +44,7 @@ class DistributedDataParallel(nn.Module):
         self.n_chunks = n_chunks
         self.overlap = overlap
         self._works = []
+        self.timing = None        # a list: reduce_late appends (event before the waits, event after) = exposed exchange time
         # Exchange dtype.  bf16 (default) halves the bytes on the xGMI links -- the exchange is link-bound at 2 and 4 GPUs
         # and a third of the step at 8: every slice is rounded to bf16 once it is final, summed by RCCL in
         # bf16, and clip + AdamW read the bf16 sums directly (no unpack pass).  The rounding (2^-9 relative per element) is
@@ -141,10 +142,22 @@ class DistributedDataParallel(nn.Module):
     def reduce_phase(self, name):
         self._launch(self.phase_bounds()[name])
 
+    def exchange_bytes(self):
+        """bytes this rank hands to the all-reduces of one step (the whole flat gradient buffer, in the exchange dtype)"""
+        n = sum(b - a for chunks in self.phase_bounds().values() for a, b in chunks) if self.overlap else self.module.store.flat_g.numel()
+        return n * (2 if self.bf16 else 4)
+
     def reduce_late(self):
         self._launch(self.phase_bounds()["end"])
+        ev = None
+        if self.timing is not None and self.module.store.flat_g.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
         self._works = []
 
     def allreduce_gradients(self):

@@ -1,10 +1,11 @@
 """Host-side utilities with the reference's names and behaviour (util/misc.py of ubc-vision/RefTR):
 NestedTensor (:308-333), nested_tensor_from_tensor_list (:288-305), distributed helpers (:351-431),
-reduce_dict (:136-160), SmoothedValue / MetricLogger (:31-90,163-250)."""
+reduce_dict (:136-160); the loops' meters are reftr_amd's own StatBoard (one table, one device -> host copy per iteration)
+instead of the reference's SmoothedValue / MetricLogger objects (:31-90,163-250)."""
 import datetime
 import os
 import time
-from collections import defaultdict, deque
+from collections import deque
 
 import torch
 import torch.distributed as dist
@@ -102,75 +103,87 @@ def reduce_dict(input_dict, average=True):
         return {k: v for k, v in zip(names, values)}
 
 
-class SmoothedValue(object):
-    def __init__(self, window_size=20, fmt=None):
-        self.deque = deque(maxlen=window_size)
-        self.total = 0.0
-        self.count = 0
-        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+class StatBoard:
+    """The meters of a training / evaluation loop as ONE table instead of one object per scalar (the reference keeps a
+    SmoothedValue per loss and calls .item() on each of them every iteration, util/misc.py:31-90,163-250: ~25 host syncs per
+    iteration, which were free at 700 ms a step and are not at 7 ms).
 
-    def update(self, value, n=1):
-        self.deque.append(value)
-        self.count += n
-        self.total += value * n
+    Two feeds, both sync-free by themselves:
+      add(**scalars)            host numbers of one iteration (the engine reads ALL of an iteration's scalars with one stacked
+                                device -> host copy, the same one that serves the reference's `math.isfinite(loss)` check);
+      add_device(names, vec)    a 1-D device tensor of one iteration's scalars: accumulated on the device (one add), read back
+                                only when something is printed or summarised.
+    Statistics per name: last value, mean of the last `window` iterations, global mean (= the reference's `global_avg`,
+    what train_one_epoch / evaluate return)."""
+
+    def __init__(self, window=20, delimiter="  "):
+        self.window, self.delimiter = int(window), delimiter
+        self.total, self.count, self.last, self.recent = {}, {}, {}, {}
+        self._dev = None                   # [names, fp64 sums on the device, iterations, last vector]
+
+    # ---- feeds
+    def add(self, **scalars):
+        tens = [k for k, v in scalars.items() if torch.is_tensor(v)]
+        if tens:                           # tensors (the eager loop body returns them): ONE stacked copy for all of them
+            vals = torch.stack([scalars[k].detach().reshape(()).float() for k in tens]).tolist()
+            scalars = dict(scalars, **dict(zip(tens, vals)))
+        for k, v in scalars.items():
+            v = float(v)
+            self.total[k] = self.total.get(k, 0.0) + v
+            self.count[k] = self.count.get(k, 0) + 1
+            self.last[k] = v
+            self.recent.setdefault(k, deque(maxlen=self.window)).append(v)
+
+    def add_device(self, names, vec):
+        names = tuple(names)
+        if self._dev is not None and self._dev[0] != names:
+            self._drain()
+        if self._dev is None:
+            self._dev = [names, torch.zeros(len(names), dtype=torch.float64, device=vec.device), 0, None]
+        self._dev[1] += vec.detach().to(torch.float64)
+        self._dev[2] += 1
+        self._dev[3] = vec.detach()
+
+    def _drain(self):
+        if self._dev is None:
+            return
+        names, sums, n, last = self._dev
+        self._dev = None
+        host = torch.cat([sums, last.to(torch.float64)]).tolist()          # the only device -> host copy of this feed
+        for i, k in enumerate(names):
+            self.total[k] = self.total.get(k, 0.0) + host[i]
+            self.count[k] = self.count.get(k, 0) + n
+            self.last[k] = host[len(names) + i]
+            self.recent.setdefault(k, deque(maxlen=self.window)).append(host[len(names) + i])
+
+    # ---- read-outs
+    def global_avg(self):
+        self._drain()
+        return {k: self.total[k] / max(self.count[k], 1) for k in self.total}
 
     def synchronize_between_processes(self):
+        """sums and counts of every meter over the ranks, one all-reduce (the reference: one barrier + all-reduce per meter)"""
+        self._drain()
         if not is_dist_avail_and_initialized():
             return
+        names = sorted(self.total)
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
-        dist.barrier()
+        t = torch.tensor([self.total[k] for k in names] + [float(self.count[k]) for k in names], dtype=torch.float64, device=dev)
         dist.all_reduce(t)
         t = t.tolist()
-        self.count, self.total = int(t[0]), t[1]
-
-    @property
-    def median(self):
-        return torch.tensor(list(self.deque)).median().item()
-
-    @property
-    def avg(self):
-        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
-
-    @property
-    def global_avg(self):
-        return self.total / max(self.count, 1)
-
-    @property
-    def max(self):
-        return max(self.deque)
-
-    @property
-    def value(self):
-        return self.deque[-1]
+        for i, k in enumerate(names):
+            self.total[k], self.count[k] = t[i], int(t[len(names) + i])
 
     def __str__(self):
-        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+        self._drain()
+        parts = []
+        for k in self.total:
+            r = self.recent[k]
+            parts.append("{}: {:.4g} (last {}: {:.4g}, all: {:.4g})".format(k, self.last[k], len(r), sum(r) / max(len(r), 1),
+                                                                            self.total[k] / max(self.count[k], 1)))
+        return self.delimiter.join(parts)
 
-
-class MetricLogger(object):
-    def __init__(self, delimiter="\t"):
-        self.meters = defaultdict(SmoothedValue)
-        self.delimiter = delimiter
-
-    def update(self, **kwargs):
-        for k, v in kwargs.items():
-            if isinstance(v, torch.Tensor):
-                v = v.item()
-            self.meters[k].update(float(v))
-
-    def add_meter(self, name, meter):
-        self.meters[name] = meter
-
-    def synchronize_between_processes(self):
-        for meter in self.meters.values():
-            meter.synchronize_between_processes()
-
-    def __str__(self):
-        return self.delimiter.join("{}: {}".format(n, str(m)) for n, m in self.meters.items())
-
-    def log_every(self, iterable, print_freq, header=None):
-        header = header or ""
+    def log_every(self, iterable, print_freq, header=""):
         start = time.time()
         n = len(iterable)
         for i, obj in enumerate(iterable):

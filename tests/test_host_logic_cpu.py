@@ -286,3 +286,53 @@ def test_dp_exchange_slices_follow_the_backward_order(monkeypatch):
     assert set(pb) == {"main", "bert", "end"}
     assert sorted(pb["bert"])[0][0] == sl["bert"][0] and sorted(pb["bert"])[-1][1] == sl["bert_hi"][1]
     assert sorted(pb["end"])[0][0] == sl["end"][0] and sorted(pb["end"])[-1][1] == sl["layer4"][1]
+
+
+def test_bench_gpus_flag_decides_the_launch():
+    """`bench.py --gpus N` never times a different number of GPUs than asked for -- without a launcher it
+    re-executes itself as N ranks (torch.distributed.run on 127.0.0.1), under a launcher the world size must equal the flag."""
+    import bench
+    assert bench.launch_decision(1, {}) == ("run", 1)
+    assert bench.launch_decision(8, {}) == ("spawn", 8)
+    assert bench.launch_decision(2, {"WORLD_SIZE": "2", "RANK": "1"}) == ("run", 2)
+    assert bench.launch_decision(1, {"WORLD_SIZE": "1"}) == ("run", 1)
+    for gpus, env in ((8, {"WORLD_SIZE": "2"}), (1, {"WORLD_SIZE": "4"}), (0, {})):
+        what, msg = bench.launch_decision(gpus, env)
+        assert what == "refuse" and isinstance(msg, str)
+
+
+def test_bench_spawn_builds_the_drivers_command(monkeypatch):
+    """The command `bench.py --gpus 2` re-executes is the driver's own launch line (one rank per GPU, rendezvous on 127.0.0.1);
+    checked up to the launch itself (no GPU here)."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    assert bench.spawn_ranks(2, ["--gpus", "2", "--steps", "3", "--warmup", "1"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_stat_board_feeds_and_world2_reduction_shapes():
+    """reftr_amd.util.misc.StatBoard: host rows and device vectors give the same global averages the reference's meters would
+    (mean over iterations), tensors are read with one stacked copy, windows hold the last values."""
+    import torch
+    from reftr_amd.util.misc import StatBoard
+    b = StatBoard(window=3)
+    for i in range(5):
+        b.add(loss=float(i), lr=0.1, grad_norm=torch.tensor([2.0 * i]))
+        b.add_device(("a", "b_unscaled"), torch.tensor([1.0 * i, 10.0 * i]))
+    avg = b.global_avg()
+    assert avg["loss"] == 2.0 and abs(avg["lr"] - 0.1) < 1e-12 and avg["grad_norm"] == 4.0
+    assert avg["a"] == 2.0 and avg["b_unscaled"] == 20.0
+    assert list(b.recent["loss"]) == [2.0, 3.0, 4.0] and b.last["a"] == 4.0
+    assert "loss: 4" in str(b)
+    b.synchronize_between_processes()          # no process group: a no-op
+    assert b.global_avg()["loss"] == 2.0

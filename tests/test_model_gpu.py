@@ -525,3 +525,40 @@ def test_captured_step_static_batch_filled_in_place(hip):
     print("static-batch losses", l_copy, l_static, la)
     assert abs(l_copy[0] - l_static[0]) < 1e-6 * abs(l_copy[0]) and abs(l_copy[1] - l_static[1]) < 2e-3 * abs(l_copy[1])
     assert abs(la - l_copy[0]) > 1e-3 * abs(la)             # the two batches are different problems
+
+
+def test_captured_graphs_of_different_input_kinds_leave_no_stale_gradients(hip, monkeypatch):
+    """Overwrite-mode gradients under graph replay: a single-phrase step (T == 1: the decoder's self-attention q/k
+    projections produce NO gradient) replayed right after a multi-phrase step (T > 1: they do) must not see the multi-phrase
+    step's q/k gradients -- the clear of 'registered but not written this step' is part of every step's own launches, not of
+    host history baked into the capture.  Checked against the same alternation with the full per-step clear
+    (REFTR_OVERWRITE=0): gradient norms of every step and the never-written matrix itself."""
+    from reftr_amd.engine_vg import captured_train_step
+    from reftr_amd.optim import FusedAdamW
+    single = to_cuda(*make_inputs("e2e_single", B=2, H=96, W=128, L=12))
+    multi = to_cuda(*make_inputs("e2e_multi", B=2, H=96, W=128, L=12, n_phrase=3))
+    seq = [multi, single, multi, single, single, multi, single]
+    key = "vl_transformer.decoder.layers.0.self_attn.in_proj_weight"
+    res = {}
+    for ow in ("1", "0"):
+        monkeypatch.setenv("REFTR_OVERWRITE", ow)
+        model, crit, P, ocfg = build(small=True)
+        model.cfg.dropout = 0.0
+        opt = FusedAdamW(model, lr=1e-5, lr_backbone=1e-6, weight_decay=1e-4)
+        model.train()
+        E = model.cfg.hidden
+        norms, qk = [], []
+        for s, tg in seq:
+            _, _, _, gn = captured_train_step(model, crit, s, tg, opt, None, max_norm=0.1)
+            norms.append(float(gn))
+            qk.append(float(model.store.G[key][: 2 * E].norm()))
+        assert len(model._captured_steps) == 2
+        res[ow] = (norms, qk)
+    (n1, q1), (n0, q0) = res["1"], res["0"]
+    print("\n[stale-gradient check] grad norms overwrite", ["%.4f" % v for v in n1], "full clear", ["%.4f" % v for v in n0])
+    for i, (s, _) in enumerate(seq):
+        if "phrase" not in s:               # single-phrase step: the q/k rows of the in_proj gradient are exactly zero
+            assert q1[i] == 0.0 and q0[i] == 0.0, (i, q1[i], q0[i])
+        else:
+            assert q1[i] > 0.0
+        assert abs(n1[i] - n0[i]) < 5e-2 * n0[i], (i, n1[i], n0[i])

@@ -54,6 +54,25 @@ def test_box_postprocess_ragged_multi_query_integer_sizes(hip):
         assert torch.equal(r["boxes"].cpu(), b), i
 
 
+def test_box_postprocess_more_than_64_phrase_slots(hip):
+    """The reference handles any number of phrase slots (post_process.py:62-70); the kernel walks them 64 at a time with an
+    ordered running rank (P > 64 used to be rejected).  P = 150, ragged validity, exact against the oracle."""
+    from reftr_amd.models.post_process import PostProcessVGMultiPhrase
+    g = torch.Generator().manual_seed(11)
+    B, P, K = 3, 150, 1
+    pred = torch.rand(B, P, K, 4, generator=g)
+    valid = torch.rand(B, P, generator=g) < 0.4
+    valid[1] = True
+    mask = valid[:, :, None].expand(B, P, K).reshape(B, P * K)
+    sizes = torch.tensor([[480, 640], [333, 500], [640, 427]])
+    for scale in (False, True):
+        res = PostProcessVGMultiPhrase()({"pred_boxes": pred.cuda(), "phrase_mask": mask.cuda()}, sizes.cuda(), scale)
+        ref = O.postprocess_boxes(pred, mask, sizes, scale)
+        for i, (r, b) in enumerate(zip(res, ref)):
+            assert r["boxes"].shape == b.shape == (int(valid[i].sum()), 4)
+            assert torch.equal(r["boxes"].cpu(), b), (scale, i)
+
+
 def test_mask_postprocess_matches_reference_golden_exactly(hip):
     from reftr_amd.models.post_process import PostProcessSegm
     g = np.load(os.path.join(GOLD, "seg_single.npz"))
