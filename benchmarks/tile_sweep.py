@@ -10,6 +10,7 @@ SHAPES = [("l1 64->256 @160", 204800, 64, 256), ("l1 256->64 @160", 204800, 256,
           ("l4 512->2048 @20", 3200, 512, 2048), ("l4 2048->512 @20", 3200, 2048, 512), ("l4 1024->512 @40", 12800, 1024, 512),
           ("enc 256->256", 3520, 256, 256), ("enc 256->2048", 3520, 256, 2048), ("enc 2048->256", 3520, 2048, 256),
           ("bert 768->768", 320, 768, 768), ("bert 768->3072", 320, 768, 3072), ("bert 3072->768", 320, 3072, 768),
+          ("bert 768->2304", 320, 768, 2304), ("bert 2304->768", 320, 2304, 768),
           ("big 4096^3", 4096, 4096, 4096)]
 def graph_time(fn, iters=20):
     fn(); torch.cuda.synchronize()

@@ -1,0 +1,79 @@
+"""Proves (or breaks) the bf16 rounding-flip noise floor claimed in DESIGN.md §4 -- CPU only, test infrastructure.
+
+Two forwards of the SAME computation: the oracle in q=True mode (bf16 rounding points of the HIP path) with torch's fp32
+accumulation order, and the same mode with every contraction accumulated in fp64 (`accumulate_fp64`) -- identical operands,
+identical rounding points, only the summation order / accumulation precision differs, which is exactly what separates the
+MFMA path from the oracle.  Reported per stage (stem+layers, c5, encoder memory, decoder hs, logits, boxes) as rel-L2:
+if these distances are at the level the HIP-vs-oracle tests measure (logits ~6e-3), the floor is the format's; if they were
+~1e-3 the HIP path would carry a systematic term.
+
+    python oracle/noise_floor.py [--size 320] [--batch 2] [--small]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import reftr_oracle as O          # noqa: E402
+from oracle.shapes import param_shapes        # noqa: E402
+from oracle.synth import make_inputs          # noqa: E402
+from oracle.weights import formula_state      # noqa: E402
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def stages(o):
+    out = {"c5": o["c5"], "memory": o["memory"], "hs": o["hs"], "logits": o["logits"], "boxes": o["logits"].sigmoid()}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=320)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--small", action="store_true", help="reduced depth (2+2+2 layers), 96x128")
+    ap.add_argument("--multi", action="store_true")
+    a = ap.parse_args()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    if a.small:
+        ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2))
+        B, Hh, Ww, Lq = 2, 96, 128, 12
+    else:
+        ocfg = O.Cfg()
+        B, Hh, Ww, Lq = a.batch, a.size, a.size, 40
+    tag = "e2e_multi" if a.multi else "e2e_single"
+    samples, targets = make_inputs(tag, B=B, H=Hh, W=Ww, L=Lq, n_phrase=3 if a.multi else 0)
+    P = formula_state(param_shapes(ocfg))
+    t0 = time.time()
+    with torch.no_grad():
+        o32 = stages(O.reftr_forward(P, samples, ocfg, q=True))
+        with O.accumulate_fp64():
+            o64 = stages(O.reftr_forward(P, samples, ocfg, q=True))
+            f64 = stages(O.reftr_forward(P, samples, ocfg, q=False))
+        f32 = stages(O.reftr_forward(P, samples, ocfg, q=False))
+        with O.fp32_trunk(3):
+            t3 = stages(O.reftr_forward(P, samples, ocfg, q=True))
+        with O.fp32_trunk(1):
+            t1 = stages(O.reftr_forward(P, samples, ocfg, q=True))
+            with O.accumulate_fp64():
+                t1_64 = stages(O.reftr_forward(P, samples, ocfg, q=True))
+    res = {"workload": f"{tag} B={B} {Hh}x{Ww} L={Lq} depth={'2+2+2' if a.small else '12+6+6'}", "seconds": time.time() - t0,
+           "q_fp32order_vs_q_fp64acc": {k: rel(o32[k], o64[k]) for k in o32},
+           "q_vs_fp32_reference_arithmetic": {k: rel(o32[k], f32[k]) for k in o32},
+           "fp32_vs_fp64acc_reference_arithmetic": {k: rel(f32[k], f64[k]) for k in o32},
+           # what a precision knob would buy: the residual trunk kept in fp32 (operands still bf16) -- distance to the fp32
+           # reference arithmetic, and the order-floor that is left with it
+           "q_fp32trunk_layer3up_vs_fp32_reference": {k: rel(t3[k], f32[k]) for k in o32},
+           "q_fp32trunk_all_vs_fp32_reference": {k: rel(t1[k], f32[k]) for k in o32},
+           "q_fp32trunk_all_fp32order_vs_fp64acc": {k: rel(t1[k], t1_64[k]) for k in o32}}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

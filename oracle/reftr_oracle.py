@@ -64,6 +64,65 @@ class Cfg:
     giou_loss_coef: float = 1.0   # main_vg.py:135 (default 1)
 
 
+# ----------------------------------------------------------------------------------------------
+# Accumulation order of every contraction (conv / linear / bmm / matmul).  Default: torch's fp32 kernels (what the golden
+# vectors were pinned with).  Inside `with accumulate_fp64():` the SAME operands are multiplied and summed in fp64 and the
+# result is rounded to fp32 once -- another summation order of the same computation, with the same bf16 rounding points
+# around it when q=True.  The distance between the two `q=True` forwards is the floor any bf16-operand implementation with its
+# own accumulation order (the MFMA path) can be expected to sit at (tests/test_oracle_golden.py).
+# ----------------------------------------------------------------------------------------------
+_ACC = {"fp64": False, "fp32_trunk_from": 0}      # fp32_trunk_from = L > 0: experiment, see `fp32_trunk`
+
+
+class fp32_trunk:
+    """Experiment knob (not a mode of the product): in q=True forwards, the residual trunk of ResNet stages >= `first_layer`
+    (conv3 + identity outputs) is NOT rounded to bf16 when stored -- only re-rounded where it enters the next GEMM as an
+    operand.  oracle/noise_floor.py uses it to show how much of the end-to-end distance the stored-trunk rounding carries."""
+
+    def __init__(self, first_layer=3):
+        self.first = first_layer
+
+    def __enter__(self):
+        self._old = _ACC["fp32_trunk_from"]
+        _ACC["fp32_trunk_from"] = self.first
+
+    def __exit__(self, *a):
+        _ACC["fp32_trunk_from"] = self._old
+
+
+class accumulate_fp64:
+    def __enter__(self):
+        self._old = _ACC["fp64"]
+        _ACC["fp64"] = True
+
+    def __exit__(self, *a):
+        _ACC["fp64"] = self._old
+
+
+def _d(t):
+    return None if t is None else t.double()
+
+
+def conv2d_acc(x, w, b=None, *a, **k):
+    if _ACC["fp64"]:
+        return F.conv2d(_d(x), _d(w), _d(b), *a, **k).float()
+    return F.conv2d(x, w, b, *a, **k)
+
+
+def linear_acc(x, w, b=None):
+    if _ACC["fp64"]:
+        return F.linear(_d(x), _d(w), _d(b)).float()
+    return F.linear(x, w, b)
+
+
+def bmm_acc(a, b):
+    return torch.bmm(a.double(), b.double()).float() if _ACC["fp64"] else torch.bmm(a, b)
+
+
+def matmul_acc(a, b):
+    return torch.matmul(a.double(), b.double()).float() if _ACC["fp64"] else torch.matmul(a, b)
+
+
 class _Round(torch.autograd.Function):
     """bf16 rounding point, applied to the value going forward and to the gradient coming back."""
 
@@ -95,28 +154,28 @@ def frozen_bn_affine(P, pfx, eps=1e-5):
     return scale.detach(), shift.detach()
 
 
-def conv_bn(x, P, conv, bn, stride=1, padding=0, q=False, relu=True, residual=None):
+def conv_bn(x, P, conv, bn, stride=1, padding=0, q=False, relu=True, residual=None, round_out=True):
     w = P[conv + "weight"]
     scale, shift = frozen_bn_affine(P, bn)
     if q:   # HIP path: scale folded into the bf16 weight, output stored as bf16
-        y = F.conv2d(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, stride, padding) + shift.view(1, -1, 1, 1)
+        y = conv2d_acc(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, stride, padding) + shift.view(1, -1, 1, 1)
     else:
-        y = F.conv2d(x, w, None, stride, padding) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        y = conv2d_acc(x, w, None, stride, padding) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if residual is not None:
         y = y + residual
     if relu:
         y = F.relu(y)
-    return rq(y, q)
+    return rq(y, q and round_out)
 
 
-def bottleneck(x, P, pfx, stride, q=False):
+def bottleneck(x, P, pfx, stride, q=False, trunk_round=True):
     """ResNet v1.5 bottleneck (stride on the 3x3), SURVEY.md A1."""
     idt = x
     if (pfx + "downsample.0.weight") in P:
-        idt = conv_bn(x, P, pfx + "downsample.0.", pfx + "downsample.1.", stride, 0, q, relu=False)
+        idt = conv_bn(x, P, pfx + "downsample.0.", pfx + "downsample.1.", stride, 0, q, relu=False, round_out=trunk_round)
     y = conv_bn(x, P, pfx + "conv1.", pfx + "bn1.", 1, 0, q)
     y = conv_bn(y, P, pfx + "conv2.", pfx + "bn2.", stride, 1, q)
-    return conv_bn(y, P, pfx + "conv3.", pfx + "bn3.", 1, 0, q, relu=True, residual=idt)
+    return conv_bn(y, P, pfx + "conv3.", pfx + "bn3.", 1, 0, q, relu=True, residual=idt, round_out=trunk_round)
 
 
 def resnet_body(x, P, pfx="img_backbone.0.body.", layers=(3, 4, 6, 3), q=False):
@@ -125,16 +184,17 @@ def resnet_body(x, P, pfx="img_backbone.0.body.", layers=(3, 4, 6, 3), q=False):
     scale, shift = frozen_bn_affine(P, pfx + "bn1.")
     w = P[pfx + "conv1.weight"]
     if q:
-        y = F.conv2d(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, 2, 3) + shift.view(1, -1, 1, 1)
+        y = conv2d_acc(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, 2, 3) + shift.view(1, -1, 1, 1)
     else:
-        y = F.conv2d(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        y = conv2d_acc(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     y = rq(F.relu(y), q)
     y = F.max_pool2d(y, 3, 2, 1)
     outs = []
     for li, n in enumerate(layers):
         for bi in range(n):
             stride = 2 if (bi == 0 and li > 0) else 1
-            y = bottleneck(y, P, f"{pfx}layer{li + 1}.{bi}.", stride, q)
+            t32 = _ACC["fp32_trunk_from"]
+            y = bottleneck(y, P, f"{pfx}layer{li + 1}.{bi}.", stride, q, trunk_round=not (t32 and li + 1 >= t32))
         outs.append(y)
     return outs
 
@@ -169,7 +229,7 @@ def sine_pos(mask, num_pos_feats=128, temperature=10000.0):
 # small building blocks
 # ----------------------------------------------------------------------------------------------
 def linear(x, P, pfx, q=False):
-    return F.linear(rq(x, q), rq_fwd(P[pfx + "weight"], q), P[pfx + "bias"])
+    return linear_acc(rq(x, q), rq_fwd(P[pfx + "weight"], q), P[pfx + "bias"])
 
 
 def layer_norm(x, P, pfx, eps=1e-5):
@@ -196,19 +256,19 @@ def mha(P, pfx, query, key, value, key_padding_mask, nheads, p_drop=0.0, train=F
     W, bias = P[pfx + "in_proj_weight"], P[pfx + "in_proj_bias"]
     Lq, B, _ = query.shape
     Lk = key.shape[0]
-    qh = F.linear(rq(query, q), rq_fwd(W[:E], q), bias[:E]) * (dh ** -0.5)
-    kh = F.linear(rq(key, q), rq_fwd(W[E:2 * E], q), bias[E:2 * E])
-    vh = F.linear(rq(value, q), rq_fwd(W[2 * E:], q), bias[2 * E:])
+    qh = linear_acc(rq(query, q), rq_fwd(W[:E], q), bias[:E]) * (dh ** -0.5)
+    kh = linear_acc(rq(key, q), rq_fwd(W[E:2 * E], q), bias[E:2 * E])
+    vh = linear_acc(rq(value, q), rq_fwd(W[2 * E:], q), bias[2 * E:])
     qh = rq(qh, q).reshape(Lq, B * nheads, dh).transpose(0, 1)
     kh = rq(kh, q).reshape(Lk, B * nheads, dh).transpose(0, 1)
     vh = rq(vh, q).reshape(Lk, B * nheads, dh).transpose(0, 1)
-    scores = torch.bmm(qh, kh.transpose(1, 2))
+    scores = bmm_acc(qh, kh.transpose(1, 2))
     if key_padding_mask is not None:
         scores = scores.view(B, nheads, Lq, Lk).masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
         scores = scores.view(B * nheads, Lq, Lk)
     attn = drop(F.softmax(scores, dim=-1), p_drop, train)
-    out = torch.bmm(attn, vh).transpose(0, 1).reshape(Lq, B, E)
-    return F.linear(rq(out, q), rq_fwd(P[pfx + "out_proj.weight"], q), P[pfx + "out_proj.bias"])
+    out = bmm_acc(attn, vh).transpose(0, 1).reshape(Lq, B, E)
+    return linear_acc(rq(out, q), rq_fwd(P[pfx + "out_proj.weight"], q), P[pfx + "out_proj.bias"])
 
 
 def encoder_layer(x, pos, kpm, P, pfx, cfg, train=False, q=False):
@@ -255,9 +315,9 @@ def bert_forward(P, ids, attn_mask, bc: BertCfg, pfx="lang_backbone.", train=Fal
         qh = rq(linear(h, P, lp + "attention.self.query.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
         kh = rq(linear(h, P, lp + "attention.self.key.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
         vh = rq(linear(h, P, lp + "attention.self.value.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
-        s = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(dh) + add_mask
+        s = matmul_acc(qh, kh.transpose(-1, -2)) / math.sqrt(dh) + add_mask
         a = drop(F.softmax(s, dim=-1), bc.dropout, train)
-        ctx = torch.matmul(a, vh).transpose(1, 2).reshape(B, L, bc.hidden)
+        ctx = matmul_acc(a, vh).transpose(1, 2).reshape(B, L, bc.hidden)
         o = drop(linear(ctx, P, lp + "attention.output.dense.", q), bc.dropout, train)
         h = layer_norm(h + o, P, lp + "attention.output.LayerNorm.", bc.eps)
         f = F.gelu(linear(h, P, lp + "intermediate.dense.", q))
@@ -277,7 +337,7 @@ def query_encoder(P, ctx, phrase_feat, mask_ctx, cfg, pfx="query_encoder.", trai
     k = linear(ctx[:, 0:1, :], P, pfx + "linear1.", q)
     qs = linear(ctx, P, pfx + "linear2.", q).transpose(1, 2)
     v = linear(ctx, P, pfx + "linear3.", q).unsqueeze(1)
-    w = torch.bmm(k, qs).expand(-1, n_ph, -1).masked_fill(mask_ctx, float("-inf"))
+    w = bmm_acc(k, qs).expand(-1, n_ph, -1).masked_fill(mask_ctx, float("-inf"))
     w = F.softmax(w, dim=-1).unsqueeze(-1)
     c = (v * w).sum(dim=-2)
     c = layer_norm(linear(c, P, pfx + "context_out.0.", q), P, pfx + "context_out.1.")
@@ -321,7 +381,7 @@ def reftr_forward(P, samples, cfg: Cfg, train=False, q=False):
     m5 = mask_downsample(img_mask, c5.shape[-2:])
     pos5 = sine_pos(m5, E // 2)
     # input_proj: 1x1 conv + GroupNorm(32) (models/reftr_transformer.py:121-125,174)
-    src = F.conv2d(rq(c5, q), rq_fwd(P["input_proj.0.0.weight"], q), P["input_proj.0.0.bias"])
+    src = conv2d_acc(rq(c5, q), rq_fwd(P["input_proj.0.0.weight"], q), P["input_proj.0.0.bias"])
     src = F.group_norm(src, 32, P["input_proj.0.1.weight"], P["input_proj.0.1.bias"], 1e-5)
 
     sent, smask = samples["sentence"], samples["sentence_mask"]
@@ -386,7 +446,7 @@ def mh_attention_map(P, qv, k, mask, nheads, pfx="bbox_attention.", q=False):
     qv [B,Q,E], k [B,E,h,w], mask [B,h,w] bool (True = pad) -> [B,Q,nheads,h,w]."""
     E = qv.shape[-1]
     qq = linear(qv, P, pfx + "q_linear.", q)
-    kk = F.conv2d(rq(k, q), rq_fwd(P[pfx + "k_linear.weight"], q)[:, :, None, None], P[pfx + "k_linear.bias"])
+    kk = conv2d_acc(rq(k, q), rq_fwd(P[pfx + "k_linear.weight"], q)[:, :, None, None], P[pfx + "k_linear.bias"])
     qh = qq.view(qq.shape[0], qq.shape[1], nheads, E // nheads)
     kh = kk.view(kk.shape[0], nheads, E // nheads, kk.shape[-2], kk.shape[-1])
     w = torch.einsum("bqnc,bnchw->bqnhw", qh * float(E / nheads) ** -0.5, kh)
@@ -403,7 +463,7 @@ def mask_head(P, x, bbox_mask, fpns, pfx="mask_head.", q=False):
         return t.unsqueeze(1).repeat(1, int(n), 1, 1, 1).flatten(0, 1)
 
     def conv(t, name, pad):
-        return F.conv2d(rq(t, q), rq_fwd(P[pfx + name + ".weight"], q), P[pfx + name + ".bias"], padding=pad)
+        return conv2d_acc(rq(t, q), rq_fwd(P[pfx + name + ".weight"], q), P[pfx + name + ".bias"], padding=pad)
 
     def gn(t, name):
         return F.relu(F.group_norm(t, 8, P[pfx + name + ".weight"], P[pfx + name + ".bias"], 1e-5))
@@ -450,8 +510,8 @@ def cem_forward(P, rec_feat, res_feat, pfx="cem_block.", q=False):
     ec = F.softmax(linear(res, P, pfx + "c2.", q=False), dim=-2)
     r = F.normalize(linear(rec, P, pfx + "c3.", q), dim=-1)
     s = F.normalize(res, dim=-1).transpose(-1, -2)
-    tsc = torch.clamp((torch.bmm(r, s) + 1.0) / 2.0, 1e-6, 1.0 - 1e-6)
-    energy = torch.bmm(torch.bmm(es.transpose(-1, -2), tsc), ec)
+    tsc = torch.clamp((bmm_acc(r, s) + 1.0) / 2.0, 1e-6, 1.0 - 1e-6)
+    energy = bmm_acc(bmm_acc(es.transpose(-1, -2), tsc), ec)
     return -1.0 * torch.sum(torch.log(energy + 1e-6)) * 1.0 / B
 
 

@@ -120,15 +120,28 @@ def _clone_batch(samples, targets):
 def _copy_batch(dst_s, dst_t, samples, targets):
     if samples is dst_s and targets is dst_t:        # the caller filled the static buffers in place (CapturedTrainStep.batch)
         return
+    dst, src = [], []
     for k, v in samples.items():
         if isinstance(v, utils.NestedTensor):
-            dst_s[k].tensors.copy_(v.tensors, non_blocking=True); dst_s[k].mask.copy_(v.mask, non_blocking=True)
+            dst += [dst_s[k].tensors, dst_s[k].mask]; src += [v.tensors, v.mask]
         elif torch.is_tensor(v):
-            dst_s[k].copy_(v, non_blocking=True)
+            dst.append(dst_s[k]); src.append(v)
     for d, t in zip(dst_t, targets):
         for k, v in t.items():
             if torch.is_tensor(v):
-                d[k].copy_(v, non_blocking=True)
+                dst.append(d[k]); src.append(v)
+    # device -> device with matching dtypes (the steady state of a loop: batches come from the prefetcher): ONE multi-tensor
+    # copy for the ~20 small fields instead of a launch each -- they sit on the critical path between two replays
+    big = [i for i, (a, b) in enumerate(zip(dst, src)) if a.numel() >= (1 << 20) or a.dtype != b.dtype or a.device != b.device
+           or a.shape != b.shape]
+    for i in big:
+        dst[i].copy_(src[i], non_blocking=True)
+    groups = {}
+    for i in range(len(dst)):
+        if i not in set(big):
+            groups.setdefault(dst[i].dtype, []).append(i)
+    for idx in groups.values():                       # one launch per dtype (the multi-tensor fast path wants uniform lists)
+        torch._foreach_copy_([dst[i] for i in idx], [src[i] for i in idx], non_blocking=True)
 
 
 # Stream capture is made thread-local: torch.distributed's RCCL watchdog thread polls hipEventQuery on its own schedule,
@@ -482,19 +495,28 @@ def captured_train_step(model, criterion, samples, targets, optimizer, lr_schedu
             if other is not cap:
                 other.flush()
     cap(samples, targets)
-    if lookahead is not None:                 # host work under the replay: next batch's H2D hand-over + staging copies
-        nxt = lookahead()
-        if nxt is not None and nxt[0] is not None:
-            cap.stage(*nxt)
     # ONE device -> host copy for everything the loop looks at (losses for the meters and the finite check, gradient norm);
-    # under data parallelism the loss entries are first averaged over the ranks in one all-reduce (util/misc.py:136-160)
+    # under data parallelism the loss entries are first averaged over the ranks in one all-reduce (util/misc.py:136-160).
+    # The copy is enqueued right behind the replay, into pinned memory; the host then spends the step's run time fetching and
+    # staging the NEXT batch (H2D hand-over, copies into the graph's input buffers -- stream-ordered BEHIND the stats copy) and
+    # only then waits for the copy's event: the staging copies run while the host is already launching the next replay.
     stats = cap.stats
     k = len(cap.stat_names)
     if utils.get_world_size() > 1:
         stats = stats.clone()
         torch.distributed.all_reduce(stats[:k])
         stats[:k] /= utils.get_world_size()
-    host = stats.tolist()
+    if getattr(cap, "_stats_host", None) is None:
+        cap._stats_host = torch.empty(stats.numel(), dtype=torch.float32).pin_memory()
+        cap._stats_event = torch.cuda.Event()
+    cap._stats_host.copy_(stats, non_blocking=True)
+    cap._stats_event.record()
+    if lookahead is not None:
+        nxt = lookahead()
+        if nxt is not None and nxt[0] is not None:
+            cap.stage(*nxt)
+    cap._stats_event.synchronize()
+    host = cap._stats_host.tolist()
     weight_dict = criterion.weight_dict
     unscaled = {f"{n}_unscaled": v for n, v in zip(cap.stat_names, host)}
     scaled = {n: v * weight_dict[n] for n, v in zip(cap.stat_names, host) if n in weight_dict}

@@ -47,6 +47,11 @@ def hash_keep(seed, idx, p):
     # 8-wave workgroups
     (200, 256, 256, 51), (3520, 2048, 256, 52), (333, 192, 72, 53), (12800, 256, 1024, 54), (129, 64, 68, 51),
     (700, 256, 264, 61), (3520, 2048, 256, 62), (333, 192, 328, 63),
+    # software-pipelined LDS-DMA variants (fragments of tile kt+1 read under the MFMAs of tile kt): one K tile, odd and even counts
+    (129, 64, 68, 231), (200, 256, 256, 231), (3520, 2048, 256, 233), (320, 768, 3072, 233), (333, 192, 72, 221), (333, 320, 72, 221),
+    (320, 768, 3072, 81), (320, 3072, 768, 281), (333, 192, 72, 281), (129, 64, 68, 282), (320, 768, 768, 282), (333, 320, 72, 283),
+    (320, 3072, 768, 284), (50, 128, 40, 281),
+    (200, 256, 256, 211), (700, 320, 264, 251), (3520, 2048, 256, 252), (129, 64, 68, 251), (12800, 256, 1024, 251),
 ])
 def test_linear_fwd(hip, M, K, N, hint):
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -100,7 +105,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54, 61, 62, 63])
+@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54, 61, 62, 63, 211, 221, 231, 233, 251, 252])
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", [CONV_CASES[1], CONV_CASES[4], CONV_CASES[2]])
 def test_conv_dma_variants(hip, hint, B, H, W, Ci, Co, k, s, p):
     """The LDS-DMA tile variants against torch fp32: forward gather and transposed (backward-data) gather."""

@@ -187,3 +187,35 @@ def test_roberta_backbone_golden():
     assert rel(gp[:20], g["grad_pos_emb"]) < 1e-4 and rel(gw[[101, 102]], g["grad_word_rows"]) < 1e-4
     # rows 0 / 1 (unused / padding position: masked keys pass no gradient) stay zero, token positions start at 2
     assert float(gp[:2].abs().sum()) == 0 and float(gp[2:14].abs().sum()) > 0
+
+
+def test_bf16_rounding_flip_floor_is_a_property_of_the_format_not_of_an_implementation():
+    """two forwards of the SAME q=True computation (bf16 rounding points of the HIP path) that differ only
+    in the accumulation of every contraction -- torch's fp32 order vs fp64 (`O.accumulate_fp64`) -- at configs[0] size and full
+    depth.  In fp32 arithmetic the order is invisible (< 1e-5); with bf16 operands the two orders land ~6-8e-3 apart on the
+    logits and ~1.3-1.6e-3 on the boxes: the level at which the HIP path sits relative to the q-oracle
+    (tests/test_parity_fullsize_gpu.py).  A distance <= 2e-3 here would have meant the HIP path carries a systematic term."""
+    import torch
+    from oracle import reftr_oracle as O
+    from oracle.shapes import param_shapes
+    from oracle.synth import make_inputs
+    from oracle.weights import formula_state
+    ocfg = O.Cfg()
+    P = formula_state(param_shapes(ocfg))
+    samples, _ = make_inputs("e2e_single", B=2, H=320, W=320, L=40)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    with torch.no_grad():
+        a = O.reftr_forward(P, samples, ocfg, q=True)
+        f = O.reftr_forward(P, samples, ocfg, q=False)
+        with O.accumulate_fp64():
+            b = O.reftr_forward(P, samples, ocfg, q=True)
+            g = O.reftr_forward(P, samples, ocfg, q=False)
+    floor = {k: rel(a[k], b[k]) for k in ("c5", "memory", "logits")}
+    floor["boxes"] = rel(a["logits"].sigmoid(), b["logits"].sigmoid())
+    exact = {k: rel(f[k], g[k]) for k in ("c5", "memory", "logits")}
+    print("\n[order floor, configs[0] full depth] q=True fp32-order vs fp64-acc:", {k: "%.2e" % v for k, v in floor.items()},
+          "| fp32 arithmetic:", {k: "%.1e" % v for k, v in exact.items()})
+    assert all(v < 1e-5 for v in exact.values()), exact
+    assert 3e-3 < floor["logits"] < 2e-2 and 3e-3 < floor["c5"] < 2e-2 and 6e-4 < floor["boxes"] < 4e-3, floor
