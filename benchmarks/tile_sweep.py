@@ -12,19 +12,41 @@ SHAPES = [("l1 64->256 @160", 204800, 64, 256), ("l1 256->64 @160", 204800, 256,
           ("bert 768->768", 320, 768, 768), ("bert 768->3072", 320, 768, 3072), ("bert 3072->768", 320, 3072, 768),
           ("bert 768->2304", 320, 768, 2304), ("bert 2304->768", 320, 2304, 768),
           ("big 4096^3", 4096, 4096, 4096)]
+# FLUSH=1: every timed launch runs on COLD caches, as in the training step (weights untouched since the last step, activations
+# at best in the MALL): a 640 MB streaming pass between launches evicts L2 + MALL; its own time (a graph of flushes only) is
+# subtracted.  Warm back-to-back launches (the default) flatter deep software pipelines: round 3 measured the pipelined 128 x 128
+# tile 17 % faster warm and 12 % slower in the step.
+FLUSH = os.environ.get("FLUSH", "0") == "1"
+_fl = None
+def _flush():
+    global _fl
+    if _fl is None:
+        _fl = (torch.empty(160 << 20, dtype=torch.float32, device="cuda"), torch.zeros(1, device="cuda"))
+    _fl[0].add_(1.0)
 def graph_time(fn, iters=20):
-    fn(); torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
+    def body():
+        if FLUSH: _flush()
         fn()
-    torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
-        for _ in range(iters): fn()
-    g.replay(); torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    body(); torch.cuda.synchronize()
+    def timed(b):
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            b()
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            for _ in range(iters): b()
+        g.replay(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    t = timed(body)
+    if FLUSH:
+        global _flush_us
+        if "_flush_us" not in globals():
+            _flush_us = timed(_flush)
+        t -= _flush_us
+    return t
 if __name__ != "__main__":
     CONVS = SHAPES = []
 elif os.environ.get("ONLY") == "lin":

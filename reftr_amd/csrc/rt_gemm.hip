@@ -319,8 +319,27 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         else if (a.N > 64 && t128 >= 384) hint = 1;
         else if (t12864 >= 256) hint = 2;
         else hint = 3;
-        static const int tilev = getenv("REFTR_TILEV") ? atoi(getenv("REFTR_TILEV")) : 2;
-        if (dma && tilev >= 2) {
+        static const int tilev = getenv("REFTR_TILEV") ? atoi(getenv("REFTR_TILEV")) : 3;
+        if (dma && tilev >= 3) {
+            // round 3 (profiles/r03_tile_sweep_warm.txt / _cold.txt, r03_instep_ab.txt).  Two lessons: (1) back-to-back launches of
+            // one shape on warm caches are a misleading yardstick -- the software-pipelined K loop (hints 2xx: fragments of tile
+            // kt+1 read under the MFMAs of tile kt, one barrier per K tile) wins 8-20 % there and LOSES in the step, where the
+            // weights come from HBM and the kernels are bound by bytes in flight per CU; the sweep now has a cold mode (FLUSH=1)
+            // and only what wins in both is adopted: the pipelined 3-stage forms (64 x 64 on the layer4-sized 3x3 convolutions,
+            // 128 x 128 at ONE workgroup per CU where the tiles do not fill two per CU anyway: layer3's 3x3).  (2) The M = B * L
+            // Linears of the language branch (<= 96 tiles of 64 x 64: 60 CUs pulling at ~50 GB/s each) run on 32 x 32 tiles
+            // (4x the workgroups), the other few-tile products on the 3-stage 64 x 64 tile also for K < 1024.
+            static const int smallt = getenv("REFTR_SMALLT") ? atoi(getenv("REFTR_SMALLT")) : 1;
+            static const int pipe = getenv("REFTR_PIPE") ? atoi(getenv("REFTR_PIPE")) : 3;         // bit 0: 128x128 / 3 stages, bit 1: 64x64 / 3 stages
+            const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+            const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+            if (dense && smallt && a.M <= 1024 && t64 < 256 && (a.N & 7) == 0) hint = t64 <= 96 ? 281 : 33;
+            else if (a.K < 1024) hint = (a.N >= 128 && t128 >= 384 && t128 <= 512) ? 51 : 31;
+            else if (dense && a.K >= 2048 && a.N >= 128 && t256 >= 512) hint = 262;     // big products only; none in the step
+            else if (a.N > 64 && (t128 >= 384 || (a.K >= 2048 && t128 >= 192))) hint = (!dense && (pipe & 1) && a.K >= 2048 && t128 <= 256) ? 252 : 51;
+            else if (t12864 >= 256) hint = 21;
+            else hint = (!dense && (pipe & 2)) ? 233 : 33;
+        } else if (dma && tilev >= 2) {
             // round 2 (profiles/r02_tile_sweep_8wave.txt): the 128x128 tile runs on 8-wave workgroups (2 x 4 waves, 16 waves per CU
             // at two workgroups: beats the 4-wave form on every shape); it takes over the long reductions with >= 1.5 rounds of
             // tiles (or >= 0.75 rounds from K = 2048 up) and the short ones whose tiles fill exactly one round of 2 per CU
@@ -364,7 +383,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         case 61: return launch_gemm_dma<256, 128, 2, 1, 8>(a, s);
         case 62: return launch_gemm_dma<256, 128, 3, 1, 8>(a, s);
         case 63: return launch_gemm_dma<128, 256, 2, 1, 8>(a, s);
-        case 211: case 221: case 231: case 233: case 251: case 252:
+        case 211: case 221: case 231: case 233: case 251: case 252: case 261: case 262:
         case 81: case 281: case 282: case 283: case 284: return rt_launch_gemm_pipe(a, hint, s);
         default: return RT_ERR_BADARG;
     }

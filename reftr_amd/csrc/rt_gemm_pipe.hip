@@ -12,6 +12,8 @@ int rt_launch_gemm_pipe(const GemmArgs& a, int hint, hipStream_t s) {
         case 211: return launch_gemm_dma<128, 128, 2, 2, 4, 1>(a, s);
         case 251: return launch_gemm_dma<128, 128, 2, 2, 8, 1>(a, s);
         case 252: return launch_gemm_dma<128, 128, 3, 1, 8, 1>(a, s);
+        case 261: return launch_gemm_dma_dense<256, 128, 2, 1, 8, 1>(a, s);
+        case 262: return launch_gemm_dma_dense<256, 128, 3, 1, 8, 1>(a, s);
         // small tiles for the few-row Linears (BERT at M = B * L = 320: 60 tiles of 64 x 64 leave 196 CUs idle and every busy CU's
         // load path at ~50 GB/s; 32-row / 32-column tiles put the same bytes through 2-4x the CUs): dense rows only
         case 81:  return launch_gemm_dma_dense<32, 32, 3, 4, 4, 0>(a, s);

@@ -437,72 +437,118 @@ class Lookahead:
         return self.batch
 
 
-def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4, lookahead=None):
-    """`train_step` with the same return value, replayed from hipGraphs: the first batch of an input shape captures a
-    CapturedTrainStep (kept on the model), later batches of that shape replay it.  Falls back to the eager `train_step` for
-    CPU tensors, foreign optimizers and once more than `max_shapes` different shapes have been seen (variable-size data).
-    `lookahead` (a Lookahead) is called while the replay runs: the next batch is fetched and staged into the graph's input
-    buffers under the current step instead of in front of the next one."""
+class _EagerResult:
+    """finish() of a step that ran eagerly: the values are already there."""
+
+    def __init__(self, res):
+        self.res = res
+
+    def finish(self):
+        return self.res
+
+
+class _ReplayInFlight:
+    """A replayed step between its launch and its host read-out (`finish`)."""
+
+    def __init__(self, cap, criterion):
+        self.cap, self.criterion = cap, criterion
+
+    def finish(self):
+        cap = self.cap
+        cap._stats_event.synchronize()
+        host = cap._stats_host.tolist()
+        k = len(cap.stat_names)
+        weight_dict = self.criterion.weight_dict
+        unscaled = {f"{n}_unscaled": v for n, v in zip(cap.stat_names, host)}
+        scaled = {n: v * weight_dict[n] for n, v in zip(cap.stat_names, host) if n in weight_dict}
+        loss_value = sum(scaled.values())
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            print(unscaled)
+            sys.exit(1)
+        return loss_value, scaled, unscaled, host[k]
+
+
+def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4, lookahead=None):
+    """Launches one iteration of the loop body and returns a handle; `handle.finish()` waits for it and returns what
+    `train_step` returns.  Between the two the caller may do host work (the epoch loop books the previous iteration's meters).
+
+    Replayed from hipGraphs: the first batch of an input shape captures a CapturedTrainStep (kept on the model), later batches
+    of that shape replay it; CPU tensors, foreign optimizers and more than `max_shapes` different shapes (variable-size data)
+    run the eager `train_step`.  `lookahead` (a Lookahead) is called while the replay runs: the next batch is fetched and staged
+    into the graph's input buffers under the current step instead of in front of the next one.
+
+    Everything the host does between an iteration's read-out and the next launch is device idle time, so the steady state is
+    short: a batch that the previous iteration already staged is recognised by identity (no shape key, no lookups), the
+    scheduler step and the stats copy are issued right behind the launch."""
     inner = getattr(model, "module", model)
     caps = inner.__dict__.setdefault("_captured_steps", {})
-    img = samples.get("img")
-    ok = (isinstance(img, utils.NestedTensor) and img.tensors.is_cuda and hasattr(optimizer, "clip_grad_norm_")
-          and os.environ.get("REFTR_TRAIN_GRAPH", "1") == "1")
-    key = None
-    if ok:
-        key = (CapturedTrainStep.shape_key(samples, targets), id(criterion), id(optimizer), float(max_norm), model.training)
-        ok = key in caps or len(caps) < max_shapes
-    if utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1:
-        # Data parallel: replaying, capturing and the eager loop issue DIFFERENT collective sequences (a capture adds the
-        # num_boxes all-reduce of its constructor and warm-up iterations with real gradient exchanges), and both the shape
-        # key (per-image box counts, image sizes) and the capture budget are rank-local.  The choice is therefore made
-        # collectively: replay only if EVERY rank holds a capture for its batch, capture only if every rank would capture,
-        # otherwise every rank runs the eager step.  One 2-word MIN all-reduce per iteration, issued while the device is
-        # idle behind the previous iteration's loss .item().
-        mine = ok
-        ok = dp_capture_decision(ok and key in caps, ok and key not in caps, inner.store.device) != "eager"
-        if mine and not ok:
-            # this rank could have replayed / captured, another one could not (its capture budget is spent, or its batch has a
-            # shape this rank already holds while the other must still capture): the whole job runs this iteration eagerly.
-            # Said once per shape -- a run that quietly degrades to eager launches is 2-3x slower.
-            seen = inner.__dict__.setdefault("_dp_eager_logged", set())
-            if key not in seen:
-                seen.add(key)
-                print(f"[reftr_amd] rank {utils.get_rank()}: data-parallel step runs eagerly (ranks disagree on replay/capture for this "
-                      f"input shape; {len(caps)} of {max_shapes} captures in use)", file=sys.stderr)
-    if not ok:
-        for other in caps.values():             # a pending (deferred) update must land before the eager forward
-            other.flush()
-        return train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm)
-    cap = caps.get(key)
-    if cap is None:
-        for other in caps.values():             # one pending (deferred) update at a time
-            other.flush()
-        # the capture's warm-up iterations are real updates on this batch: take them back, so that the loop sees exactly one
-        # update per batch, like the eager loop
-        st = inner.store
-        snap = (st.flat_p.clone(), optimizer.m.clone(), optimizer.v.clone(), optimizer.step_dev.clone(), optimizer.step_count,
-                inner.seed_dev.clone(), inner._step)
-        cap = caps[key] = CapturedTrainStep(model, criterion, optimizer, max_norm, samples, targets)
-        cap.reset_pending()
-        st.flat_p.copy_(snap[0]); optimizer.m.copy_(snap[1]); optimizer.v.copy_(snap[2]); optimizer.step_dev.copy_(snap[3])
-        optimizer.step_count = snap[4]
-        inner.seed_dev.copy_(snap[5]); inner._step = snap[6]
-        inner.mark_dirty(full=True)
-        del snap
+    dist_on = utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1
+    cap = inner.__dict__.get("_staged_cap")
+    if cap is not None and not dist_on and cap._staged is not None and cap._staged[0] is samples and cap._staged[1] is targets \
+            and cap.criterion is criterion and cap.optimizer is optimizer and cap.max_norm == max_norm and cap.training == model.training:
+        pass                                                   # steady state: staged by the previous iteration's lookahead
     else:
-        for other in caps.values():
-            if other is not cap:
+        cap = None
+        img = samples.get("img")
+        ok = (isinstance(img, utils.NestedTensor) and img.tensors.is_cuda and hasattr(optimizer, "clip_grad_norm_")
+              and os.environ.get("REFTR_TRAIN_GRAPH", "1") == "1")
+        key = None
+        if ok:
+            key = (CapturedTrainStep.shape_key(samples, targets), id(criterion), id(optimizer), float(max_norm), model.training)
+            ok = key in caps or len(caps) < max_shapes
+        if dist_on:
+            # Data parallel: replaying, capturing and the eager loop issue DIFFERENT collective sequences (a capture adds the
+            # num_boxes all-reduce of its constructor and warm-up iterations with real gradient exchanges), and both the shape
+            # key (per-image box counts, image sizes) and the capture budget are rank-local.  The choice is therefore made
+            # collectively: replay only if EVERY rank holds a capture for its batch, capture only if every rank would capture,
+            # otherwise every rank runs the eager step.  One 2-word MIN all-reduce per iteration, issued while the device is
+            # idle behind the previous iteration's read-out.
+            mine = ok
+            ok = dp_capture_decision(ok and key in caps, ok and key not in caps, inner.store.device) != "eager"
+            if mine and not ok:
+                # this rank could have replayed / captured, another one could not (its capture budget is spent, or its batch has a
+                # shape this rank already holds while the other must still capture): the whole job runs this iteration eagerly.
+                # Said once per shape -- a run that quietly degrades to eager launches is 2-3x slower.
+                seen = inner.__dict__.setdefault("_dp_eager_logged", set())
+                if key not in seen:
+                    seen.add(key)
+                    print(f"[reftr_amd] rank {utils.get_rank()}: data-parallel step runs eagerly (ranks disagree on replay/capture for "
+                          f"this input shape; {len(caps)} of {max_shapes} captures in use)", file=sys.stderr)
+        if not ok:
+            for other in caps.values():             # a pending (deferred) update must land before the eager forward
                 other.flush()
+            return _EagerResult(train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm))
+        cap = caps.get(key)
+        if cap is None:
+            for other in caps.values():             # one pending (deferred) update at a time
+                other.flush()
+            # the capture's warm-up iterations are real updates on this batch: take them back, so that the loop sees exactly one
+            # update per batch, like the eager loop
+            st = inner.store
+            snap = (st.flat_p.clone(), optimizer.m.clone(), optimizer.v.clone(), optimizer.step_dev.clone(), optimizer.step_count,
+                    inner.seed_dev.clone(), inner._step)
+            cap = caps[key] = CapturedTrainStep(model, criterion, optimizer, max_norm, samples, targets)
+            cap.training = model.training
+            cap.reset_pending()
+            st.flat_p.copy_(snap[0]); optimizer.m.copy_(snap[1]); optimizer.v.copy_(snap[2]); optimizer.step_dev.copy_(snap[3])
+            optimizer.step_count = snap[4]
+            inner.seed_dev.copy_(snap[5]); inner._step = snap[6]
+            inner.mark_dirty(full=True)
+            del snap
+        else:
+            for other in caps.values():
+                if other is not cap:
+                    other.flush()
     cap(samples, targets)
     # ONE device -> host copy for everything the loop looks at (losses for the meters and the finite check, gradient norm);
     # under data parallelism the loss entries are first averaged over the ranks in one all-reduce (util/misc.py:136-160).
-    # The copy is enqueued right behind the replay, into pinned memory; the host then spends the step's run time fetching and
-    # staging the NEXT batch (H2D hand-over, copies into the graph's input buffers -- stream-ordered BEHIND the stats copy) and
-    # only then waits for the copy's event: the staging copies run while the host is already launching the next replay.
+    # The copy is enqueued right behind the replay, into pinned memory; the host then spends the step's run time on the
+    # scheduler, on fetching and staging the NEXT batch (H2D hand-over, copies into the graph's input buffers -- stream-ordered
+    # BEHIND the stats copy) and only then waits for the copy's event.
     stats = cap.stats
-    k = len(cap.stat_names)
-    if utils.get_world_size() > 1:
+    if dist_on:
+        k = len(cap.stat_names)
         stats = stats.clone()
         torch.distributed.all_reduce(stats[:k])
         stats[:k] /= utils.get_world_size()
@@ -511,23 +557,19 @@ def captured_train_step(model, criterion, samples, targets, optimizer, lr_schedu
         cap._stats_event = torch.cuda.Event()
     cap._stats_host.copy_(stats, non_blocking=True)
     cap._stats_event.record()
+    if lr_scheduler is not None:
+        lr_scheduler.step()          # host state only; the device reads the new rates when the next launch syncs them
+    inner.__dict__["_staged_cap"] = None
     if lookahead is not None:
         nxt = lookahead()
-        if nxt is not None and nxt[0] is not None:
-            cap.stage(*nxt)
-    cap._stats_event.synchronize()
-    host = cap._stats_host.tolist()
-    weight_dict = criterion.weight_dict
-    unscaled = {f"{n}_unscaled": v for n, v in zip(cap.stat_names, host)}
-    scaled = {n: v * weight_dict[n] for n, v in zip(cap.stat_names, host) if n in weight_dict}
-    loss_value = sum(scaled.values())
-    if not math.isfinite(loss_value):
-        print("Loss is {}, stopping training".format(loss_value))
-        print(unscaled)
-        sys.exit(1)
-    if lr_scheduler is not None:
-        lr_scheduler.step()
-    return loss_value, scaled, unscaled, host[k]
+        if nxt is not None and nxt[0] is not None and cap.stage(*nxt):
+            inner.__dict__["_staged_cap"] = cap
+    return _ReplayInFlight(cap, criterion)
+
+
+def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4, lookahead=None):
+    """`train_step` with the same return value, on `begin_train_step` (launch) + `finish` (read-out)."""
+    return begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm, max_shapes, lookahead).finish()
 
 
 def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, device, epoch, max_norm=0):
@@ -537,14 +579,21 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
     header = "Epoch: [{}]".format(epoch)
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
+    booked = None
     for _ in board.log_every(range(len(data_loader)), 50, header):
         # the loop body of engine_vg.py:40-72 -- replayed from hipGraphs for fixed-shape data (RefCOCO: 640 x 640, L = 40);
-        # the replayed path hands back host numbers (one stacked copy per iteration), the eager one device scalars
+        # the replayed path hands back host numbers (one stacked copy per iteration), the eager one device scalars.  The
+        # iteration is read out (finite check included) BEFORE the next one is launched, as in the reference; only the meter
+        # bookkeeping of iteration i is done after iteration i+1 is on the device.
         ahead = Lookahead(prefetcher.next)
-        loss_value, scaled, unscaled, gnorm = captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm,
-                                                                  lookahead=ahead)
-        board.add(loss=loss_value, **scaled, **unscaled, lr=optimizer.param_groups[0]["lr"], grad_norm=gnorm)
+        step = begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm, lookahead=ahead)
+        if booked is not None:
+            board.add(**booked)
+        loss_value, scaled, unscaled, gnorm = step.finish()
+        booked = dict(loss=loss_value, **scaled, **unscaled, lr=optimizer.param_groups[0]["lr"], grad_norm=gnorm)
         samples, targets = ahead()
+    if booked is not None:
+        board.add(**booked)
     board.synchronize_between_processes()
     print("Averaged stats:", board)
     return board.global_avg()

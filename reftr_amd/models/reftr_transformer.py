@@ -402,6 +402,19 @@ class RefTR(nn.Module):
         """The boundaries this model's backward actually passes (serial schedule: BERT is cut in thirds only from 3 layers up)."""
         return tuple(b for b in self.BOUNDARIES if self.cfg.bert.layers >= 3 or b not in ("bert_hi", "bert_mid"))
 
+    def bert_cuts(self):
+        """{BERT layer index: boundary reached right after that layer's backward} of the interleaved schedule.
+        REFTR_DDP_BERT_CUTS=2 (default, round 3): BERT's backward in HALVES -- layers 11-6 + pooler beside ResNet layer4, layers 5-0 +
+        embeddings beside layer3 -- so that every BERT byte (72 % of the exchange) is on the wire before ResNet layer2's backward
+        starts and only layer2-3's 17 MB (bf16: 8.6 MB) are exposed at the end.  =3: thirds (round 2: the last third, 107 MB in
+        bf16, finished together with layer2 and was exchanged exposed)."""
+        nl = self.cfg.bert.layers
+        if nl < 3:
+            return {}
+        if os.environ.get("REFTR_DDP_BERT_CUTS", "2") == "3":
+            return {(2 * nl) // 3: "pair4", nl // 3: "pair3"}
+        return {nl // 2: "pair4"}             # the second call of the walk runs to the end of BERT (embeddings included): "pair3"
+
     @property
     def dp_mode(self):
         return bool(self._stops) or any(self._phase_hooks.values())
@@ -565,7 +578,7 @@ class RefTR(nn.Module):
             net.side.join(); net.wg.join()
             yield "main"
             nl = cfg.bert.layers
-            cuts = {(2 * nl) // 3: "pair4", nl // 3: "pair3"} if nl >= 3 else {}
+            cuts = self.bert_cuts()
             if sv["pctx"] is None:
                 passes = [(sv["bctx"], d_seq, dpool)]
             else:

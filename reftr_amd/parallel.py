@@ -110,6 +110,11 @@ class DistributedDataParallel(nn.Module):
         if self.module.dp_schedule == "interleave":
             l3 = off("img_backbone.0.body.layer3.0.conv1.weight")
             assert ra <= l3 <= l4
+            cuts = self.module.bert_cuts()
+            if len(cuts) == 1:              # halves: BERT is complete (embeddings included) at 'pair3'; only ResNet layer2 is left
+                half = lay(next(iter(cuts)))
+                assert ba <= half <= bb
+                return {"main": (ma, kb), "pair4": [(l4, rb), (half, bb)], "pair3": [(l3, l4), (ba, half)], "end": [(ra, l3)]}
             return {"main": (ma, kb), "pair4": [(l4, rb), (hi, bb)], "pair3": [(l3, l4), (mid, hi)], "end": [(ra, l3), (ba, mid)]}
         return {"main": (ma, kb), "bert_hi": (hi, bb), "bert_mid": (mid, hi), "bert": (ba, mid),
                 "layer4": (l4, rb), "end": (ra, l4)}

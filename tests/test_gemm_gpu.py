@@ -51,6 +51,7 @@ def hash_keep(seed, idx, p):
     (129, 64, 68, 231), (200, 256, 256, 231), (3520, 2048, 256, 233), (320, 768, 3072, 233), (333, 192, 72, 221), (333, 320, 72, 221),
     (320, 768, 3072, 81), (320, 3072, 768, 281), (333, 192, 72, 281), (129, 64, 68, 282), (320, 768, 768, 282), (333, 320, 72, 283),
     (320, 3072, 768, 284), (50, 128, 40, 281),
+    (700, 256, 264, 261), (3520, 2048, 256, 262),
     (200, 256, 256, 211), (700, 320, 264, 251), (3520, 2048, 256, 252), (129, 64, 68, 251), (12800, 256, 1024, 251),
 ])
 def test_linear_fwd(hip, M, K, N, hint):

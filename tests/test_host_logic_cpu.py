@@ -225,13 +225,19 @@ def test_optimizer_state_roundtrip_with_torch_adamw(masks):
     assert [g_["lr"] for g_ in back.param_groups] == [1e-4, 1e-5, 1e-5, 1e-4] and back.param_groups[0]["weight_decay"] == 1e-4
 
 
-def test_dp_interleaved_schedule_pairs_bert_thirds_with_resnet_stages(monkeypatch):
-    """REFTR_DDP_SCHEDULE=interleave (default): BERT's backward keeps its own stream; the slices that are final together -- a BERT
-    third and the ResNet stage that ran beside it -- are exchanged at one boundary; disjoint and covering."""
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("cuts", ["2", "3"])
+def test_dp_interleaved_schedule_pairs_bert_parts_with_resnet_stages(monkeypatch, cuts):
+    """REFTR_DDP_SCHEDULE=interleave (default): BERT's backward keeps its own stream; the slices that are final together -- a part
+    of BERT and the ResNet stage that ran beside it -- are exchanged at one boundary; disjoint and covering.  BERT is walked in
+    halves (default, round 3: nothing of BERT is left for the exposed end) or thirds (REFTR_DDP_BERT_CUTS=3)."""
     from reftr_amd.models import layout as L
     from reftr_amd.models.reftr_transformer import RefTR
     from reftr_amd.parallel import DistributedDataParallel
     monkeypatch.delenv("REFTR_DDP_SCHEDULE", raising=False)
+    monkeypatch.setenv("REFTR_DDP_BERT_CUTS", cuts)
     cfg = L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=6))
     m = RefTR(cfg, device="cpu")
     ddp = DistributedDataParallel(m, n_chunks=7)
@@ -242,12 +248,20 @@ def test_dp_interleaved_schedule_pairs_bert_thirds_with_resnet_stages(monkeypatc
     assert spans[0][0] == 0 and spans[-1][1] == st.flat_g.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     off = lambda n: st.offset[n][1]                                       # noqa: E731
     q = "lang_backbone.encoder.layer.%d.attention.self.query.weight"
-    assert sl["pair4"] == [(off("img_backbone.0.body.layer4.0.conv1.weight"), st.group_range[L.GROUP_BACKBONE][1]),
-                           (off(q % 4), st.group_range[L.GROUP_BERT][1])]
-    assert sl["pair3"] == [(off("img_backbone.0.body.layer3.0.conv1.weight"), off("img_backbone.0.body.layer4.0.conv1.weight")),
-                           (off(q % 2), off(q % 4))]
-    assert sl["end"] == [(st.group_range[L.GROUP_BACKBONE][0], off("img_backbone.0.body.layer3.0.conv1.weight")),
-                         (st.group_range[L.GROUP_BERT][0], off(q % 2))]
+    l3, l4 = off("img_backbone.0.body.layer3.0.conv1.weight"), off("img_backbone.0.body.layer4.0.conv1.weight")
+    (ra, rb), (ba, bb) = st.group_range[L.GROUP_BACKBONE], st.group_range[L.GROUP_BERT]
+    if cuts == "3":
+        assert m.bert_cuts() == {4: "pair4", 2: "pair3"}
+        assert sl["pair4"] == [(l4, rb), (off(q % 4), bb)]
+        assert sl["pair3"] == [(l3, l4), (off(q % 2), off(q % 4))]
+        assert sl["end"] == [(ra, l3), (ba, off(q % 2))]
+    else:
+        assert m.bert_cuts() == {3: "pair4"}
+        assert sl["pair4"] == [(l4, rb), (off(q % 3), bb)]
+        assert sl["pair3"] == [(l3, l4), (ba, off(q % 3))]                # embeddings + layers 0-2: BERT is complete here
+        assert sl["end"] == [(ra, l3)]                                   # only ResNet layer2 is exchanged exposed
+        exposed = sum(b - a for a, b in sl["end"])
+        assert exposed < 0.05 * st.flat_g.numel()
     pb = ddp.phase_bounds()
     assert list(pb) == ["main", "pair4", "pair3", "end"]
     chunks = sorted(c for v in pb.values() for c in v)
