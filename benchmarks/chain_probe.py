@@ -18,6 +18,11 @@ def chain_hot():
     t = x
     for _ in range(64):
         t, _ = hip.linear(t, W[0])
+bias = torch.randn(256, device=dev); res = torch.randn(8, 256, device=dev)
+def chain_hot_epi():          # decoder-style link: + bias, + fp32 residual, fp32 and bf16 outputs
+    t = x
+    for _ in range(64):
+        t, _ = hip.linear(t, W[0], bias=bias, res_f32=res, out_bf16=True, out_f32=True)
 def chain_cold():
     flush.fill_(1)            # evict L2 / infinity cache
     t = x
@@ -35,6 +40,7 @@ def chain_ffn_cold():
     for i in range(32):
         h, _ = hip.linear(t, Wbig[i]); t, _ = hip.linear(h, Wbig[i + 32].t().contiguous() if False else Wbig[i].view(256, 2048))
 for name, fn, n in (("trivial rows_add", chain_trivial, 64), ("skinny 256x256 hot weights", chain_hot, 64),
+                    ("skinny 256x256 hot + bias + res", chain_hot_epi, 64),
                     ("layernorm 8 rows", chain_ln, 64)):
     print("%-32s %.2f us per link" % (name, graph_time(fn, iters=5) / n))
 tf = graph_time(flush_only, iters=5)

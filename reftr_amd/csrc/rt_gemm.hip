@@ -210,8 +210,55 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_dma_grouped_kernel(const 
 // Skinny path (M <= 16 rows: the decoder / query-encoder / box-head Linears over B*n_q tokens).  No LDS tiles:
 // a workgroup owns 16 output features, its 4 waves split K four ways and stream both operands straight from
 // global memory into MFMA fragments (A = 16 weight rows, B = the <=16 token rows), then reduce through LDS.
+// Round 3: these launches are latency chains (86 per step at ~5 us for <= 1 MB of weights each), so the kernel is built around
+// round trips: (1) the epilogue's operands (bias, residuals, gates) are requested FIRST -- they depend on nothing computed here;
+// (2) a wave requests its whole K slice (CH k-steps = 2 * CH loads in flight; bounds-checked buffer loads, so ragged N / M rows
+// and steps past the slice are out-of-range zeros and the code is branch-free) before the first MFMA instead of 4 steps at a
+// time: linear2 of a decoder layer (K = 2048 over 16 workgroups) went from four dependent L2/HBM round trips to two.
+template <int CH>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt,
                                                           const GemmArgs p) {
+    __shared__ f32x4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nrow = n0 + li;
+    const int n = n0 + lg * 4;
+    const bool out_ok = wave == 0 && n < p.N && li < p.M;
+    Epi4Pre pre;
+    if (out_ok) pre = epi4_prefetch(p, li, n);
+    constexpr int OOB = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wgt), 0, p.wgt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(src), 0, p.src_bytes, 0x00020000);
+    const int w_off = nrow < p.N ? (nrow * p.K + lg * 8) * 2 : OOB;
+    const int x_off = li < p.M ? (li * p.K + lg * 8) * 2 : OOB;
+    const int ksteps = p.K >> 5;                       // 32-wide steps
+    const int per = (ksteps + 3) >> 2;
+    const int k_begin = wave * per, k_end = min(k_begin + per, ksteps);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    for (int ks = k_begin; ks < k_end; ks += CH) {
+        u32x4 wv[CH], xv[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const bool in = ks + j < k_end;
+            wv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, in ? w_off : OOB, (ks + j) << 6, 0);
+            xv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, in ? x_off : OOB, (ks + j) << 6, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wv[j]), *reinterpret_cast<bf16x8*>(&xv[j]), acc, 0, 0, 0);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (out_ok) epilogue4<true>(p, li, n, acc, &pre);
+}
+
+// round-2 form, kept as the A/B baseline (REFTR_SKINNY_V=1): 4 k-steps in flight, epilogue operands loaded after the reduction
+__global__ __launch_bounds__(256) void skinny_gemm_kernel_v1(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt,
+                                                             const GemmArgs p) {
     __shared__ f32x4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -220,7 +267,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
     const bool n_ok = nrow < p.N, m_ok = li < p.M;
     const bf16_t* wp = wgt + (size_t)(n_ok ? nrow : 0) * p.K + lg * 8;
     const bf16_t* xp = src + (size_t)(m_ok ? li : 0) * p.K + lg * 8;
-    const int ksteps = p.K >> 5;                       // 32-wide steps
+    const int ksteps = p.K >> 5;
     const int per = (ksteps + 3) >> 2;
     const int k_begin = wave * per, k_end = min(k_begin + per, ksteps);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -303,7 +350,13 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
 
     const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
     if (d->tile_hint == 0 && dense && a.M <= 16) {
-        hipLaunchKernelGGL(skinny_gemm_kernel, dim3((unsigned)((a.N + 15) / 16)), dim3(256), 0, s, a.src, a.wgt, a);
+        const dim3 grid((unsigned)((a.N + 15) / 16));
+        const int per = ((a.K >> 5) + 3) >> 2;          // k-steps per wave: the whole slice in flight when it fits 8 steps
+        static const int skinny_v = getenv("REFTR_SKINNY_V") ? atoi(getenv("REFTR_SKINNY_V")) : 2;
+        if (skinny_v == 1) hipLaunchKernelGGL(skinny_gemm_kernel_v1, grid, dim3(256), 0, s, a.src, a.wgt, a);
+        else if (per <= 2) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, dim3(256), 0, s, a.src, a.wgt, a);
+        else if (per <= 4) hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, s, a.src, a.wgt, a);
+        else hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(256), 0, s, a.src, a.wgt, a);
         RT_CHECK_LAUNCH();
         return RT_OK;
     }

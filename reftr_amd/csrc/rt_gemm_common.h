@@ -16,8 +16,26 @@ struct GemmArgs {
 
 // epilogue of one lane's 4 consecutive output features of row m:
 // +bias -> [+res] -> act -> dropout -> [+res] -> *gate -> *gelu'(preact) -> *(1 - dtanh^2) -> store
-static __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) {
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+// The operands epilogue4 reads, fetched ahead of the reduction (skinny kernel: the M <= 16 launches are pure latency chains --
+// launch -> operand loads -> MFMA -> LDS reduce -> EPILOGUE LOADS -> stores -- and the epilogue's loads depend on nothing the
+// kernel computes, so they are requested first and cost no round trip of their own).
+struct Epi4Pre { f32x4 bias, res; bf16x4 resb, gate, preact, dtanh; };
+static __device__ __forceinline__ Epi4Pre epi4_prefetch(const GemmArgs& p, int m, int n) {
+    Epi4Pre e;
+    const size_t o = (size_t)m * p.N + n;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    e.bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : z;
+    e.res = p.res_f32 ? *reinterpret_cast<const f32x4*>(p.res_f32 + o) : z;
+    e.resb = p.res_bf16 ? *reinterpret_cast<const bf16x4*>(p.res_bf16 + o) : bf16x4{};
+    e.gate = p.gate ? *reinterpret_cast<const bf16x4*>(p.gate + o) : bf16x4{};
+    e.preact = p.preact ? *reinterpret_cast<const bf16x4*>(p.preact + o) : bf16x4{};
+    e.dtanh = p.dtanh ? *reinterpret_cast<const bf16x4*>(p.dtanh + o) : bf16x4{};
+    return e;
+}
+
+template <bool PRE = false>
+static __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v, const Epi4Pre* e = nullptr) {
+    if (p.bias) v += PRE ? e->bias : *reinterpret_cast<const f32x4*>(p.bias + n);
     const size_t o = (size_t)m * p.N + n;
     if (p.out_preact) {
         bf16x4 pv;
@@ -26,9 +44,9 @@ static __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n
         *reinterpret_cast<bf16x4*>(p.out_preact + o) = pv;
     }
     if (p.res_first) {
-        if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
+        if (p.res_f32) v += PRE ? e->res : *reinterpret_cast<const f32x4*>(p.res_f32 + o);
         if (p.res_bf16) {
-            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
+            const bf16x4 rr = PRE ? e->resb : *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
         }
@@ -52,25 +70,25 @@ static __device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n
             v[r] = (rt_hash32(seed, (uint32_t)((o + r) >> p.drop_shift)) >= thresh) ? v[r] * keep_scale : 0.f;
     }
     if (!p.res_first) {
-        if (p.res_f32) v += *reinterpret_cast<const f32x4*>(p.res_f32 + o);
+        if (p.res_f32) v += PRE ? e->res : *reinterpret_cast<const f32x4*>(p.res_f32 + o);
         if (p.res_bf16) {
-            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
+            const bf16x4 rr = PRE ? e->resb : *reinterpret_cast<const bf16x4*>(p.res_bf16 + o);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
         }
     }
     if (p.gate) {
-        const bf16x4 gg = *reinterpret_cast<const bf16x4*>(p.gate + o);
+        const bf16x4 gg = PRE ? e->gate : *reinterpret_cast<const bf16x4*>(p.gate + o);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = ((float)gg[r] > 0.f) ? v[r] * p.gate_scale : 0.f;
     }
     if (p.preact) {
-        const bf16x4 uu = *reinterpret_cast<const bf16x4*>(p.preact + o);
+        const bf16x4 uu = PRE ? e->preact : *reinterpret_cast<const bf16x4*>(p.preact + o);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= rt_gelu_grad((float)uu[r]);
     }
     if (p.dtanh) {
-        const bf16x4 tt = *reinterpret_cast<const bf16x4*>(p.dtanh + o);
+        const bf16x4 tt = PRE ? e->dtanh : *reinterpret_cast<const bf16x4*>(p.dtanh + o);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= (1.f - (float)tt[r] * (float)tt[r]);
     }

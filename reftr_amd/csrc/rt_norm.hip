@@ -41,7 +41,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const rt_layernorm_d
     }
     const float rstd = rsqrtf(rt_wave_sum(ss) / D + p.eps);
     if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
-    const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
@@ -149,9 +148,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const rt_layerno
     constexpr int D = 256 * V;
     const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (size_t)row * D);
     f32x4 v[V];
+    // every load of the kernel is requested up front (one round trip): the affine parameters and the positional rows do not depend
+    // on the statistics, but sit behind the mean / rstd stores in program order (possible aliasing), where the compiler leaves them
+    const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
+    f32x4 gam_[V], bet_[V], pos_[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = xr[i * 64 + lane];
+        gam_[i] = *reinterpret_cast<const f32x4*>(p.gamma + c); bet_[i] = *reinterpret_cast<const f32x4*>(p.beta + c);
+        pos_[i] = p.ypos_bf16 ? *reinterpret_cast<const f32x4*>(p.pos + (size_t)orow * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) { v[i] = xr[i * 64 + lane]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    for (int i = 0; i < V; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = rt_wave_sum(s) * (1.f / D);
     float ss = 0.f;
 #pragma unroll
@@ -160,7 +170,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const rt_layerno
         for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; ss += d * d; }
     const float rstd = rsqrtf(rt_wave_sum(ss) * (1.f / D) + p.eps);
     if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
-    const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const rt_layerno
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = (i * 64 + lane) * 4;
-        const f32x4 gam = *reinterpret_cast<const f32x4*>(p.gamma + c), bet = *reinterpret_cast<const f32x4*>(p.beta + c);
+        const f32x4 gam = gam_[i], bet = bet_[i];
         f32x4 y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const rt_layerno
             *reinterpret_cast<bf16x4*>(yb + o) = b;
         }
         if (ypb) {
-            const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + o);
+            const f32x4 ps = pos_[i];
             bf16x4 b;
 #pragma unroll
             for (int e = 0; e < 4; ++e) b[e] = (bf16_t)(y[e] + ps[e]);

@@ -197,8 +197,13 @@ class CapturedTrainStep:
             self.phases = ["bert"] if inner.dp_schedule == "serial" else ["main"]
         self.two_phase = bool(self.phases)
         inner._stops = frozenset(self.phases)
-        self.deferred = (not self.two_phase and not self._post and hasattr(optimizer, "enable_deferred")
-                         and os.environ.get("REFTR_DEFER_OPT", "1") == "1")
+        can_defer = hasattr(optimizer, "enable_deferred") and os.environ.get("REFTR_DEFER_OPT", "1") == "1"
+        self.deferred = can_defer and not self.two_phase and not self._post
+        # data parallel (round 3): the same deferred schedule across the segment graphs -- the AdamW pass of iteration i sits at
+        # the head of iteration i+1's FIRST graph (its BERT slice on the language stream under the ResNet forward, reading the
+        # all-reduced bf16 gradients of iteration i, which nothing rewrites before this iteration's first exchange boundary), the
+        # last graph ends with the gradient norm.  REFTR_DEFER_DP=0: clip + AdamW in the last graph (round 2).
+        self.deferred_dp = can_defer and not self.deferred and os.environ.get("REFTR_DEFER_DP", "1") == "1"
         self._pending = False
         self._staged = None
         if self.deferred:
@@ -206,21 +211,25 @@ class CapturedTrainStep:
             return
         if hasattr(optimizer, "enable_device_lr"):
             optimizer.enable_device_lr()
+        if self.deferred_dp:
+            self._deferred_hooks()
+        head = self._head_deferred if self.deferred_dp else self._fwd_bwd
+        tail = self._tail_deferred if self.deferred_dp else self._opt
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    self._fwd_bwd()
+                    head()
                     for name in self.phases:
                         self._run(self._phase_hooks.get(name, ()))
                         inner.continue_backward()
-                    self._run(self._post); self._opt()
+                    self._run(self._post); tail()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()     # no collective in flight while capturing (see _CAPTURE_MODE)
             self.g_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode=_CAPTURE_MODE):
-                self.out = self._fwd_bwd()
+                self.out = head()
             self.g_seg = []
             for name in self.phases:                 # the segment that FOLLOWS boundary `name`
                 g = torch.cuda.CUDAGraph()
@@ -231,14 +240,18 @@ class CapturedTrainStep:
             self.g_bb = self.g_seg[-1] if self.g_seg else None
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
-                self._opt()
+                tail()
+            if self.deferred_dp:
+                self.grad_norm = optimizer.grad_norm
+                self._pending = True                   # the last warm-up iteration's update
+                self._set_flush(True)
         finally:
             inner._phase_hooks, inner._post_backward_hooks = self._phase_hooks, self._post
             inner._stops = frozenset()
             criterion.num_boxes_static = None
 
     # ------------------------------------------------------------------ deferred optimizer schedule
-    def _init_deferred(self, warmup):
+    def _deferred_hooks(self):
         from .models import layout as L
         inner, opt = self.inner, self.optimizer
         opt.enable_deferred()
@@ -246,6 +259,24 @@ class CapturedTrainStep:
         assert be == inner.store.flat_p.numel() or be > bb, "BERT is the last group of the flat buffers"
         self._hooks = ((lambda: opt.apply_pending(span=(0, bb)) if bb > 0 else None),
                        (lambda: opt.apply_pending(span=(bb, be))))
+
+    def _head_deferred(self):
+        """[AdamW of the previous iteration | forward | loss | backward up to the first boundary]"""
+        inner = self.inner
+        self._set_flush(False)
+        inner._pre_update = self._hooks
+        try:
+            return self._fwd_bwd()
+        finally:
+            inner._pre_update = None
+
+    def _tail_deferred(self):
+        self.grad_norm = self.optimizer.finish_step(self.max_norm)
+        self._pack_stats()
+
+    def _init_deferred(self, warmup):
+        inner, opt = self.inner, self.optimizer
+        self._deferred_hooks()
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -288,7 +319,7 @@ class CapturedTrainStep:
 
     def flush(self):
         """Applies the pending update now (before an eager forward, a checkpoint, an optimizer.step())."""
-        if not (self.deferred and self._pending):
+        if not ((self.deferred or self.deferred_dp) and self._pending):
             return
         self._pending = False
         self._set_flush(False)
@@ -299,7 +330,7 @@ class CapturedTrainStep:
     def reset_pending(self):
         """Forgets the pending update (after the caller has restored weights / optimizer state by hand)."""
         self._pending = False
-        if self.deferred:
+        if self.deferred or self.deferred_dp:
             self.optimizer.clear_pending()
             self._set_flush(False)
 
@@ -387,7 +418,7 @@ class CapturedTrainStep:
             self._set_flush(True)
             return self.out[0], self.out[1], self.grad_norm
         lrs = [g["lr"] for g in self.optimizer.param_groups]
-        if lrs != self._lrs:
+        if lrs != self._lrs and not self.deferred_dp:
             if getattr(self.optimizer, "lr_dev", None) is not None:
                 self._lrs = lrs
                 self.optimizer.sync_lr()          # stream-ordered, in front of this iteration's optimizer graph
@@ -395,14 +426,21 @@ class CapturedTrainStep:
                 self.refresh_lr()
         self._stage_in(samples, targets)
         self._refresh_num_boxes(targets)
-        self.g_fb.replay()
+        self.g_fb.replay()                # deferred: applies iteration i-1's update with the rates synced at iteration i-1
+        if self.deferred_dp and lrs != self._lrs:
+            self._lrs = lrs
+            self.optimizer.sync_lr()      # this iteration's rates, for the update the NEXT replay (or flush) applies
         for name, g in zip(self.phases, self.g_seg):
             self._run(self._phase_hooks.get(name, ()))       # this slice is final: its all-reduce goes out now ...
             g.replay()                                       # ... and runs under the next segment of backward
         self._run(self._post)
         self.g_opt.replay()
         self.optimizer.step_count += 1
-        self.inner.mark_dirty()          # eager forwards after a replay must rebuild the bf16 operands
+        if self.deferred_dp:
+            self._pending = True
+            self._set_flush(True)
+        else:
+            self.inner.mark_dirty()      # eager forwards after a replay must rebuild the bf16 operands
         return self.out[0], self.out[1], self.grad_norm
 
     def refresh_lr(self):

@@ -403,17 +403,22 @@ class RefTR(nn.Module):
         return tuple(b for b in self.BOUNDARIES if self.cfg.bert.layers >= 3 or b not in ("bert_hi", "bert_mid"))
 
     def bert_cuts(self):
-        """{BERT layer index: boundary reached right after that layer's backward} of the interleaved schedule.
-        REFTR_DDP_BERT_CUTS=2 (default, round 3): BERT's backward in HALVES -- layers 11-6 + pooler beside ResNet layer4, layers 5-0 +
-        embeddings beside layer3 -- so that every BERT byte (72 % of the exchange) is on the wire before ResNet layer2's backward
-        starts and only layer2-3's 17 MB (bf16: 8.6 MB) are exposed at the end.  =3: thirds (round 2: the last third, 107 MB in
-        bf16, finished together with layer2 and was exchanged exposed)."""
+        """{BERT layer index: boundary reached right after that layer's backward} of the interleaved schedule
+        (REFTR_DDP_BERT_CUTS; compute cost measured through single-rank RCCL, profiles/r03_ddp_single_rank.txt):
+          "3"  thirds (round 2): layers 11-8 + pooler beside ResNet layer4, 7-4 beside layer3, 3-0 + embeddings beside layer2 --
+               cheapest compute (8.21 ms), but the last third (107 MB in bf16) becomes final together with layer2 and is
+               exchanged exposed;
+          "2"  halves (round 3 default): layers 11-6 + pooler beside layer4, layers 5-0 + embeddings beside layer3, so that every
+               BERT byte is on the wire before layer2's backward starts and only layer2-3's slice (8.6 MB in bf16) is exposed at
+               the end; +0.13 ms of compute (the first half outlasts layer4's backward);
+          "1"  one cut at two thirds (11-8 | 7-0 + embeddings): +0.17 ms."""
         nl = self.cfg.bert.layers
         if nl < 3:
             return {}
-        if os.environ.get("REFTR_DDP_BERT_CUTS", "2") == "3":
+        mode = os.environ.get("REFTR_DDP_BERT_CUTS", "2")
+        if mode == "3":
             return {(2 * nl) // 3: "pair4", nl // 3: "pair3"}
-        return {nl // 2: "pair4"}             # the second call of the walk runs to the end of BERT (embeddings included): "pair3"
+        return {(nl // 2 if mode == "2" else (2 * nl) // 3): "pair4"}   # the walk's second leg runs to the end of BERT: "pair3"
 
     @property
     def dp_mode(self):

@@ -228,11 +228,11 @@ def test_optimizer_state_roundtrip_with_torch_adamw(masks):
 import pytest as _pytest
 
 
-@_pytest.mark.parametrize("cuts", ["2", "3"])
+@_pytest.mark.parametrize("cuts", ["1", "2", "3"])
 def test_dp_interleaved_schedule_pairs_bert_parts_with_resnet_stages(monkeypatch, cuts):
     """REFTR_DDP_SCHEDULE=interleave (default): BERT's backward keeps its own stream; the slices that are final together -- a part
     of BERT and the ResNet stage that ran beside it -- are exchanged at one boundary; disjoint and covering.  BERT is walked in
-    halves (default, round 3: nothing of BERT is left for the exposed end) or thirds (REFTR_DDP_BERT_CUTS=3)."""
+    two legs (default "1": cut at two thirds, or "2": halves -- nothing of BERT is left for the exposed end) or thirds ("3")."""
     from reftr_amd.models import layout as L
     from reftr_amd.models.reftr_transformer import RefTR
     from reftr_amd.parallel import DistributedDataParallel
@@ -256,9 +256,10 @@ def test_dp_interleaved_schedule_pairs_bert_parts_with_resnet_stages(monkeypatch
         assert sl["pair3"] == [(l3, l4), (off(q % 2), off(q % 4))]
         assert sl["end"] == [(ra, l3), (ba, off(q % 2))]
     else:
-        assert m.bert_cuts() == {3: "pair4"}
-        assert sl["pair4"] == [(l4, rb), (off(q % 3), bb)]
-        assert sl["pair3"] == [(l3, l4), (ba, off(q % 3))]                # embeddings + layers 0-2: BERT is complete here
+        c = 3 if cuts == "2" else 4
+        assert m.bert_cuts() == {c: "pair4"}
+        assert sl["pair4"] == [(l4, rb), (off(q % c), bb)]
+        assert sl["pair3"] == [(l3, l4), (ba, off(q % c))]                # embeddings + the lower layers: BERT is complete here
         assert sl["end"] == [(ra, l3)]                                   # only ResNet layer2 is exchanged exposed
         exposed = sum(b - a for a, b in sl["end"])
         assert exposed < 0.05 * st.flat_g.numel()
