@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const rt_layernorm_d
     }
     const float rstd = rsqrtf(rt_wave_sum(ss) / D + p.eps);
     if (lane == 0) { if (p.mean) p.mean[row] = mean; if (p.rstd) p.rstd[row] = rstd; }
+    const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
     const bool do_drop = p.drop_p > 0.f;
     const uint32_t thresh = rt_drop_thresh(p.drop_p);
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
