@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_reg_kernel(const rt_attn_des
 
 // ------------------------------------------------------------------------------------------------ dQ (+ delta)
 template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_desc p) {
+__device__ __forceinline__ void attn_bwd_dq_body(const rt_attn_bwd_desc& p, const int by) {
     constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Skp = (p.Sk + 31) & ~31;
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_
         sBias[j] = (j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + j])) ? 0.f : -INFINITY;
     __syncthreads();
 
-    const int q = blockIdx.y * (16 * NW) + wave * 16 + li;
-    if (blockIdx.y * (16 * NW) + wave * 16 >= p.Sq) return;
+    const int q = by * (16 * NW) + wave * 16 + li;
+    if (by * (16 * NW) + wave * 16 >= p.Sq) return;
     bf16x8 qf[KH], dof[KH], of[KH];
     load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
     load_bfrag<DH>((const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, q, p.Sq, p.ldo, lg, dof);
@@ -393,8 +393,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int DH, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd_desc p) {
+// OWN_DELTA: delta[i] = sum_d dO[i, d] * O[i, d] is recomputed here for the head's query rows (64-128 B of O and dO per row)
+// instead of being read from the dQ kernel's output: the two halves of the backward then do not depend on each other and run
+// as ONE launch (attn_bwd_fused_kernel) -- on the encoder's chain that is a 17 us kernel and a graph-node boundary less per layer.
+template <int DH, int NW, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_dkv_body(const rt_attn_bwd_desc& p, const int by) {
     constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Sqp = (p.Sq + 31) & ~31;
@@ -409,12 +412,27 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd
                     sD, (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, p.ldo, p.Sq, Sqp, threadIdx.x, 64 * NW);
     for (int i = threadIdx.x; i < Sqp; i += 64 * NW) {
         sL[i] = (i < p.Sq) ? p.lse[(size_t)bh * p.Sq + i] : INFINITY;       // padded query rows: p = exp(-inf) = 0
-        sDel[i] = (i < p.Sq) ? p.delta[(size_t)bh * p.Sq + i] : 0.f;
+        float del = 0.f;
+        if (i < p.Sq) {
+            if (OWN_DELTA) {
+                const bf16_t* orow = (const bf16_t*)p.out + ((size_t)b * p.Sq + i) * p.ldo + h * DH;
+                const bf16_t* drow = (const bf16_t*)p.dout + ((size_t)b * p.Sq + i) * p.ldo + h * DH;
+#pragma unroll
+                for (int c = 0; c < DH; c += 8) {
+                    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + c), dv8 = *reinterpret_cast<const bf16x8*>(drow + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) del += (float)dv8[e] * (float)ov[e];
+                }
+            } else {
+                del = p.delta[(size_t)bh * p.Sq + i];
+            }
+        }
+        sDel[i] = del;
     }
     __syncthreads();
 
-    const int key = blockIdx.y * (16 * NW) + wave * 16 + li;         // this lane's key (MFMA column)
-    if (blockIdx.y * (16 * NW) + wave * 16 >= p.Sk) return;
+    const int key = by * (16 * NW) + wave * 16 + li;         // this lane's key (MFMA column)
+    if (by * (16 * NW) + wave * 16 >= p.Sk) return;
     bf16x8 kf[KH], vf[KH];
     load_bfrag<DH>((const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, key, p.Sk, p.ldk, lg, kf);
     load_bfrag<DH>((const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, key, p.Sk, p.ldv, lg, vf);
@@ -473,6 +491,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd
             *reinterpret_cast<bf16x4*>(vro + t * 16 + lg * 4) = c2;
         }
     }
+}
+
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const rt_attn_bwd_desc p) {
+    attn_bwd_dq_body<DH, NW>(p, (int)blockIdx.y);
+}
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const rt_attn_bwd_desc p) {
+    attn_bwd_dkv_body<DH, NW, false>(p, (int)blockIdx.y);
+}
+// both halves in one launch: blockIdx.y < ny_dq -> the dQ row blocks, the rest -> the dK / dV key blocks
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const rt_attn_bwd_desc p, const int ny_dq) {
+    if ((int)blockIdx.y < ny_dq) attn_bwd_dq_body<DH, NW>(p, (int)blockIdx.y);
+    else attn_bwd_dkv_body<DH, NW, true>(p, (int)blockIdx.y - ny_dq);
 }
 
 // Opt a kernel into the full 160 KiB of dynamic LDS once per kernel (not per launch: keeps launches capturable in a
@@ -729,6 +762,17 @@ extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
     const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
     const dim3 g1(d->B * d->H, (d->Sq + 16 * nw - 1) / (16 * nw)), g2(d->B * d->H, (d->Sk + 16 * nw - 1) / (16 * nw));
     int rc;
+    static const int fused_env = getenv("REFTR_ATTN_BWD_FUSED") ? atoi(getenv("REFTR_ATTN_BWD_FUSED")) : 1;
+    if (fused_env && nw == 8) {
+        const size_t smem = smem1 > smem2 ? smem1 : smem2;
+        const dim3 g(d->B * d->H, g1.y + g2.y);
+#define RT_ATTN_BWD_F(DHV) do { if ((rc = set_smem(attn_bwd_fused_kernel<DHV, 8>, smem)) != RT_OK) return rc; \
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<DHV, 8>), g, dim3(512), smem, s, *d, (int)g1.y); } while (0)
+        if (d->dh == 32) RT_ATTN_BWD_F(32); else RT_ATTN_BWD_F(64);
+#undef RT_ATTN_BWD_F
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
 #define RT_ATTN_BWD(DHV, NWV) do { if ((rc = set_smem(attn_bwd_dq_kernel<DHV, NWV>, smem1)) != RT_OK) return rc; \
         if ((rc = set_smem(attn_bwd_dkv_kernel<DHV, NWV>, smem2)) != RT_OK) return rc; \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, NWV>), g1, dim3(64 * NWV), smem1, s, *d); \

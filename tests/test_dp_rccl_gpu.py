@@ -53,7 +53,8 @@ def test_dp_schedule_single_rank_rccl_follows_the_eager_loop(hip, single_rank_gr
         if mode == "dp-graph":
             p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
             cap = CapturedTrainStep(runner, crit, opt, 0.1, s, tg, warmup=1)
-            assert not cap.deferred and cap.phases == names and len(cap.g_seg) == 3
+            assert not cap.deferred and cap.deferred_dp and cap.phases == names and len(cap.g_seg) == 3
+            cap.reset_pending()                 # the warm-up iteration's (deferred) update is taken back with the weights
             model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
             model.mark_dirty(full=True)
         losses, first = [], None
@@ -64,6 +65,8 @@ def test_dp_schedule_single_rank_rccl_follows_the_eager_loop(hip, single_rank_gr
                 lv, _, _, gn = train_step(runner, crit, s, tg, opt, None, max_norm=0.1)
             losses.append(lv)
             if it == 0:
+                if mode == "dp-graph":
+                    cap.flush()                 # deferred optimizer: the update of this iteration lands now (as state_dict() would force it)
                 torch.cuda.synchronize()
                 g = model.store.flat_g16.float() if getattr(model.store, "flat_g16", None) is not None else model.store.flat_g.clone()
                 first = (g, model.store.flat_p.clone(), float(gn))

@@ -185,7 +185,8 @@ def test_captured_step_matches_eager(hip, two_phase):
             cap.reset_pending()
             model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
             model.mark_dirty(full=True)
-            assert cap.deferred == (not two_phase)      # single-process default: AdamW of step i at the head of step i+1
+            # AdamW of step i at the head of step i+1: one graph (single process) or across the segment graphs (data parallel)
+            assert cap.deferred == (not two_phase) and cap.deferred_dp == bool(two_phase)
         losses, norms, first = [], [], None
         for it in range(3):
             if mode == "eager":
@@ -231,7 +232,7 @@ def test_captured_deferred_update_follows_the_lr_schedule(hip, two_phase):
         if mode == "graph":
             p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
             cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg, warmup=1, force_two_phase=two_phase)
-            assert cap.deferred == (not two_phase)
+            assert cap.deferred == (not two_phase) and cap.deferred_dp == bool(two_phase)
             cap.reset_pending()
             model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
             graph_id = id(cap.g_fb)
@@ -243,7 +244,7 @@ def test_captured_deferred_update_follows_the_lr_schedule(hip, two_phase):
             else:
                 cap(s, tg)
         if mode == "graph":
-            assert id(cap.g_fb) == graph_id and cap._pending == (not two_phase)
+            assert id(cap.g_fb) == graph_id and cap._pending
             sd = model.state_dict()                      # applies the pending (4th) update first
             assert not cap._pending
             w = sd[key].float().cpu()
