@@ -50,6 +50,10 @@ class Net:
         self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
         self.trivial_sa = os.environ.get("REFTR_TRIVIAL_SA", "1") != "0"
         self.fold_sa = os.environ.get("REFTR_FOLD_SA", "1") != "0"
+        # measured (profiles/r03_side_stream_probes.txt): the decoder layers' memory-gradient products on the language stream beside
+        # the decoder's backward chain cost +0.2 ms -- a 440-workgroup launch beside the chain's 1-16-workgroup kernels delays them
+        # more than leaving the chain saves; off by default
+        self.kv_dgrad_side = os.environ.get("REFTR_DEC_KV_SIDE", "0") != "0"
         self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
@@ -444,7 +448,13 @@ class Net:
         grp = H.GemmGroup()                      # two accumulators, two independent products, one launch
         self.lin_bwd(p + "multihead_attn.v", dv2, mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
         self.lin_bwd(p + "multihead_attn.k", dk2, memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
-        grp.run()
+        # Nothing on the decoder's chain reads the memory gradients, so the M = B*S launch COULD leave the chain (a ~12 us node per
+        # layer) for the language stream, which is idle until BERT's backward (REFTR_DEC_KV_SIDE=1; the accumulations stay ordered
+        # on that one stream and the caller joins before its first own write to the accumulators) -- measured slower, see __init__.
+        if self.kv_dgrad_side and self.side.enabled:
+            self.side.run(grp.run, dv2, dk2, mem16, memp16)
+        else:
+            grp.run()
         _, dt1q = self.lin_bwd(p + "multihead_attn.q", dq2, r["t1q16"], out_bf16=False, out_f32=True, acc2_f32=dqpos_acc)
         du, dub = self.ln_bwd(du2, r["u"], p + "norm1.", *r["st1"], dy2=dt1q, drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
         if r["fold"]:           # the head-dropout mask of the forward, applied by the backward-data product's epilogue

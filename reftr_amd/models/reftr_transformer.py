@@ -527,6 +527,8 @@ class RefTR(nn.Module):
         dcat_rows = dcat.view(2 * N, E)
         _, dcob = net.ln_bwd(dcat_rows, sv["co"], qe + "context_out.1.", *sv["cst"], rowmap=(1, 2, 0), want_f32=False)
         _, dc = net.lin_bwd(qe + "context_out.0.", dcob, sv["c16"], out_bf16=False, out_f32=True)
+        if net.kv_dgrad_side:
+            net.side.join()             # REFTR_DEC_KV_SIDE=1: the decoder layers' memory-gradient products ran on the language stream
         H.rows_add(N, E, a_f32=dcat_rows, a_map=(1, 2, 0), out_f32=dmem, accumulate=2, o_map=(-Pn, S, 0))
         dk, dqs, dvs = H.qenc_attn_bwd(sv["kq"], sv["qs"].view(B, Lq, E), sv["vs"].view(B, Lq, E), sv["qw"], dc.view(B, Pn, E))
         dk16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
