@@ -21,10 +21,6 @@
 #include "rt_common.h"
 #include <stdlib.h>
 
-#ifndef ATTN_PAD32
-#define ATTN_PAD32 16
-#endif
-
 namespace {
 
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
@@ -45,11 +41,9 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
 }
 
 template <int DH> struct Geo {
-    // LDS row stride (bytes).  dh = 64: + 32 B (conflict-free for both access patterns).  dh = 32 (the encoder, S = 440 rows per
-    // head): + 16 B only -- some fragment reads become 2-way conflicts, but K + V (or Q + dO) of a head then take 75 KB instead
-    // of 88 KB and TWO workgroups fit a CU: the fused backward's dQ and dK/dV halves (512 workgroups) are resident together
-    // instead of running as two rounds (round 3; REFTR build knob ATTN_PAD32)
-    static constexpr int RS = DH * 2 + (DH == 32 ? ATTN_PAD32 : 32);
+    // LDS row stride (bytes): + 32 B, conflict-free for both access patterns (a 16-B pad for dh = 32 would fit two workgroups per CU at
+    // S = 440; measured identical -- the kernels are bound by the CU's VALU work, profiles/r03_side_stream_probes.txt)
+    static constexpr int RS = DH * 2 + 32;
     static constexpr int KH = DH / 32;         // MFMA k-steps over the head dim
     static constexpr int DT = DH / 16;         // 16-wide output tiles over the head dim
 };
@@ -533,7 +527,7 @@ int set_smem(K kernel, size_t bytes) {
 
 size_t smem_bytes(int inner, int dh) {
     const size_t ip = (size_t)((inner + 31) & ~31);
-    return 2 * ip * (dh * 2 + (dh == 32 ? ATTN_PAD32 : 32)) + 2 * sizeof(float) * ip;
+    return 2 * ip * (dh * 2 + 32) + 2 * sizeof(float) * ip;
 }
 
 }  // namespace
