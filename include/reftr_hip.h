@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* rt_stream_t; /* hipStream_t */
 
-enum { RT_OK = 0, RT_ERR_BADARG = -1, RT_ERR_UNSUPPORTED = -2 };
+enum { RT_OK = 0, RT_ERR_BADARG = -1, RT_ERR_UNSUPPORTED = -2, RT_ERR_COMM = -3 };
 enum { RT_ACT_NONE = 0, RT_ACT_RELU = 1, RT_ACT_GELU = 2, RT_ACT_TANH = 3 };
 
 /* Library identity: returns the ABI version (bumped on any signature change). */
@@ -506,6 +506,10 @@ typedef struct rt_adamw_desc {
     const void* g16;          /* optional bf16 gradient buffer read INSTEAD of g (the exchanged gradients of a data-parallel run) */
 } rt_adamw_desc;
 int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream);
+/* rt_sgd_flat — torch.optim.SGD(momentum, weight_decay), the reference's --sgd optimizer (main_vg.py:263-265), over the same flat
+ * buffers and with the same descriptor: m = momentum buffer (zero-initialised), beta1 = momentum, v / beta2 / eps / step unused:
+ *   g' = clip * grad_scale * g + wd * p;  m = beta1 * m + g';  p -= lr * m.   Clip coefficient and 1/world as in rt_adamw_flat. */
+int rt_sgd_flat(const rt_adamw_desc* d, rt_stream_t stream);
 /* rt_zero_chunks — clears `n` chunks of an fp32 buffer in one launch: table (DEVICE, static) = n x {int64 element offset, int64
  * element count (<= 16384)}.  Used for the gradient tensors that are accumulated with atomics (biases, norm parameters,
  * embeddings) when the weight matrices are produced in overwrite mode and the full clear of the gradient buffer is skipped. */
@@ -586,6 +590,26 @@ typedef struct rt_box_post_desc {
     int32_t B, P, K;
 } rt_box_post_desc;
 int rt_box_postprocess(const rt_box_post_desc* d, rt_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * rt_comm_* — the data-parallel gradient exchange: what the reference gets from
+ * torch.nn.parallel.DistributedDataParallel (main_vg.py:290-296) after util/misc.py:392-431 set up one process per GPU.
+ * RCCL over xGMI, bound at run time (dlopen: the copy the process already holds -- torch.distributed's -- or the system's);
+ * RT_ERR_UNSUPPORTED when no RCCL can be loaded, RT_ERR_COMM (+ a line on stderr) when RCCL reports an error.
+ *   rt_comm_unique_id  rank 0 fills 128 opaque bytes; the caller carries them to every rank (any out-of-band channel);
+ *   rt_comm_init       collective over all ranks (one process per GPU, the device current at the call is the rank's);
+ *   rt_comm_allreduce  in-place SUM all-reduce of `n` buffers (device pointers, element counts) of one dtype, issued as one
+ *                      group on `stream` -- asynchronous: ordered behind the work already enqueued on `stream`, the caller
+ *                      joins its compute stream with an event;
+ *   rt_comm_destroy    releases the communicator.
+ * Thread-compatible: one caller thread per device.
+ * ------------------------------------------------------------------------------------------ */
+typedef void* rt_comm_t;
+enum { RT_COMM_F32 = 0, RT_COMM_BF16 = 1 };
+int rt_comm_unique_id(void* id128);
+int rt_comm_init(const void* id128, int rank, int world, rt_comm_t* out);
+int rt_comm_allreduce(rt_comm_t comm, void* const* bufs, const int64_t* counts, int n, int dtype, rt_stream_t stream);
+int rt_comm_destroy(rt_comm_t comm);
 
 #ifdef __cplusplus
 }

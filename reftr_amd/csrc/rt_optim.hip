@@ -87,6 +87,44 @@ __global__ __launch_bounds__(256) void adamw_kernel(const rt_adamw_desc p, const
     }
 }
 
+// torch.optim.SGD(momentum, weight_decay) as the reference builds it with --sgd (main_vg.py:263-265: momentum 0.9, dampening 0, no
+// Nesterov): g' = clip * scale * g + wd * p;  buf = momentum * buf + g'  (a zero-initialised buffer makes step 1 "buf = g'");
+// p -= lr * buf.  Same descriptor as AdamW: m = momentum buffer, beta1 = momentum, v / beta2 / eps unused.  20 B per parameter.
+__global__ __launch_bounds__(256) void sgd_kernel(const rt_adamw_desc p) {
+    if (p.active && p.active[0] == 0) return;
+    const float total = sqrtf(p.gnorm_sq ? p.gnorm_sq[0] : 0.f) * p.grad_scale;
+    float coef = 1.f;
+    if (p.max_norm > 0.f) coef = fminf(1.f, p.max_norm / (total + 1e-6f));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.gnorm_out) p.gnorm_out[0] = total;
+    const float gs = p.grad_scale * coef;
+    const size_t i0 = (size_t)p.span_begin >> 2, n4 = (size_t)p.span_end >> 2;
+    float4* P4 = reinterpret_cast<float4*>(p.p);
+    const float4* G4 = reinterpret_cast<const float4*>(p.g);
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x4_t* G16 = reinterpret_cast<const bf16x4_t*>(p.g16);
+    float4* M4 = reinterpret_cast<float4*>(p.m);
+    for (size_t i = i0 + blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t e = i << 2;
+        float lr = 0.f, wd = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < p.n_ranges && e >= (size_t)p.range_begin[r] && e < (size_t)p.range_end[r]) {
+                lr = p.lr_dev ? p.lr_dev[r] : p.range_lr[r]; wd = p.range_wd[r];
+            }
+        float4 pv = P4[i], mv = M4[i], gv;
+        if (G16) { const bf16x4_t h = G16[i]; gv = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+        else gv = G4[i];
+        float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float g = gp[c] * gs + wd * pp[c];
+            mp[c] = p.beta1 * mp[c] + g;
+            pp[c] -= lr * mp[c];
+        }
+        P4[i] = pv; M4[i] = mv;
+    }
+}
+
 __global__ void counter_add_kernel(int32_t* c, int32_t inc) { c[0] += inc; }
 
 }  // namespace
@@ -130,6 +168,18 @@ extern "C" int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream) {
     int blocks = (int)(((size_t)(a.span_end - a.span_begin) / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;
     static const int nt_env = getenv("REFTR_ADAMW_NT") ? atoi(getenv("REFTR_ADAMW_NT")) : 1;
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, nt_env);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_sgd_flat(const rt_adamw_desc* d, rt_stream_t stream) {
+    if (!d || !d->p || (!d->g && !d->g16) || !d->m || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8) return RT_ERR_BADARG;
+    for (int r = 0; r < d->n_ranges; ++r) if ((d->range_begin[r] & 3) || (d->range_end[r] & 3)) return RT_ERR_BADARG;
+    rt_adamw_desc a = *d;
+    if (a.span_begin == 0 && a.span_end == 0) a.span_end = a.n;
+    if (a.span_begin < 0 || a.span_end > a.n || a.span_begin >= a.span_end || (a.span_begin & 3) || (a.span_end & 3)) return RT_ERR_BADARG;
+    int blocks = (int)(((size_t)(a.span_end - a.span_begin) / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -267,6 +267,7 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_sqnorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
+    "rt_sgd_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_zero_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "rt_counter_add": (c_int, [c_void_p, c_int32, c_void_p]),
     "rt_ln_param_grad_grouped": (c_int, [POINTER(LnPgJob), c_int, c_void_p]),
@@ -282,6 +283,10 @@ _SIGNATURES = {
     "rt_attn_map_bwd": (c_int, [POINTER(AttnMapBwdDesc), c_void_p]),
     "rt_seg_concat": (c_int, [POINTER(SegConcatDesc), c_void_p]),
     "rt_mask_loss": (c_int, [POINTER(MaskLossDesc), c_void_p]),
+    "rt_comm_unique_id": (c_int, [c_void_p]),
+    "rt_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "rt_comm_allreduce": (c_int, [c_void_p, POINTER(c_void_p), POINTER(ctypes.c_int64), c_int, c_int, c_void_p]),
+    "rt_comm_destroy": (c_int, [c_void_p]),
 }
 
 _lib = None
@@ -843,9 +848,10 @@ def sqnorm(g, out):
 
 
 def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_scale=1.0, max_norm=0.0,
-               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None, active=None, lr_dev=None, span=None, g16=None):
+               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None, active=None, lr_dev=None, span=None, g16=None, sgd=False):
     """ranges = [(begin, end, lr, wd), ...] element ranges of the flat buffers (multiples of 4); span = (begin, end)
-    restricts the launch to that element span; active / lr_dev: device words (see rt_adamw_desc)."""
+    restricts the launch to that element span; active / lr_dev: device words (see rt_adamw_desc).  sgd=True: rt_sgd_flat
+    (m = momentum buffer, beta1 = momentum, v unused)."""
     d = AdamWDesc()
     d.p, d.g, d.m, d.v, d.n = _p(p), _p(g), _p(m), _p(v), p.numel()
     d.gnorm_sq, d.gnorm_out = _p(gnorm_sq), _p(gnorm_out)
@@ -856,7 +862,10 @@ def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_
     d.g16 = _p(g16)
     for i, (b, e, lr, wd) in enumerate(ranges):
         d.range_begin[i], d.range_end[i], d.range_lr[i], d.range_wd[i] = b, e, lr, wd
-    _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")
+    if sgd:
+        _check(lib().rt_sgd_flat(ctypes.byref(d), _stream()), "rt_sgd_flat")
+    else:
+        _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")
 
 
 def small_dgrad(dy_f32, w_f32, gate=None):
@@ -1109,6 +1118,45 @@ def img_collate_norm(images, H, W, mean, std):
     m = (c_float * 3)(*[float(v) for v in mean]); s_ = (c_float * 3)(*[float(v) for v in std])
     _check(lib().rt_img_collate_norm(_p(tab), _p(out), _p(mask), B, H, W, m, s_, _stream()), "rt_img_collate_norm")
     return out, mask
+
+
+# --------------------------------------------------------------------------------------------
+# gradient exchange behind the C ABI (rt_comm_*: RCCL bound at run time)
+# --------------------------------------------------------------------------------------------
+class Comm:
+    """One RCCL communicator of this process (one process per GPU) through rt_comm_*.  `uid` travels from rank 0 to the other
+    ranks by whatever channel the caller has (reftr_amd.parallel uses the torch.distributed rendezvous that main_vg.py set up)."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _check(lib().rt_comm_unique_id(buf), "rt_comm_unique_id")
+        return bytes(buf.raw)
+
+    def __init__(self, uid, rank, world):
+        assert len(uid) == 128
+        h = c_void_p()
+        _check(lib().rt_comm_init(ctypes.create_string_buffer(uid, 128), int(rank), int(world), ctypes.byref(h)), "rt_comm_init")
+        self.handle, self.rank, self.world = h, rank, world
+
+    def allreduce(self, tensors, stream=None):
+        """In-place SUM all-reduce of contiguous device tensors of one dtype (fp32 or bf16), one RCCL group, asynchronous on
+        `stream` (default: the current stream)."""
+        tensors = [t for t in tensors if t.numel()]
+        if not tensors:
+            return
+        dt = tensors[0].dtype
+        assert dt in (torch.float32, torch.bfloat16) and all(t.dtype == dt and t.is_cuda and t.is_contiguous() for t in tensors)
+        n = len(tensors)
+        ptrs = (c_void_p * n)(*[t.data_ptr() for t in tensors])
+        cnts = (ctypes.c_int64 * n)(*[t.numel() for t in tensors])
+        s = stream.cuda_stream if stream is not None else _stream()
+        _check(lib().rt_comm_allreduce(self.handle, ptrs, cnts, n, 0 if dt == torch.float32 else 1, s), "rt_comm_allreduce")
+
+    def destroy(self):
+        if self.handle:
+            _check(lib().rt_comm_destroy(self.handle), "rt_comm_destroy")
+            self.handle = None
 
 
 class SideStream:

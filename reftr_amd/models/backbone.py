@@ -36,7 +36,7 @@ class ResNetBody:
         inpl = 64
         for li, n in enumerate(cfg.resnet_layers):
             planes = 64 * 2 ** li
-            tr = li > 0
+            tr = li > 0 and getattr(cfg, "train_backbone", True)     # lr_backbone 0: nothing trains, nothing is saved for backward
             stage = []
             for bi in range(n):
                 p = f"{self.PFX}layer{li + 1}.{bi}."

@@ -44,6 +44,7 @@ class ModelConfig:
     aux_loss: bool = True
     resnet_layers: tuple = (3, 4, 6, 3)   # resnet50; resnet101 = (3, 4, 23, 3)
     masks: bool = False                   # RefTRSeg: RES head (bbox_attention + mask_head), single phrase, no aux loss
+    train_backbone: bool = True           # False: --lr_backbone 0 freezes the whole ResNet (backbone.py:87-89,150)
     cem: bool = False                     # --ablation cem_loss: CEM block + loss_cem (reftr_segmentation.py:16-41, 62-64)
     bert: BertConfig = field(default_factory=BertConfig)
 
@@ -67,7 +68,7 @@ def _bn(pfx, c, out):
         out.append((pfx + k, (c,), "buffer"))
 
 
-def resnet_table(pfx, layers):
+def resnet_table(pfx, layers, train=True):
     """Returns [(name, shape, kind)], kind in {'param', 'frozen', 'buffer'} (backbone.py:87-89: conv1 and
     layer1 never train; FrozenBatchNorm2d tensors are buffers, backbone.py:52-57)."""
     t = [(pfx + "conv1.weight", (64, 3, 7, 7), "frozen")]
@@ -75,7 +76,7 @@ def resnet_table(pfx, layers):
     inpl = 64
     for li, n in enumerate(layers):
         planes = 64 * 2 ** li
-        kind = "frozen" if li == 0 else "param"
+        kind = "frozen" if (li == 0 or not train) else "param"
         for bi in range(n):
             p = f"{pfx}layer{li + 1}.{bi}."
             t.append((p + "conv1.weight", (planes, inpl, 1, 1), kind)); _bn(p + "bn1.", planes, t)
@@ -215,7 +216,7 @@ def phys_dims(cfg: ModelConfig):
 def full_table(cfg: ModelConfig):
     """All tensors of the model.  Trainable ones are listed group by group (main, backbone, bert) in the
     order they are laid out in the flat parameter buffer."""
-    return main_table(cfg) + (seg_table(cfg) if cfg.masks else []) + (cem_table(cfg) if cfg.masks and cfg.cem else []) + resnet_table("img_backbone.0.body.", cfg.resnet_layers) + bert_table("lang_backbone.", cfg.bert)
+    return main_table(cfg) + (seg_table(cfg) if cfg.masks else []) + (cem_table(cfg) if cfg.masks and cfg.cem else []) + resnet_table("img_backbone.0.body.", cfg.resnet_layers, cfg.train_backbone) + bert_table("lang_backbone.", cfg.bert)
 
 
 def reference_param_order(cfg: ModelConfig):
@@ -227,8 +228,8 @@ def reference_param_order(cfg: ModelConfig):
     names = []
     pfx = "img_backbone.0.body."
     for li, n in enumerate(cfg.resnet_layers):
-        if li == 0:
-            continue                      # conv1 / layer1 are frozen (backbone.py:87-89): not in any param group
+        if li == 0 or not cfg.train_backbone:
+            continue                      # conv1 / layer1 (or, with lr_backbone 0, everything) are frozen (backbone.py:87-89): in no param group
         for bi in range(n):
             p = f"{pfx}layer{li + 1}.{bi}."
             for c in ("conv1", "conv2", "conv3"):

@@ -570,9 +570,13 @@ class RefTR(nn.Module):
                                    st.G["input_proj.0.1.weight"], st.G["input_proj.0.1.bias"], 32, 1e-5, dy2=dxb,
                                    rows_per_img=S, row_off=Lq)
         # input_proj's data / weight gradient (main group) -- in front of the BERT branch so that the main group is final first
-        g_c5, _ = net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], gate=sv["c5"])
+        if cfg.train_backbone:
+            g_c5, _ = net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], gate=sv["c5"])
+        else:                                   # frozen ResNet (--lr_backbone 0): input_proj's weight gradient only
+            net.lin_bwd("input_proj.0.0.", dip16.view(B * HW, E), sv["c5"], need_dx=False)
+            g_c5 = None
         if getattr(self, "_debug", False):
-            self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=g_c5.clone())
+            self._dbg = dict(dlogits=dlogits.clone(), dhs=dhs.clone(), dmem=dmem_dbg, g_c5=None if g_c5 is None else g_c5.clone())
         net.wg.flush()               # transformer weight gradients queued so far -> their own stream, from here
         dp = self.dp_mode
         # ---- BERT backward (sentence pass; phrase pass for multi-phrase inputs).  Single GPU: on the side stream,
@@ -597,7 +601,7 @@ class RefTR(nn.Module):
                     for layer in net.bert_bwd_layers(ctx, a, b_, stops=tuple(cuts) if last else ()):
                         yield cuts[layer]
             bg = _bert_thirds()
-            rg = self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra)
+            rg = self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra) if cfg.train_backbone else iter(())
 
             def _advance_bert():
                 for _ in bg:
@@ -644,7 +648,7 @@ class RefTR(nn.Module):
             net.side.run(_bert_bwd, d_seq, dpool)
         # ---- ResNet body (its gradients are the last to become final); data parallel: layer4's slice (64 % of the ResNet
         # bytes) is final -- and exchanged -- before layer3 / layer2 run
-        for stage in self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra):
+        for stage in (self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra) if cfg.train_backbone else ()):
             if dp and stage == 4:
                 net.flush_wgrads(); self.body.wgs.join()
                 yield "layer4"
@@ -672,10 +676,6 @@ def build_config(args):
                                   "position_encoding.py:59-84) is not built: every reference config uses the sine encoding")
     if pe not in ("v2", "sine"):
         raise ValueError(f"not supported {pe}")                     # as position_encoding.py:95
-    if float(getattr(args, "lr_backbone", 1e-5)) <= 0:
-        raise NotImplementedError("lr_backbone <= 0 freezes the whole ResNet in the reference (train_backbone = False, "
-                                  "models/modeling/backbone.py:87-89,150) and drops its parameters from the optimizer and the "
-                                  "clip norm; this build always trains layer2-4")
     if bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss" and int(args.hidden_dim) != 256:
         raise NotImplementedError("--ablation cem_loss with hidden_dim != 256: the CEM kernels (rt_cem_fwd / rt_cem_bwd) are built for "
                                   "hidden_dim // 16 == 16 channels (every reference config uses hidden_dim 256)")
@@ -690,6 +690,9 @@ def build_config(args):
                          ffn=args.dim_feedforward, dropout=args.dropout, max_lang_seq=args.max_lang_seq,
                          n_q=args.num_queries_per_phrase, aux_loss=args.aux_loss, resnet_layers=layers, bert=bc,
                          masks=bool(getattr(args, "masks", False)),
+                         # lr_backbone <= 0 freezes the whole ResNet (train_backbone = False, models/modeling/backbone.py:87-89,150):
+                         # its parameters leave the optimizer and the clip norm, its backward is not run
+                         train_backbone=float(getattr(args, "lr_backbone", 1e-5)) > 0,
                          cem=bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss")
 
 

@@ -13,6 +13,8 @@ from .models import layout as L
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    SGD = False
+
     def __init__(self, model, lr=1e-4, lr_backbone=1e-5, lr_bert=None, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
                  lr_mask_branch_proj=1.0):
         self.model = getattr(model, "module", model)
@@ -85,7 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
                      g16=getattr(st, "flat_g16", None),
                      gnorm_out=self.grad_norm, grad_scale=getattr(self.model, "_grad_scale", 1.0),
                      max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"], step_dev=self.step_dev,
-                     active=self.active, lr_dev=self.lr_dev, span=span)
+                     active=self.active, lr_dev=self.lr_dev, span=span, sgd=self.SGD)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -213,9 +215,58 @@ class FusedAdamW(torch.optim.Optimizer):
                     g[k] = s_[k]
 
 
+class FusedSGD(FusedAdamW):
+    """torch.optim.SGD(param_dicts, lr, momentum=0.9, weight_decay) -- the reference's `--sgd` optimizer (main_vg.py:263-265) --
+    on the same flat buffers, schedules (deferred update under graph replay, device learning rates, data-parallel bf16
+    gradients) and clip path as FusedAdamW: `m` is the momentum buffer, `v` is not allocated, rt_sgd_flat is the kernel."""
+    SGD = True
+
+    def __init__(self, model, lr=1e-4, lr_backbone=1e-5, lr_bert=None, weight_decay=1e-4, momentum=0.9, lr_mask_branch_proj=1.0):
+        super().__init__(model, lr=lr, lr_backbone=lr_backbone, lr_bert=lr_bert, weight_decay=weight_decay, betas=(momentum, 0.0),
+                         lr_mask_branch_proj=lr_mask_branch_proj)
+        self.v = self.m[:4]                      # never read by rt_sgd_flat (a 16-byte placeholder keeps the shared call sites simple)
+        for g in self.param_groups:
+            g["momentum"] = momentum
+
+    def state_dict(self):
+        """torch.optim.SGD's format: per-parameter `momentum_buffer` keyed by the parameter's index in the reference's group order."""
+        if self._flush_pending is not None:
+            self._flush_pending()
+        st = self.model.store
+        state, groups, idx = {}, [], 0
+        for g, ns in zip(self.param_groups, self._names):
+            ids = []
+            for n in ns:
+                if self.step_count > 0:
+                    state[idx] = {"momentum_buffer": st.view_of(self.m, n).detach().clone(memory_format=torch.contiguous_format)}
+                ids.append(idx); idx += 1
+            pg = {k: v for k, v in g.items() if k not in ("params", "group_id", "betas", "eps")}
+            pg.update(dampening=0, nesterov=False, maximize=False, foreach=None, differentiable=False, fused=None, params=ids)
+            groups.append(pg)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        if self._flush_pending is not None:
+            self._flush_pending()
+        st = self.model.store
+        flat = [n for ns in self._names for n in ns]
+        assert sum(len(g["params"]) for g in sd["param_groups"]) == len(flat), "optimizer state does not match this model's parameters"
+        with torch.no_grad():
+            for i, s_ in sd["state"].items():
+                if s_.get("momentum_buffer") is not None:
+                    st.view_of(self.m, flat[int(i)]).copy_(s_["momentum_buffer"])
+        self.step_count = 1 if sd["state"] else 0
+        self.step_dev.fill_(self.step_count)
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            for k in ("lr", "weight_decay", "momentum", "initial_lr"):
+                if k in s_:
+                    g[k] = s_[k]
+
+
 def build_optimizer(model, args):
-    """The optimizer main_vg.py:234-268 builds, on the fused kernels (AdamW; --sgd is not built and raises)."""
+    """The optimizer main_vg.py:234-268 builds, on the fused kernels: AdamW, or SGD(momentum 0.9) with --sgd."""
     if getattr(args, "sgd", False):
-        raise NotImplementedError("--sgd (torch.optim.SGD, main_vg.py:263-265) is not built: every reference config trains with AdamW")
+        return FusedSGD(model, lr=args.lr, lr_backbone=args.lr_backbone, weight_decay=args.weight_decay,
+                        lr_mask_branch_proj=getattr(args, "lr_mask_branch_proj", 1.0))
     return FusedAdamW(model, lr=args.lr, lr_backbone=args.lr_backbone, weight_decay=args.weight_decay,
                       lr_mask_branch_proj=getattr(args, "lr_mask_branch_proj", 1.0))

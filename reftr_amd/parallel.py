@@ -53,6 +53,19 @@ class DistributedDataParallel(nn.Module):
         self.bf16 = self.active and os.environ.get("REFTR_DDP_DTYPE", "bf16") == "bf16"
         if self.bf16:
             module.store.flat_g16 = torch.zeros_like(module.store.flat_g, dtype=torch.bfloat16)
+        # REFTR_COMM=abi: the all-reduces go through the library's own RCCL binding (rt_comm_*, include/reftr_hip.h) on a
+        # dedicated exchange stream instead of through torch.distributed's process group; the rendezvous that main_vg.py set up
+        # (util/misc.py:392-431) only carries the 128-byte communicator id from rank 0.  Default: torch.distributed (the path
+        # the CPU/gloo tests and the single-rank GPU tests exercise on every build).
+        self.comm = None
+        if self.active and os.environ.get("REFTR_COMM", "torch") == "abi" and module.store.flat_g.is_cuda:
+            from . import hip as H
+            uid = [H.Comm.unique_id() if dist.get_rank() == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            self.comm = H.Comm(uid[0], dist.get_rank(), self.world)
+            self._cstream = torch.cuda.Stream()
+            self._cpending = False
         module._grad_scale = 1.0 / self.world
         if self.world > 1 and broadcast:      # DDP constructor: parameters + buffers from rank 0 (C2)
             for buf in module.store.flat.values():
@@ -105,10 +118,11 @@ class DistributedDataParallel(nn.Module):
         nl = cfg.bert.layers
         lay = lambda i: off(f"lang_backbone.encoder.layer.{i}.attention.self.query.weight")   # noqa: E731
         hi, mid = (lay((2 * nl) // 3), lay(nl // 3)) if nl >= 3 else (ba, ba)
-        l4 = off("img_backbone.0.body.layer4.0.conv1.weight")
+        frozen_bb = rb == ra                                                 # --lr_backbone 0: no ResNet slice at all
+        l4 = ra if frozen_bb else off("img_backbone.0.body.layer4.0.conv1.weight")
         assert ba <= mid <= hi <= bb and ra <= l4 <= rb
         if self.module.dp_schedule == "interleave":
-            l3 = off("img_backbone.0.body.layer3.0.conv1.weight")
+            l3 = ra if frozen_bb else off("img_backbone.0.body.layer3.0.conv1.weight")
             assert ra <= l3 <= l4
             cuts = self.module.bert_cuts()
             if len(cuts) == 1:              # halves: BERT is complete (embeddings included) at 'pair3'; only ResNet layer2 is left
@@ -142,6 +156,11 @@ class DistributedDataParallel(nn.Module):
                 if b > a:
                     g16[a:b].copy_(g[a:b])            # round the final slice; the all-reduce is ordered behind it
             g = g16
+        if self.comm is not None:
+            self._cstream.wait_stream(torch.cuda.current_stream())       # behind the slice's producers (and its rounding)
+            self.comm.allreduce([g[a:b] for a, b in bounds if b > a], stream=self._cstream)
+            self._cpending = True
+            return
         self._works += [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in bounds if b > a]
 
     def reduce_phase(self, name):
@@ -160,6 +179,9 @@ class DistributedDataParallel(nn.Module):
             ev[0].record()
         for w in self._works:
             w.wait()
+        if self.comm is not None and self._cpending:
+            torch.cuda.current_stream().wait_stream(self._cstream)
+            self._cpending = False
         if ev is not None:
             ev[1].record()
             self.timing.append(ev)
@@ -169,4 +191,7 @@ class DistributedDataParallel(nn.Module):
         self._launch(self.chunk_bounds())
         for w in self._works:
             w.wait()
+        if self.comm is not None and self._cpending:
+            torch.cuda.current_stream().wait_stream(self._cstream)
+            self._cpending = False
         self._works = []

@@ -160,3 +160,48 @@ def test_bf16_vs_fp32_gradient_exchange_of_two_emulated_ranks_along_a_trajectory
     for a, b, c in rows:
         assert a < 2e-3           # ||sum|| : the 2^-9 rounding errors average out over 10^8 elements
         assert b > 0.995 and c < 0.1
+
+
+def test_rt_comm_single_rank_allreduce_through_the_c_abi(hip, single_rank_group):
+    """rt_comm_* (include/reftr_hip.h): RCCL bound at run time -- the copy torch.distributed already loaded -- communicator of
+    one rank, grouped in-place SUM all-reduce of fp32 and bf16 buffers on a side stream: a one-rank sum is the identity."""
+    uid = hip.Comm.unique_id()
+    assert len(uid) == 128
+    comm = hip.Comm(uid, 0, 1)
+    st = torch.cuda.Stream()
+    for dt in (torch.float32, torch.bfloat16):
+        a = torch.randn(1 << 20, device="cuda").to(dt); b = torch.randn(12345, device="cuda").to(dt)
+        a0, b0 = a.clone(), b.clone()
+        st.wait_stream(torch.cuda.current_stream())
+        comm.allreduce([a, b, a[:0]], stream=st)
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        assert torch.equal(a, a0) and torch.equal(b, b0)
+    comm.destroy()
+
+
+def test_dp_wrapper_on_the_c_abi_exchange_matches_the_torch_distributed_one(hip, single_rank_group, monkeypatch):
+    """REFTR_COMM=abi: the same schedule with the library's own RCCL binding: three eager data-parallel steps give the same
+    losses, gradient norm and weights as the torch.distributed exchange (single rank: both sums are the identity, bit for bit up
+    to the atomics-order noise of two runs)."""
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.optim import FusedAdamW
+    from reftr_amd.parallel import DistributedDataParallel
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    out = {}
+    for mode in ("torch", "abi"):
+        monkeypatch.setenv("REFTR_COMM", mode)
+        model, crit, P, ocfg = build(small=True)
+        model.eval()
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        runner = DistributedDataParallel(model)
+        assert (runner.comm is not None) == (mode == "abi")
+        res = [train_step(runner, crit, s, tg, opt, None, max_norm=0.1) for _ in range(3)]
+        torch.cuda.synchronize()
+        out[mode] = ([r[0] for r in res], float(res[0][3]), model.store.flat_p.clone())
+        if runner.comm is not None:
+            runner.comm.destroy()
+    (lt, gt, pt), (la, ga, pa) = out["torch"], out["abi"]
+    assert abs(lt[0] - la[0]) < 1e-6 * abs(lt[0]) and abs(gt - ga) < 2e-3 * gt      # atomics-order noise of two backward runs: 4e-4
+    assert abs(lt[2] - la[2]) < 5e-2 * abs(lt[2]) and rel(pa, pt) < 2e-4

@@ -172,6 +172,56 @@ def test_optimizer_groups_follow_reference_param_groups():
     assert abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12
 
 
+def test_sgd_flag_builds_the_momentum_optimizer_with_torch_sgd_state_format():
+    """--sgd (main_vg.py:263-265): build_optimizer returns the fused SGD(momentum 0.9) on the reference's four param groups; its
+    state_dict has torch.optim.SGD's layout (momentum_buffer per parameter index) and round-trips."""
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.optim import FusedAdamW, FusedSGD, build_optimizer
+    cfg, _ = small()
+    m = RefTR(cfg, device="cpu")
+    opt = build_optimizer(m, ref_args(sgd=True))
+    assert isinstance(opt, FusedSGD) and [g["lr"] for g in opt.param_groups] == [1e-4, 1e-5, 1e-5, 1e-4]
+    assert all(g["momentum"] == 0.9 for g in opt.param_groups) and opt.v.numel() == 4
+    assert type(build_optimizer(m, ref_args())) is FusedAdamW
+    opt.m.uniform_(-1, 1); opt.step_count = 1
+    sd = opt.state_dict()
+    n_params = sum(len(g["params"]) for g in sd["param_groups"])
+    assert sorted(sd["state"]) == list(range(n_params)) and set(sd["state"][0]) == {"momentum_buffer"}
+    named = dict(m.named_parameters())
+    order = [n for ns in opt._names for n in ns]
+    assert sd["state"][3]["momentum_buffer"].shape == named[order[3]].shape
+    opt2 = build_optimizer(RefTR(cfg, device="cpu"), ref_args(sgd=True))
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 1            # (the flat buffers' alignment padding between groups is not part of any parameter)
+    assert all(torch.equal(opt2.model.store.view_of(opt2.m, n), m.store.view_of(opt.m, n)) for n in order)
+    ref = torch.optim.SGD([{"params": g["params"], "lr": g["lr"]} for g in opt.param_groups if g["params"]], lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    assert set(ref.state_dict()["param_groups"][0]) - {"params"} <= set(sd["param_groups"][0]) | {"initial_lr"}
+
+
+def test_lr_backbone_zero_freezes_the_resnet_like_the_reference():
+    """--lr_backbone 0 (models/modeling/backbone.py:87-89,150: train_backbone = False): every ResNet parameter has requires_grad
+    False, leaves the optimizer's param groups (the backbone group is empty, like the reference's filtered list) and the flat
+    trainable buffer; the state_dict contract is unchanged."""
+    from reftr_amd import build_reftr
+    from reftr_amd.models import layout as L
+    from reftr_amd.optim import build_optimizer
+    model, criterion, _ = build_reftr(ref_args(lr_backbone=0.0))
+    ref_model, _, _ = build_reftr(ref_args())
+    assert not model.cfg.train_backbone and ref_model.cfg.train_backbone
+    assert set(model.state_dict()) == set(ref_model.state_dict())
+    named = dict(model.named_parameters())
+    assert all(not p.requires_grad for n, p in named.items() if n.startswith("img_backbone."))
+    assert all(p.requires_grad for n, p in named.items() if not n.startswith("img_backbone."))
+    st = model.store
+    b, e = st.group_range[L.GROUP_BACKBONE]
+    assert b == e
+    opt = build_optimizer(model, ref_args(lr_backbone=0.0))
+    assert opt.param_groups[1]["params"] == [] and len(opt.param_groups[0]["params"]) > 0
+    n_ref = sum(p.numel() for p in ref_model.parameters() if p.requires_grad)
+    n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert n_ref - n == sum(p.numel() for nme, p in ref_model.named_parameters() if nme.startswith("img_backbone.") and p.requires_grad)
+
+
 def test_reference_param_order_matches_fixture():
     """layout.reference_param_order == the imported reference's named_parameters() order (fixture minted in the build
     container from RefTR / RefTRSeg themselves, oracle/gen_golden*.py recipe)."""

@@ -563,3 +563,42 @@ def test_captured_graphs_of_different_input_kinds_leave_no_stale_gradients(hip, 
         else:
             assert q1[i] > 0.0
         assert abs(n1[i] - n0[i]) < 5e-2 * n0[i], (i, n1[i], n0[i])
+
+
+def test_lr_backbone_zero_trains_everything_but_the_resnet(hip):
+    """--lr_backbone 0 (models/modeling/backbone.py:87-89,150): same forward, the ResNet's backward is not run and its weights do
+    not move (no update, no weight decay), every other gradient equals the regular model's (the losses do not depend on who is
+    trainable), and the clip norm only counts what is trained."""
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.optim import FusedAdamW
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2))
+    P = formula_state(param_shapes(ocfg))
+    res = {}
+    for train_bb in (True, False):
+        cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), train_backbone=train_bb)
+        model = RefTR(cfg, device="cuda")
+        model.load_state_dict(P, strict=True)
+        model.eval()
+        crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        lv, _, _, gn = train_step(model, crit, s, tg, opt, None, max_norm=0.1)
+        torch.cuda.synchronize()
+        sd = model.state_dict()
+        grads = {n: model.store.G[n].detach().float().cpu().clone() for n in model.store.G}
+        res[train_bb] = (lv, float(gn), sd, grads)
+    (l1, g1, sd1, gr1), (l0, g0, sd0, gr0) = res[True], res[False]
+    assert abs(l1 - l0) < 1e-6 * abs(l1)                                        # same forward
+    bb = [k for k in P if k.startswith("img_backbone.") and "weight" in k and "layer" in k and "bn" not in k and "downsample.1" not in k]
+    assert all(torch.equal(sd0[k].cpu(), P[k]) for k in bb)                   # frozen: bit-identical to the loaded weights
+    assert any(not torch.equal(sd1[k].cpu(), P[k]) for k in bb)               # regular model: they moved
+    assert not any(n.startswith("img_backbone.") for n in gr0)                # no gradient storage for the ResNet at all
+    common = [n for n in gr0 if gr0[n].norm() > 0]
+    a = torch.cat([gr0[n].reshape(-1) for n in common]); b = torch.cat([gr1[n].reshape(-1) for n in common])
+    assert rel(a, b) < 1e-3                                                   # atomics-order noise only
+    assert g0 < g1                                                            # the clip norm lost the ResNet's share
+    assert rel(sd0["bbox_embed.layers.1.weight"], sd1["bbox_embed.layers.1.weight"]) < 1e-5

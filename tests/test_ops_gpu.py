@@ -331,6 +331,29 @@ def test_sqnorm_adamw(hip):
     assert rel(pc, torch.cat([P["a"], P["b"]])) < 1e-6
 
 
+def test_sgd_flat_matches_torch_sgd_with_clipping_and_param_groups(hip):
+    """rt_sgd_flat = the reference's --sgd optimizer (torch.optim.SGD(momentum=0.9, weight_decay), main_vg.py:263-265) behind
+    clip_grad_norm_(0.1): three steps on two parameter groups with different learning rates, against torch itself."""
+    g = torch.Generator().manual_seed(12)
+    n = 4096 * 2 + 8
+    p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g) * 0.01
+    ranges = [(0, 4096, 1e-2, 1e-4), (4096, n, 1e-3, 1e-4)]
+    a = torch.nn.Parameter(p[:4096].clone()); b = torch.nn.Parameter(p[4096:].clone())
+    ref = torch.optim.SGD([{"params": [a], "lr": 1e-2}, {"params": [b], "lr": 1e-3}], lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    pc = p.cuda(); m = torch.zeros(n, device="cuda"); v = m[:4]
+    sq = torch.zeros(1, device="cuda"); gn = torch.zeros(1, device="cuda")
+    for step in (1, 2, 3):
+        a.grad = (gr[:4096] * step).clone(); b.grad = (gr[4096:] * step).clone()
+        total = torch.nn.utils.clip_grad_norm_([a, b], 0.1)
+        ref.step()
+        gs = gr.cuda() * step
+        hip.sqnorm(gs, sq)
+        hip.adamw_flat(pc, gs, m, v, step=step, ranges=ranges, gnorm_sq=sq, gnorm_out=gn, max_norm=0.1, beta1=0.9, sgd=True)
+        assert abs(float(gn) - float(total)) < 1e-5 * float(total)
+    assert rel(pc, torch.cat([a.detach(), b.detach()])) < 1e-6
+    assert rel(m, torch.cat([ref.state[a]["momentum_buffer"], ref.state[b]["momentum_buffer"]])) < 1e-5
+
+
 def test_sqnorm_adamw_bf16_gradients_spans_active_and_device_lr(hip):
     """The optimizer variants the engine uses: gradients read from a bf16 buffer (the data-parallel exchange format) give
     exactly what the fp32 path gives on the same (bf16-representable) values; the update issued as two spans equals one
