@@ -151,13 +151,19 @@ def main():
     world = arg
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists for the product)"
+    # REFTR_BENCH_ONE_DEVICE=1 + REFTR_DIST_BACKEND=gloo: every rank on GPU 0 with gloo carrying the (device-tensor) collectives --
+    # NOT a measurement: a functional run of the whole N > 1 control flow (segment graphs, collectives between replays, deferred
+    # optimizer, collective capture decisions) on a one-GPU box, where RCCL refuses two ranks on one device (benchmarks/dp_smoke_gloo.sh)
+    one_dev = os.environ.get("REFTR_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     assert torch.cuda.device_count() > local, f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible"
     torch.cuda.set_device(local)
     force_dist = os.environ.get("REFTR_DDP_FORCE") == "1"        # one-GPU exercise of the data-parallel schedule
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("REFTR_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
     dev = torch.device("cuda", local)
 
     from reftr_amd import hip

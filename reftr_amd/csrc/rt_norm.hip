@@ -7,8 +7,7 @@
 namespace {
 
 constexpr int LN_MAX_PER_LANE = 16;   // D <= 1024
-constexpr int GN_PIX = 8;             // pixels per GroupNorm statistics workgroup: the per-thread pixel loop is a dependent-load
-                                      // chain (64 pixels = 45 us for a 3 MB tensor); 8 keeps it at ~6 us for ~400 workgroups
+constexpr int GN_BWD_PIX = 32;        // pixels per workgroup of the backward statistics kernel (8 loads in flight per thread)
 
 __device__ __forceinline__ int map_row(int r, int grp_rows, int grp_stride, int grp_off) {
     if (grp_rows > 0) return (r / grp_rows) * grp_stride + grp_off + (r % grp_rows);
@@ -368,7 +367,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const rt_groupnorm_desc p
 // backward pass 1: per (b, g): sums of g=dy*gamma and g*xhat; per channel dgamma/dbeta
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const rt_groupnorm_bwd_desc p) {
     const int b = blockIdx.y, c = threadIdx.x;
-    const int p0 = blockIdx.x * GN_PIX, p1 = min(p0 + GN_PIX, p.HW);
+    const int p0 = blockIdx.x * GN_BWD_PIX, p1 = min(p0 + GN_BWD_PIX, p.HW);
     const int cpg = p.C / p.G;
     const float inv_n = 1.f / (float)(cpg * p.HW);
     float s1 = 0.f, s2 = 0.f, dg = 0.f, db = 0.f;
@@ -377,13 +376,26 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const rt_groupnorm_bw
         const float mean = st[0] * inv_n;
         const float rstd = rsqrtf(fmaxf(st[1] * inv_n - mean * mean, 0.f) + p.eps);
         const float gam = p.gamma[c];
-        for (int pix = p0; pix < p1; ++pix) {
-            const size_t o = ((size_t)b * p.out_rows_per_img + p.out_row_off + pix) * p.C + c;
-            float d = p.dy[o];
-            if (p.dy2) d += p.dy2[o];
-            const float xh = (p.x[((size_t)b * p.HW + pix) * p.C + c] - mean) * rstd;
-            dg += d * xh; db += d;
-            s1 += d * gam; s2 += d * gam * xh;
+        // 8 pixels' loads in flight at a time (the plain loop is a chain of load -> accumulate round trips), 32 pixels per workgroup:
+        // a quarter of the per-channel atomics of the 8-pixel blocking (round 3: 22.7 -> see profiles/r03 kernel stats)
+        for (int q0 = p0; q0 < p1; q0 += 8) {
+            float dv[8], xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pix = q0 + j < p1 ? q0 + j : p1 - 1;
+                const size_t o = ((size_t)b * p.out_rows_per_img + p.out_row_off + pix) * p.C + c;
+                dv[j] = p.dy[o];
+                if (p.dy2) dv[j] += p.dy2[o];
+                xv[j] = p.x[((size_t)b * p.HW + pix) * p.C + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (q0 + j >= p1) continue;
+                const float d = dv[j];
+                const float xh = (xv[j] - mean) * rstd;
+                dg += d * xh; db += d;
+                s1 += d * gam; s2 += d * gam * xh;
+            }
         }
     }
     for (int o = cpg >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
@@ -510,7 +522,7 @@ extern "C" int rt_groupnorm_bwd(const rt_groupnorm_bwd_desc* d, rt_stream_t stre
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = rt_zero_f32(d->bstats, 2 * (size_t)d->B * d->G, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((d->HW + GN_PIX - 1) / GN_PIX, d->B), dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3((d->HW + GN_BWD_PIX - 1) / GN_BWD_PIX, d->B), dim3(256), 0, s, *d);
     RT_CHECK_LAUNCH();
     const size_t total = (size_t)d->B * d->HW * d->C;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;

@@ -597,12 +597,21 @@ __global__ __launch_bounds__(256) void small_m_wgrad_grouped_kernel(const SmallJ
     const int kk = (int)(i % k4) * 4, n = (int)(i / k4);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     float gs = 0.f;
-    for (int m = 0; m < q.M; ++m) {
-        const float g = (float)dy[(size_t)m * q.N + n];
-        gs += g;
-        const bf16x4 xv = *reinterpret_cast<const bf16x4*>(x + (size_t)m * q.K + kk);
+    // all <= 16 rows' loads are requested before the first use (rows past M re-read the last row: cache hits, masked out below):
+    // the launch is a few thousand workgroups of one load round trip each, not M of them
+    float gv[16]; bf16x4 xv[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] += g * (float)xv[r];
+    for (int m = 0; m < 16; ++m) {
+        const int mm = m < q.M ? m : q.M - 1;
+        gv[m] = (float)dy[(size_t)mm * q.N + n];
+        xv[m] = *reinterpret_cast<const bf16x4*>(x + (size_t)mm * q.K + kk);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        if (m >= q.M) continue;
+        gs += gv[m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += gv[m] * (float)xv[m][r];
     }
     f32x4* o = reinterpret_cast<f32x4*>(q.dw + (size_t)n * q.K + kk);
     *o = q.overwrite ? a : *o + a;

@@ -34,14 +34,16 @@ class DistributedDataParallel(nn.Module):
     `reduce_phase(name)` / `reduce_late` are the hook points; CapturedTrainStep calls them between its graphs, the eager loop
     gets them from the model's backward."""
 
-    def __init__(self, module, n_chunks=8, broadcast=True, overlap=True):
+    def __init__(self, module, n_chunks=None, broadcast=True, overlap=True):
         super().__init__()
         self.module = module
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         # REFTR_DDP_FORCE=1: run the exchange schedule (single-rank RCCL all-reduces) even with one process, so the
         # multi-GPU code path can be exercised on a one-GPU box
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("REFTR_DDP_FORCE") == "1")
-        self.n_chunks = n_chunks
+        # pieces per exchange are at most 1/n_chunks of the buffer (REFTR_DDP_CHUNKS): fewer, larger all-reduces cost fewer
+        # launches beside the backward and suit the ring's per-message latency; more pieces start moving earlier
+        self.n_chunks = int(os.environ.get("REFTR_DDP_CHUNKS", "2")) if n_chunks is None else n_chunks
         self.overlap = overlap
         self._works = []
         self.timing = None        # a list: reduce_late appends (event before the waits, event after) = exposed exchange time
