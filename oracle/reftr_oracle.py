@@ -56,6 +56,7 @@ class Cfg:
     aux_loss: bool = True
     resnet_layers: tuple = (3, 4, 6, 3)
     bert: BertCfg = field(default_factory=BertCfg)
+    pos_learned: bool = False     # --position_embedding learned (position_encoding.py:59-84)
     masks: bool = False           # RefTRSeg (reftr_segmentation.py): RES head on top of the single-phrase REC model
     cem: bool = False             # --ablation cem_loss: the CEM block + loss_cem (reftr_segmentation.py:16-41, 62-64, 146-147)
     mask_loss_coef: float = 1.0   # main_vg.py (default 1)
@@ -206,6 +207,14 @@ def mask_downsample(mask, size):
     iy = torch.floor(torch.arange(h, dtype=torch.float32) * (H / h)).long().clamp(max=H - 1)
     ix = torch.floor(torch.arange(w, dtype=torch.float32) * (W / w)).long().clamp(max=W - 1)
     return mask[:, iy][:, :, ix]
+
+
+def learned_pos(P, B, h, w, pfx="img_backbone.1."):
+    """PositionEmbeddingLearned.forward (models/modeling/position_encoding.py:74-84): [col_embed[x] | row_embed[y]] per pixel."""
+    x_emb = P[pfx + "col_embed.weight"][:w]
+    y_emb = P[pfx + "row_embed.weight"][:h]
+    pos = torch.cat([x_emb.unsqueeze(0).repeat(h, 1, 1), y_emb.unsqueeze(1).repeat(1, w, 1)], dim=-1)
+    return pos.permute(2, 0, 1).unsqueeze(0).repeat(B, 1, 1, 1)       # [B, 256, h, w]
 
 
 def sine_pos(mask, num_pos_feats=128, temperature=10000.0):
@@ -379,7 +388,7 @@ def reftr_forward(P, samples, cfg: Cfg, train=False, q=False):
     feats = resnet_body(img, P, layers=cfg.resnet_layers, q=q)
     c5 = feats[-1]
     m5 = mask_downsample(img_mask, c5.shape[-2:])
-    pos5 = sine_pos(m5, E // 2)
+    pos5 = learned_pos(P, m5.shape[0], m5.shape[1], m5.shape[2]) if cfg.pos_learned else sine_pos(m5, E // 2)
     # input_proj: 1x1 conv + GroupNorm(32) (models/reftr_transformer.py:121-125,174)
     src = conv2d_acc(rq(c5, q), rq_fwd(P["input_proj.0.0.weight"], q), P["input_proj.0.0.bias"])
     src = F.group_norm(src, 32, P["input_proj.0.1.weight"], P["input_proj.0.1.bias"], 1e-5)
@@ -666,6 +675,8 @@ def total_loss(losses, wd):
 # ----------------------------------------------------------------------------------------------
 def is_trainable(name):
     """backbone.py:87-89: conv1 / layer1 frozen; FrozenBN tensors are buffers."""
+    if name.startswith("img_backbone.1."):          # PositionEmbeddingLearned tables
+        return True
     if name.startswith("img_backbone."):
         if any(s in name for s in ("running_mean", "running_var", ".bn", "downsample.1.")):
             return False

@@ -70,6 +70,8 @@ def param_shapes(cfg):
         lin(p + "0.", o, i); ln(p + "1.", o); lin(p + "4.", o, o); ln(p + "5.", o)
 
     s.update(resnet_shapes("img_backbone.0.body.", cfg.resnet_layers))
+    if getattr(cfg, "pos_learned", False):
+        s["img_backbone.1.row_embed.weight"] = (50, E // 2); s["img_backbone.1.col_embed.weight"] = (50, E // 2)
     s.update(bert_shapes("lang_backbone.", cfg.bert))
     vt = "vl_transformer."
     s[vt + "level_embed"] = (1, E)

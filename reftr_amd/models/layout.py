@@ -44,6 +44,7 @@ class ModelConfig:
     aux_loss: bool = True
     resnet_layers: tuple = (3, 4, 6, 3)   # resnet50; resnet101 = (3, 4, 23, 3)
     masks: bool = False                   # RefTRSeg: RES head (bbox_attention + mask_head), single phrase, no aux loss
+    pos_learned: bool = False             # --position_embedding learned: PositionEmbeddingLearned (position_encoding.py:59-84)
     train_backbone: bool = True           # False: --lr_backbone 0 freezes the whole ResNet (backbone.py:87-89,150)
     cem: bool = False                     # --ablation cem_loss: CEM block + loss_cem (reftr_segmentation.py:16-41, 62-64)
     bert: BertConfig = field(default_factory=BertConfig)
@@ -135,6 +136,9 @@ def main_table(cfg: ModelConfig):
 
     for i, (o, k) in enumerate(((E, E), (E, E), (4, E))):
         lin(f"bbox_embed.layers.{i}.", o, k)
+    if cfg.pos_learned:                   # Joiner[1] = PositionEmbeddingLearned(E // 2): two nn.Embedding(50, E // 2), main lr group
+        t.append(("img_backbone.1.row_embed.weight", (50, E // 2), "param"))
+        t.append(("img_backbone.1.col_embed.weight", (50, E // 2), "param"))
     vt = "vl_transformer."
     if cfg.dec_layers > 0:
         ln(vt + "decoder.norm.", E)
@@ -236,6 +240,8 @@ def reference_param_order(cfg: ModelConfig):
                 names.append(p + c + ".weight")
             if bi == 0:
                 names.append(p + "downsample.0.weight")
+    if cfg.pos_learned:                   # img_backbone = Joiner(backbone, position_embedding): module 1 follows module 0
+        names += ["img_backbone.1.row_embed.weight", "img_backbone.1.col_embed.weight"]
     lb = "lang_backbone."
     e = lb + "embeddings."
     names += [e + "word_embeddings.weight", e + "position_embeddings.weight", e + "token_type_embeddings.weight",

@@ -126,6 +126,8 @@ class RefTR(nn.Module):
                 v = torch.empty(shape, dtype=torch.float32)
                 if name.startswith("lang_backbone."):
                     v.normal_(0.0, 0.02, generator=g)
+                elif name.startswith("img_backbone.1."):
+                    v.uniform_(0.0, 1.0, generator=g)                     # PositionEmbeddingLearned.reset_parameters, position_encoding.py:70-72
                 elif name.startswith("img_backbone."):
                     v.normal_(0.0, math.sqrt(2.0 / (fan_out * rf)), generator=g)
                 elif name == "vl_transformer.level_embed":
@@ -280,6 +282,14 @@ class RefTR(nn.Module):
             H.rows_add(1, E, a_f32=st.P[vt + "level_embed"], b_f32=st.P[vt + "token_type_embeddings.weight"],
                        b_map=(-1, 0, 1), out_f32=addv)
             H.mask_posenc(mask_u8, h, w, E, addv, kpm, Lq, pos, S, Lq)
+            if cfg.pos_learned:
+                # PositionEmbeddingLearned (position_encoding.py:74-84): pos[:, y, x] = [col_embed[x] | row_embed[y]], the same for
+                # every image and independent of the padding mask; the image rows of `pos` (sine values above; the kernel is still
+                # what downsamples the padding mask) are overwritten.  O(h * w * E) glue: a table lookup, no arithmetic to port.
+                assert h <= 50 and w <= 50, "PositionEmbeddingLearned has 50 rows / columns (position_encoding.py:65-66)"
+                col = st.P["img_backbone.1.col_embed.weight"][:w]; row = st.P["img_backbone.1.row_embed.weight"][:h]
+                pe = torch.cat([col.unsqueeze(0).expand(h, w, -1), row.unsqueeze(1).expand(h, w, -1)], dim=-1).reshape(HW, E) + addv
+                pos.view(B, S, E)[:, Lq:, :] = pe
             return r + (pos, kpm)
         seq16, pooled16, bctx, pos, kpm = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
         feats, bb_saved = self.body.forward(x)
@@ -382,7 +392,7 @@ class RefTR(nn.Module):
             mp_ctx=mp_ctx, ip=ip, gn_stats=gn_stats, kpm=kpm, qmask=qmask, ctxmask=ctxmask, enc=enc, mem16=mem16,
             memp16=memp16, mem32=mem32, cls16=cls16, lang16=lang16, kq=kq, qs=qs, vs=vs, qw=qw, c16=c16, co=co,
             cst=(cm, cr), fq_ctx=fq_ctx, dec=dec, hs_stats=hs_stats, t3s=t3s, hs16=hs16, y1=y1, y2=y2, pooled16=pooled16,
-            phrase_mask=(qmask == 0).view(B, T), memory=mem32)
+            phrase_mask=(qmask == 0).view(B, T), memory=mem32, hw=(h, w))
         if self.seg is not None:            # RES head on the last decoder layer (reftr_segmentation.py:136-146)
             pad_u8 = kpm[:, Lq:].contiguous()
             pred_masks, mask_att, seg_sv = self.seg.forward(hs16[(NL - 1) * N:], mem16, mem32, src32, pad_u8, feats, B, S, Lq, h, w)
@@ -561,6 +571,11 @@ class RefTR(nn.Module):
                 net.flush_wgrads_side(2) # first half of the encoder's weight gradients, beside the second half's chain
         H.pos_grad(dpos, st.G[vt + "lang_pos_embeddings.weight"], st.G[vt + "token_type_embeddings.weight"],
                    st.G[vt + "level_embed"], B, S, Lq)
+        if cfg.pos_learned:             # d col_embed[x] = sum over images and rows, d row_embed[y] = sum over images and columns
+            h5, w5 = sv["hw"]
+            gi = dpos.view(B, S, E)[:, Lq:, :].reshape(B, h5, w5, E).sum(0)
+            st.G["img_backbone.1.col_embed.weight"][:w5] += gi[..., :E // 2].sum(0)
+            st.G["img_backbone.1.row_embed.weight"][:h5] += gi[..., E // 2:].sum(1)
 
         # ---- sequence inputs: map_sentence (language rows) and input_proj + GroupNorm (image rows)
         d_seq = net.mlp_bwd(sv["ms_ctx"], dxa, "map_sentence.", dy_rowmap=(Lq, S, 0), dy2=dxb)
@@ -671,9 +686,6 @@ def build_config(args):
         raise NotImplementedError("--dilation (layer4 stride replaced by dilation, models/modeling/backbone.py:120-125) is not "
                                   "built: no reference config uses it")
     pe = getattr(args, "position_embedding", "sine")
-    if pe in ("v3", "learned"):
-        raise NotImplementedError("--position_embedding learned (PositionEmbeddingLearned, models/modeling/"
-                                  "position_encoding.py:59-84) is not built: every reference config uses the sine encoding")
     if pe not in ("v2", "sine"):
         raise ValueError(f"not supported {pe}")                     # as position_encoding.py:95
     if bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss" and int(args.hidden_dim) != 256:
@@ -693,6 +705,7 @@ def build_config(args):
                          # lr_backbone <= 0 freezes the whole ResNet (train_backbone = False, models/modeling/backbone.py:87-89,150):
                          # its parameters leave the optimizer and the clip norm, its backward is not run
                          train_backbone=float(getattr(args, "lr_backbone", 1e-5)) > 0,
+                         pos_learned=pe in ("v3", "learned"),          # position_encoding.py:91-92
                          cem=bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss")
 
 

@@ -230,6 +230,10 @@ def test_reference_param_order_matches_fixture():
     for tag, masks in (("rec", False), ("seg", True)):
         cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), masks=masks)
         assert L.reference_param_order(cfg) == [str(x) for x in g[tag]]
+    g2 = np.load(os.path.join(ROOT, "tests", "golden", "e2e_learned_pos.npz"))     # --position_embedding learned: Joiner[1] holds parameters
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), pos_learned=True)
+    assert L.reference_param_order(cfg) == [str(x) for x in g2["param_order"]]
+    assert L.lr_group("img_backbone.1.row_embed.weight") == L.GROUP_MAIN          # lr_backbone_names = ['img_backbone.0'], main_vg.py:29
 
 
 @pytest.mark.parametrize("masks", [False, True])

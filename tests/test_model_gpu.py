@@ -412,6 +412,37 @@ def test_checkpoint_resume_is_exact(hip, tmp_path):
     assert rel(model2.store.flat_p, model.store.flat_p) < 1e-6
 
 
+def test_learned_position_embedding_vs_reference_golden(hip):
+    """--position_embedding learned (position_encoding.py:59-84): forward, loss and the gradients of the two embedding tables
+    against the fixture minted from the reference built with that flag."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR, build_config
+    g = np.load(os.path.join(GOLD, "e2e_learned_pos.npz"))
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), pos_learned=True)
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), pos_learned=True)
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda")
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    samples, targets = make_inputs("e2e_learned", B=2, H=96, W=128, L=12, n_phrase=3)
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    assert rel(out["pred_logits"].sigmoid(), g["boxes"]) < 5e-3
+    ld = crit(out, tg)
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    assert abs(float(total) - float(g["total_loss"])) < 5e-3 * float(g["total_loss"])
+    model.store.flat_g.zero_()
+    total.backward()
+    for key, name in (("grad_row", "img_backbone.1.row_embed.weight"), ("grad_col", "img_backbone.1.col_embed.weight")):
+        mine, ref = model.store.G[name].float().cpu(), torch.from_numpy(g[key])
+        assert rel(mine, ref) < 3e-2, (key, rel(mine, ref))
+        assert float(mine[4:].abs().sum()) == 0            # 3 x 4 feature map: the other 46 table rows get no gradient
+    assert rel(model.store.G["vl_transformer.level_embed"], g["grad_level_embed"]) < 3e-2
+    assert rel(model.store.G["bbox_embed.layers.2.weight"], g["grad_bbox2_w"]) < 3e-2
+
+
 def test_roberta_backbone_vs_reference_golden(hip):
     """RoBERTa language backbone (f4): exact integer position ids + the same encoder kernels, against the golden vectors
     minted from the reference with HF RobertaModel."""

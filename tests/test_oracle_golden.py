@@ -167,6 +167,25 @@ def test_cem_block_golden():
             assert rel(mine, torch.from_numpy(g[key])) < 1e-4, k
 
 
+def test_learned_position_embedding_golden():
+    """--position_embedding learned (models/modeling/position_encoding.py:59-84): [col_embed[x] | row_embed[y]] per pixel, the
+    same for every image; fixture minted from the reference built with that flag (oracle/gen_golden_learned.py)."""
+    g = gold("e2e_learned_pos")
+    cfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), pos_learned=True)
+    P = formula_state(param_shapes(cfg))
+    samples, targets = make_inputs("e2e_learned", B=2, H=96, W=128, L=12, n_phrase=3)
+    rk, ck = "img_backbone.1.row_embed.weight", "img_backbone.1.col_embed.weight"
+    leaves = {k: P[k].requires_grad_(True) for k in (rk, ck, "vl_transformer.level_embed")}
+    out = O.reftr_forward(P, samples, cfg)
+    assert rel(out["logits"].sigmoid(), g["boxes"]) < 1e-5
+    total = O.total_loss(O.criterion(out, targets), O.weight_dict(cfg))
+    assert abs(float(total) - float(g["total_loss"])) < 1e-5 * float(g["total_loss"])
+    gr, gc, gl = torch.autograd.grad(total, [leaves[rk], leaves[ck], leaves["vl_transformer.level_embed"]])
+    assert rel(gr, g["grad_row"]) < 1e-4 and rel(gc, g["grad_col"]) < 1e-4 and rel(gl, g["grad_level_embed"]) < 1e-4
+    # a 96 x 128 image is 3 x 4 at stride 32: only rows 0..2 / columns 0..3 of the 50-entry tables are touched
+    assert float(gr[3:].abs().sum()) == 0 and float(gc[4:].abs().sum()) == 0 and float(gr[:3].abs().min()) > 0
+
+
 def test_roberta_backbone_golden():
     """RefTR with a HF RobertaModel language backbone (configs/flickr30k/RefTR_flickr_roberta.sh): position ids from the
     padding index, one token type, eps 1e-5."""
