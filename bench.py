@@ -251,6 +251,9 @@ def main():
                 "exposed_exchange_ms": (sum(exposed) / len(exposed)) if exposed else None,
                 "note": "exposed = time the compute stream waits for outstanding all-reduces after backward (HIP events, rank 0, mean over the timed steps)"}
 
+    dc = getattr(model.net, "dec_counters", None)           # cooperative decoder launch (rt_decoder_fwd): word -1 = "a wait gave up"
+    if dc is not None and int(dc[-1]) != 0:
+        raise RuntimeError("rt_decoder_fwd: a stage wait gave up (a workgroup never arrived) -- the timed steps are not valid")
     import math
     assert math.isfinite(loss_value) and abs(loss_value) < 1e3, f"training step produced a non-finite / absurd loss ({loss_value})"
     ms_per_step = el / args.steps * 1e3

@@ -611,6 +611,46 @@ int rt_comm_init(const void* id128, int rank, int world, rt_comm_t* out);
 int rt_comm_allreduce(rt_comm_t comm, void* const* bufs, const int64_t* counts, int n, int dtype, rt_stream_t stream);
 int rt_comm_destroy(rt_comm_t comm);
 
+/* --------------------------------------------------------------------------------------------
+ * rt_decoder_fwd — the TransformerDecoder stack of the referring queries as ONE cooperative launch
+ * (models/modeling/transformer.py:105-143 the stack, :231-252 one layer, forward_post; one query per image: M = B rows, the
+ * self-attention over a single key is the V projection with its per-head probability dropout).  Equivalent, operation for
+ * operation, to the launched chain  rt_conv_gemm (self_attn.v, out_proj) -> rt_layernorm_fwd -> rt_conv_gemm (multihead_attn.q) ->
+ * rt_attn_fwd -> rt_conv_gemm (out_proj) -> rt_layernorm_fwd -> rt_conv_gemm (linear1, linear2) -> rt_layernorm_fwd  per layer:
+ * the saved tensors it writes are the chain's (bit-identical), so the backward is unchanged.  Workgroups stay resident and hand
+ * the row block from stage to stage through global memory (write-through stores + one counter per stage, csrc/rt_decoder.hip).
+ *   counters: 7 * n_layers + 1 zeroed words; the last one is set to 1 if a wait gave up (a workgroup never arrived).
+ *   K / V of layer l: bf16 [B * S, ldkv] (multihead_attn.k / .v of memory + pos / memory, computed beforehand for every layer).
+ * Supported: width 256, 8 heads, F = 2048, M <= 16, S <= 768, n_layers <= RT_DEC_MAX_LAYERS; else RT_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------ */
+#define RT_DEC_MAX_LAYERS 8
+typedef struct rt_decoder_layer_fwd {
+    const void *Wv, *Wo, *Wq, *Wo2, *W1, *W2;            /* bf16 [N][K]: self_attn v / out_proj, multihead_attn q / out_proj, linear1 / 2 */
+    const float *bv, *bo, *bq, *bo2, *b1, *b2;
+    const float *g1, *be1, *g2, *be2, *g3, *be3;         /* norm1..3 weight / bias */
+    const void *k2, *v2;
+    void *o, *t1q16, *q2, *o2, *t2_16, *hdn, *t3_16;      /* bf16 saved tensors: [M,256] (hdn: [M,F]) */
+    float *u, *u2, *u3;                                   /* fp32 pre-norm sums [M,256] */
+    float *mean1, *rstd1, *mean2, *rstd2, *mean3, *rstd3; /* [M] */
+    float *lse2;                                          /* [B, H] */
+    float *t3_f32;                                        /* norm3 output rows, fp32 [M,256] (the shared decoder norm's input) */
+    uint32_t seed_ad, seed_d1, seed_ad2, seed_d2, seed_dh, seed_d3;   /* dropout sites, in the chain's order */
+} rt_decoder_layer_fwd;
+typedef struct rt_decoder_fwd_desc {
+    rt_decoder_layer_fwd layer[RT_DEC_MAX_LAYERS];
+    const float*   t32;        /* [M,256] the stack's input (tgt) */
+    const void*    t16;        /* bf16 copy */
+    const float*   qpos;       /* [M,256] query_pos */
+    const uint8_t* kpm;        /* [B, S] key padding mask (1 = ignore) or NULL */
+    uint32_t*      counters;
+    const uint32_t* seed_dev;  /* optional, see rt_conv_gemm_desc */
+    int32_t n_layers, M, H, S, F, ldkv;
+    float   drop_p, eps, scale;
+} rt_decoder_fwd_desc;
+int rt_decoder_fwd(const rt_decoder_fwd_desc* d, rt_stream_t stream);
+/* REFTR_DEC_TRACE=1 only: 1024 wall-clock stamps (100 MHz) of the last launch's stage boundaries, host buffer */
+int rt_decoder_trace(uint32_t* out1024);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,523 @@
+// The decoder's query chain as ONE cooperative launch (transformer.py:231-252 x dec_layers, one query per image).
+//
+// With a single referring query per image the decoder works on M = B rows: every Linear is a 16-column-tile GEMV whose cost
+// as a launch is the launch itself (~5 us per link, ~66 links per forward).  Here DEC_G workgroups stay resident for the whole
+// stack and hand the M x 256 row block from stage to stage through global memory:
+//   * a stage's producers write their columns with write-through stores (sc0 sc1), wait for the stores, and add 1 to the stage's
+//     counter; its consumers poll that counter (agent-scope load) and read the rows with cache-bypassing loads (sc0 sc1).  No L2
+//     writeback / invalidate: measured 1.6-2.1 us per hand-off (benchmarks/probes/grid_barrier_probe.hip) against ~5 us per
+//     launched link;
+//   * everything that does not depend on the row block -- the stage's weight fragments, biases, the (b, h) K / V rows of the
+//     cross-attention -- is requested BEFORE the wait, so it arrives while the workgroup polls;
+//   * LayerNorm is not a stage: each consumer recomputes it on the M <= 16 rows (one wave per row, the arithmetic of
+//     layernorm_fwd_vec_kernel) and keeps the fp32 result in LDS as the residual of the stage after next;
+//   * four waves per workgroup (one per SIMD: the whole 512-register file per lane, the K / V rows of an attention stage stay in
+//     registers across the wait); thread 0 polls -- its first poll returns behind its own prefetches, which the stage needs anyway.
+// Arithmetic is the launched chain's, operation for operation (the K split over four waves and the reduction order of
+// skinny_gemm_kernel, attn_q1_fwd_kernel's softmax, the same dropout sites and indices): the outputs are bit-identical to the
+// chain's and the launched backward consumes the saved tensors unchanged (tests/test_decoder_coop_gpu.py).
+// Stage map of one layer (counter, producers):  S1 v-proj+head dropout (16) -> S2 out_proj+res (16) -> [LN1] S3 q-proj (16) ->
+// S4 cross-attention, one (b, h) per workgroup (min(G, B*H)) -> S5 out_proj+res (16) -> [LN2] S6 linear1+relu (F/16 tiles over G)
+// -> S7 linear2+res (16) -> [LN3] next layer's S1.
+#include "rt_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int DEC_E = 256;            // model width (16 column tiles: the "core" workgroups 0..15 own one each)
+constexpr int DEC_CORE = DEC_E / 16;
+constexpr int DEC_COH = 17;           // buffer cache policy sc0 | sc1
+constexpr int DEC_MAXK = 3;           // keys per thread of the attention stage: S <= 768
+constexpr int DEC_NT = 4;             // linear1 column tiles per workgroup (F / 16 / G <= 4)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dec_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4 dec_ld16(const void* base, int byte_off) {          // coherent (cache-bypassing) 16-B load
+    return __builtin_amdgcn_raw_buffer_load_b128(dec_rsrc(base), byte_off, 0, DEC_COH);
+}
+__device__ __forceinline__ void dec_st16(void* base, int byte_off, u32x4 v) {        // write-through stores
+    __builtin_amdgcn_raw_buffer_store_b128(v, dec_rsrc(base), byte_off, 0, DEC_COH);
+}
+__device__ __forceinline__ void dec_st8(void* base, int byte_off, u32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, dec_rsrc(base), byte_off, 0, DEC_COH);
+}
+__device__ __forceinline__ void dec_st2(void* base, int byte_off, bf16_t v) {
+    __builtin_amdgcn_raw_buffer_store_b16(*reinterpret_cast<unsigned short*>(&v), dec_rsrc(base), byte_off, 0, DEC_COH);
+}
+
+struct DecSmem {
+    f32x4 red[4][64];
+    float ln32[16][DEC_E];           // fp32 LayerNorm output of the stage before: the residual of the next product
+    float sm32[4][32];
+    float redf[8];
+    int err;
+};
+
+// ---- grid-level hand-off ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dec_arrive(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// `spin`: polls before a wait gives up (a workgroup that never arrives is reported through the error word, never a hang)
+__device__ __forceinline__ void dec_wait(unsigned* cnt, unsigned target, unsigned* err, int spin) {
+    if (threadIdx.x == 0) {
+        int guard = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++guard < spin) {}
+        if (guard >= spin) *err = 1u;
+    }
+    __syncthreads();
+}
+
+// ---- row block -> LDS (bf16 operand rows, stride ld) -------------------------------------------------------------------------
+template <bool COH>
+__device__ __forceinline__ void dec_rows_to_lds(const bf16_t* src, int M, int K, bf16_t* xa, int ld) {
+    const int t = threadIdx.x;
+    const int per_row = K >> 3, pieces = M * per_row;
+    if (t < 256) {
+        for (int i0 = 0; i0 < pieces; i0 += 256 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 256 + t;
+                if (i < pieces) v[j] = COH ? dec_ld16(src, i * 16) : *reinterpret_cast<const u32x4*>(src + (size_t)i * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 256 + t;
+                if (i < pieces) {
+                    const int r = i / per_row, c = i - r * per_row;
+                    *reinterpret_cast<u32x4*>(xa + r * ld + c * 8) = v[j];
+                }
+            }
+        }
+    }
+}
+
+// ---- LayerNorm of the M rows (layernorm_fwd_vec_kernel<1>'s arithmetic): fp32 result -> ln32, bf16(y [+ pos]) -> xa ----------
+struct DecLnOut { float* y_f32; bf16_t* y_bf16; bf16_t* ypos_bf16; float* mean; float* rstd; };
+template <bool COH>
+__device__ __forceinline__ void dec_ln_rows(const float* u, int M, const float* gamma, const float* beta, const float* pos, float eps,
+                                            DecSmem& sm, bf16_t* xa, int ld, bool writer, const DecLnOut& o) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < 4) {
+        const int c = lane * 4;
+        const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma + c), bet = *reinterpret_cast<const f32x4*>(beta + c);
+        for (int row = wave; row < M; row += 4) {
+            f32x4 v;
+            if (COH) { const u32x4 raw = dec_ld16(u, (row * DEC_E + c) * 4); v = *reinterpret_cast<const f32x4*>(&raw); }
+            else v = *reinterpret_cast<const f32x4*>(u + (size_t)row * DEC_E + c);
+            const f32x4 ps = pos ? *reinterpret_cast<const f32x4*>(pos + (size_t)row * DEC_E + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float s = (v[0] + v[1]) + (v[2] + v[3]);
+            const float mean = rt_wave_sum(s) * (1.f / DEC_E);
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; ss += d * d; }
+            const float rstd = rsqrtf(rt_wave_sum(ss) * (1.f / DEC_E) + eps);
+            f32x4 y;
+            bf16x4 yb, yp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[e] - mean) * rstd * gam[e] + bet[e];
+                yb[e] = (bf16_t)y[e];
+                yp[e] = (bf16_t)(y[e] + ps[e]);
+            }
+            *reinterpret_cast<f32x4*>(&sm.ln32[row][c]) = y;
+            *reinterpret_cast<bf16x4*>(xa + row * ld + c) = pos ? yp : yb;
+            if (writer) {
+                const size_t off = (size_t)row * DEC_E + c;
+                if (lane == 0) { if (o.mean) o.mean[row] = mean; if (o.rstd) o.rstd[row] = rstd; }
+                if (o.y_f32) *reinterpret_cast<f32x4*>(o.y_f32 + off) = y;
+                if (o.y_bf16) *reinterpret_cast<bf16x4*>(o.y_bf16 + off) = yb;
+                if (o.ypos_bf16) *reinterpret_cast<bf16x4*>(o.ypos_bf16 + off) = yp;
+            }
+        }
+    }
+}
+
+// ---- weight fragments of one 16-column tile: lane (li, lg) holds W[n0 + li][32 ks + 8 lg .. + 7] for its wave's K steps ------
+template <int PER>
+__device__ __forceinline__ void dec_load_w(const bf16_t* W, int K, int n0, u32x4 (&wv)[PER]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < 4) {
+        const bf16_t* row = W + (size_t)(n0 + (lane & 15)) * K + (lane >> 4) * 8 + wave * PER * 32;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) wv[j] = *reinterpret_cast<const u32x4*>(row + j * 32);
+    }
+}
+
+// one tile: K split over the four compute waves (PER 32-wide steps each, ascending), partial sums added wave 0 + 1 + 2 + 3, the
+// epilogue on wave 0: lane (li, lg) owns row m = li, features n0 + 4 lg .. + 3 -- skinny_gemm_kernel's schedule exactly.
+template <int PER, class Epi>
+__device__ __forceinline__ void dec_tile(const u32x4 (&wv)[PER], const bf16_t* xa, int ld, int M, int n0, DecSmem& sm, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    if (wave < 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* xr = xa + li * ld + lg * 8 + wave * PER * 32;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + j * 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&wv[j]), xv, acc, 0, 0, 0);
+        }
+        sm.red[wave][lane] = acc;
+    }
+    __syncthreads();
+    if (wave == 0 && li < M) {
+        const f32x4 acc = sm.red[0][lane] + sm.red[1][lane] + sm.red[2][lane] + sm.red[3][lane];
+        epi(li, n0 + lg * 4, acc);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ f32x4 dec_dropout(f32x4 v, float p, uint32_t seed, uint32_t idx0, int shift) {
+    const uint32_t thresh = rt_drop_thresh(p);
+    const float ks = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (rt_hash32(seed, (idx0 + r) >> shift) >= thresh) ? v[r] * ks : 0.f;
+    return v;
+}
+__device__ __forceinline__ u32x2 dec_pack4(f32x4 v) {
+    bf16x4 b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
+    return *reinterpret_cast<u32x2*>(&b);
+}
+
+// ---- cross-attention of one (b, h): attn_q1_fwd_kernel's arithmetic; K / V rows arrive before the wait ------------------------
+struct DecRow { bf16x8 c[4]; };
+struct DecKV { DecRow k[DEC_MAXK], v[DEC_MAXK]; bool ok[DEC_MAXK]; };
+__device__ __forceinline__ void dec_attn_prefetch(const rt_decoder_fwd_desc& p, const rt_decoder_layer_fwd& L, int bh, DecKV& kv) {
+    const int t = threadIdx.x;
+    if (t < 256) {
+        const int b = bh / p.H, h = bh - b * p.H;
+#pragma unroll
+        for (int i = 0; i < DEC_MAXK; ++i) {
+            const int j = t + i * 256;
+            const int jj = j < p.S ? j : 0;
+            kv.ok[i] = j < p.S && !(p.kpm && p.kpm[(size_t)b * p.S + jj]);
+            const bf16_t* kr = (const bf16_t*)L.k2 + ((size_t)b * p.S + jj) * p.ldkv + h * 32;
+            const bf16_t* vr = (const bf16_t*)L.v2 + ((size_t)b * p.S + jj) * p.ldkv + h * 32;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                kv.k[i].c[c] = *reinterpret_cast<const bf16x8*>(kr + c * 8);
+                kv.v[i].c[c] = *reinterpret_cast<const bf16x8*>(vr + c * 8);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void dec_attn(const rt_decoder_fwd_desc& p, const rt_decoder_layer_fwd& L, int bh, const DecKV& kv,
+                                         DecSmem& sm, uint32_t dseed) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const bool cw = wave < 4;
+    float q[32], sc[DEC_MAXK], o[32];
+    float m = -INFINITY;
+    if (cw) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4 raw = dec_ld16(L.q2, ((b * DEC_E) + h * 32 + c * 8) * 2);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e];
+        }
+#pragma unroll
+        for (int i = 0; i < DEC_MAXK; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += (float)kv.k[i].c[c][e] * q[c * 8 + e];
+            sc[i] = kv.ok[i] ? a * p.scale : -INFINITY;
+            m = fmaxf(m, sc[i]);
+        }
+        m = rt_wave_max(m);
+        if (lane == 0) sm.redf[wave] = m;
+    }
+    __syncthreads();
+    m = fmaxf(fmaxf(sm.redf[0], sm.redf[1]), fmaxf(sm.redf[2], sm.redf[3]));
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    float l = 0.f;
+    if (cw) {
+#pragma unroll
+        for (int i = 0; i < DEC_MAXK; ++i) { sc[i] = __expf(sc[i] - ms); l += sc[i]; }
+        l = rt_wave_sum(l);
+        if (lane == 0) sm.redf[4 + wave] = l;
+    }
+    __syncthreads();
+    l = sm.redf[4] + sm.redf[5] + sm.redf[6] + sm.redf[7];
+    const float inv_l = 1.f / l;                 // fully masked row: NaN below, as the reference
+    if (t == 0) L.lse2[bh] = ms + __logf(l);
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    if (cw) {
+#pragma unroll
+        for (int i = 0; i < DEC_MAXK; ++i) {
+            const int j = t + i * 256;
+            if (j >= p.S) continue;
+            float pr = sc[i] * inv_l;
+            if (do_drop) pr = (rt_hash32(dseed, (uint32_t)((size_t)bh * p.S + j)) >= thresh) ? pr * ks : 0.f;
+            if (pr != 0.f || pr != pr) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[c * 8 + e] += pr * (float)kv.v[i].c[c][e];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = rt_wave_sum(o[d]);
+    }
+    __syncthreads();
+    if (cw && lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 32; ++d) sm.sm32[wave][d] = o[d];
+    }
+    __syncthreads();
+    if (t < 32) {
+        const float mine = sm.sm32[0][t] + sm.sm32[1][t] + sm.sm32[2][t] + sm.sm32[3][t];
+        dec_st2(L.o2, ((b * DEC_E) + h * 32 + t) * 2, (bf16_t)mine);
+    }
+}
+
+__global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_desc p, const int G, const int spin, unsigned* trace) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dec_smem_raw[];
+    DecSmem& sm = *reinterpret_cast<DecSmem*>(dec_smem_raw);
+    bf16_t* xa = reinterpret_cast<bf16_t*>(dec_smem_raw + sizeof(DecSmem));       // [16][K + 8] bf16 operand rows of the current product
+    const int wg = blockIdx.x, t = threadIdx.x;
+    const int M = p.M, F = p.F;
+    const bool core = wg < DEC_CORE, writer = wg == 0;
+    const int ldE = DEC_E + 8, ldF = F + 8;
+    const int n0 = wg * 16;                                  // a core workgroup's column tile of every 256-wide product
+    const int n_bh = M * p.H;
+    const unsigned n_attn = (unsigned)(n_bh < G ? n_bh : G);
+    const int f_tiles = F >> 4;
+    const unsigned n_ffn = (unsigned)(f_tiles < G ? f_tiles : G);
+    const bool drop = p.drop_p > 0.f;
+    unsigned* err = p.counters + 7 * p.n_layers;
+    const int lane = t & 63, li = lane & 15, lg = lane >> 4, wave = t >> 6;
+
+    // REFTR_DEC_TRACE: workgroups 0 (core) and G - 1 stamp the 100 MHz wall clock at every stage boundary
+    int tr_i = 0;
+    unsigned* tr = (trace && t == 0 && (wg == 0 || wg == G - 1)) ? trace + (wg == 0 ? 0 : 512) : nullptr;
+#define DEC_STAMP() do { if (tr) tr[tr_i++] = (unsigned)wall_clock64(); } while (0)
+    DEC_STAMP();
+    u32x4 w2[2];            // K = 256: two 32-wide steps per wave
+    if (core) dec_load_w<2>((const bf16_t*)p.layer[0].Wv, DEC_E, n0, w2);
+    for (int l = 0; l < p.n_layers; ++l) {
+        const rt_decoder_layer_fwd& L = p.layer[l];
+        unsigned* cnt = p.counters + 7 * l;
+        if (core) {
+            // ================= S1: o = headdrop(t16 Wv^T + bv); t = LN3 of the layer before (or the stack's input)
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bv + n0 + lg * 4);
+            if (l == 0) {
+                dec_rows_to_lds<false>((const bf16_t*)p.t16, M, DEC_E, xa, ldE);
+                if (t < 256) for (int i = t; i < M * (DEC_E / 4); i += 256)
+                    *reinterpret_cast<f32x4*>(&sm.ln32[0][0] + i * 4) = *reinterpret_cast<const f32x4*>(p.t32 + (size_t)i * 4);
+            } else {
+                const rt_decoder_layer_fwd& Lp = p.layer[l - 1];
+                dec_wait(cnt - 1, DEC_CORE, err, spin); DEC_STAMP();
+                const DecLnOut out{Lp.t3_f32, (bf16_t*)Lp.t3_16, nullptr, Lp.mean3, Lp.rstd3};
+                dec_ln_rows<true>(Lp.u3, M, Lp.g3, Lp.be3, nullptr, p.eps, sm, xa, ldE, writer, out);
+            }
+            __syncthreads();
+            {
+                const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_ad) : 0u;
+                dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                    v += bias;
+                    if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 5);
+                    dec_st8(L.o, (m * DEC_E + n) * 2, dec_pack4(v));
+                });
+            }
+            dec_arrive(cnt + 0); DEC_STAMP();
+            // ================= S2: u = t + drop(o Wo^T + bo)
+            dec_load_w<2>((const bf16_t*)L.Wo, DEC_E, n0, w2);
+            if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bo + n0 + lg * 4);
+            dec_wait(cnt + 0, DEC_CORE, err, spin); DEC_STAMP();
+            dec_rows_to_lds<true>((const bf16_t*)L.o, M, DEC_E, xa, ldE);
+            __syncthreads();
+            {
+                const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d1) : 0u;
+                dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                    v += bias;
+                    if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 0);
+                    v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
+                    dec_st16(L.u, (m * DEC_E + n) * 4, *reinterpret_cast<u32x4*>(&v));
+                });
+            }
+            dec_arrive(cnt + 1); DEC_STAMP();
+            // ================= S3: q2 = (LN1(u) + query_pos) Wq^T + bq
+            dec_load_w<2>((const bf16_t*)L.Wq, DEC_E, n0, w2);
+            if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bq + n0 + lg * 4);
+            dec_wait(cnt + 1, DEC_CORE, err, spin); DEC_STAMP();
+            {
+                const DecLnOut out{nullptr, nullptr, (bf16_t*)L.t1q16, L.mean1, L.rstd1};
+                dec_ln_rows<true>(L.u, M, L.g1, L.be1, p.qpos, p.eps, sm, xa, ldE, writer, out);
+            }
+            __syncthreads();
+            dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                v += bias;
+                dec_st8(L.q2, (m * DEC_E + n) * 2, dec_pack4(v));
+            });
+            dec_arrive(cnt + 2); DEC_STAMP();
+        }
+        // ================= S4: cross-attention, (b, h) = wg, wg + G, ...
+        if (wg < (int)n_attn) {
+            const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_ad2) : 0u;
+            DecKV kv;
+            dec_attn_prefetch(p, L, wg, kv);
+            dec_wait(cnt + 2, DEC_CORE, err, spin); DEC_STAMP();
+            for (int bh = wg; bh < n_bh; bh += G) {
+                if (bh != wg) dec_attn_prefetch(p, L, bh, kv);
+                dec_attn(p, L, bh, kv, sm, seed);
+            }
+            dec_arrive(cnt + 3); DEC_STAMP();
+        }
+        if (core) {
+            // ================= S5: u2 = t1 + drop(o2 Wo2^T + bo2)
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            dec_load_w<2>((const bf16_t*)L.Wo2, DEC_E, n0, w2);
+            if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bo2 + n0 + lg * 4);
+            dec_wait(cnt + 3, n_attn, err, spin); DEC_STAMP();
+            dec_rows_to_lds<true>((const bf16_t*)L.o2, M, DEC_E, xa, ldE);
+            __syncthreads();
+            {
+                const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d2) : 0u;
+                dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                    v += bias;
+                    if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 0);
+                    v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
+                    dec_st16(L.u2, (m * DEC_E + n) * 4, *reinterpret_cast<u32x4*>(&v));
+                });
+            }
+            dec_arrive(cnt + 4); DEC_STAMP();
+        }
+        // ================= S6: hdn = drop(relu(LN2(u2) W1^T + b1)), column tiles wg, wg + G, ...
+        if (wg < (int)n_ffn) {
+            u32x4 w1[DEC_NT][2];
+            f32x4 b1[DEC_NT];
+#pragma unroll
+            for (int i = 0; i < DEC_NT; ++i) {
+                const int tile = wg + i * G;
+                if (tile < f_tiles) {
+                    dec_load_w<2>((const bf16_t*)L.W1, DEC_E, tile * 16, w1[i]);
+                    if (wave == 0) b1[i] = *reinterpret_cast<const f32x4*>(L.b1 + tile * 16 + lg * 4);
+                }
+            }
+            dec_wait(cnt + 4, DEC_CORE, err, spin); DEC_STAMP();
+            {
+                const DecLnOut out{nullptr, (bf16_t*)L.t2_16, nullptr, L.mean2, L.rstd2};
+                dec_ln_rows<true>(L.u2, M, L.g2, L.be2, nullptr, p.eps, sm, xa, ldE, writer, out);
+            }
+            __syncthreads();
+            const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_dh) : 0u;
+#pragma unroll
+            for (int i = 0; i < DEC_NT; ++i) {
+                const int tile = wg + i * G;
+                if (tile < f_tiles) {
+                    const f32x4 bb = b1[i];
+                    dec_tile<2>(w1[i], xa, ldE, M, tile * 16, sm, [&](int m, int n, f32x4 v) {
+                        v += bb;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * F + n), 0);
+                        dec_st8(L.hdn, (m * F + n) * 2, dec_pack4(v));
+                    });
+                }
+            }
+            dec_arrive(cnt + 5); DEC_STAMP();
+        }
+        if (core) {
+            // ================= S7: u3 = t2 + drop(hdn W2^T + b2)      (K = F: 16 steps per wave at F = 2048)
+            u32x4 wf[16];
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            dec_load_w<16>((const bf16_t*)L.W2, F, n0, wf);
+            if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.b2 + n0 + lg * 4);
+            dec_wait(cnt + 5, n_ffn, err, spin); DEC_STAMP();
+            dec_rows_to_lds<true>((const bf16_t*)L.hdn, M, F, xa, ldF);
+            __syncthreads();
+            {
+                const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d3) : 0u;
+                dec_tile<16>(wf, xa, ldF, M, n0, sm, [&](int m, int n, f32x4 v) {
+                    v += bias;
+                    if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 0);
+                    v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
+                    dec_st16(L.u3, (m * DEC_E + n) * 4, *reinterpret_cast<u32x4*>(&v));
+                });
+            }
+            dec_arrive(cnt + 6); DEC_STAMP();
+            if (l + 1 < p.n_layers) dec_load_w<2>((const bf16_t*)p.layer[l + 1].Wv, DEC_E, n0, w2);
+        }
+    }
+    // ---- the last layer's norm3 (statistics, bf16 rows, the fp32 rows the shared decoder norm reads)
+    if (writer && p.n_layers > 0) {
+        const rt_decoder_layer_fwd& Lp = p.layer[p.n_layers - 1];
+        dec_wait(p.counters + 7 * (p.n_layers - 1) + 6, DEC_CORE, err, spin); DEC_STAMP();
+        const DecLnOut out{Lp.t3_f32, (bf16_t*)Lp.t3_16, nullptr, Lp.mean3, Lp.rstd3};
+        dec_ln_rows<true>(Lp.u3, M, Lp.g3, Lp.be3, nullptr, p.eps, sm, xa, ldE, true, out);
+    }
+}
+
+int dec_spin() {
+    static const int v = getenv("REFTR_DEC_SPIN") ? atoi(getenv("REFTR_DEC_SPIN")) : (1 << 22);
+    return v;
+}
+unsigned* dec_trace_buf() {           // REFTR_DEC_TRACE=1: 1024 words, read back by rt_decoder_trace
+    static unsigned* buf = nullptr;
+    static const int on = getenv("REFTR_DEC_TRACE") ? atoi(getenv("REFTR_DEC_TRACE")) : 0;
+    static bool tried = false;
+    if (on && !tried) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(hipStreamPerThread, &st);
+        tried = true;
+        if (hipMalloc(&buf, 4096) != hipSuccess) { buf = nullptr; (void)hipGetLastError(); } else (void)hipMemset(buf, 0, 4096);
+    }
+    return buf;
+}
+int dec_groups() {
+    static const int g = getenv("REFTR_DEC_G") ? atoi(getenv("REFTR_DEC_G")) : 64;
+    return g;
+}
+
+}  // namespace
+
+extern "C" int rt_decoder_fwd(const rt_decoder_fwd_desc* d, rt_stream_t stream) {
+    if (!d || !d->t32 || !d->t16 || !d->qpos || !d->counters) return RT_ERR_BADARG;
+    if (d->n_layers < 1 || d->n_layers > RT_DEC_MAX_LAYERS) return RT_ERR_UNSUPPORTED;
+    const int G = dec_groups();
+    if (G < DEC_CORE || G > 128) return RT_ERR_UNSUPPORTED;
+    if (d->M < 1 || d->M > 16 || d->H * 32 != DEC_E || d->S < 1 || d->S > 256 * DEC_MAXK) return RT_ERR_UNSUPPORTED;
+    if (d->F != 2048 || (d->F >> 4) > DEC_NT * G || (d->ldkv & 7)) return RT_ERR_UNSUPPORTED;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const rt_decoder_layer_fwd& L = d->layer[l];
+        if (!L.Wv || !L.Wo || !L.Wq || !L.Wo2 || !L.W1 || !L.W2 || !L.k2 || !L.v2 || !L.o || !L.u || !L.q2 || !L.o2 || !L.u2 ||
+            !L.hdn || !L.u3 || !L.lse2 || !L.t1q16 || !L.t2_16 || !L.t3_16) return RT_ERR_BADARG;
+    }
+    const size_t smem = sizeof(DecSmem) + (size_t)16 * (d->F + 8) * 2;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(decoder_fwd_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, *d, G, dec_spin(), dec_trace_buf());
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+/* debugging aid (REFTR_DEC_TRACE=1): copies the 1024 stage time stamps of the last launch (100 MHz ticks; words 0.. = workgroup 0,
+   words 512.. = the last workgroup) to `out`; returns RT_ERR_UNSUPPORTED when tracing is off. */
+extern "C" int rt_decoder_trace(uint32_t* out) {
+    unsigned* b = dec_trace_buf();
+    if (!b) return RT_ERR_UNSUPPORTED;
+    if (!out) return RT_OK;                  // allocation only (call once before any stream capture)
+    if (hipDeviceSynchronize() != hipSuccess) return RT_ERR_BADARG;
+    return (int)hipMemcpy(out, b, 4096, hipMemcpyDeviceToHost);
+}

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -229,6 +229,25 @@ class MaskLossDesc(Structure):
                 ("lddp", c_int32), ("inv_norm", c_float)]
 
 
+DEC_MAX_LAYERS = 8
+
+
+class DecoderLayerFwd(Structure):
+    _PTRS = ("Wv", "Wo", "Wq", "Wo2", "W1", "W2", "bv", "bo", "bq", "bo2", "b1", "b2", "g1", "be1", "g2", "be2", "g3", "be3",
+             "k2", "v2", "o", "t1q16", "q2", "o2", "t2_16", "hdn", "t3_16", "u", "u2", "u3",
+             "mean1", "rstd1", "mean2", "rstd2", "mean3", "rstd3", "lse2", "t3_f32")
+    _SEEDS = ("seed_ad", "seed_d1", "seed_ad2", "seed_d2", "seed_dh", "seed_d3")
+    _fields_ = [(n, c_void_p) for n in _PTRS] + [(n, c_uint32) for n in _SEEDS]
+
+
+class DecoderFwdDesc(Structure):
+    _fields_ = [("layer", DecoderLayerFwd * DEC_MAX_LAYERS),
+                ("t32", c_void_p), ("t16", c_void_p), ("qpos", c_void_p), ("kpm", c_void_p), ("counters", c_void_p),
+                ("seed_dev", c_void_p),
+                ("n_layers", c_int32), ("M", c_int32), ("H", c_int32), ("S", c_int32), ("F", c_int32), ("ldkv", c_int32),
+                ("drop_p", c_float), ("eps", c_float), ("scale", c_float)]
+
+
 _SIGNATURES = {
     "rt_abi_version": (c_int, []),
     "rt_device_arch": (c_int, [c_int, c_char_p, c_int]),
@@ -287,6 +306,8 @@ _SIGNATURES = {
     "rt_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "rt_comm_allreduce": (c_int, [c_void_p, POINTER(c_void_p), POINTER(ctypes.c_int64), c_int, c_int, c_void_p]),
     "rt_comm_destroy": (c_int, [c_void_p]),
+    "rt_decoder_fwd": (c_int, [POINTER(DecoderFwdDesc), c_void_p]),
+    "rt_decoder_trace": (c_int, [c_void_p]),
 }
 
 _lib = None
@@ -634,6 +655,38 @@ def attn_bwd(q, k, v, out, dout, lse, kpm, *, B, H, Sq, Sk, dh, scale, drop_p=0.
     assert _ld(dout) == _ld(out)
     _check(lib().rt_attn_bwd(ctypes.byref(d), _stream()), "rt_attn_bwd")
     return dq, dk, dv
+
+
+def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, eps=1e-5):
+    """The decoder stack of one-query-per-image inputs as one cooperative launch (rt_decoder_fwd).  `layers`: one dict per
+    layer, keys = DecoderLayerFwd._PTRS (tensors) + DecoderLayerFwd._SEEDS (ints); every output tensor is allocated by the
+    caller (they are the launched chain's saved tensors).  Returns the counters tensor (word 7 * n_layers = failure flag)."""
+    M = t32.shape[0]
+    d = DecoderFwdDesc()
+    assert 1 <= len(layers) <= DEC_MAX_LAYERS
+    for i, lay in enumerate(layers):
+        L = d.layer[i]
+        for n in DecoderLayerFwd._PTRS:
+            setattr(L, n, _p(lay[n]))
+        for n in DecoderLayerFwd._SEEDS:
+            setattr(L, n, lay[n] & 0xFFFFFFFF)
+    counters = torch.zeros(7 * len(layers) + 1, dtype=torch.int32, device=t32.device)
+    d.t32, d.t16, d.qpos, d.kpm, d.counters = _p(t32), _p(t16), _p(qpos), _p(kpm), _p(counters)
+    d.seed_dev = _seedp(drop_p)
+    d.n_layers, d.M, d.H, d.S, d.F, d.ldkv = len(layers), M, H, S, F, _ld(layers[0]["k2"])
+    d.drop_p, d.eps, d.scale = drop_p, eps, scale
+    _check(lib().rt_decoder_fwd(ctypes.byref(d), _stream()), "rt_decoder_fwd")
+    return counters
+
+
+def decoder_trace(readback=True):
+    """REFTR_DEC_TRACE=1: (workgroup 0 stamps, last workgroup stamps) of the last rt_decoder_fwd launch, 100 MHz ticks."""
+    buf = (c_uint32 * 1024)()
+    _check(lib().rt_decoder_trace(ctypes.cast(buf, c_void_p) if readback else None), "rt_decoder_trace")
+    if not readback:
+        return None
+    a = list(buf)
+    return a[:512], a[512:]
 
 
 # --------------------------------------------------------------------------------------------

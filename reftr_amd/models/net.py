@@ -54,6 +54,8 @@ class Net:
         # the decoder's backward chain cost +0.2 ms -- a 440-workgroup launch beside the chain's 1-16-workgroup kernels delays them
         # more than leaving the chain saves; off by default
         self.kv_dgrad_side = os.environ.get("REFTR_DEC_KV_SIDE", "0") != "0"
+        # the decoder's forward chain as one cooperative launch (csrc/rt_decoder.hip) whenever its shape allows
+        self.dec_coop = os.environ.get("REFTR_DEC_COOP", "1") != "0"
         self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
@@ -428,6 +430,53 @@ class Net:
         t3_32, t3_16, t3q16, m3, r3 = self.ln_fwd(u3, p + "norm3.", pos=qpos, y_f32=t3_out)
         r.update(u3=u3, st3=(m3, r3))
         return t3_32, t3_16, t3q16, r
+
+    def dec_stack_coop_ok(self, N, T, S, n_layers, fold_sa):
+        """Shapes rt_decoder_fwd covers: one query per image on the folded self-attention path, the reference's widths."""
+        cfg = self.cfg
+        return (self.dec_coop and T == 1 and fold_sa and self.trivial_sa and self.fold_sa and cfg.hidden == 256 and cfg.nheads == 8
+                and cfg.ffn == 2048 and N <= 16 and S <= 768 and 1 <= n_layers <= H.DEC_MAX_LAYERS)
+
+    def dec_stack_fwd_coop(self, prefixes, t32, t16, tq16, qpos, kvs, kpm, B, S, t3_all):
+        """All decoder layers in ONE launch (rt_decoder_fwd).  Writes exactly the tensors the per-layer chain (dec_layer_fwd,
+        folded path) saves -- same values bit for bit -- and returns the same per-layer dicts, so dec_layer_bwd is unchanged."""
+        cfg = self.cfg
+        E, F, N = cfg.hidden, cfg.ffn, t32.shape[0]
+        dev = t32.device
+        bf, f32 = torch.bfloat16, torch.float32
+        layers, saved = [], []
+        t16_in = t16
+        for i, p in enumerate(prefixes):
+            r = {"t16": t16_in, "tq16": tq16 if i == 0 else None, "trivial": True, "fold": True, "qk": None, "v": None, "lse": None}
+            for k in ("ad", "d1", "ad2", "d2", "dh", "d3"):       # the chain's site order
+                r[k] = self._drop(cfg.dropout)
+            sm = torch.empty(6, N, dtype=f32, device=dev)         # mean / rstd of norm1..3
+            act = torch.empty(5, N, E, dtype=bf, device=dev)      # o, t1q16, q2, o2, t2_16
+            pre = torch.empty(3, N, E, dtype=f32, device=dev)     # u, u2, u3
+            t3_16 = torch.empty(N, E, dtype=bf, device=dev)
+            hdn = torch.empty(N, F, dtype=bf, device=dev)
+            lse2 = torch.empty(B, cfg.nheads, 1, dtype=f32, device=dev)
+            k2, v2 = kvs[i]
+            r.update(o=act[0], t1q16=act[1], q2=act[2], o2=act[3], t2_16=act[4], u=pre[0], u2=pre[1], u3=pre[2], hdn=hdn,
+                     st1=(sm[0], sm[1]), st2=(sm[2], sm[3]), st3=(sm[4], sm[5]), k2=k2, v2=v2, lse2=lse2)
+            L = self.lins
+            lay = dict(Wv=L[p + "self_attn.v"].W, Wo=L[p + "self_attn.out_proj."].W, Wq=L[p + "multihead_attn.q"].W,
+                       Wo2=L[p + "multihead_attn.out_proj."].W, W1=L[p + "linear1."].W, W2=L[p + "linear2."].W,
+                       bv=L[p + "self_attn.v"].b32, bo=L[p + "self_attn.out_proj."].b32, bq=L[p + "multihead_attn.q"].b32,
+                       bo2=L[p + "multihead_attn.out_proj."].b32, b1=L[p + "linear1."].b32, b2=L[p + "linear2."].b32,
+                       g1=self.P(p + "norm1.weight"), be1=self.P(p + "norm1.bias"), g2=self.P(p + "norm2.weight"),
+                       be2=self.P(p + "norm2.bias"), g3=self.P(p + "norm3.weight"), be3=self.P(p + "norm3.bias"),
+                       k2=k2, v2=v2, o=act[0], t1q16=act[1], q2=act[2], o2=act[3], t2_16=act[4], hdn=hdn, t3_16=t3_16,
+                       u=pre[0], u2=pre[1], u3=pre[2], mean1=sm[0], rstd1=sm[1], mean2=sm[2], rstd2=sm[3], mean3=sm[4], rstd3=sm[5],
+                       lse2=lse2, t3_f32=t3_all[i * N:(i + 1) * N],
+                       seed_ad=r["ad"][1], seed_d1=r["d1"][1], seed_ad2=r["ad2"][1], seed_d2=r["d2"][1], seed_dh=r["dh"][1],
+                       seed_d3=r["d3"][1])
+            layers.append(lay); saved.append(r)
+            t16_in = t3_16
+        dh = E // cfg.nheads
+        drop_p = saved[0]["ad"][0]
+        self.dec_counters = H.decoder_fwd(layers, t32, t16, qpos, kpm, H=cfg.nheads, S=S, F=F, drop_p=drop_p, scale=dh ** -0.5)
+        return saved
 
     def dec_layer_bwd(self, p, r, g_a, g_b, mem16, memp16, qmask, kpm, B, T, S, dmem_acc, dmemp_acc, dqpos_acc):
         """g_a (+ g_b) = gradient w.r.t. this layer's output t3.  Returns (dt_a, dt_q): their sum is the

@@ -373,10 +373,14 @@ class RefTR(nn.Module):
         t3_all = torch.empty(NL * N, E, dtype=torch.float32, device=dev)      # every layer's output, for the shared norm
         t32, t16, tq16 = tgt32, tgt16, tgtq16
         kvs = net.dec_kv_all([f"{vt}decoder.layers.{i}." for i in range(NL)], mem16, memp16) if NL else []
-        for i in range(NL):
+        fold_sa = "phrase" not in samples and nq == 1
+        coop = NL > 0 and net.dec_stack_coop_ok(N, T, S, NL, fold_sa)
+        if coop:
+            dec = net.dec_stack_fwd_coop([f"{vt}decoder.layers.{i}." for i in range(NL)], t32, t16, tq16, qpos, kvs, kpm, B, S, t3_all)
+        for i in range(0 if coop else NL):
             t32, t16, tq16, r = net.dec_layer_fwd(f"{vt}decoder.layers.{i}.", t32, t16, tq16, qpos, mem16, memp16,
                                                   qmask, kpm, B, T, S, kv=kvs[i], t3_out=t3_all[i * N:(i + 1) * N],
-                                                  fold_sa="phrase" not in samples and nq == 1)
+                                                  fold_sa=fold_sa)
             dec.append(r)
         # decoder.norm on every layer's output (transformer.py:131-141, return_intermediate): ONE launch over the stack
         hm = hr = None

@@ -1,0 +1,146 @@
+"""GPU: the decoder stack as one cooperative launch (rt_decoder_fwd, csrc/rt_decoder.hip) against the launched chain it replaces
+(transformer.py:231-252 per layer).  The cooperative kernel repeats the chain's arithmetic operation for operation, so the bar is
+bit equality of every tensor the backward reads, in eval mode and with dropout on, at the test size and at configs[1]'s B = 8."""
+import os
+
+import pytest
+import torch
+
+from oracle import reftr_oracle as O
+from oracle.shapes import param_shapes
+from oracle.synth import make_inputs
+from oracle.weights import formula_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__ as g
+    g.build()
+    from reftr_amd import hip as H
+    return H
+
+
+def to_cuda(samples, targets):
+    from reftr_amd.util.misc import NestedTensor
+    s = {k: v.cuda() for k, v in samples.items() if k not in ("img", "img_mask")}
+    s["img"] = NestedTensor(samples["img"].cuda(), samples["img_mask"].cuda())
+    return s, [{k: v.cuda() for k, v in t.items()} for t in targets]
+
+
+def build(dec_layers, B, H, W):
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    ocfg = O.Cfg(enc_layers=2, dec_layers=dec_layers, bert=O.BertCfg(layers=2))
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=dec_layers, bert=L.BertConfig(layers=2))
+    model = RefTR(cfg, device="cuda")
+    model.load_state_dict(formula_state(param_shapes(ocfg)), strict=True)
+    torch.manual_seed(3)
+    model.store.P["bbox_embed.layers.2.weight"].normal_(0, 0.02)       # a zero head hides the decoder from the loss
+    model.mark_dirty()
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    samples, targets = make_inputs("coop", B=B, H=H, W=W, L=12)
+    s, tg = to_cuda(samples, targets)
+    return model, crit, s, tg
+
+
+SAVED = ("t16", "o", "u", "t1q16", "q2", "o2", "lse2", "u2", "t2_16", "hdn", "u3")
+
+
+def run(model, crit, s, tg, coop, train, seed=10, backward=False):
+    model.net.dec_coop = coop
+    model.train(train)
+    model.seed_dev.fill_(seed)
+    out = model(s)
+    sv = model._saved
+    dec = [{k: r[k].detach().clone() for k in SAVED} | {f"st{j}{h}": r[f"st{j}"][h].detach().clone() for j in (1, 2, 3) for h in (0, 1)}
+           for r in sv["dec"]]
+    res = dict(logits=out["pred_logits"].detach().clone(), t3s=sv["t3s"].detach().clone(), dec=dec)
+    if coop:
+        assert int(model.net.dec_counters[-1]) == 0, "a cooperative wait gave up"
+    if backward:
+        ld = crit(out, tg)
+        total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        model.store.flat_g.zero_()
+        total.backward()
+        res["grad"] = model.store.flat_g.detach().clone()
+    return res
+
+
+def assert_same(a, b):
+    assert torch.equal(a["logits"], b["logits"])
+    assert torch.equal(a["t3s"], b["t3s"])
+    for i, (ra, rb) in enumerate(zip(a["dec"], b["dec"])):
+        for k in ra:
+            assert torch.equal(ra[k], rb[k]), (i, k, float((ra[k].float() - rb[k].float()).abs().max()))
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("B,dec_layers,H,W", [(2, 2, 96, 128), (8, 6, 192, 160), (13, 3, 64, 64)])
+def test_cooperative_decoder_is_bit_identical_to_the_launched_chain(hip, B, dec_layers, H, W, train):
+    model, crit, s, tg = build(dec_layers, B, H, W)
+    ref = run(model, crit, s, tg, coop=False, train=train)
+    assert any(float(r["hdn"].abs().sum()) > 0 for r in ref["dec"])
+    for rep in range(5):                     # hand-offs are timing dependent: repeat
+        got = run(model, crit, s, tg, coop=True, train=train)
+        assert_same(got, ref)
+    if train:                                # another step seed: other masks, still identical
+        a = run(model, crit, s, tg, coop=False, train=True, seed=77)
+        b = run(model, crit, s, tg, coop=True, train=True, seed=77)
+        assert not torch.equal(a["logits"], ref["logits"])
+        assert_same(b, a)
+
+
+def test_backward_consumes_the_cooperative_forward_unchanged(hip):
+    """The launched backward reads the tensors the cooperative forward saved: gradients equal the chain's up to the order of
+    the atomically accumulated pieces (biases, norm parameters)."""
+    model, crit, s, tg = build(3, 4, 96, 128)
+    a = run(model, crit, s, tg, coop=False, train=True, backward=True)
+    b = run(model, crit, s, tg, coop=True, train=True, backward=True)
+    assert_same(b, a)
+    d = float((a["grad"] - b["grad"]).norm() / a["grad"].norm())
+    assert d < 1e-5, d
+
+
+def test_unsupported_shapes_keep_the_chain(hip):
+    """Multi-phrase inputs (T > 1: real self-attention among the phrase queries) do not take the cooperative path."""
+    model, crit, s, tg = build(2, 2, 96, 128)
+    assert model.net.dec_stack_coop_ok(8, 1, 440, 6, True)
+    assert not model.net.dec_stack_coop_ok(8, 3, 440, 6, True)
+    assert not model.net.dec_stack_coop_ok(8, 1, 440, 6, False)
+    assert not model.net.dec_stack_coop_ok(17, 1, 440, 6, True)
+    assert not model.net.dec_stack_coop_ok(8, 1, 900, 6, True)
+
+
+def test_many_replays_under_a_captured_graph(hip):
+    """The cooperative launch inside a captured training step: 200 replays, no wait gives up, losses finite and equal to the
+    chain-built graph's on the same seeds."""
+    from reftr_amd.engine_vg import CapturedTrainStep
+    from reftr_amd.optim import FusedAdamW
+    losses = {}
+    for coop in (False, True):
+        os.environ["REFTR_DEC_COOP"] = "1" if coop else "0"
+        try:
+            model, crit, s, tg = build(3, 8, 128, 128)
+            model.net.dec_coop = coop
+            model.train()
+            opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+            cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg)
+            model.seed_dev.fill_(5)
+            vals = []
+            for i in range(200):
+                l = cap(s, tg)[0]
+                if i % 20 == 0:
+                    vals.append(float(l))
+            cap.flush()
+            if coop:
+                assert int(model.net.dec_counters[-1]) == 0
+            losses[coop] = vals
+        finally:
+            os.environ.pop("REFTR_DEC_COOP", None)
+    assert all(v == v and abs(v) < 1e4 for v in losses[True])
+    # the two graphs differ by the order of the atomically accumulated gradient pieces only (warm-up steps included)
+    assert abs(losses[True][0] - losses[False][0]) <= 2e-3 * abs(losses[False][0])
+    assert all(abs(a - b) < 2e-2 * abs(b) for a, b in zip(losses[True], losses[False]))
