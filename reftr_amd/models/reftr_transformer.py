@@ -89,6 +89,11 @@ class RefTR(nn.Module):
         # iteration's AdamW update at the head of this forward -- the BERT slice on the language stream, concurrently with
         # the ResNet forward -- and the engine's callback that applies a still-pending update before anyone else reads
         self._pre_update = None
+        # single-process training: the BERT slice's share of the gradient norm is taken on the language stream as soon as that
+        # slice is final (see _backward_gen); (begin, end, device scalar) for the optimizer, None when not taken
+        self._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0"
+        self._norm_split = None
+        self._sq_bert = torch.zeros(1, dtype=torch.float32, device=device)
         self._flush_pending = None
         self._zero_grad_side = False      # engine-driven: clear the gradient buffer on the language stream under the encoder
         self._pending = None
@@ -439,6 +444,7 @@ class RefTR(nn.Module):
         return bool(self._stops) or any(self._phase_hooks.values())
 
     def _backward_impl(self, dlogits, dmasks=None, dcem=None):
+        self._norm_split = None
         if self._bwd_gen is not None:
             # the previous backward stopped at a data-parallel boundary and was never resumed (an exception in the loop): its
             # half-written gradient set is void.  A backward armed for THIS step by zero_grad(fast=True) keeps its state (the
@@ -462,6 +468,10 @@ class RefTR(nn.Module):
         self._bwd_gen = None
         H.set_seed_dev(None)
         self.store.finish_overwrite()
+        if self._norm_split is not None:         # a matrix of the BERT slice cleared AFTER its squared norm was taken: void
+            b0, b1, _ = self._norm_split
+            if any(b0 <= off < b1 for off, _n in self.store.last_stale):
+                self._norm_split = None
         for hook in self._post_backward_hooks:
             hook()
         return None
@@ -663,6 +673,13 @@ class RefTR(nn.Module):
                     net.bert_bwd(sv["bctx"], d_seq, None)
                     net.bert_bwd(sv["pctx"], None, dpool)
                 net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
+                if self._norm_side:
+                    # Every gradient of the BERT slice (63 % of the buffer) is final here, ~1.5 ms before the ResNet backward ends:
+                    # its share of the clip norm is reduced on this stream now; the optimizer adds the rest (optim.finish_step).
+                    net.flush_wgrads()   # the slice's queued LayerNorm-parameter / grouped weight gradients (nothing else is queued)
+                    b0, b1 = st.group_range[L.GROUP_BERT]
+                    H.sqnorm(st.flat_g[b0:b1], self._sq_bert)
+                    self._norm_split = (b0, b1, self._sq_bert)
             net.flush_wgrads_side(4)     # encoder / map_sentence weight gradients: language stream, in front of the BERT branch
             net.side.run(_bert_bwd, d_seq, dpool)
         # ---- ResNet body (its gradients are the last to become final); data parallel: layer4's slice (64 % of the ResNet

@@ -82,6 +82,7 @@ class ParamStore:
         self.G = {n: self._view(self.flat_g, n, o) for n, (b, o) in self.offset.items() if b == "p"}
         # overwrite-mode bookkeeping (see the module docstring): registered matrices {data_ptr: (offset, numel)}
         self._ow, self._ow_table, self._armed, self._written, self._stale_tables = {}, None, False, set(), {}
+        self.last_stale = ()
 
     # ------------------------------------------------------------------ overwrite-mode gradient production
     def register_overwritable(self, gw):
@@ -135,9 +136,11 @@ class ParamStore:
         would otherwise keep the gradient of whichever step last wrote it; a captured graph bakes its host-side decisions in,
         so the clear must be part of every step's own launches: a T == 1 graph replayed after a T > 1 graph clears what the
         T > 1 step left behind.)"""
+        self.last_stale = ()
         if not self._armed:
             return
         missing = frozenset(self._ow) - self._written
+        self.last_stale = tuple(self._ow[k] for k in missing)          # (offset, numel) of what this step left unwritten
         if missing:
             ent = self._stale_tables.get(missing)
             if ent is None:

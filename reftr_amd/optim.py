@@ -64,10 +64,23 @@ class FusedAdamW(torch.optim.Optimizer):
         g16 = getattr(self.model.store, "flat_g16", None)
         return g16 if g16 is not None else self.model.store.flat_g
 
+    def _sqnorm_all(self):
+        """Squared norm of the whole gradient buffer into self.sq.  When the backward already reduced the BERT slice on the
+        language stream (model._norm_split, single-process fp32 gradients only), only the rest is read here."""
+        g = self._grad_buffer()
+        split = getattr(self.model, "_norm_split", None)
+        st = self.model.store
+        if split is not None and g is st.flat_g and split[1] == st.flat_g.numel() and split[0] > 0:
+            H.sqnorm(g[:split[0]], self.sq)
+            self.sq.add_(split[2])
+            self.model._norm_split = None
+        else:
+            H.sqnorm(g, self.sq)
+
     def clip_grad_norm_(self, max_norm):
         """Launches the global-norm reduction; the clip coefficient itself is applied inside the AdamW kernel.
         Returns the device scalar that holds the total norm after step()."""
-        H.sqnorm(self._grad_buffer(), self.sq)
+        self._sqnorm_all()
         self._max_norm, self._have_sq = float(max_norm), True
         return self.grad_norm
 
@@ -149,7 +162,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def finish_step(self, max_norm):
         """End of an iteration in deferred mode: total gradient norm, step counter, 'update pending' flag.  The weights
         are NOT touched; grad_norm holds this iteration's (pre-clip) norm like clip_grad_norm_'s return value."""
-        H.sqnorm(self._grad_buffer(), self.sq)
+        self._sqnorm_all()
         self._max_norm = float(max_norm)
         H.counter_add(self.step_dev, 1)
         H.counter_add(self.active, 1)

@@ -453,6 +453,34 @@ def test_learned_position_embedding_vs_reference_golden(hip):
     assert rel(model.store.G["bbox_embed.layers.2.weight"], g["grad_bbox2_w"]) < 3e-2
 
 
+def test_clip_norm_with_the_bert_share_taken_on_the_language_stream(hip):
+    """Single process: the BERT slice's squared gradient norm is reduced on the language stream right after BERT's backward
+    (reftr_transformer._backward_gen), the optimizer reads only the rest of the buffer (optim._sqnorm_all): the total equals
+    the norm of the whole buffer, in eager steps and with the split switched off."""
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.optim import FusedAdamW
+    model, crit, P, ocfg = build(small=True)
+    model.train()
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    opt = FusedAdamW(model, lr=0.0, lr_backbone=0.0, weight_decay=0.0)
+    norms = {}
+    for split in (True, False):
+        model._norm_side = split
+        model.seed_dev.fill_(3)
+        _, _, _, gn = train_step(model, crit, s, tg, opt, None, max_norm=0.1)
+        torch.cuda.synchronize()
+        full = float(model.store.flat_g.double().norm())
+        assert abs(float(gn) - full) < 1e-5 * full, (split, float(gn), full)
+        if split:
+            from reftr_amd.models import layout as L
+            b0, b1 = model.store.group_range[L.GROUP_BERT]
+            assert abs(float(model._sq_bert) - float(model.store.flat_g[b0:b1].double().pow(2).sum())) < 1e-4 * float(model._sq_bert)
+            assert model._norm_split is None                   # consumed by the optimizer
+        norms[split] = float(gn)
+    assert abs(norms[True] - norms[False]) < 1e-4 * norms[False]
+
+
 def test_roberta_backbone_vs_reference_golden(hip):
     """RoBERTa language backbone (f4): exact integer position ids + the same encoder kernels, against the golden vectors
     minted from the reference with HF RobertaModel."""
