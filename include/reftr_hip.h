@@ -618,12 +618,15 @@ int rt_comm_destroy(rt_comm_t comm);
  * operation, to the launched chain  rt_conv_gemm (self_attn.v, out_proj) -> rt_layernorm_fwd -> rt_conv_gemm (multihead_attn.q) ->
  * rt_attn_fwd -> rt_conv_gemm (out_proj) -> rt_layernorm_fwd -> rt_conv_gemm (linear1, linear2) -> rt_layernorm_fwd  per layer:
  * the saved tensors it writes are the chain's (bit-identical), so the backward is unchanged.  Workgroups stay resident and hand
- * the row block from stage to stage through global memory (write-through stores + one counter per stage, csrc/rt_decoder.hip).
- *   counters: 7 * n_layers + 1 zeroed words; the last one is set to 1 if a wait gave up (a workgroup never arrived).
+ * the row block from stage to stage through global memory as tagged 8-byte units (csrc/rt_decoder.hip).
+ *   handoff: RT_DEC_HANDOFF_BYTES of device memory, zeroed ONCE by the caller and then owned by the launches (word 0 = launch
+ *            epoch, advanced by every launch; word 1 is set to 1 if a consumer gave up waiting for its rows).  Launches that
+ *            share a buffer must be ordered on one stream.
  *   K / V of layer l: bf16 [B * S, ldkv] (multihead_attn.k / .v of memory + pos / memory, computed beforehand for every layer).
  * Supported: width 256, 8 heads, F = 2048, M <= 16, S <= 768, n_layers <= RT_DEC_MAX_LAYERS; else RT_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------ */
 #define RT_DEC_MAX_LAYERS 8
+#define RT_DEC_HANDOFF_BYTES (256 + 16 * 256 * 36 + 16 * 2048 * 4)
 typedef struct rt_decoder_layer_fwd {
     const void *Wv, *Wo, *Wq, *Wo2, *W1, *W2;            /* bf16 [N][K]: self_attn v / out_proj, multihead_attn q / out_proj, linear1 / 2 */
     const float *bv, *bo, *bq, *bo2, *b1, *b2;
@@ -642,7 +645,7 @@ typedef struct rt_decoder_fwd_desc {
     const void*    t16;        /* bf16 copy */
     const float*   qpos;       /* [M,256] query_pos */
     const uint8_t* kpm;        /* [B, S] key padding mask (1 = ignore) or NULL */
-    uint32_t*      counters;
+    uint32_t*      handoff;
     const uint32_t* seed_dev;  /* optional, see rt_conv_gemm_desc */
     int32_t n_layers, M, H, S, F, ldkv;
     float   drop_p, eps, scale;

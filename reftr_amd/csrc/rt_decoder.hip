@@ -3,10 +3,13 @@
 // With a single referring query per image the decoder works on M = B rows: every Linear is a 16-column-tile GEMV whose cost
 // as a launch is the launch itself (~5 us per link, ~66 links per forward).  Here DEC_G workgroups stay resident for the whole
 // stack and hand the M x 256 row block from stage to stage through global memory:
-//   * a stage's producers write their columns with write-through stores (sc0 sc1), wait for the stores, and add 1 to the stage's
-//     counter; its consumers poll that counter (agent-scope load) and read the rows with cache-bypassing loads (sc0 sc1).  No L2
-//     writeback / invalidate: measured 1.6-2.1 us per hand-off (benchmarks/probes/grid_barrier_probe.hip) against ~5 us per
-//     launched link;
+//   * the hand-off carries its own validity: a producer writes its columns as 8-byte units {4 bytes of data, 4-byte tag} with
+//     write-through stores (sc0 sc1) and moves on -- no store acknowledgement, no counter; a consumer reads the units with
+//     cache-bypassing loads and simply re-reads until every tag is the one of (this launch, this layer, this stage).  One memory
+//     round trip per hand-off instead of three (store ack -> counter -> poll -> data read: the first version of this kernel,
+//     5.2 us per stage measured with the stage trace below; a counter-only barrier probes at 1.6-2.1 us,
+//     benchmarks/probes/grid_barrier_probe.hip) against ~4-5 us per launched link.  The tag's launch part is a word in the
+//     hand-off buffer that workgroup 0 advances at the very end, so the buffer never needs clearing;
 //   * everything that does not depend on the row block -- the stage's weight fragments, biases, the (b, h) K / V rows of the
 //     cross-attention -- is requested BEFORE the wait, so it arrives while the workgroup polls;
 //   * LayerNorm is not a stage: each consumer recomputes it on the M <= 16 rows (one wave per row, the arithmetic of
@@ -17,7 +20,7 @@
 // skinny_gemm_kernel, attn_q1_fwd_kernel's softmax, the same dropout sites and indices): the outputs are bit-identical to the
 // chain's and the launched backward consumes the saved tensors unchanged (tests/test_decoder_coop_gpu.py).
 // Stage map of one layer (counter, producers):  S1 v-proj+head dropout (16) -> S2 out_proj+res (16) -> [LN1] S3 q-proj (16) ->
-// S4 cross-attention, one (b, h) per workgroup (min(G, B*H)) -> S5 out_proj+res (16) -> [LN2] S6 linear1+relu (F/16 tiles over G)
+// S4 cross-attention, one (b, h) per workgroup -> S5 out_proj+res (16) -> [LN2] S6 linear1+relu (F/16 tiles over G)
 // -> S7 linear2+res (16) -> [LN3] next layer's S1.
 #include "rt_common.h"
 #include <stdlib.h>
@@ -57,84 +60,115 @@ struct DecSmem {
     int err;
 };
 
-// ---- grid-level hand-off ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dec_arrive(unsigned* cnt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have landed
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// `spin`: polls before a wait gives up (a workgroup that never arrives is reported through the error word, never a hang)
-__device__ __forceinline__ void dec_wait(unsigned* cnt, unsigned target, unsigned* err, int spin) {
-    if (threadIdx.x == 0) {
+// ---- hand-off through tagged units --------------------------------------------------------------------------------------------
+// Region layout (bytes from the buffer start; words 0 / 1 = launch epoch / failure flag):
+constexpr int LL_HDR = 256;
+constexpr int LL_O = LL_HDR, LL_U = LL_O + 16 * 256 * 4, LL_Q2 = LL_U + 16 * 256 * 8, LL_O2 = LL_Q2 + 16 * 256 * 4,
+              LL_U2 = LL_O2 + 16 * 256 * 4, LL_U3 = LL_U2 + 16 * 256 * 8, LL_HDN = LL_U3 + 16 * 256 * 8;      // hdn: 16 * F * 4 bytes
+__device__ __forceinline__ unsigned ll_tag(unsigned epoch, int layer, int stage) { return (epoch << 8) | (unsigned)(layer * 8 + stage + 1); }
+
+// bf16 row block [M][K] (unit = 2 bf16 + tag) -> LDS operand rows
+__device__ __forceinline__ void ll_rows_to_lds(unsigned char* ll, int region, unsigned tag, int M, int K, bf16_t* xa, int ld,
+                                               unsigned* err, int spin) {
+    const int t = threadIdx.x;
+    const int per_row = K >> 2, pieces = M * per_row;            // 16-byte pieces: 2 units = 4 bf16
+    for (int i0 = 0; i0 < pieces; i0 += 256 * 8) {
+        u32x4 v[8];
         int guard = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++guard < spin) {}
-        if (guard >= spin) *err = 1u;
+        bool ok;
+        do {
+            asm volatile("" ::: "memory");       // the loads below must be re-issued on every pass
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 256 + t;
+                if (i < pieces) v[j] = dec_ld16(ll + region, i * 16);
+            }
+            ok = true;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 256 + t;
+                if (i < pieces) ok = ok && v[j][1] == tag && v[j][3] == tag;
+            }
+        } while (!ok && ++guard < spin);
+        if (!ok) *err = 1u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * 256 + t;
+            if (i < pieces) {
+                const int r = i / per_row, c = i - r * per_row;
+                *reinterpret_cast<u32x2*>(xa + r * ld + c * 4) = u32x2{v[j][0], v[j][2]};
+            }
+        }
     }
-    __syncthreads();
+}
+// producer side: 4 consecutive bf16 features of row m (one 16-byte store), 4 consecutive fp32 features (two)
+__device__ __forceinline__ void ll_put_bf16x4(unsigned char* ll, int region, unsigned tag, int elem, u32x2 packed) {
+    dec_st16(ll + region, elem * 4, u32x4{packed[0], tag, packed[1], tag});
+}
+__device__ __forceinline__ void ll_put_f32x4(unsigned char* ll, int region, unsigned tag, int elem, f32x4 v) {
+    dec_st16(ll + region, elem * 8, u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag});
+    dec_st16(ll + region, elem * 8 + 16, u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag});
 }
 
-// ---- row block -> LDS (bf16 operand rows, stride ld) -------------------------------------------------------------------------
 template <bool COH>
 __device__ __forceinline__ void dec_rows_to_lds(const bf16_t* src, int M, int K, bf16_t* xa, int ld) {
     const int t = threadIdx.x;
     const int per_row = K >> 3, pieces = M * per_row;
-    if (t < 256) {
-        for (int i0 = 0; i0 < pieces; i0 += 256 * 8) {
-            u32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * 256 + t;
-                if (i < pieces) v[j] = COH ? dec_ld16(src, i * 16) : *reinterpret_cast<const u32x4*>(src + (size_t)i * 8);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * 256 + t;
-                if (i < pieces) {
-                    const int r = i / per_row, c = i - r * per_row;
-                    *reinterpret_cast<u32x4*>(xa + r * ld + c * 8) = v[j];
-                }
-            }
-        }
+    for (int i = t; i < pieces; i += 256) {
+        const int r = i / per_row, c = i - r * per_row;
+        *reinterpret_cast<u32x4*>(xa + r * ld + c * 8) = *reinterpret_cast<const u32x4*>(src + (size_t)i * 8);
     }
 }
 
 // ---- LayerNorm of the M rows (layernorm_fwd_vec_kernel<1>'s arithmetic): fp32 result -> ln32, bf16(y [+ pos]) -> xa ----------
 struct DecLnOut { float* y_f32; bf16_t* y_bf16; bf16_t* ypos_bf16; float* mean; float* rstd; };
-template <bool COH>
-__device__ __forceinline__ void dec_ln_rows(const float* u, int M, const float* gamma, const float* beta, const float* pos, float eps,
+// `ll` != nullptr: the rows come from a tagged fp32 region (4 units per lane), else from `u` (plain memory)
+__device__ __forceinline__ void dec_ln_rows(const float* u, unsigned char* ll, int region, unsigned tag, unsigned* err, int spin,
+                                            int M, const float* gamma, const float* beta, const float* pos, float eps,
                                             DecSmem& sm, bf16_t* xa, int ld, bool writer, const DecLnOut& o) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave < 4) {
-        const int c = lane * 4;
-        const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma + c), bet = *reinterpret_cast<const f32x4*>(beta + c);
-        for (int row = wave; row < M; row += 4) {
-            f32x4 v;
-            if (COH) { const u32x4 raw = dec_ld16(u, (row * DEC_E + c) * 4); v = *reinterpret_cast<const f32x4*>(&raw); }
-            else v = *reinterpret_cast<const f32x4*>(u + (size_t)row * DEC_E + c);
-            const f32x4 ps = pos ? *reinterpret_cast<const f32x4*>(pos + (size_t)row * DEC_E + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const float s = (v[0] + v[1]) + (v[2] + v[3]);
-            const float mean = rt_wave_sum(s) * (1.f / DEC_E);
-            float ss = 0.f;
+    const int c = lane * 4;
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma + c), bet = *reinterpret_cast<const f32x4*>(beta + c);
+    for (int row = wave; row < M; row += 4) {
+        f32x4 v;
+        if (ll) {
+            u32x4 a, b;
+            int guard = 0;
+            bool ok;
+            do {
+            asm volatile("" ::: "memory");       // the loads below must be re-issued on every pass
+                a = dec_ld16(ll + region, (row * DEC_E + c) * 8);
+                b = dec_ld16(ll + region, (row * DEC_E + c) * 8 + 16);
+                ok = a[1] == tag && a[3] == tag && b[1] == tag && b[3] == tag;
+            } while (!ok && ++guard < spin);
+            if (!ok) *err = 1u;
+            v = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(b[0]), __uint_as_float(b[2])};
+        } else {
+            v = *reinterpret_cast<const f32x4*>(u + (size_t)row * DEC_E + c);
+        }
+        const f32x4 ps = pos ? *reinterpret_cast<const f32x4*>(pos + (size_t)row * DEC_E + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float s = (v[0] + v[1]) + (v[2] + v[3]);
+        const float mean = rt_wave_sum(s) * (1.f / DEC_E);
+        float ss = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; ss += d * d; }
-            const float rstd = rsqrtf(rt_wave_sum(ss) * (1.f / DEC_E) + eps);
-            f32x4 y;
-            bf16x4 yb, yp;
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; ss += d * d; }
+        const float rstd = rsqrtf(rt_wave_sum(ss) * (1.f / DEC_E) + eps);
+        f32x4 y;
+        bf16x4 yb, yp;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = (v[e] - mean) * rstd * gam[e] + bet[e];
-                yb[e] = (bf16_t)y[e];
-                yp[e] = (bf16_t)(y[e] + ps[e]);
-            }
-            *reinterpret_cast<f32x4*>(&sm.ln32[row][c]) = y;
-            *reinterpret_cast<bf16x4*>(xa + row * ld + c) = pos ? yp : yb;
-            if (writer) {
-                const size_t off = (size_t)row * DEC_E + c;
-                if (lane == 0) { if (o.mean) o.mean[row] = mean; if (o.rstd) o.rstd[row] = rstd; }
-                if (o.y_f32) *reinterpret_cast<f32x4*>(o.y_f32 + off) = y;
-                if (o.y_bf16) *reinterpret_cast<bf16x4*>(o.y_bf16 + off) = yb;
-                if (o.ypos_bf16) *reinterpret_cast<bf16x4*>(o.ypos_bf16 + off) = yp;
-            }
+        for (int e = 0; e < 4; ++e) {
+            y[e] = (v[e] - mean) * rstd * gam[e] + bet[e];
+            yb[e] = (bf16_t)y[e];
+            yp[e] = (bf16_t)(y[e] + ps[e]);
+        }
+        *reinterpret_cast<f32x4*>(&sm.ln32[row][c]) = y;
+        *reinterpret_cast<bf16x4*>(xa + row * ld + c) = pos ? yp : yb;
+        if (writer) {
+            const size_t off = (size_t)row * DEC_E + c;
+            if (lane == 0) { if (o.mean) o.mean[row] = mean; if (o.rstd) o.rstd[row] = rstd; }
+            if (o.y_f32) *reinterpret_cast<f32x4*>(o.y_f32 + off) = y;
+            if (o.y_bf16) *reinterpret_cast<bf16x4*>(o.y_bf16 + off) = yb;
+            if (o.ypos_bf16) *reinterpret_cast<bf16x4*>(o.ypos_bf16 + off) = yp;
         }
     }
 }
@@ -211,43 +245,52 @@ __device__ __forceinline__ void dec_attn_prefetch(const rt_decoder_fwd_desc& p, 
     }
 }
 __device__ __forceinline__ void dec_attn(const rt_decoder_fwd_desc& p, const rt_decoder_layer_fwd& L, int bh, const DecKV& kv,
-                                         DecSmem& sm, uint32_t dseed) {
+                                         DecSmem& sm, uint32_t dseed, unsigned char* ll, unsigned tag_q, unsigned tag_o, unsigned* err, int spin) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = bh / p.H, h = bh - b * p.H;
-    const bool cw = wave < 4;
     float q[32], sc[DEC_MAXK], o[32];
     float m = -INFINITY;
-    if (cw) {
+    {   // the 32 query features of (b, h): 16 tagged units, the same 128 bytes for every lane
+        u32x4 raw[8];
+        int guard = 0;
+        bool ok;
+        do {
+            asm volatile("" ::: "memory");       // the loads below must be re-issued on every pass
+            ok = true;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32x4 raw = dec_ld16(L.q2, ((b * DEC_E) + h * 32 + c * 8) * 2);
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(&raw);
+            for (int c = 0; c < 8; ++c) {
+                raw[c] = dec_ld16(ll + LL_Q2, (b * DEC_E + h * 32 + c * 4) * 4);
+                ok = ok && raw[c][1] == tag_q && raw[c][3] == tag_q;
+            }
+        } while (!ok && ++guard < spin);
+        if (!ok) *err = 1u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) q[c * 8 + e] = (float)v[e];
+        for (int c = 0; c < 8; ++c) {
+            const unsigned w0 = raw[c][0], w1 = raw[c][2];
+            const bf16x2 lo = *reinterpret_cast<const bf16x2*>(&w0), hi = *reinterpret_cast<const bf16x2*>(&w1);
+            q[c * 4 + 0] = (float)lo[0]; q[c * 4 + 1] = (float)lo[1]; q[c * 4 + 2] = (float)hi[0]; q[c * 4 + 3] = (float)hi[1];
         }
-#pragma unroll
-        for (int i = 0; i < DEC_MAXK; ++i) {
-            float a = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a += (float)kv.k[i].c[c][e] * q[c * 8 + e];
-            sc[i] = kv.ok[i] ? a * p.scale : -INFINITY;
-            m = fmaxf(m, sc[i]);
-        }
-        m = rt_wave_max(m);
-        if (lane == 0) sm.redf[wave] = m;
     }
+#pragma unroll
+    for (int i = 0; i < DEC_MAXK; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += (float)kv.k[i].c[c][e] * q[c * 8 + e];
+        sc[i] = kv.ok[i] ? a * p.scale : -INFINITY;
+        m = fmaxf(m, sc[i]);
+    }
+    m = rt_wave_max(m);
+    if (lane == 0) sm.redf[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(sm.redf[0], sm.redf[1]), fmaxf(sm.redf[2], sm.redf[3]));
     const float ms = (m == -INFINITY) ? 0.f : m;
     float l = 0.f;
-    if (cw) {
 #pragma unroll
-        for (int i = 0; i < DEC_MAXK; ++i) { sc[i] = __expf(sc[i] - ms); l += sc[i]; }
-        l = rt_wave_sum(l);
-        if (lane == 0) sm.redf[4 + wave] = l;
-    }
+    for (int i = 0; i < DEC_MAXK; ++i) { sc[i] = __expf(sc[i] - ms); l += sc[i]; }
+    l = rt_wave_sum(l);
+    if (lane == 0) sm.redf[4 + wave] = l;
     __syncthreads();
     l = sm.redf[4] + sm.redf[5] + sm.redf[6] + sm.redf[7];
     const float inv_l = 1.f / l;                 // fully masked row: NaN below, as the reference
@@ -257,32 +300,35 @@ __device__ __forceinline__ void dec_attn(const rt_decoder_fwd_desc& p, const rt_
     const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
 #pragma unroll
     for (int d = 0; d < 32; ++d) o[d] = 0.f;
-    if (cw) {
 #pragma unroll
-        for (int i = 0; i < DEC_MAXK; ++i) {
-            const int j = t + i * 256;
-            if (j >= p.S) continue;
-            float pr = sc[i] * inv_l;
-            if (do_drop) pr = (rt_hash32(dseed, (uint32_t)((size_t)bh * p.S + j)) >= thresh) ? pr * ks : 0.f;
-            if (pr != 0.f || pr != pr) {
+    for (int i = 0; i < DEC_MAXK; ++i) {
+        const int j = t + i * 256;
+        if (j >= p.S) continue;
+        float pr = sc[i] * inv_l;
+        if (do_drop) pr = (rt_hash32(dseed, (uint32_t)((size_t)bh * p.S + j)) >= thresh) ? pr * ks : 0.f;
+        if (pr != 0.f || pr != pr) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[c * 8 + e] += pr * (float)kv.v[i].c[c][e];
-            }
+                for (int e = 0; e < 8; ++e) o[c * 8 + e] += pr * (float)kv.v[i].c[c][e];
         }
-#pragma unroll
-        for (int d = 0; d < 32; ++d) o[d] = rt_wave_sum(o[d]);
     }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = rt_wave_sum(o[d]);
     __syncthreads();
-    if (cw && lane == 0) {
+    if (lane == 0) {
 #pragma unroll
         for (int d = 0; d < 32; ++d) sm.sm32[wave][d] = o[d];
     }
     __syncthreads();
-    if (t < 32) {
-        const float mine = sm.sm32[0][t] + sm.sm32[1][t] + sm.sm32[2][t] + sm.sm32[3][t];
-        dec_st2(L.o2, ((b * DEC_E) + h * 32 + t) * 2, (bf16_t)mine);
+    if (t < 16) {                                // thread t: features 2t, 2t + 1 of the head -> one unit + the saved bf16 pair
+        bf16x2 pr;
+        pr[0] = (bf16_t)(sm.sm32[0][2 * t] + sm.sm32[1][2 * t] + sm.sm32[2][2 * t] + sm.sm32[3][2 * t]);
+        pr[1] = (bf16_t)(sm.sm32[0][2 * t + 1] + sm.sm32[1][2 * t + 1] + sm.sm32[2][2 * t + 1] + sm.sm32[3][2 * t + 1]);
+        const int e = b * DEC_E + h * 32 + 2 * t;
+        const unsigned bits = *reinterpret_cast<const unsigned*>(&pr);
+        dec_st8(ll + LL_O2, e * 4, u32x2{bits, tag_o});
+        *reinterpret_cast<unsigned*>((bf16_t*)L.o2 + e) = bits;
     }
 }
 
@@ -296,12 +342,12 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
     const int ldE = DEC_E + 8, ldF = F + 8;
     const int n0 = wg * 16;                                  // a core workgroup's column tile of every 256-wide product
     const int n_bh = M * p.H;
-    const unsigned n_attn = (unsigned)(n_bh < G ? n_bh : G);
     const int f_tiles = F >> 4;
-    const unsigned n_ffn = (unsigned)(f_tiles < G ? f_tiles : G);
     const bool drop = p.drop_p > 0.f;
-    unsigned* err = p.counters + 7 * p.n_layers;
-    const int lane = t & 63, li = lane & 15, lg = lane >> 4, wave = t >> 6;
+    unsigned char* ll = reinterpret_cast<unsigned char*>(p.handoff);
+    unsigned* err = p.handoff + 1;
+    const unsigned epoch = p.handoff[0];                     // advanced by workgroup 0 when the whole stack is done
+    const int lane = t & 63, lg = lane >> 4, wave = t >> 6;
 
     // REFTR_DEC_TRACE: workgroups 0 (core) and G - 1 stamp the 100 MHz wall clock at every stage boundary
     int tr_i = 0;
@@ -312,95 +358,105 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
     if (core) dec_load_w<2>((const bf16_t*)p.layer[0].Wv, DEC_E, n0, w2);
     for (int l = 0; l < p.n_layers; ++l) {
         const rt_decoder_layer_fwd& L = p.layer[l];
-        unsigned* cnt = p.counters + 7 * l;
         if (core) {
             // ================= S1: o = headdrop(t16 Wv^T + bv); t = LN3 of the layer before (or the stack's input)
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bv + n0 + lg * 4);
             if (l == 0) {
                 dec_rows_to_lds<false>((const bf16_t*)p.t16, M, DEC_E, xa, ldE);
-                if (t < 256) for (int i = t; i < M * (DEC_E / 4); i += 256)
+                for (int i = t; i < M * (DEC_E / 4); i += 256)
                     *reinterpret_cast<f32x4*>(&sm.ln32[0][0] + i * 4) = *reinterpret_cast<const f32x4*>(p.t32 + (size_t)i * 4);
             } else {
                 const rt_decoder_layer_fwd& Lp = p.layer[l - 1];
-                dec_wait(cnt - 1, DEC_CORE, err, spin); DEC_STAMP();
                 const DecLnOut out{Lp.t3_f32, (bf16_t*)Lp.t3_16, nullptr, Lp.mean3, Lp.rstd3};
-                dec_ln_rows<true>(Lp.u3, M, Lp.g3, Lp.be3, nullptr, p.eps, sm, xa, ldE, writer, out);
+                dec_ln_rows(nullptr, ll, LL_U3, ll_tag(epoch, l - 1, 6), err, spin, M, Lp.g3, Lp.be3, nullptr, p.eps, sm, xa, ldE, writer, out);
             }
+            DEC_STAMP();
             __syncthreads();
             {
                 const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_ad) : 0u;
+                const unsigned tag = ll_tag(epoch, l, 0);
                 dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
                     v += bias;
                     if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 5);
-                    dec_st8(L.o, (m * DEC_E + n) * 2, dec_pack4(v));
+                    const u32x2 pk = dec_pack4(v);
+                    ll_put_bf16x4(ll, LL_O, tag, m * DEC_E + n, pk);
+                    *reinterpret_cast<u32x2*>((bf16_t*)L.o + m * DEC_E + n) = pk;
                 });
             }
-            dec_arrive(cnt + 0); DEC_STAMP();
+            DEC_STAMP();
             // ================= S2: u = t + drop(o Wo^T + bo)
             dec_load_w<2>((const bf16_t*)L.Wo, DEC_E, n0, w2);
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bo + n0 + lg * 4);
-            dec_wait(cnt + 0, DEC_CORE, err, spin); DEC_STAMP();
-            dec_rows_to_lds<true>((const bf16_t*)L.o, M, DEC_E, xa, ldE);
+            ll_rows_to_lds(ll, LL_O, ll_tag(epoch, l, 0), M, DEC_E, xa, ldE, err, spin);
+            DEC_STAMP();
             __syncthreads();
             {
                 const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d1) : 0u;
+                const unsigned tag = ll_tag(epoch, l, 1);
                 dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
                     v += bias;
                     if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 0);
                     v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
-                    dec_st16(L.u, (m * DEC_E + n) * 4, *reinterpret_cast<u32x4*>(&v));
+                    ll_put_f32x4(ll, LL_U, tag, m * DEC_E + n, v);
+                    *reinterpret_cast<f32x4*>(L.u + m * DEC_E + n) = v;
                 });
             }
-            dec_arrive(cnt + 1); DEC_STAMP();
+            DEC_STAMP();
             // ================= S3: q2 = (LN1(u) + query_pos) Wq^T + bq
             dec_load_w<2>((const bf16_t*)L.Wq, DEC_E, n0, w2);
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bq + n0 + lg * 4);
-            dec_wait(cnt + 1, DEC_CORE, err, spin); DEC_STAMP();
             {
                 const DecLnOut out{nullptr, nullptr, (bf16_t*)L.t1q16, L.mean1, L.rstd1};
-                dec_ln_rows<true>(L.u, M, L.g1, L.be1, p.qpos, p.eps, sm, xa, ldE, writer, out);
+                dec_ln_rows(nullptr, ll, LL_U, ll_tag(epoch, l, 1), err, spin, M, L.g1, L.be1, p.qpos, p.eps, sm, xa, ldE, writer, out);
             }
+            DEC_STAMP();
             __syncthreads();
-            dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
-                v += bias;
-                dec_st8(L.q2, (m * DEC_E + n) * 2, dec_pack4(v));
-            });
-            dec_arrive(cnt + 2); DEC_STAMP();
+            {
+                const unsigned tag = ll_tag(epoch, l, 2);
+                dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                    v += bias;
+                    const u32x2 pk = dec_pack4(v);
+                    ll_put_bf16x4(ll, LL_Q2, tag, m * DEC_E + n, pk);
+                    *reinterpret_cast<u32x2*>((bf16_t*)L.q2 + m * DEC_E + n) = pk;
+                });
+            }
+            DEC_STAMP();
         }
         // ================= S4: cross-attention, (b, h) = wg, wg + G, ...
-        if (wg < (int)n_attn) {
+        if (wg < n_bh) {
             const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_ad2) : 0u;
             DecKV kv;
-            dec_attn_prefetch(p, L, wg, kv);
-            dec_wait(cnt + 2, DEC_CORE, err, spin); DEC_STAMP();
             for (int bh = wg; bh < n_bh; bh += G) {
-                if (bh != wg) dec_attn_prefetch(p, L, bh, kv);
-                dec_attn(p, L, bh, kv, sm, seed);
+                dec_attn_prefetch(p, L, bh, kv);
+                dec_attn(p, L, bh, kv, sm, seed, ll, ll_tag(epoch, l, 2), ll_tag(epoch, l, 3), err, spin);
+                __syncthreads();
             }
-            dec_arrive(cnt + 3); DEC_STAMP();
+            DEC_STAMP();
         }
         if (core) {
             // ================= S5: u2 = t1 + drop(o2 Wo2^T + bo2)
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
             dec_load_w<2>((const bf16_t*)L.Wo2, DEC_E, n0, w2);
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bo2 + n0 + lg * 4);
-            dec_wait(cnt + 3, n_attn, err, spin); DEC_STAMP();
-            dec_rows_to_lds<true>((const bf16_t*)L.o2, M, DEC_E, xa, ldE);
+            ll_rows_to_lds(ll, LL_O2, ll_tag(epoch, l, 3), M, DEC_E, xa, ldE, err, spin);
+            DEC_STAMP();
             __syncthreads();
             {
                 const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d2) : 0u;
+                const unsigned tag = ll_tag(epoch, l, 4);
                 dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
                     v += bias;
                     if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 0);
                     v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
-                    dec_st16(L.u2, (m * DEC_E + n) * 4, *reinterpret_cast<u32x4*>(&v));
+                    ll_put_f32x4(ll, LL_U2, tag, m * DEC_E + n, v);
+                    *reinterpret_cast<f32x4*>(L.u2 + m * DEC_E + n) = v;
                 });
             }
-            dec_arrive(cnt + 4); DEC_STAMP();
+            DEC_STAMP();
         }
         // ================= S6: hdn = drop(relu(LN2(u2) W1^T + b1)), column tiles wg, wg + G, ...
-        if (wg < (int)n_ffn) {
+        if (wg < f_tiles) {
             u32x4 w1[DEC_NT][2];
             f32x4 b1[DEC_NT];
 #pragma unroll
@@ -411,13 +467,14 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
                     if (wave == 0) b1[i] = *reinterpret_cast<const f32x4*>(L.b1 + tile * 16 + lg * 4);
                 }
             }
-            dec_wait(cnt + 4, DEC_CORE, err, spin); DEC_STAMP();
             {
                 const DecLnOut out{nullptr, (bf16_t*)L.t2_16, nullptr, L.mean2, L.rstd2};
-                dec_ln_rows<true>(L.u2, M, L.g2, L.be2, nullptr, p.eps, sm, xa, ldE, writer, out);
+                dec_ln_rows(nullptr, ll, LL_U2, ll_tag(epoch, l, 4), err, spin, M, L.g2, L.be2, nullptr, p.eps, sm, xa, ldE, writer, out);
             }
+            DEC_STAMP();
             __syncthreads();
             const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_dh) : 0u;
+            const unsigned tag = ll_tag(epoch, l, 5);
 #pragma unroll
             for (int i = 0; i < DEC_NT; ++i) {
                 const int tile = wg + i * G;
@@ -428,11 +485,13 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                         if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * F + n), 0);
-                        dec_st8(L.hdn, (m * F + n) * 2, dec_pack4(v));
+                        const u32x2 pk = dec_pack4(v);
+                        ll_put_bf16x4(ll, LL_HDN, tag, m * F + n, pk);
+                        *reinterpret_cast<u32x2*>((bf16_t*)L.hdn + m * F + n) = pk;
                     });
                 }
             }
-            dec_arrive(cnt + 5); DEC_STAMP();
+            DEC_STAMP();
         }
         if (core) {
             // ================= S7: u3 = t2 + drop(hdn W2^T + b2)      (K = F: 16 steps per wave at F = 2048)
@@ -440,33 +499,37 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
             dec_load_w<16>((const bf16_t*)L.W2, F, n0, wf);
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.b2 + n0 + lg * 4);
-            dec_wait(cnt + 5, n_ffn, err, spin); DEC_STAMP();
-            dec_rows_to_lds<true>((const bf16_t*)L.hdn, M, F, xa, ldF);
+            ll_rows_to_lds(ll, LL_HDN, ll_tag(epoch, l, 5), M, F, xa, ldF, err, spin);
+            DEC_STAMP();
             __syncthreads();
             {
                 const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d3) : 0u;
+                const unsigned tag = ll_tag(epoch, l, 6);
                 dec_tile<16>(wf, xa, ldF, M, n0, sm, [&](int m, int n, f32x4 v) {
                     v += bias;
                     if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 0);
                     v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
-                    dec_st16(L.u3, (m * DEC_E + n) * 4, *reinterpret_cast<u32x4*>(&v));
+                    ll_put_f32x4(ll, LL_U3, tag, m * DEC_E + n, v);
+                    *reinterpret_cast<f32x4*>(L.u3 + m * DEC_E + n) = v;
                 });
             }
-            dec_arrive(cnt + 6); DEC_STAMP();
+            DEC_STAMP();
             if (l + 1 < p.n_layers) dec_load_w<2>((const bf16_t*)p.layer[l + 1].Wv, DEC_E, n0, w2);
         }
     }
-    // ---- the last layer's norm3 (statistics, bf16 rows, the fp32 rows the shared decoder norm reads)
+    // ---- the last layer's norm3 (statistics, bf16 rows, the fp32 rows the shared decoder norm reads); then the launch epoch moves on:
+    // every workgroup read it at its start, and nothing of this launch is in flight once the last u3 is complete
     if (writer && p.n_layers > 0) {
         const rt_decoder_layer_fwd& Lp = p.layer[p.n_layers - 1];
-        dec_wait(p.counters + 7 * (p.n_layers - 1) + 6, DEC_CORE, err, spin); DEC_STAMP();
         const DecLnOut out{Lp.t3_f32, (bf16_t*)Lp.t3_16, nullptr, Lp.mean3, Lp.rstd3};
-        dec_ln_rows<true>(Lp.u3, M, Lp.g3, Lp.be3, nullptr, p.eps, sm, xa, ldE, true, out);
+        dec_ln_rows(nullptr, ll, LL_U3, ll_tag(epoch, p.n_layers - 1, 6), err, spin, M, Lp.g3, Lp.be3, nullptr, p.eps, sm, xa, ldE, true, out);
+        if (t == 0) p.handoff[0] = epoch + 1;
+        DEC_STAMP();
     }
 }
 
 int dec_spin() {
-    static const int v = getenv("REFTR_DEC_SPIN") ? atoi(getenv("REFTR_DEC_SPIN")) : (1 << 22);
+    static const int v = getenv("REFTR_DEC_SPIN") ? atoi(getenv("REFTR_DEC_SPIN")) : (1 << 17);
     return v;
 }
 unsigned* dec_trace_buf() {           // REFTR_DEC_TRACE=1: 1024 words, read back by rt_decoder_trace
@@ -489,7 +552,7 @@ int dec_groups() {
 }  // namespace
 
 extern "C" int rt_decoder_fwd(const rt_decoder_fwd_desc* d, rt_stream_t stream) {
-    if (!d || !d->t32 || !d->t16 || !d->qpos || !d->counters) return RT_ERR_BADARG;
+    if (!d || !d->t32 || !d->t16 || !d->qpos || !d->handoff) return RT_ERR_BADARG;
     if (d->n_layers < 1 || d->n_layers > RT_DEC_MAX_LAYERS) return RT_ERR_UNSUPPORTED;
     const int G = dec_groups();
     if (G < DEC_CORE || G > 128) return RT_ERR_UNSUPPORTED;

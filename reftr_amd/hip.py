@@ -242,7 +242,7 @@ class DecoderLayerFwd(Structure):
 
 class DecoderFwdDesc(Structure):
     _fields_ = [("layer", DecoderLayerFwd * DEC_MAX_LAYERS),
-                ("t32", c_void_p), ("t16", c_void_p), ("qpos", c_void_p), ("kpm", c_void_p), ("counters", c_void_p),
+                ("t32", c_void_p), ("t16", c_void_p), ("qpos", c_void_p), ("kpm", c_void_p), ("handoff", c_void_p),
                 ("seed_dev", c_void_p),
                 ("n_layers", c_int32), ("M", c_int32), ("H", c_int32), ("S", c_int32), ("F", c_int32), ("ldkv", c_int32),
                 ("drop_p", c_float), ("eps", c_float), ("scale", c_float)]
@@ -657,10 +657,22 @@ def attn_bwd(q, k, v, out, dout, lse, kpm, *, B, H, Sq, Sk, dh, scale, drop_p=0.
     return dq, dk, dv
 
 
+DEC_HANDOFF_BYTES = 256 + 16 * 256 * 36 + 16 * 2048 * 4
+_DEC_HANDOFF = {}
+
+
+def decoder_handoff(dev):
+    """The per-device hand-off buffer of rt_decoder_fwd (zeroed once; word 1 = failure flag)."""
+    buf = _DEC_HANDOFF.get(dev)
+    if buf is None:
+        buf = _DEC_HANDOFF[dev] = torch.zeros(DEC_HANDOFF_BYTES // 4, dtype=torch.int32, device=dev)
+    return buf
+
+
 def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, eps=1e-5):
     """The decoder stack of one-query-per-image inputs as one cooperative launch (rt_decoder_fwd).  `layers`: one dict per
     layer, keys = DecoderLayerFwd._PTRS (tensors) + DecoderLayerFwd._SEEDS (ints); every output tensor is allocated by the
-    caller (they are the launched chain's saved tensors).  Returns the counters tensor (word 7 * n_layers = failure flag)."""
+    caller (they are the launched chain's saved tensors).  Returns the hand-off buffer's header [epoch, failure flag]."""
     M = t32.shape[0]
     d = DecoderFwdDesc()
     assert 1 <= len(layers) <= DEC_MAX_LAYERS
@@ -670,13 +682,13 @@ def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, eps=1e-5
             setattr(L, n, _p(lay[n]))
         for n in DecoderLayerFwd._SEEDS:
             setattr(L, n, lay[n] & 0xFFFFFFFF)
-    counters = torch.zeros(7 * len(layers) + 1, dtype=torch.int32, device=t32.device)
-    d.t32, d.t16, d.qpos, d.kpm, d.counters = _p(t32), _p(t16), _p(qpos), _p(kpm), _p(counters)
+    handoff = decoder_handoff(t32.device)
+    d.t32, d.t16, d.qpos, d.kpm, d.handoff = _p(t32), _p(t16), _p(qpos), _p(kpm), _p(handoff)
     d.seed_dev = _seedp(drop_p)
     d.n_layers, d.M, d.H, d.S, d.F, d.ldkv = len(layers), M, H, S, F, _ld(layers[0]["k2"])
     d.drop_p, d.eps, d.scale = drop_p, eps, scale
     _check(lib().rt_decoder_fwd(ctypes.byref(d), _stream()), "rt_decoder_fwd")
-    return counters
+    return handoff[:2]
 
 
 def decoder_trace(readback=True):

@@ -115,8 +115,9 @@ def test_unsupported_shapes_keep_the_chain(hip):
 
 
 def test_many_replays_under_a_captured_graph(hip):
-    """The cooperative launch inside a captured training step: 200 replays, no wait gives up, losses finite and equal to the
-    chain-built graph's on the same seeds."""
+    """The cooperative launch inside a captured training step, 200 replays.  With learning rate 0 the weights never move, so
+    the loss of replay i is a function of the step seed only: the cooperative graph and the chain-built graph must print the
+    SAME losses, bit for bit, on every replay (the hand-off tags change with every launch; no consumer may give up)."""
     from reftr_amd.engine_vg import CapturedTrainStep
     from reftr_amd.optim import FusedAdamW
     losses = {}
@@ -126,21 +127,16 @@ def test_many_replays_under_a_captured_graph(hip):
             model, crit, s, tg = build(3, 8, 128, 128)
             model.net.dec_coop = coop
             model.train()
-            opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+            opt = FusedAdamW(model, lr=0.0, lr_backbone=0.0, weight_decay=0.0)
             cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg)
             model.seed_dev.fill_(5)
-            vals = []
-            for i in range(200):
-                l = cap(s, tg)[0]
-                if i % 20 == 0:
-                    vals.append(float(l))
+            vals = [float(cap(s, tg)[0]) for i in range(200)]
             cap.flush()
             if coop:
                 assert int(model.net.dec_counters[-1]) == 0
+                assert int(model.net.dec_counters[0]) >= 200          # the launch epoch advanced with every replay
             losses[coop] = vals
         finally:
             os.environ.pop("REFTR_DEC_COOP", None)
-    assert all(v == v and abs(v) < 1e4 for v in losses[True])
-    # the two graphs differ by the order of the atomically accumulated gradient pieces only (warm-up steps included)
-    assert abs(losses[True][0] - losses[False][0]) <= 2e-3 * abs(losses[False][0])
-    assert all(abs(a - b) < 2e-2 * abs(b) for a, b in zip(losses[True], losses[False]))
+    assert len(set(losses[False])) > 150                              # dropout: a new mask set per replay
+    assert losses[True] == losses[False]
