@@ -19,9 +19,11 @@
 // Arithmetic is the launched chain's, operation for operation (the K split over four waves and the reduction order of
 // skinny_gemm_kernel, attn_q1_fwd_kernel's softmax, the same dropout sites and indices): the outputs are bit-identical to the
 // chain's and the launched backward consumes the saved tensors unchanged (tests/test_decoder_coop_gpu.py).
-// Stage map of one layer (counter, producers):  S1 v-proj+head dropout (16) -> S2 out_proj+res (16) -> [LN1] S3 q-proj (16) ->
-// S4 cross-attention, one (b, h) per workgroup -> S5 out_proj+res (16) -> [LN2] S6 linear1+relu (F/16 tiles over G)
-// -> S7 linear2+res (16) -> [LN3] next layer's S1.
+// Stage map of one layer:  S1 v-proj + head dropout -> S2 out_proj + residual -> [LN1] S3 q-proj -> S4 cross-attention ->
+// S5 out_proj + residual -> [LN2] S6 linear1 + relu -> S7 linear2 + residual -> [LN3] next layer's S1.  The 256-wide products
+// (S1-S3, S5, S7) run on the 16 "core" workgroups (one 16-column tile each); the cross-attention (one (b, h) per workgroup) and
+// linear1 (F / 16 tiles) on the G - 16 "workers", which therefore hold their K / V rows and weight fragments long before the
+// rows they wait for exist.
 #include "rt_common.h"
 #include <stdlib.h>
 
@@ -67,32 +69,33 @@ constexpr int LL_O = LL_HDR, LL_U = LL_O + 16 * 256 * 4, LL_Q2 = LL_U + 16 * 256
               LL_U2 = LL_O2 + 16 * 256 * 4, LL_U3 = LL_U2 + 16 * 256 * 8, LL_HDN = LL_U3 + 16 * 256 * 8;      // hdn: 16 * F * 4 bytes
 __device__ __forceinline__ unsigned ll_tag(unsigned epoch, int layer, int stage) { return (epoch << 8) | (unsigned)(layer * 8 + stage + 1); }
 
-// bf16 row block [M][K] (unit = 2 bf16 + tag) -> LDS operand rows
+// bf16 row block [M][K] (unit = 2 bf16 + tag) -> LDS operand rows; NL 16-byte loads per thread in flight per round trip
+template <int NL>
 __device__ __forceinline__ void ll_rows_to_lds(unsigned char* ll, int region, unsigned tag, int M, int K, bf16_t* xa, int ld,
                                                unsigned* err, int spin) {
     const int t = threadIdx.x;
     const int per_row = K >> 2, pieces = M * per_row;            // 16-byte pieces: 2 units = 4 bf16
-    for (int i0 = 0; i0 < pieces; i0 += 256 * 8) {
-        u32x4 v[8];
+    for (int i0 = 0; i0 < pieces; i0 += 256 * NL) {
+        u32x4 v[NL];
         int guard = 0;
         bool ok;
         do {
             asm volatile("" ::: "memory");       // the loads below must be re-issued on every pass
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NL; ++j) {
                 const int i = i0 + j * 256 + t;
                 if (i < pieces) v[j] = dec_ld16(ll + region, i * 16);
             }
             ok = true;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NL; ++j) {
                 const int i = i0 + j * 256 + t;
                 if (i < pieces) ok = ok && v[j][1] == tag && v[j][3] == tag;
             }
         } while (!ok && ++guard < spin);
         if (!ok) *err = 1u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NL; ++j) {
             const int i = i0 + j * 256 + t;
             if (i < pieces) {
                 const int r = i / per_row, c = i - r * per_row;
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
     const int wg = blockIdx.x, t = threadIdx.x;
     const int M = p.M, F = p.F;
     const bool core = wg < DEC_CORE, writer = wg == 0;
+    const int wk = wg - DEC_CORE, NW = G - DEC_CORE;         // worker id / count: attention and linear1 run on the workers
     const int ldE = DEC_E + 8, ldF = F + 8;
     const int n0 = wg * 16;                                  // a core workgroup's column tile of every 256-wide product
     const int n_bh = M * p.H;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             // ================= S2: u = t + drop(o Wo^T + bo)
             dec_load_w<2>((const bf16_t*)L.Wo, DEC_E, n0, w2);
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bo + n0 + lg * 4);
-            ll_rows_to_lds(ll, LL_O, ll_tag(epoch, l, 0), M, DEC_E, xa, ldE, err, spin);
+            ll_rows_to_lds<4>(ll, LL_O, ll_tag(epoch, l, 0), M, DEC_E, xa, ldE, err, spin);
             DEC_STAMP();
             __syncthreads();
             {
@@ -423,11 +427,11 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             }
             DEC_STAMP();
         }
-        // ================= S4: cross-attention, (b, h) = wg, wg + G, ...
-        if (wg < n_bh) {
+        // ================= S4: cross-attention, (b, h) = worker id, + number of workers, ...
+        if (!core && wk < n_bh) {
             const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_ad2) : 0u;
             DecKV kv;
-            for (int bh = wg; bh < n_bh; bh += G) {
+            for (int bh = wk; bh < n_bh; bh += NW) {
                 dec_attn_prefetch(p, L, bh, kv);
                 dec_attn(p, L, bh, kv, sm, seed, ll, ll_tag(epoch, l, 2), ll_tag(epoch, l, 3), err, spin);
                 __syncthreads();
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
             dec_load_w<2>((const bf16_t*)L.Wo2, DEC_E, n0, w2);
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.bo2 + n0 + lg * 4);
-            ll_rows_to_lds(ll, LL_O2, ll_tag(epoch, l, 3), M, DEC_E, xa, ldE, err, spin);
+            ll_rows_to_lds<4>(ll, LL_O2, ll_tag(epoch, l, 3), M, DEC_E, xa, ldE, err, spin);
             DEC_STAMP();
             __syncthreads();
             {
@@ -455,13 +459,13 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             }
             DEC_STAMP();
         }
-        // ================= S6: hdn = drop(relu(LN2(u2) W1^T + b1)), column tiles wg, wg + G, ...
-        if (wg < f_tiles) {
+        // ================= S6: hdn = drop(relu(LN2(u2) W1^T + b1)), column tiles worker id, + number of workers, ...
+        if (!core && wk < f_tiles) {
             u32x4 w1[DEC_NT][2];
             f32x4 b1[DEC_NT];
 #pragma unroll
             for (int i = 0; i < DEC_NT; ++i) {
-                const int tile = wg + i * G;
+                const int tile = wk + i * NW;
                 if (tile < f_tiles) {
                     dec_load_w<2>((const bf16_t*)L.W1, DEC_E, tile * 16, w1[i]);
                     if (wave == 0) b1[i] = *reinterpret_cast<const f32x4*>(L.b1 + tile * 16 + lg * 4);
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             }
             {
                 const DecLnOut out{nullptr, (bf16_t*)L.t2_16, nullptr, L.mean2, L.rstd2};
-                dec_ln_rows(nullptr, ll, LL_U2, ll_tag(epoch, l, 4), err, spin, M, L.g2, L.be2, nullptr, p.eps, sm, xa, ldE, writer, out);
+                dec_ln_rows(nullptr, ll, LL_U2, ll_tag(epoch, l, 4), err, spin, M, L.g2, L.be2, nullptr, p.eps, sm, xa, ldE, wk == 0, out);
             }
             DEC_STAMP();
             __syncthreads();
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             const unsigned tag = ll_tag(epoch, l, 5);
 #pragma unroll
             for (int i = 0; i < DEC_NT; ++i) {
-                const int tile = wg + i * G;
+                const int tile = wk + i * NW;
                 if (tile < f_tiles) {
                     const f32x4 bb = b1[i];
                     dec_tile<2>(w1[i], xa, ldE, M, tile * 16, sm, [&](int m, int n, f32x4 v) {
@@ -499,7 +503,12 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
             dec_load_w<16>((const bf16_t*)L.W2, F, n0, wf);
             if (wave == 0) bias = *reinterpret_cast<const f32x4*>(L.b2 + n0 + lg * 4);
-            ll_rows_to_lds(ll, LL_HDN, ll_tag(epoch, l, 5), M, F, xa, ldF, err, spin);
+            {   // t2 = LN2(u2): this product's residual (the workers recompute it as linear1's operand)
+                const DecLnOut none{nullptr, nullptr, nullptr, nullptr, nullptr};
+                dec_ln_rows(nullptr, ll, LL_U2, ll_tag(epoch, l, 4), err, spin, M, L.g2, L.be2, nullptr, p.eps, sm, xa, ldE, false, none);
+                __syncthreads();         // xa is reused for the hdn rows below
+            }
+            ll_rows_to_lds<16>(ll, LL_HDN, ll_tag(epoch, l, 5), M, F, xa, ldF, err, spin);
             DEC_STAMP();
             __syncthreads();
             {
@@ -545,7 +554,7 @@ unsigned* dec_trace_buf() {           // REFTR_DEC_TRACE=1: 1024 words, read bac
     return buf;
 }
 int dec_groups() {
-    static const int g = getenv("REFTR_DEC_G") ? atoi(getenv("REFTR_DEC_G")) : 64;
+    static const int g = getenv("REFTR_DEC_G") ? atoi(getenv("REFTR_DEC_G")) : 80;
     return g;
 }
 
@@ -555,9 +564,9 @@ extern "C" int rt_decoder_fwd(const rt_decoder_fwd_desc* d, rt_stream_t stream) 
     if (!d || !d->t32 || !d->t16 || !d->qpos || !d->handoff) return RT_ERR_BADARG;
     if (d->n_layers < 1 || d->n_layers > RT_DEC_MAX_LAYERS) return RT_ERR_UNSUPPORTED;
     const int G = dec_groups();
-    if (G < DEC_CORE || G > 128) return RT_ERR_UNSUPPORTED;
+    if (G <= DEC_CORE || G > 144) return RT_ERR_UNSUPPORTED;
     if (d->M < 1 || d->M > 16 || d->H * 32 != DEC_E || d->S < 1 || d->S > 256 * DEC_MAXK) return RT_ERR_UNSUPPORTED;
-    if (d->F != 2048 || (d->F >> 4) > DEC_NT * G || (d->ldkv & 7)) return RT_ERR_UNSUPPORTED;
+    if (d->F != 2048 || (d->F >> 4) > DEC_NT * (G - DEC_CORE) || (d->ldkv & 7)) return RT_ERR_UNSUPPORTED;
     for (int l = 0; l < d->n_layers; ++l) {
         const rt_decoder_layer_fwd& L = d->layer[l];
         if (!L.Wv || !L.Wo || !L.Wq || !L.Wo2 || !L.W1 || !L.W2 || !L.k2 || !L.v2 || !L.o || !L.u || !L.q2 || !L.o2 || !L.u2 ||

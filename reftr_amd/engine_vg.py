@@ -610,6 +610,15 @@ def captured_train_step(model, criterion, samples, targets, optimizer, lr_schedu
     return begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm, max_shapes, lookahead).finish()
 
 
+def _check_cooperative(model):
+    """rt_decoder_fwd reports a consumer that gave up waiting (a workgroup that never became resident) through a device word;
+    a loop that produced numbers from such a launch must not return them."""
+    inner = getattr(model, "module", model)
+    dc = getattr(getattr(inner, "net", None), "dec_counters", None)
+    if dc is not None and int(dc[-1]) != 0:
+        raise RuntimeError("rt_decoder_fwd: a stage hand-off timed out (workgroups not co-resident?) -- set REFTR_DEC_COOP=0")
+
+
 def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, device, epoch, max_norm=0):
     model.train()
     criterion.train()
@@ -632,6 +641,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
         samples, targets = ahead()
     if booked is not None:
         board.add(**booked)
+    _check_cooperative(model)
     board.synchronize_between_processes()
     print("Averaged stats:", board)
     return board.global_avg()
@@ -734,6 +744,7 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
             if "image_id" in tg:
                 results_dict[int(tg["image_id"])] = res["boxes"].cpu().numpy().tolist()
         samples, targets = prefetcher.next()
+    _check_cooperative(model)
     board.synchronize_between_processes()
     stats = board.global_avg()
     if utils.is_dist_avail_and_initialized():

@@ -56,6 +56,7 @@ class Net:
         self.kv_dgrad_side = os.environ.get("REFTR_DEC_KV_SIDE", "0") != "0"
         # the decoder's forward chain as one cooperative launch (csrc/rt_decoder.hip) whenever its shape allows
         self.dec_coop = os.environ.get("REFTR_DEC_COOP", "1") != "0"
+        self._dec_cus = None
         self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
@@ -434,7 +435,10 @@ class Net:
     def dec_stack_coop_ok(self, N, T, S, n_layers, fold_sa):
         """Shapes rt_decoder_fwd covers: one query per image on the folded self-attention path, the reference's widths."""
         cfg = self.cfg
-        return (self.dec_coop and T == 1 and fold_sa and self.trivial_sa and self.fold_sa and cfg.hidden == 256 and cfg.nheads == 8
+        if self._dec_cus is None:            # the launch needs its ~80 workgroups resident at once, one per compute unit
+            dev = self.store.device
+            self._dec_cus = torch.cuda.get_device_properties(dev).multi_processor_count if str(dev).startswith("cuda") else 0
+        return (self.dec_coop and self._dec_cus >= 160 and T == 1 and fold_sa and self.trivial_sa and self.fold_sa and cfg.hidden == 256 and cfg.nheads == 8
                 and cfg.ffn == 2048 and N <= 16 and S <= 768 and 1 <= n_layers <= H.DEC_MAX_LAYERS)
 
     def dec_stack_fwd_coop(self, prefixes, t32, t16, tq16, qpos, kvs, kpm, B, S, t3_all):
