@@ -308,12 +308,17 @@ class CapturedTrainStep:
         self._set_flush(False)
         inner._pre_update = self._hooks
         inner._zero_grad_side = os.environ.get("REFTR_ZERO_SIDE", "0") == "1" and inner.net.side.enabled
+        # backward and clip norm are one unit here (nothing touches the gradient buffer in between): the BERT slice's share of the
+        # norm may be taken on the language stream as soon as that slice is final (reftr_transformer._backward_gen)
+        inner._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0"
         try:
             out = self._fwd_bwd(zero=not inner._zero_grad_side)
+            self.grad_norm = opt.finish_step(self.max_norm)
         finally:
             inner._pre_update = None
             inner._zero_grad_side = False
-        self.grad_norm = opt.finish_step(self.max_norm)
+            inner._norm_side = False
+            inner._norm_split = None
         self._pack_stats()
         return out
 

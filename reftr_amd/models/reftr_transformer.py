@@ -89,9 +89,10 @@ class RefTR(nn.Module):
         # iteration's AdamW update at the head of this forward -- the BERT slice on the language stream, concurrently with
         # the ResNet forward -- and the engine's callback that applies a still-pending update before anyone else reads
         self._pre_update = None
-        # single-process training: the BERT slice's share of the gradient norm is taken on the language stream as soon as that
-        # slice is final (see _backward_gen); (begin, end, device scalar) for the optimizer, None when not taken
-        self._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0"
+        # single-process captured training step: the BERT slice's share of the gradient norm is taken on the language stream as
+        # soon as that slice is final (see _backward_gen); (begin, end, device scalar) for the optimizer, None when not taken.
+        # Anything that edits the gradient buffer between backward and the clip (gradient surgery, an exchange) must leave it off.
+        self._norm_side = False          # switched on by engine_vg.CapturedTrainStep around its own backward + clip-norm unit only
         self._norm_split = None
         self._sq_bert = torch.zeros(1, dtype=torch.float32, device=device)
         self._flush_pending = None

@@ -465,6 +465,7 @@ def test_clip_norm_with_the_bert_share_taken_on_the_language_stream(hip):
     s, tg = to_cuda(samples, targets)
     opt = FusedAdamW(model, lr=0.0, lr_backbone=0.0, weight_decay=0.0)
     norms = {}
+    assert model._norm_side is False          # off unless an engine that owns backward + clip as one unit switches it on
     for split in (True, False):
         model._norm_side = split
         model.seed_dev.fill_(3)
@@ -479,6 +480,16 @@ def test_clip_norm_with_the_bert_share_taken_on_the_language_stream(hip):
             assert model._norm_split is None                   # consumed by the optimizer
         norms[split] = float(gn)
     assert abs(norms[True] - norms[False]) < 1e-4 * norms[False]
+    # the captured single-process step takes the split and switches it off again behind itself
+    from reftr_amd.engine_vg import CapturedTrainStep
+    model._norm_side = False
+    cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg)
+    gn = cap(s, tg)[2]
+    torch.cuda.synchronize()
+    full = float(model.store.flat_g.double().norm())
+    assert abs(float(gn) - full) < 1e-5 * full and float(model._sq_bert) > 0
+    assert model._norm_side is False and model._norm_split is None
+    cap.flush()
 
 
 def test_roberta_backbone_vs_reference_golden(hip):

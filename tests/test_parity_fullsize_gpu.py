@@ -236,9 +236,10 @@ def test_cfg1_full_depth_backward_is_the_derivative_of_the_forward(hip):
     """Self-consistency at full depth, free of any oracle noise: the eval-mode forward is bit-deterministic, so central
     differences of the scalar s(theta) = sum(logits * W) along a direction v measure the directional derivative of the function
     the kernels compute; it must equal <flat_g, v> from the hand-written backward.  v = the normalised gradient of each
-    learning-rate group (main | ResNet | BERT), step sized for a 2 % change of s (far above the bf16 staircase of the forward).
-    Together with the forward parity above this pins the gradients: a wrong-but-consistent layer would show up in the forward,
-    a wrong backward formula shows up here."""
+    learning-rate group (main | ResNet | BERT), step sized for a 2 % change of s (far above the bf16 staircase of the forward),
+    averaged over independent operand dithers (one draw carries +-5 % of rounding noise, see MEASURED_FD).  Together with the
+    forward parity above this bounds the gradients: a wrong-but-consistent layer would show up in the forward, a wrong backward
+    formula (a missing term, a factor) shows up here at >= 10 %; the per-kernel tests are the tight ones (2e-5)."""
     from reftr_amd.models import layout as L
     samples, targets = make_inputs("e2e_single", B=2, H=320, W=320, L=40)
     model, crit, P, ocfg = build_full()
@@ -246,40 +247,57 @@ def test_cfg1_full_depth_backward_is_the_derivative_of_the_forward(hip):
     # operands (the forward would not move at all for the Linear weights).  Dither every fp32 master uniformly over exactly
     # +-1 ulp of its bf16 value (an interval that holds exactly two rounding boundaries whatever the mantissa -- a dither
     # relative to the VALUE would hold 2 boundaries per 1..2 ulps and inflate the difference quotient by E[2/m] = 1.39), so
-    # that operand rounding acts as unbiased stochastic rounding of the perturbation (noise over ~10^8 weights: < 1 %).
-    gen = torch.Generator(device="cuda").manual_seed(5)
+    # that operand rounding acts as unbiased stochastic rounding of the perturbation.
     st = model.store
-    _, ex = torch.frexp(st.flat_p)                       # |p| = m * 2^ex, m in [0.5, 1): bf16 ulp = 2^(ex - 8)
-    ulp = torch.ldexp(torch.ones_like(st.flat_p), ex - 8) * (st.flat_p != 0)
-    st.flat_p.add_((torch.rand(st.flat_p.shape, generator=gen, device="cuda") * 2.0 - 1.0) * ulp)
-    model.mark_dirty()
     s, tg = to_cuda(samples, targets)
-    out = model(s)
-    W = formula_tensor("functional.w", tuple(out["pred_logits"].shape), 1.0, bf16=False).cuda()
-    scale = float((out["pred_logits"].detach() * W).abs().sum())
-    hip_scalar_backward(model, (out["pred_logits"] * W).sum())
-    g, p0 = st.flat_g.clone(), st.flat_p.clone()
-    res = {}
-    for name, grp in (("main", L.GROUP_MAIN), ("resnet", L.GROUP_BACKBONE), ("bert", L.GROUP_BERT)):
-        a, b = st.group_range[grp]
-        gn = float(g[a:b].double().norm())
-        v = torch.zeros_like(g); v[a:b] = g[a:b] / gn
-        eps = 0.02 * scale / gn
-        vals = []
-        for sign in (1.0, -1.0):
-            st.flat_p.copy_(p0 + sign * eps * v)
-            model.mark_dirty()
-            with torch.no_grad():
-                vals.append(float((model(s)["pred_logits"].double() * W.double()).sum()))
-        fd = (vals[0] - vals[1]) / (2 * eps)
-        res[name] = (fd, gn, abs(fd - gn) / gn)
-    st.flat_p.copy_(p0); model.mark_dirty()
-    print("\n[cfg1 directional derivative] " + "  ".join(f"{k}: fd={v[0]:.4e} <g,v>={v[1]:.4e} rel={v[2]:.2e}" for k, v in res.items()))
-    for k, v in res.items():
-        assert v[2] < MEASURED_FD[k] * 1.5, (k, v)
+    base = st.flat_p.clone()
+    _, ex = torch.frexp(base)                            # |p| = m * 2^ex, m in [0.5, 1): bf16 ulp = 2^(ex - 8)
+    ulp = torch.ldexp(torch.ones_like(base), ex - 8) * (base != 0)
+    W = None
+    runs = []
+    for seed in FD_SEEDS:                                # independent dithers: the rounding noise of one draw is a few per cent
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        st.flat_p.copy_(base + (torch.rand(base.shape, generator=gen, device="cuda") * 2.0 - 1.0) * ulp)
+        model.mark_dirty()
+        out = model(s)
+        if W is None:
+            W = formula_tensor("functional.w", tuple(out["pred_logits"].shape), 1.0, bf16=False).cuda()
+        scale = float((out["pred_logits"].detach() * W).abs().sum())
+        hip_scalar_backward(model, (out["pred_logits"] * W).sum())
+        g, p0 = st.flat_g.clone(), st.flat_p.clone()
+        res = {}
+        for name, grp in (("main", L.GROUP_MAIN), ("resnet", L.GROUP_BACKBONE), ("bert", L.GROUP_BERT)):
+            a, b = st.group_range[grp]
+            gn = float(g[a:b].double().norm())
+            v = torch.zeros_like(g); v[a:b] = g[a:b] / gn
+            eps = 0.02 * scale / gn
+            vals = []
+            for sign in (1.0, -1.0):
+                st.flat_p.copy_(p0 + sign * eps * v)
+                model.mark_dirty()
+                with torch.no_grad():
+                    vals.append(float((model(s)["pred_logits"].double() * W.double()).sum()))
+            fd = (vals[0] - vals[1]) / (2 * eps)
+            res[name] = (fd - gn) / gn                   # signed: the rounding noise of a draw has no preferred sign
+        runs.append(res)
+    st.flat_p.copy_(base); model.mark_dirty()
+    mean = {k: sum(r[k] for r in runs) / len(runs) for k in runs[0]}
+    print("\n[cfg1 directional derivative] (fd - <g,v>) / <g,v> per dither: " +
+          "  ".join(f"{k}: " + ", ".join(f"{r[k]:+.2e}" for r in runs) + f" -> mean {mean[k]:+.2e}" for k in mean))
+    for k in mean:
+        assert abs(mean[k]) < MEASURED_FD[k] * 1.5, (k, mean[k], [r[k] for r in runs])
+        assert all(abs(r[k]) < MEASURED_FD_ONE[k] * 1.5 for r in runs), (k, [r[k] for r in runs])
 
 
-MEASURED_FD = {"main": 6e-3, "resnet": 4.0e-2, "bert": 1.8e-2}      # measured 3.8e-3 / 4.0e-2 / 1.8e-2
+FD_SEEDS = (5, 6, 7, 8, 9, 10, 11, 12)
+# Measured (both attention-backward variants, 8 dithers): single draws scatter by +-4..10 % (the stochastic rounding of ~10^8 bf16
+# operands under a 2 % step), their mean sits at -3 % (main), -0.4 % (resnet), -0.0..-3 % (bert).  The negative mean is the bf16
+# noise of the gradient itself, not of the formula: g = g_true + e with e unbiased and |e| / |g| ~ 0.17 (the rel-L2 the oracle
+# comparison above measures) gives <g_true, g> / |g| = |g| / (1 + |e|^2 / |g_true|^2) = |g| (1 - 0.03).  Until round 3 this test used
+# ONE dither draw whose main-group value happened to be 3.8e-3; a kernel change that moved the gradient by 1e-3 (fused attention
+# backward) moved that single draw to 4e-2, which is how the noise was found.
+MEASURED_FD = {"main": 3.3e-2, "resnet": 2.0e-2, "bert": 3.3e-2}          # |mean over FD_SEEDS|: -2.6e-2 / -3e-3..-1.4e-2 / -3e-3..-3.0e-2
+MEASURED_FD_ONE = {"main": 9.6e-2, "resnet": 5.5e-2, "bert": 7.6e-2}      # a single dither (worst of 16 draws)
 
 
 # ---------------------------------------------------------------------------------------------- configs[3]: RefTRSeg
