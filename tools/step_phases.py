@@ -4,6 +4,9 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
 # the gradient-norm kernel ends an iteration in both schedules (deferred: [AdamW of i-1 | fwd | bwd | norm]; eager: [... norm | AdamW])
 ad = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0]]
+# (round 3: the BERT slice's share of the norm is a second, earlier sqnorm launch -- the iteration ends at the one that is followed by
+# the next iteration's AdamW, i.e. the last of each run of sqnorm launches without an adamw_kernel in between)
+ad = [i for n, i in enumerate(ad) if n + 1 == len(ad) or any("adamw_kernel" in r[0] for r in rows[i + 1:ad[n + 1]])]
 # the shortest step of the run (skips warm-up and bench.py's backlogged roofline pass behind a spin kernel)
 cands = [(rows[ad[i + 1]][2] - rows[ad[i] + 1][1], ad[i] + 1, ad[i + 1] + 1) for i in range(len(ad) - 1)
          if not any("spin_kernel" in r[0] for r in rows[ad[i] + 1:ad[i + 1] + 1])]
@@ -16,7 +19,8 @@ marks = [("AdamW of the previous step (deferred) + weight prep + pack", "adamw_k
          ("ResNet bwd (+BERT bwd)", "gn_bwd_apply"), ("gradient norm", "sqnorm")]
 idx, pos = [], 0
 for label, key in marks:
-    for i in range(pos, len(step)):
+    rng = range(pos, len(step)) if key != "sqnorm" else range(len(step) - 1, pos - 1, -1)      # the step-ending norm launch
+    for i in rng:
         if key in step[i][0]:
             idx.append((label, i)); pos = i + 1; break
 print("step: %d kernels, %.2f ms (kernel-busy %.2f ms)" % (len(step), (step[-1][2] - t0) / 1e6, sum(r[2] - r[1] for r in step) / 1e6))
