@@ -651,6 +651,37 @@ typedef struct rt_decoder_fwd_desc {
     float   drop_p, eps, scale;
 } rt_decoder_fwd_desc;
 int rt_decoder_fwd(const rt_decoder_fwd_desc* d, rt_stream_t stream);
+/* rt_decoder_bwd -- the backward of the same stack as one cooperative launch: per layer LayerNorm backward (norm3, norm2, norm1,
+ * recomputed by every consumer), the six M <= 16 backward-data products, the one-query attention backward; the launched chain
+ * rt_layernorm_bwd -> rt_conv_gemm (linear2^T gate, linear1^T + res) -> rt_layernorm_bwd -> rt_conv_gemm (out_proj^T) -> rt_attn_bwd
+ * -> rt_conv_gemm (q^T) -> rt_layernorm_bwd -> rt_conv_gemm (out_proj^T head mask, v^T + res) of transformer.py:231-252's backward.
+ * It writes what the chain writes for the launches that stay outside: the bf16 dy operands of the (grouped) weight gradients, the
+ * LayerNorm parameter-gradient partials (rt_ln_param_grad_grouped's format, (M+3)/4 blocks), dK / dV of the cross-attention (the
+ * M = B*S memory-gradient products and weight gradients), the gradient w.r.t. the stack's input and query_pos.  Same hand-off buffer
+ * and limits as rt_decoder_fwd. */
+typedef struct rt_decoder_layer_bwd {
+    const void *WT2, *WT1, *WTo2, *WTq, *WTo, *WTv;      /* bf16 backward-data operands [K_in][N_out]: linear2, linear1, multihead_attn.out_proj / q, self_attn.out_proj / v */
+    const float *g1, *g2, *g3;                            /* norm1..3 weight */
+    const float *u, *u2, *u3, *mean1, *rstd1, *mean2, *rstd2, *mean3, *rstd3;      /* saved by the forward */
+    const void *hdn, *q2, *k2, *v2, *o2;
+    const float *lse2;
+    const float *dnorm;                                   /* [M,256]: gradient w.r.t. this layer's output through the shared decoder norm */
+    void *du3b, *dhdn, *du2b, *dq2, *dub, *dv;            /* bf16 [M,256] (dhdn [M,F]): dy operands of the weight gradients */
+    void *dk2, *dv2;                                      /* bf16 [B*S, ldkv] */
+    float *part1, *part2, *part3;                         /* [(M+3)/4][2][256] */
+    uint32_t seed_ad, seed_d1, seed_ad2, seed_d2, seed_d3, reserved;
+} rt_decoder_layer_bwd;
+typedef struct rt_decoder_bwd_desc {
+    rt_decoder_layer_bwd layer[RT_DEC_MAX_LAYERS];
+    float*          dta;       /* out [M,256]: gradient w.r.t. the stack's input (tgt) */
+    float*          dqpos;     /* [M,256], accumulated (+=): gradient w.r.t. query_pos */
+    const uint8_t*  kpm;
+    uint32_t*       handoff;
+    const uint32_t* seed_dev;
+    int32_t n_layers, M, H, S, F, ldkv;
+    float   drop_p, scale, gate_scale;                    /* gate_scale = 1 / (1 - p) of linear1's dropout */
+} rt_decoder_bwd_desc;
+int rt_decoder_bwd(const rt_decoder_bwd_desc* d, rt_stream_t stream);
 /* REFTR_DEC_TRACE=1 only: 1024 wall-clock stamps (100 MHz) of the last launch's stage boundaries, host buffer */
 int rt_decoder_trace(uint32_t* out1024);
 

@@ -537,6 +537,371 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const rt_decoder_fwd_d
     }
 }
 
+// =====================================================================================================================================
+// Backward of the stack, same machinery.  Per layer (last to first), hand-offs in brackets:
+//   B1 LayerNorm3 backward of (dnorm + dta of the layer above) -> du3 (fp32, kept in LDS) / du3b     [every workgroup recomputes it]
+//   B2 workers: dhdn = relu-gate(du3b W2) * 1/(1-p)                                                  [dhdn]
+//   B3 core:    dt2 = du3 + dhdn W1                                                                  [dt2]
+//   B4 LayerNorm2 backward -> du2 (LDS, until B9) / du2b       B5 core: do2 = du2b Wo2              [do2]
+//   B6 workers: one-query attention backward of (b, h): dK, dV rows to memory, dq                    [dq2]
+//   B8 core:    dt1q = dq2 Wq (+= into d query_pos)                                                  [dt1q]
+//   B9 LayerNorm1 backward of (du2 + dt1q) -> du (LDS) / dub   B10 core: dv = head-mask(dub Wo)      [dv]
+//   B11 core:   dta = du + dv Wv                                                                     [dta -> B1 of the layer below]
+// Everything the launched chain leaves for the launches that stay outside is written in the chain's format and values.
+struct DecSmemB {
+    DecSmem a;
+    float res2[16][DEC_E];           // du2: LayerNorm2's input gradient waits here for LayerNorm1's backward
+    float pstage[4][2][DEC_E];       // one block of LayerNorm parameter-gradient partials (4 rows = 4 waves)
+};
+
+struct DecLnbSrc { const float* plain; const float* lds; unsigned char* ll; int region; unsigned tag; };
+
+// LayerNorm backward of the M rows, layernorm_bwd_vec_kernel<1>'s arithmetic (one wave per row; block b of that kernel = rows 4b..4b+3 =
+// waves 0..3 here, so the parameter-gradient partials are the same sums in the same order).
+__device__ __forceinline__ void dec_lnb_rows(const DecLnbSrc& src, const float* x, const float* mean_p, const float* rstd_p, const float* gamma,
+                                             int M, float drop2_p, uint32_t seed2, float (*res)[DEC_E], bf16_t* xa, int ld, bool writer,
+                                             bf16_t* dxb_plain, float* partials, float (*pstage)[2][DEC_E], unsigned* err, int spin) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane * 4;
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma + c);
+    const bool do_drop2 = drop2_p > 0.f;
+    const uint32_t thresh2 = rt_drop_thresh(drop2_p);
+    const float ks2 = do_drop2 ? 1.f / (1.f - drop2_p) : 1.f;
+    f32x4 dg[4], db[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { dg[b] = f32x4{0.f, 0.f, 0.f, 0.f}; db[b] = dg[b]; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma clang fp contract(off)      // as in layernorm_bwd_vec_kernel
+        const int row = b * 4 + wave;
+        if (row >= M) continue;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        bool have = false;
+        if (src.plain) { d = *reinterpret_cast<const f32x4*>(src.plain + (size_t)row * DEC_E + c); have = true; }
+        if (src.lds) { d = *reinterpret_cast<const f32x4*>(src.lds + row * DEC_E + c); have = true; }
+        if (src.ll) {
+            u32x4 a, q;
+            int guard = 0;
+            bool ok;
+            do {
+                asm volatile("" ::: "memory");
+                a = dec_ld16(src.ll + src.region, (row * DEC_E + c) * 8);
+                q = dec_ld16(src.ll + src.region, (row * DEC_E + c) * 8 + 16);
+                ok = a[1] == src.tag && a[3] == src.tag && q[1] == src.tag && q[3] == src.tag;
+            } while (!ok && ++guard < spin);
+            if (!ok) *err = 1u;
+            const f32x4 v = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(q[0]), __uint_as_float(q[2])};
+            d = have ? d + v : v;
+        }
+        const float mean = mean_p[row], rstd = rstd_p[row];
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * DEC_E + c);
+        f32x4 xh, g;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh[e] = (xv[e] - mean) * rstd;
+            const float de = d[e];
+            dg[b][e] += de * xh[e]; db[b][e] += de;
+            g[e] = de * gam[e];
+            s1 += g[e]; s2 += g[e] * xh[e];
+        }
+        s1 = rt_wave_sum(s1) * (1.f / DEC_E); s2 = rt_wave_sum(s2) * (1.f / DEC_E);
+        f32x4 dx;
+        bf16x4 bb;
+        const int o = row * DEC_E + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dx[e] = rstd * (g[e] - s1 - xh[e] * s2);
+            float d2 = dx[e];
+            if (do_drop2) d2 = (rt_hash32(seed2, (uint32_t)(o + e)) >= thresh2) ? d2 * ks2 : 0.f;
+            bb[e] = (bf16_t)d2;
+        }
+        *reinterpret_cast<f32x4*>(&res[row][c]) = dx;
+        *reinterpret_cast<bf16x4*>(xa + row * ld + c) = bb;
+        if (writer && dxb_plain) *reinterpret_cast<bf16x4*>(dxb_plain + o) = bb;
+    }
+    if (writer && partials) {                      // uniform per workgroup
+        const int nb = (M + 3) >> 2;
+        for (int b = 0; b < nb; ++b) {
+            f32x4 a = dg[0], q = db[0];
+            if (b == 1) { a = dg[1]; q = db[1]; } else if (b == 2) { a = dg[2]; q = db[2]; } else if (b == 3) { a = dg[3]; q = db[3]; }
+            *reinterpret_cast<f32x4*>(&pstage[wave][0][c]) = a;
+            *reinterpret_cast<f32x4*>(&pstage[wave][1][c]) = q;
+            __syncthreads();
+            const int cc = threadIdx.x;
+            partials[((size_t)b * 2) * DEC_E + cc] = pstage[0][0][cc] + pstage[1][0][cc] + pstage[2][0][cc] + pstage[3][0][cc];
+            partials[((size_t)b * 2 + 1) * DEC_E + cc] = pstage[0][1][cc] + pstage[1][1][cc] + pstage[2][1][cc] + pstage[3][1][cc];
+            __syncthreads();
+        }
+    }
+}
+
+// one-query attention backward of (b, h): attn_q1_bwd_kernel's arithmetic; do2 arrives as 16 tagged units
+__device__ __forceinline__ void dec_attn_bwd(const rt_decoder_bwd_desc& p, const rt_decoder_layer_bwd& L, int bh, const DecKV& kv,
+                                             DecSmem& sm, uint32_t dseed, unsigned char* ll, unsigned tag_in, unsigned tag_out,
+                                             unsigned* err, int spin) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = bh / p.H, h = bh - b * p.H;
+    float q[32], go[32], ov[32], dq[32];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bf16x8 qv = *reinterpret_cast<const bf16x8*>((const bf16_t*)L.q2 + b * DEC_E + h * 32 + c * 8);
+        const bf16x8 o8 = *reinterpret_cast<const bf16x8*>((const bf16_t*)L.o2 + b * DEC_E + h * 32 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { q[c * 8 + e] = (float)qv[e]; ov[c * 8 + e] = (float)o8[e]; }
+    }
+    {
+        u32x4 raw[8];
+        int guard = 0;
+        bool ok;
+        do {
+            asm volatile("" ::: "memory");
+            ok = true;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                raw[c] = dec_ld16(ll + LL_O2, (b * DEC_E + h * 32 + c * 4) * 4);
+                ok = ok && raw[c][1] == tag_in && raw[c][3] == tag_in;
+            }
+        } while (!ok && ++guard < spin);
+        if (!ok) *err = 1u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const unsigned w0 = raw[c][0], w1 = raw[c][2];
+            const bf16x2 lo = *reinterpret_cast<const bf16x2*>(&w0), hi = *reinterpret_cast<const bf16x2*>(&w1);
+            go[c * 4 + 0] = (float)lo[0]; go[c * 4 + 1] = (float)lo[1]; go[c * 4 + 2] = (float)hi[0]; go[c * 4 + 3] = (float)hi[1];
+        }
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) delta += go[d] * ov[d];
+    const float lse = L.lse2[bh];
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXK; ++i) {
+        const int j = t + i * 256;
+        if (j >= p.S) continue;
+        float dotk = 0.f, dotv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dotk += (float)kv.k[i].c[c][e] * q[c * 8 + e];
+        const float pr = kv.ok[i] ? __expf(dotk * p.scale - lse) : 0.f;
+        float mk = 1.f;
+        if (do_drop) mk = (rt_hash32(dseed, (uint32_t)((size_t)bh * p.S + j)) >= thresh) ? ks : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dotv += (float)kv.v[i].c[c][e] * go[c * 8 + e];
+        const float ds = pr * (mk * dotv - delta) * p.scale;
+        const float pd = pr * mk;
+        bf16_t* dkr = (bf16_t*)L.dk2 + ((size_t)b * p.S + j) * p.ldkv + h * 32;
+        bf16_t* dvr = (bf16_t*)L.dv2 + ((size_t)b * p.S + j) * p.ldkv + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 a8, b8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a8[e] = (bf16_t)(ds * q[c * 8 + e]); b8[e] = (bf16_t)(pd * go[c * 8 + e]);
+                dq[c * 8 + e] += ds * (float)kv.k[i].c[c][e];
+            }
+            *reinterpret_cast<bf16x8*>(dkr + c * 8) = a8;
+            *reinterpret_cast<bf16x8*>(dvr + c * 8) = b8;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dq[d] = rt_wave_sum(dq[d]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 32; ++d) sm.sm32[wave][d] = dq[d];
+    }
+    __syncthreads();
+    if (t < 16) {
+        bf16x2 pr;
+        pr[0] = (bf16_t)(sm.sm32[0][2 * t] + sm.sm32[1][2 * t] + sm.sm32[2][2 * t] + sm.sm32[3][2 * t]);
+        pr[1] = (bf16_t)(sm.sm32[0][2 * t + 1] + sm.sm32[1][2 * t + 1] + sm.sm32[2][2 * t + 1] + sm.sm32[3][2 * t + 1]);
+        const int e = b * DEC_E + h * 32 + 2 * t;
+        const unsigned bits = *reinterpret_cast<const unsigned*>(&pr);
+        dec_st8(ll + LL_Q2, e * 4, u32x2{bits, tag_out});
+        *reinterpret_cast<unsigned*>((bf16_t*)L.dq2 + e) = bits;
+    }
+}
+
+template <class LT>
+__device__ __forceinline__ void dec_kv_prefetch(const LT& L, const uint8_t* kpm, int H, int S, int ldkv, int bh, DecKV& kv) {
+    const int t = threadIdx.x;
+    const int b = bh / H, h = bh - b * H;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXK; ++i) {
+        const int j = t + i * 256;
+        const int jj = j < S ? j : 0;
+        kv.ok[i] = j < S && !(kpm && kpm[(size_t)b * S + jj]);
+        const bf16_t* kr = (const bf16_t*)L.k2 + ((size_t)b * S + jj) * ldkv + h * 32;
+        const bf16_t* vr = (const bf16_t*)L.v2 + ((size_t)b * S + jj) * ldkv + h * 32;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            kv.k[i].c[c] = *reinterpret_cast<const bf16x8*>(kr + c * 8);
+            kv.v[i].c[c] = *reinterpret_cast<const bf16x8*>(vr + c * 8);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void decoder_bwd_kernel(const rt_decoder_bwd_desc p, const int G, const int spin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dec_smem_raw[];
+    DecSmemB& smb = *reinterpret_cast<DecSmemB*>(dec_smem_raw);
+    DecSmem& sm = smb.a;
+    bf16_t* xa = reinterpret_cast<bf16_t*>(dec_smem_raw + sizeof(DecSmemB));
+    const int wg = blockIdx.x, t = threadIdx.x;
+    const int M = p.M, F = p.F;
+    const bool core = wg < DEC_CORE, writer = wg == 0;
+    const int wk = wg - DEC_CORE, NW = G - DEC_CORE;
+    const int ldE = DEC_E + 8, ldF = F + 8;
+    const int n0 = wg * 16;
+    const int n_bh = M * p.H;
+    const int f_tiles = F >> 4;
+    const bool drop = p.drop_p > 0.f;
+    unsigned char* ll = reinterpret_cast<unsigned char*>(p.handoff);
+    unsigned* err = p.handoff + 1;
+    const unsigned epoch = p.handoff[0];
+    const int lane = t & 63, lg = lane >> 4, wave = t >> 6;
+    (void)wave;
+    const int NL = p.n_layers;
+
+    for (int l = NL - 1; l >= 0; --l) {
+        const rt_decoder_layer_bwd& L = p.layer[l];
+        // ---- requests that depend on nothing computed here
+        u32x4 wA[DEC_NT][2];          // workers: linear2^T tiles; core: reused per product below
+        u32x4 wf[16];
+        if (!core) {
+#pragma unroll
+            for (int i = 0; i < DEC_NT; ++i) {
+                const int tile = wk + i * NW;
+                if (tile < f_tiles) dec_load_w<2>((const bf16_t*)L.WT2, DEC_E, tile * 16, wA[i]);
+            }
+        } else {
+            dec_load_w<16>((const bf16_t*)L.WT1, F, n0, wf);
+        }
+        // ================= B1: LayerNorm3 backward
+        {
+            const DecLnbSrc src{L.dnorm, nullptr, l + 1 < NL ? ll : nullptr, LL_U3, ll_tag(epoch, l + 1, 6)};
+            const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d3) : 0u;
+            dec_lnb_rows(src, L.u3, L.mean3, L.rstd3, L.g3, M, p.drop_p, seed, sm.ln32, xa, ldE, writer, (bf16_t*)L.du3b, L.part3,
+                         smb.pstage, err, spin);
+        }
+        __syncthreads();
+        if (!core) {
+            // ================= B2 (workers): dhdn = gate(du3b W2) / (1 - p)
+            if (wk < f_tiles) {
+                const unsigned tag = ll_tag(epoch, l, 0);
+#pragma unroll
+                for (int i = 0; i < DEC_NT; ++i) {
+                    const int tile = wk + i * NW;
+                    if (tile < f_tiles) {
+                        dec_tile<2>(wA[i], xa, ldE, M, tile * 16, sm, [&](int m, int n, f32x4 v) {
+                            const bf16x4 gg = *reinterpret_cast<const bf16x4*>((const bf16_t*)L.hdn + m * F + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = ((float)gg[r] > 0.f) ? v[r] * p.gate_scale : 0.f;
+                            const u32x2 pk = dec_pack4(v);
+                            ll_put_bf16x4(ll, LL_HDN, tag, m * F + n, pk);
+                            *reinterpret_cast<u32x2*>((bf16_t*)L.dhdn + m * F + n) = pk;
+                        });
+                    }
+                }
+            }
+            // ================= B6 (workers): attention backward of (b, h) = worker id, + number of workers, ...
+            if (wk < n_bh) {
+                const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_ad2) : 0u;
+                DecKV kv;
+                for (int bh = wk; bh < n_bh; bh += NW) {
+                    dec_kv_prefetch(L, p.kpm, p.H, p.S, p.ldkv, bh, kv);
+                    dec_attn_bwd(p, L, bh, kv, sm, seed, ll, ll_tag(epoch, l, 2), ll_tag(epoch, l, 3), err, spin);
+                    __syncthreads();
+                }
+            }
+            continue;
+        }
+        // ================= B3 (core): dt2 = du3 + dhdn W1
+        u32x4 w2[2];
+        ll_rows_to_lds<16>(ll, LL_HDN, ll_tag(epoch, l, 0), M, F, xa, ldF, err, spin);
+        __syncthreads();
+        {
+            const unsigned tag = ll_tag(epoch, l, 1);
+            dec_tile<16>(wf, xa, ldF, M, n0, sm, [&](int m, int n, f32x4 v) {
+                v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
+                ll_put_f32x4(ll, LL_U, tag, m * DEC_E + n, v);
+            });
+        }
+        // ================= B4: LayerNorm2 backward; B5: do2 = du2b Wo2
+        dec_load_w<2>((const bf16_t*)L.WTo2, DEC_E, n0, w2);
+        {
+            const DecLnbSrc src{nullptr, nullptr, ll, LL_U, ll_tag(epoch, l, 1)};
+            const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d2) : 0u;
+            dec_lnb_rows(src, L.u2, L.mean2, L.rstd2, L.g2, M, p.drop_p, seed, smb.res2, xa, ldE, writer, (bf16_t*)L.du2b, L.part2,
+                         smb.pstage, err, spin);
+        }
+        __syncthreads();
+        {
+            const unsigned tag = ll_tag(epoch, l, 2);
+            dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                ll_put_bf16x4(ll, LL_O2, tag, m * DEC_E + n, dec_pack4(v));
+            });
+        }
+        // ================= B8: dt1q = dq2 Wq, accumulated into d query_pos
+        dec_load_w<2>((const bf16_t*)L.WTq, DEC_E, n0, w2);
+        ll_rows_to_lds<4>(ll, LL_Q2, ll_tag(epoch, l, 3), M, DEC_E, xa, ldE, err, spin);
+        __syncthreads();
+        {
+            const unsigned tag = ll_tag(epoch, l, 4);
+            dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                ll_put_f32x4(ll, LL_U2, tag, m * DEC_E + n, v);
+                f32x4* acc = reinterpret_cast<f32x4*>(p.dqpos + m * DEC_E + n);
+                *acc += v;
+            });
+        }
+        // ================= B9: LayerNorm1 backward of (du2 + dt1q); B10: dv = head-mask(dub Wo)
+        dec_load_w<2>((const bf16_t*)L.WTo, DEC_E, n0, w2);
+        {
+            const DecLnbSrc src{nullptr, &smb.res2[0][0], ll, LL_U2, ll_tag(epoch, l, 4)};
+            const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_d1) : 0u;
+            dec_lnb_rows(src, L.u, L.mean1, L.rstd1, L.g1, M, p.drop_p, seed, sm.ln32, xa, ldE, writer, (bf16_t*)L.dub, L.part1,
+                         smb.pstage, err, spin);
+        }
+        __syncthreads();
+        {
+            const unsigned tag = ll_tag(epoch, l, 5);
+            const uint32_t seed = drop ? rt_site_seed(p.seed_dev, L.seed_ad) : 0u;
+            dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                if (drop) v = dec_dropout(v, p.drop_p, seed, (uint32_t)(m * DEC_E + n), 5);
+                const u32x2 pk = dec_pack4(v);
+                ll_put_bf16x4(ll, LL_O, tag, m * DEC_E + n, pk);
+                *reinterpret_cast<u32x2*>((bf16_t*)L.dv + m * DEC_E + n) = pk;
+            });
+        }
+        // ================= B11: dta = du + dv Wv
+        dec_load_w<2>((const bf16_t*)L.WTv, DEC_E, n0, w2);
+        ll_rows_to_lds<4>(ll, LL_O, ll_tag(epoch, l, 5), M, DEC_E, xa, ldE, err, spin);
+        __syncthreads();
+        {
+            const unsigned tag = ll_tag(epoch, l, 6);
+            dec_tile<2>(w2, xa, ldE, M, n0, sm, [&](int m, int n, f32x4 v) {
+                v += *reinterpret_cast<const f32x4*>(&sm.ln32[m][n]);
+                if (l > 0) ll_put_f32x4(ll, LL_U3, tag, m * DEC_E + n, v);
+                else *reinterpret_cast<f32x4*>(p.dta + m * DEC_E + n) = v;
+            });
+        }
+    }
+    // ---- the launch epoch moves on once nothing of this launch can still be read: workgroup 0 finished the first layer's B11 after
+    // every hand-off it consumed; the other workgroups' last reads are of tags it has seen complete ...
+    if (writer) {
+        __syncthreads();
+        if (t == 0) p.handoff[0] = epoch + 1;
+    }
+}
+
 int dec_spin() {
     static const int v = getenv("REFTR_DEC_SPIN") ? atoi(getenv("REFTR_DEC_SPIN")) : (1 << 17);
     return v;
@@ -580,6 +945,31 @@ extern "C" int rt_decoder_fwd(const rt_decoder_fwd_desc* d, rt_stream_t stream) 
         attr = true;
     }
     hipLaunchKernelGGL(decoder_fwd_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, *d, G, dec_spin(), dec_trace_buf());
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_decoder_bwd(const rt_decoder_bwd_desc* d, rt_stream_t stream) {
+    if (!d || !d->dta || !d->dqpos || !d->handoff) return RT_ERR_BADARG;
+    if (d->n_layers < 1 || d->n_layers > RT_DEC_MAX_LAYERS) return RT_ERR_UNSUPPORTED;
+    const int G = dec_groups();
+    if (G <= DEC_CORE || G > 144) return RT_ERR_UNSUPPORTED;
+    if (d->M < 1 || d->M > 16 || d->H * 32 != DEC_E || d->S < 1 || d->S > 256 * DEC_MAXK) return RT_ERR_UNSUPPORTED;
+    if (d->F != 2048 || (d->F >> 4) > DEC_NT * (G - DEC_CORE) || (d->ldkv & 7)) return RT_ERR_UNSUPPORTED;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const rt_decoder_layer_bwd& L = d->layer[l];
+        if (!L.WT2 || !L.WT1 || !L.WTo2 || !L.WTq || !L.WTo || !L.WTv || !L.g1 || !L.g2 || !L.g3 || !L.u || !L.u2 || !L.u3 || !L.mean1 ||
+            !L.rstd1 || !L.mean2 || !L.rstd2 || !L.mean3 || !L.rstd3 || !L.hdn || !L.q2 || !L.k2 || !L.v2 || !L.o2 || !L.lse2 || !L.dnorm ||
+            !L.du3b || !L.dhdn || !L.du2b || !L.dq2 || !L.dub || !L.dv || !L.dk2 || !L.dv2) return RT_ERR_BADARG;
+    }
+    const size_t smem = sizeof(DecSmemB) + (size_t)16 * (d->F + 8) * 2;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, *d, G, dec_spin());
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

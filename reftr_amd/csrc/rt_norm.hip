@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const rt_layerno
     bf16_t* dxb = (bf16_t*)p.dx_bf16;
 
     for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
+#pragma clang fp contract(off)      // rt_decoder_bwd repeats this arithmetic and must round the same way: no fused multiply-adds
         const int orow = map_row(row, p.grp_rows, p.grp_stride, p.grp_off);
         const float mean = p.mean[row], rstd = p.rstd[row];
         const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (size_t)row * D);

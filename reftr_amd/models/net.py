@@ -56,6 +56,7 @@ class Net:
         self.kv_dgrad_side = os.environ.get("REFTR_DEC_KV_SIDE", "0") != "0"
         # the decoder's forward chain as one cooperative launch (csrc/rt_decoder.hip) whenever its shape allows
         self.dec_coop = os.environ.get("REFTR_DEC_COOP", "1") != "0"
+        self.dec_coop_bwd = os.environ.get("REFTR_DEC_COOP_BWD", "1") != "0"
         self._dec_cus = None
         self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
@@ -451,7 +452,8 @@ class Net:
         layers, saved = [], []
         t16_in = t16
         for i, p in enumerate(prefixes):
-            r = {"t16": t16_in, "tq16": tq16 if i == 0 else None, "trivial": True, "fold": True, "qk": None, "v": None, "lse": None}
+            r = {"t16": t16_in, "tq16": tq16 if i == 0 else None, "trivial": True, "fold": True, "qk": None, "v": None, "lse": None,
+                 "coop": True}
             for k in ("ad", "d1", "ad2", "d2", "dh", "d3"):       # the chain's site order
                 r[k] = self._drop(cfg.dropout)
             sm = torch.empty(6, N, dtype=f32, device=dev)         # mean / rstd of norm1..3
@@ -481,6 +483,67 @@ class Net:
         drop_p = saved[0]["ad"][0]
         self.dec_counters = H.decoder_fwd(layers, t32, t16, qpos, kpm, H=cfg.nheads, S=S, F=F, drop_p=drop_p, scale=dh ** -0.5)
         return saved
+
+    def _wgrad_only(self, key, dy, x):
+        """The weight / bias gradient half of lin_bwd (the backward-data half ran inside rt_decoder_bwd)."""
+        l = self.lins[key]
+        ow = self.store.claim(l.gw)
+        if self.small_wg is not None and dy.shape[0] <= 16:
+            self.small_wg.add(dy, x, l.gw, l.gb, overwrite=ow)
+        else:
+            self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb, overwrite=ow), dy, x)
+
+    def dec_stack_bwd_coop(self, prefixes, saved, dnorm_all, mem16, memp16, kpm, B, S, dmem_acc, dmemp_acc, dqpos_acc):
+        """Backward of every decoder layer in ONE launch (rt_decoder_bwd) + what stays outside it, queued / launched exactly as
+        dec_layer_bwd would: the grouped M <= 16 weight gradients and LayerNorm parameter gradients (their dy operands and
+        partial sums come from the launch), the memory-gradient products and weight gradients of the cross-attention K / V
+        projections.  Returns the gradient w.r.t. the stack's input."""
+        cfg = self.cfg
+        E, F, N = cfg.hidden, cfg.ffn, B
+        dev = dnorm_all.device
+        bf, f32 = torch.bfloat16, torch.float32
+        nb = (N + 3) // 4
+        layers, outs = [], []
+        for i, p in enumerate(prefixes):
+            r = saved[i]
+            d16 = torch.empty(5, N, E, dtype=bf, device=dev)          # du3b, du2b, dq2, dub, dv
+            dhdn = torch.empty(N, F, dtype=bf, device=dev)
+            dkv = torch.empty(2, B * S, E, dtype=bf, device=dev)
+            parts = torch.empty(3, nb, 2, E, dtype=f32, device=dev)
+            L = self.lins
+            lay = dict(WT2=L[p + "linear2."].WT, WT1=L[p + "linear1."].WT, WTo2=L[p + "multihead_attn.out_proj."].WT,
+                       WTq=L[p + "multihead_attn.q"].WT, WTo=L[p + "self_attn.out_proj."].WT, WTv=L[p + "self_attn.v"].WT,
+                       g1=self.P(p + "norm1.weight"), g2=self.P(p + "norm2.weight"), g3=self.P(p + "norm3.weight"),
+                       u=r["u"], u2=r["u2"], u3=r["u3"], mean1=r["st1"][0], rstd1=r["st1"][1], mean2=r["st2"][0], rstd2=r["st2"][1],
+                       mean3=r["st3"][0], rstd3=r["st3"][1], hdn=r["hdn"], q2=r["q2"], k2=r["k2"], v2=r["v2"], o2=r["o2"],
+                       lse2=r["lse2"], dnorm=dnorm_all[i * N:(i + 1) * N], du3b=d16[0], dhdn=dhdn, du2b=d16[1], dq2=d16[2],
+                       dub=d16[3], dv=d16[4], dk2=dkv[0], dv2=dkv[1], part1=parts[0], part2=parts[1], part3=parts[2],
+                       seed_ad=r["ad"][1], seed_d1=r["d1"][1], seed_ad2=r["ad2"][1], seed_d2=r["d2"][1], seed_d3=r["d3"][1])
+            layers.append(lay); outs.append((d16, dhdn, dkv, parts))
+        drop_p = saved[0]["d3"][0]
+        p_dh = saved[0]["dh"][0]
+        dta = torch.empty(N, E, dtype=f32, device=dev)
+        dh = E // cfg.nheads
+        self.dec_counters = H.decoder_bwd(layers, dta, dqpos_acc, kpm, H=cfg.nheads, S=S, F=F, drop_p=drop_p, scale=dh ** -0.5,
+                                          gate_scale=1.0 / (1.0 - p_dh) if p_dh > 0 else 1.0)
+        for i in reversed(range(len(prefixes))):
+            p, r = prefixes[i], saved[i]
+            d16, dhdn, dkv, parts = outs[i]
+            self._wgrad_only(p + "linear2.", d16[0], r["hdn"])
+            self._wgrad_only(p + "linear1.", dhdn, r["t2_16"])
+            self._wgrad_only(p + "multihead_attn.out_proj.", d16[1], r["o2"])
+            grp = H.GemmGroup()                      # the M = B*S products: regular launches, as in dec_layer_bwd
+            self.lin_bwd(p + "multihead_attn.v", dkv[1], mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
+            self.lin_bwd(p + "multihead_attn.k", dkv[0], memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
+            grp.run()
+            self._wgrad_only(p + "multihead_attn.q", d16[2], r["t1q16"])
+            self._wgrad_only(p + "self_attn.out_proj.", d16[3], r["o"])
+            self._wgrad_only(p + "self_attn.v", d16[4], r["t16"])
+            for j, nm in ((2, "norm3."), (1, "norm2."), (0, "norm1.")):
+                self.ln_batch.jobs.append(H.LnPgJob(parts[j].data_ptr(), self.G(p + nm + "weight").data_ptr(),
+                                                    self.G(p + nm + "bias").data_ptr(), nb, E))
+                self.ln_batch.keep.append(parts[j])
+        return dta
 
     def dec_layer_bwd(self, p, r, g_a, g_b, mem16, memp16, qmask, kpm, B, T, S, dmem_acc, dmemp_acc, dqpos_acc):
         """g_a (+ g_b) = gradient w.r.t. this layer's output t3.  Returns (dt_a, dt_q): their sum is the

@@ -517,7 +517,12 @@ class RefTR(nn.Module):
         ga = gb = None
         hm, hr = sv["hs_stats"]
         dnorm_all, _ = net.ln_bwd(dhs, sv["t3s"], vt + "decoder.norm.", hm, hr, want_bf16=False)     # all layers, one launch
-        for i in reversed(range(NL)):
+        coop_bwd = (NL > 0 and net.dec_coop_bwd and net.ln_batch is not None and net.small_wg is not None
+                    and all(r.get("coop") for r in sv["dec"]))
+        if coop_bwd:                    # the whole stack's backward chain as one cooperative launch (rt_decoder_bwd)
+            ga = net.dec_stack_bwd_coop([f"{vt}decoder.layers.{i}." for i in range(NL)], sv["dec"], dnorm_all, sv["mem16"],
+                                        sv["memp16"], sv["kpm"], B, S, dmem, dmemp, dqpos)
+        for i in (() if coop_bwd else reversed(range(NL))):
             dnorm = dnorm_all[i * N:(i + 1) * N]
             extra = None
             if ga is not None and gb is None:

@@ -49,8 +49,9 @@ def build(dec_layers, B, H, W):
 SAVED = ("t16", "o", "u", "t1q16", "q2", "o2", "lse2", "u2", "t2_16", "hdn", "u3")
 
 
-def run(model, crit, s, tg, coop, train, seed=10, backward=False):
+def run(model, crit, s, tg, coop, train, seed=10, backward=False, coop_bwd=False):
     model.net.dec_coop = coop
+    model.net.dec_coop_bwd = coop_bwd
     model.train(train)
     model.seed_dev.fill_(seed)
     out = model(s)
@@ -66,6 +67,8 @@ def run(model, crit, s, tg, coop, train, seed=10, backward=False):
         model.store.flat_g.zero_()
         total.backward()
         res["grad"] = model.store.flat_g.detach().clone()
+        if coop_bwd:
+            assert int(model.net.dec_counters[-1]) == 0, "a cooperative wait gave up (backward)"
     return res
 
 
@@ -104,6 +107,29 @@ def test_backward_consumes_the_cooperative_forward_unchanged(hip):
     assert d < 1e-5, d
 
 
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("B,dec_layers,H,W", [(2, 2, 96, 128), (8, 6, 192, 160), (13, 3, 64, 64)])
+def test_cooperative_backward_matches_the_launched_chain(hip, B, dec_layers, H, W, train):
+    """rt_decoder_bwd against dec_layer_bwd on the same (cooperative) forward: every gradient that is not accumulated with
+    atomics is bit-identical -- the decoder's weight matrices (their dy operands come out of the cooperative launch), the
+    encoder's and input_proj's (through d memory) -- and the whole buffer agrees to the atomics' order noise."""
+    model, crit, s, tg = build(dec_layers, B, H, W)
+    a = run(model, crit, s, tg, coop=True, train=train, backward=True, coop_bwd=False)
+    for rep in range(3):
+        b = run(model, crit, s, tg, coop=True, train=train, backward=True, coop_bwd=True)
+        assert_same(b, a)
+        G = lambda res, name: model.store.view_of(res["grad"], name)
+        for i in range(dec_layers):
+            for nm in ("linear1.weight", "linear2.weight", "self_attn.out_proj.weight", "multihead_attn.out_proj.weight"):
+                key = f"vl_transformer.decoder.layers.{i}.{nm}"
+                assert torch.equal(G(a, key), G(b, key)), (key, float((G(a, key) - G(b, key)).abs().max()))
+        for key in ("vl_transformer.encoder.layers.1.linear1.weight", "vl_transformer.encoder.layers.0.self_attn.out_proj.weight",
+                    "input_proj.0.0.weight", "query_encoder.fuse_encoder_query.0.weight"):
+            assert torch.equal(G(a, key), G(b, key)), (key, float((G(a, key) - G(b, key)).abs().max()))
+        d = float((a["grad"] - b["grad"]).norm() / a["grad"].norm())
+        assert d < 2e-6, d
+
+
 def test_unsupported_shapes_keep_the_chain(hip):
     """Multi-phrase inputs (T > 1: real self-attention among the phrase queries) do not take the cooperative path."""
     model, crit, s, tg = build(2, 2, 96, 128)
@@ -126,17 +152,19 @@ def test_many_replays_under_a_captured_graph(hip):
         try:
             model, crit, s, tg = build(3, 8, 128, 128)
             model.net.dec_coop = coop
+            model.net.dec_coop_bwd = coop
             model.train()
             opt = FusedAdamW(model, lr=0.0, lr_backbone=0.0, weight_decay=0.0)
             cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg)
             model.seed_dev.fill_(5)
-            vals = [float(cap(s, tg)[0]) for i in range(200)]
+            vals = [(float(r[0]), float(r[2])) for r in (cap(s, tg) for i in range(200))]          # (loss, gradient norm)
             cap.flush()
             if coop:
                 assert int(model.net.dec_counters[-1]) == 0
-                assert int(model.net.dec_counters[0]) >= 200          # the launch epoch advanced with every replay
+                assert int(model.net.dec_counters[0]) >= 400          # the launch epoch advanced with every forward and backward launch
             losses[coop] = vals
         finally:
             os.environ.pop("REFTR_DEC_COOP", None)
-    assert len(set(losses[False])) > 150                              # dropout: a new mask set per replay
-    assert losses[True] == losses[False]
+    assert len(set(v[0] for v in losses[False])) > 150                # dropout: a new mask set per replay
+    assert [v[0] for v in losses[True]] == [v[0] for v in losses[False]]
+    assert all(abs(a[1] - b[1]) < 1e-5 * b[1] for a, b in zip(losses[True], losses[False]))      # gradient norms (atomics' order)
