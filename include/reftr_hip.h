@@ -668,6 +668,8 @@ typedef struct rt_decoder_layer_bwd {
     const float *dnorm;                                   /* [M,256]: gradient w.r.t. this layer's output through the shared decoder norm */
     void *du3b, *dhdn, *du2b, *dq2, *dub, *dv;            /* bf16 [M,256] (dhdn [M,F]): dy operands of the weight gradients */
     void *dk2, *dv2;                                      /* bf16 [B*S, ldkv] */
+    void *dk2p, *dv2p;                                    /* optional second copy with row stride ldkvp (all layers packed side by side
+                                                             for ONE K-concatenated memory-gradient product), or NULL */
     float *part1, *part2, *part3;                         /* [(M+3)/4][2][256] */
     uint32_t seed_ad, seed_d1, seed_ad2, seed_d2, seed_d3, reserved;
 } rt_decoder_layer_bwd;
@@ -680,6 +682,7 @@ typedef struct rt_decoder_bwd_desc {
     const uint32_t* seed_dev;
     int32_t n_layers, M, H, S, F, ldkv;
     float   drop_p, scale, gate_scale;                    /* gate_scale = 1 / (1 - p) of linear1's dropout */
+    int32_t ldkvp;
 } rt_decoder_bwd_desc;
 int rt_decoder_bwd(const rt_decoder_bwd_desc* d, rt_stream_t stream);
 /* REFTR_DEC_TRACE=1 only: 1024 wall-clock stamps (100 MHz) of the last launch's stage boundaries, host buffer */

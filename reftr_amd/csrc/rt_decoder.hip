@@ -710,6 +710,10 @@ __device__ __forceinline__ void dec_attn_bwd(const rt_decoder_bwd_desc& p, const
             }
             *reinterpret_cast<bf16x8*>(dkr + c * 8) = a8;
             *reinterpret_cast<bf16x8*>(dvr + c * 8) = b8;
+            if (L.dk2p) {
+                *reinterpret_cast<bf16x8*>((bf16_t*)L.dk2p + ((size_t)b * p.S + j) * p.ldkvp + h * 32 + c * 8) = a8;
+                *reinterpret_cast<bf16x8*>((bf16_t*)L.dv2p + ((size_t)b * p.S + j) * p.ldkvp + h * 32 + c * 8) = b8;
+            }
         }
     }
 #pragma unroll
@@ -960,7 +964,8 @@ extern "C" int rt_decoder_bwd(const rt_decoder_bwd_desc* d, rt_stream_t stream) 
         const rt_decoder_layer_bwd& L = d->layer[l];
         if (!L.WT2 || !L.WT1 || !L.WTo2 || !L.WTq || !L.WTo || !L.WTv || !L.g1 || !L.g2 || !L.g3 || !L.u || !L.u2 || !L.u3 || !L.mean1 ||
             !L.rstd1 || !L.mean2 || !L.rstd2 || !L.mean3 || !L.rstd3 || !L.hdn || !L.q2 || !L.k2 || !L.v2 || !L.o2 || !L.lse2 || !L.dnorm ||
-            !L.du3b || !L.dhdn || !L.du2b || !L.dq2 || !L.dub || !L.dv || !L.dk2 || !L.dv2) return RT_ERR_BADARG;
+            !L.du3b || !L.dhdn || !L.du2b || !L.dq2 || !L.dub || !L.dv || !L.dk2 || !L.dv2 || (!L.dk2p != !L.dv2p) ||
+            (L.dk2p && (d->ldkvp < DEC_E || (d->ldkvp & 7)))) return RT_ERR_BADARG;
     }
     const size_t smem = sizeof(DecSmemB) + (size_t)16 * (d->F + 8) * 2;
     static bool attr = false;

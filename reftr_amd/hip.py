@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -243,7 +243,7 @@ class DecoderLayerFwd(Structure):
 class DecoderLayerBwd(Structure):
     _PTRS = ("WT2", "WT1", "WTo2", "WTq", "WTo", "WTv", "g1", "g2", "g3", "u", "u2", "u3",
              "mean1", "rstd1", "mean2", "rstd2", "mean3", "rstd3", "hdn", "q2", "k2", "v2", "o2", "lse2", "dnorm",
-             "du3b", "dhdn", "du2b", "dq2", "dub", "dv", "dk2", "dv2", "part1", "part2", "part3")
+             "du3b", "dhdn", "du2b", "dq2", "dub", "dv", "dk2", "dv2", "dk2p", "dv2p", "part1", "part2", "part3")
     _SEEDS = ("seed_ad", "seed_d1", "seed_ad2", "seed_d2", "seed_d3", "reserved")
     _fields_ = [(n, c_void_p) for n in _PTRS] + [(n, c_uint32) for n in _SEEDS]
 
@@ -252,7 +252,7 @@ class DecoderBwdDesc(Structure):
     _fields_ = [("layer", DecoderLayerBwd * DEC_MAX_LAYERS),
                 ("dta", c_void_p), ("dqpos", c_void_p), ("kpm", c_void_p), ("handoff", c_void_p), ("seed_dev", c_void_p),
                 ("n_layers", c_int32), ("M", c_int32), ("H", c_int32), ("S", c_int32), ("F", c_int32), ("ldkv", c_int32),
-                ("drop_p", c_float), ("scale", c_float), ("gate_scale", c_float)]
+                ("drop_p", c_float), ("scale", c_float), ("gate_scale", c_float), ("ldkvp", c_int32)]
 
 
 class DecoderFwdDesc(Structure):
@@ -707,7 +707,7 @@ def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, eps=1e-5
     return handoff[:2]
 
 
-def decoder_bwd(layers, dta, dqpos, kpm, *, H, S, F, drop_p, scale, gate_scale):
+def decoder_bwd(layers, dta, dqpos, kpm, *, H, S, F, drop_p, scale, gate_scale, ldkvp=0):
     """Backward of the cooperative decoder stack (rt_decoder_bwd).  `layers`: one dict per layer (first to last), keys =
     DecoderLayerBwd._PTRS (tensors, all allocated by the caller) + the dropout seeds of the forward."""
     M = dta.shape[0]
@@ -716,13 +716,13 @@ def decoder_bwd(layers, dta, dqpos, kpm, *, H, S, F, drop_p, scale, gate_scale):
     for i, lay in enumerate(layers):
         L = d.layer[i]
         for n in DecoderLayerBwd._PTRS:
-            setattr(L, n, _p(lay[n]))
+            setattr(L, n, _p(lay.get(n)))
         for n in DecoderLayerBwd._SEEDS[:-1]:
             setattr(L, n, lay[n] & 0xFFFFFFFF)
     handoff = decoder_handoff(dta.device)
     d.dta, d.dqpos, d.kpm, d.handoff, d.seed_dev = _p(dta), _p(dqpos), _p(kpm), _p(handoff), _seedp(drop_p)
     d.n_layers, d.M, d.H, d.S, d.F, d.ldkv = len(layers), M, H, S, F, _ld(layers[0]["k2"])
-    d.drop_p, d.scale, d.gate_scale = drop_p, scale, gate_scale
+    d.drop_p, d.scale, d.gate_scale, d.ldkvp = drop_p, scale, gate_scale, ldkvp
     _check(lib().rt_decoder_bwd(ctypes.byref(d), _stream()), "rt_decoder_bwd")
     return handoff[:2]
 

@@ -57,6 +57,8 @@ class Net:
         # the decoder's forward chain as one cooperative launch (csrc/rt_decoder.hip) whenever its shape allows
         self.dec_coop = os.environ.get("REFTR_DEC_COOP", "1") != "0"
         self.dec_coop_bwd = os.environ.get("REFTR_DEC_COOP_BWD", "1") != "0"
+        self.dec_kv_pack = os.environ.get("REFTR_DEC_KV_PACK", "1") != "0"       # d memory as one K-concatenated product
+        self._kv_cat = None
         self._dec_cus = None
         self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
@@ -128,6 +130,7 @@ class Net:
             for l in self.lins.values():
                 self._prep.add(l.w32, l.N, 1, l.K, dst=l.W, dst_t=l.WT)
         self._prep.run()
+        self._refresh_kv_cat()
 
     # ------------------------------------------------------------------ helpers
     def begin_step(self, training):
@@ -485,13 +488,33 @@ class Net:
         return saved
 
     def _wgrad_only(self, key, dy, x):
-        """The weight / bias gradient half of lin_bwd (the backward-data half ran inside rt_decoder_bwd)."""
+        """The weight / bias gradient half of lin_bwd (the backward-data half ran elsewhere)."""
         l = self.lins[key]
         ow = self.store.claim(l.gw)
         if self.small_wg is not None and dy.shape[0] <= 16:
             self.small_wg.add(dy, x, l.gw, l.gb, overwrite=ow)
+        elif self.big_wg is not None and dy.shape[0] > 16:
+            self.big_wg.add(dy, x, l.gw, l.gb, overwrite=ow)
         else:
             self.wg.run(lambda: H.linear_wgrad(dy, x, l.gw, dbias=l.gb, overwrite=ow), dy, x)
+
+    def _dec_kv_wt_cat(self, prefixes):
+        """[Wv_0^T | Wv_1^T | ...] and the same for K: the backward-data operands of every layer's cross-attention K / V projection
+        side by side along the contraction axis, so that d memory = sum over layers of dV_l Wv_l is ONE product over K = layers x 256
+        (refreshed with the other operands, see refresh)."""
+        if self._kv_cat is None or self._kv_cat[0] != tuple(prefixes):
+            E = self.cfg.hidden
+            dev = self.store.device
+            bufs = {n: torch.empty(E, len(prefixes) * E, dtype=torch.bfloat16, device=dev) for n in ("k", "v")}
+            self._kv_cat = (tuple(prefixes), bufs)
+            self._refresh_kv_cat()
+        return self._kv_cat[1]
+
+    def _refresh_kv_cat(self):
+        if self._kv_cat is not None:
+            prefixes, bufs = self._kv_cat
+            for n in ("k", "v"):
+                torch.cat([self.lins[p + "multihead_attn." + n].WT for p in prefixes], dim=1, out=bufs[n])
 
     def dec_stack_bwd_coop(self, prefixes, saved, dnorm_all, mem16, memp16, kpm, B, S, dmem_acc, dmemp_acc, dqpos_acc):
         """Backward of every decoder layer in ONE launch (rt_decoder_bwd) + what stays outside it, queued / launched exactly as
@@ -504,6 +527,9 @@ class Net:
         bf, f32 = torch.bfloat16, torch.float32
         nb = (N + 3) // 4
         layers, outs = [], []
+        NLd = len(prefixes)
+        pack = self.dec_kv_pack and NLd > 1
+        dkv_all = torch.empty(2, B * S, NLd * E, dtype=bf, device=dev) if pack else None       # [dK_0 | dK_1 | ...], [dV_0 | ...]
         for i, p in enumerate(prefixes):
             r = saved[i]
             d16 = torch.empty(5, N, E, dtype=bf, device=dev)          # du3b, du2b, dq2, dub, dv
@@ -519,23 +545,29 @@ class Net:
                        lse2=r["lse2"], dnorm=dnorm_all[i * N:(i + 1) * N], du3b=d16[0], dhdn=dhdn, du2b=d16[1], dq2=d16[2],
                        dub=d16[3], dv=d16[4], dk2=dkv[0], dv2=dkv[1], part1=parts[0], part2=parts[1], part3=parts[2],
                        seed_ad=r["ad"][1], seed_d1=r["d1"][1], seed_ad2=r["ad2"][1], seed_d2=r["d2"][1], seed_d3=r["d3"][1])
+            if pack:
+                lay.update(dk2p=dkv_all[0][:, i * E:(i + 1) * E], dv2p=dkv_all[1][:, i * E:(i + 1) * E])
             layers.append(lay); outs.append((d16, dhdn, dkv, parts))
         drop_p = saved[0]["d3"][0]
         p_dh = saved[0]["dh"][0]
         dta = torch.empty(N, E, dtype=f32, device=dev)
         dh = E // cfg.nheads
         self.dec_counters = H.decoder_bwd(layers, dta, dqpos_acc, kpm, H=cfg.nheads, S=S, F=F, drop_p=drop_p, scale=dh ** -0.5,
-                                          gate_scale=1.0 / (1.0 - p_dh) if p_dh > 0 else 1.0)
+                                          gate_scale=1.0 / (1.0 - p_dh) if p_dh > 0 else 1.0, ldkvp=NLd * E if pack else 0)
         for i in reversed(range(len(prefixes))):
             p, r = prefixes[i], saved[i]
             d16, dhdn, dkv, parts = outs[i]
             self._wgrad_only(p + "linear2.", d16[0], r["hdn"])
             self._wgrad_only(p + "linear1.", dhdn, r["t2_16"])
             self._wgrad_only(p + "multihead_attn.out_proj.", d16[1], r["o2"])
-            grp = H.GemmGroup()                      # the M = B*S products: regular launches, as in dec_layer_bwd
-            self.lin_bwd(p + "multihead_attn.v", dkv[1], mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
-            self.lin_bwd(p + "multihead_attn.k", dkv[0], memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
-            grp.run()
+            if pack:                                 # weight gradients queued; the memory gradient is one product below
+                self._wgrad_only(p + "multihead_attn.v", dkv[1], mem16)
+                self._wgrad_only(p + "multihead_attn.k", dkv[0], memp16)
+            else:
+                grp = H.GemmGroup()                  # the M = B*S products: regular launches, as in dec_layer_bwd
+                self.lin_bwd(p + "multihead_attn.v", dkv[1], mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
+                self.lin_bwd(p + "multihead_attn.k", dkv[0], memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
+                grp.run()
             self._wgrad_only(p + "multihead_attn.q", d16[2], r["t1q16"])
             self._wgrad_only(p + "self_attn.out_proj.", d16[3], r["o"])
             self._wgrad_only(p + "self_attn.v", d16[4], r["t16"])
@@ -543,6 +575,14 @@ class Net:
                 self.ln_batch.jobs.append(H.LnPgJob(parts[j].data_ptr(), self.G(p + nm + "weight").data_ptr(),
                                                     self.G(p + nm + "bias").data_ptr(), nb, E))
                 self.ln_batch.keep.append(parts[j])
+        if pack:
+            # d memory += [dV_0 | dV_1 | ...] [Wv_0^T | Wv_1^T | ...]^T (and K with memory + pos): one launch, K = layers x 256, instead
+            # of one read-modify-write launch per layer behind the cooperative one
+            cat = self._dec_kv_wt_cat(prefixes)
+            grp = H.GemmGroup()
+            H.linear(dkv_all[1], cat["v"], res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
+            H.linear(dkv_all[0], cat["k"], res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
+            grp.run()
         return dta
 
     def dec_layer_bwd(self, p, r, g_a, g_b, mem16, memp16, qmask, kpm, B, T, S, dmem_acc, dmemp_acc, dqpos_acc):

@@ -110,24 +110,37 @@ def test_backward_consumes_the_cooperative_forward_unchanged(hip):
 @pytest.mark.parametrize("train", [False, True])
 @pytest.mark.parametrize("B,dec_layers,H,W", [(2, 2, 96, 128), (8, 6, 192, 160), (13, 3, 64, 64)])
 def test_cooperative_backward_matches_the_launched_chain(hip, B, dec_layers, H, W, train):
-    """rt_decoder_bwd against dec_layer_bwd on the same (cooperative) forward: every gradient that is not accumulated with
-    atomics is bit-identical -- the decoder's weight matrices (their dy operands come out of the cooperative launch), the
-    encoder's and input_proj's (through d memory) -- and the whole buffer agrees to the atomics' order noise."""
+    """rt_decoder_bwd against dec_layer_bwd on the same (cooperative) forward.  With the memory gradient formed as the chain forms
+    it (one read-modify-write product per layer) every gradient that is not accumulated with atomics is bit-identical -- the
+    decoder's weight matrices (their dy operands come out of the cooperative launch), the encoder's and input_proj's (through
+    d memory) -- and the whole buffer agrees to the atomics' order noise.  With the default single K-concatenated product
+    (REFTR_DEC_KV_PACK) d memory has another fp32 summation order: the decoder's own gradients stay bit-identical, what flows
+    through d memory moves by rounding flips (the bf16 noise floor of DESIGN.md section 4: ~1e-3 of the buffer)."""
     model, crit, s, tg = build(dec_layers, B, H, W)
     a = run(model, crit, s, tg, coop=True, train=train, backward=True, coop_bwd=False)
-    for rep in range(3):
-        b = run(model, crit, s, tg, coop=True, train=train, backward=True, coop_bwd=True)
-        assert_same(b, a)
-        G = lambda res, name: model.store.view_of(res["grad"], name)
-        for i in range(dec_layers):
-            for nm in ("linear1.weight", "linear2.weight", "self_attn.out_proj.weight", "multihead_attn.out_proj.weight"):
-                key = f"vl_transformer.decoder.layers.{i}.{nm}"
-                assert torch.equal(G(a, key), G(b, key)), (key, float((G(a, key) - G(b, key)).abs().max()))
-        for key in ("vl_transformer.encoder.layers.1.linear1.weight", "vl_transformer.encoder.layers.0.self_attn.out_proj.weight",
-                    "input_proj.0.0.weight", "query_encoder.fuse_encoder_query.0.weight"):
-            assert torch.equal(G(a, key), G(b, key)), (key, float((G(a, key) - G(b, key)).abs().max()))
-        d = float((a["grad"] - b["grad"]).norm() / a["grad"].norm())
-        assert d < 2e-6, d
+    G = lambda res, name: model.store.view_of(res["grad"], name)
+    dec_keys = [f"vl_transformer.decoder.layers.{i}.{nm}" for i in range(dec_layers)
+                for nm in ("linear1.weight", "linear2.weight", "self_attn.out_proj.weight", "multihead_attn.out_proj.weight")]
+    mem_keys = ("vl_transformer.encoder.layers.1.linear1.weight", "vl_transformer.encoder.layers.0.self_attn.out_proj.weight",
+                "input_proj.0.0.weight")
+    try:
+        for pack in (False, True):
+            model.net.dec_kv_pack = pack
+            for rep in range(2):
+                b = run(model, crit, s, tg, coop=True, train=train, backward=True, coop_bwd=True)
+                assert_same(b, a)
+                for key in dec_keys + ["query_encoder.fuse_encoder_query.0.weight"]:
+                    assert torch.equal(G(a, key), G(b, key)), (pack, key, float((G(a, key) - G(b, key)).abs().max()))
+                d = float((a["grad"] - b["grad"]).norm() / a["grad"].norm())
+                if pack:
+                    assert d < 5e-3, d
+                    assert all(float((G(a, k) - G(b, k)).norm() / G(a, k).norm()) < 5e-3 for k in mem_keys)
+                else:
+                    assert d < 2e-6, d
+                    for key in mem_keys:
+                        assert torch.equal(G(a, key), G(b, key)), (key, float((G(a, key) - G(b, key)).abs().max()))
+    finally:
+        model.net.dec_kv_pack = True
 
 
 def test_unsupported_shapes_keep_the_chain(hip):
@@ -167,4 +180,5 @@ def test_many_replays_under_a_captured_graph(hip):
             os.environ.pop("REFTR_DEC_COOP", None)
     assert len(set(v[0] for v in losses[False])) > 150                # dropout: a new mask set per replay
     assert [v[0] for v in losses[True]] == [v[0] for v in losses[False]]
-    assert all(abs(a[1] - b[1]) < 1e-5 * b[1] for a, b in zip(losses[True], losses[False]))      # gradient norms (atomics' order)
+    # gradient norms: the atomics' order + the packed d-memory product's summation order (rounding flips downstream of d memory)
+    assert all(abs(a[1] - b[1]) < 5e-3 * b[1] for a, b in zip(losses[True], losses[False]))
