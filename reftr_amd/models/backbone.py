@@ -9,6 +9,8 @@ Backward convention: every gradient tensor that flows between blocks is dL/d(pre
 mask of a tensor is applied by the kernel that PRODUCES its gradient (`gate=` epilogue), so no separate
 elementwise backward kernels run.
 """
+import torch
+
 from .. import hip as H
 from . import layout as L
 
@@ -109,8 +111,9 @@ class ResNetBody:
                            act=H.ACT_RELU if relu else H.ACT_NONE)
         return y, (B, Ho, Wo), geom
 
-    def forward(self, img):
-        """img fp32 [B,3,H,W] -> (list of the 4 stage outputs as ([M, C] bf16, (B,h,w))), saved-for-backward)."""
+    def forward(self, img, ready=None):
+        """img fp32 [B,3,H,W] -> (list of the 4 stage outputs as ([M, C] bf16, (B,h,w))), saved-for-backward).
+        `ready`: event after which the TRAINABLE convolutions' operands are current (the frozen stem / layer1 do not wait)."""
         B, _, Hh, Ww = img.shape
         Ho, Wo, _, _ = H.stem_geometry(Hh, Ww)
         xp = H.img_pack(img)
@@ -121,6 +124,9 @@ class ResNetBody:
         feats, saved = [], []
         for stage in self.blocks:
             for b in stage:
+                if ready is not None and b.trainable:
+                    torch.cuda.current_stream().wait_event(ready)
+                    ready = None
                 rec = {"x": x, "shp": shp}
                 idt = x
                 if b.down is not None:

@@ -92,6 +92,10 @@ class RefTR(nn.Module):
         # single-process captured training step: the BERT slice's share of the gradient norm is taken on the language stream as
         # soon as that slice is final (see _backward_gen); (begin, end, device scalar) for the optimizer, None when not taken.
         # Anything that edits the gradient buffer between backward and the clip (gradient surgery, an exchange) must leave it off.
+        # measured (profiles/r03_side_stream_probes.txt): the main-slice AdamW pass beside the frozen stem / layer1 instead of in
+        # front of them changes nothing (7.295 vs 7.295 ms over four interleaved pairs) -- both are HBM-bound; off by default
+        self._pre_side = os.environ.get("REFTR_PRE_SIDE", "0") != "0"
+        self._bb_ready = None
         self._norm_side = False          # switched on by engine_vg.CapturedTrainStep around its own backward + clip-norm unit only
         self._norm_split = None
         self._sq_bert = torch.zeros(1, dtype=torch.float32, device=device)
@@ -213,9 +217,22 @@ class RefTR(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, samples):
+        self._bb_ready = None
         if self._pre_update is not None:
-            self._pre_update[0]()
-            self.mark_dirty()
+            if self._pre_side and self.net.side.enabled and not self._full_refresh:
+                # Deferred optimizer: the pending AdamW pass over the main / mask / ResNet slices and the refresh of the trainable
+                # convolutions' operands go to the language stream (in front of the BERT slice's pass): the stem and layer1 are
+                # frozen, so the ResNet's forward starts at once and only its first trainable block waits (body.forward).
+                def _pre_main():
+                    self._pre_update[0]()
+                    self.mark_dirty()
+                    self.refresh_operands()
+                self.net.side.run(_pre_main)
+                self._bb_ready = torch.cuda.Event()
+                self._bb_ready.record(self.net.side.stream)
+            else:
+                self._pre_update[0]()
+                self.mark_dirty()
         elif self._flush_pending is not None:
             self._flush_pending()
         self.refresh_operands()
@@ -298,7 +315,7 @@ class RefTR(nn.Module):
                 pos.view(B, S, E)[:, Lq:, :] = pe
             return r + (pos, kpm)
         seq16, pooled16, bctx, pos, kpm = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
-        feats, bb_saved = self.body.forward(x)
+        feats, bb_saved = self.body.forward(x, ready=self._bb_ready)
         c5, (_, h5, w5) = feats[-1]
         assert (h5, w5) == (h, w)
         x32 = torch.empty(M, E, dtype=torch.float32, device=dev)
