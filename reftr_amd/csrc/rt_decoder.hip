@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const rt_decoder_bwd_d
 }
 
 int dec_spin() {
-    static const int v = getenv("REFTR_DEC_SPIN") ? atoi(getenv("REFTR_DEC_SPIN")) : (1 << 17);
+    static const int v = getenv("REFTR_DEC_SPIN") ? atoi(getenv("REFTR_DEC_SPIN")) : (1 << 20);
     return v;
 }
 unsigned* dec_trace_buf() {           // REFTR_DEC_TRACE=1: 1024 words, read back by rt_decoder_trace

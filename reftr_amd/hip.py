@@ -674,18 +674,15 @@ def attn_bwd(q, k, v, out, dout, lse, kpm, *, B, H, Sq, Sk, dh, scale, drop_p=0.
 
 
 DEC_HANDOFF_BYTES = 256 + 16 * 256 * 36 + 16 * 2048 * 4
-_DEC_HANDOFF = {}
 
 
 def decoder_handoff(dev):
-    """The per-device hand-off buffer of rt_decoder_fwd (zeroed once; word 1 = failure flag)."""
-    buf = _DEC_HANDOFF.get(dev)
-    if buf is None:
-        buf = _DEC_HANDOFF[dev] = torch.zeros(DEC_HANDOFF_BYTES // 4, dtype=torch.int32, device=dev)
-    return buf
+    """A hand-off buffer for rt_decoder_fwd / rt_decoder_bwd (zeroed once; word 0 = launch epoch, word 1 = failure flag).  Its owner
+    (one model) keeps it for all its launches: they are ordered on the model's stream."""
+    return torch.zeros(DEC_HANDOFF_BYTES // 4, dtype=torch.int32, device=dev)
 
 
-def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, eps=1e-5):
+def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, handoff, eps=1e-5):
     """The decoder stack of one-query-per-image inputs as one cooperative launch (rt_decoder_fwd).  `layers`: one dict per
     layer, keys = DecoderLayerFwd._PTRS (tensors) + DecoderLayerFwd._SEEDS (ints); every output tensor is allocated by the
     caller (they are the launched chain's saved tensors).  Returns the hand-off buffer's header [epoch, failure flag]."""
@@ -698,7 +695,6 @@ def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, eps=1e-5
             setattr(L, n, _p(lay[n]))
         for n in DecoderLayerFwd._SEEDS:
             setattr(L, n, lay[n] & 0xFFFFFFFF)
-    handoff = decoder_handoff(t32.device)
     d.t32, d.t16, d.qpos, d.kpm, d.handoff = _p(t32), _p(t16), _p(qpos), _p(kpm), _p(handoff)
     d.seed_dev = _seedp(drop_p)
     d.n_layers, d.M, d.H, d.S, d.F, d.ldkv = len(layers), M, H, S, F, _ld(layers[0]["k2"])
@@ -707,7 +703,7 @@ def decoder_fwd(layers, t32, t16, qpos, kpm, *, H, S, F, drop_p, scale, eps=1e-5
     return handoff[:2]
 
 
-def decoder_bwd(layers, dta, dqpos, kpm, *, H, S, F, drop_p, scale, gate_scale, ldkvp=0):
+def decoder_bwd(layers, dta, dqpos, kpm, *, H, S, F, drop_p, scale, gate_scale, handoff, ldkvp=0):
     """Backward of the cooperative decoder stack (rt_decoder_bwd).  `layers`: one dict per layer (first to last), keys =
     DecoderLayerBwd._PTRS (tensors, all allocated by the caller) + the dropout seeds of the forward."""
     M = dta.shape[0]
@@ -719,7 +715,6 @@ def decoder_bwd(layers, dta, dqpos, kpm, *, H, S, F, drop_p, scale, gate_scale, 
             setattr(L, n, _p(lay.get(n)))
         for n in DecoderLayerBwd._SEEDS[:-1]:
             setattr(L, n, lay[n] & 0xFFFFFFFF)
-    handoff = decoder_handoff(dta.device)
     d.dta, d.dqpos, d.kpm, d.handoff, d.seed_dev = _p(dta), _p(dqpos), _p(kpm), _p(handoff), _seedp(drop_p)
     d.n_layers, d.M, d.H, d.S, d.F, d.ldkv = len(layers), M, H, S, F, _ld(layers[0]["k2"])
     d.drop_p, d.scale, d.gate_scale, d.ldkvp = drop_p, scale, gate_scale, ldkvp

@@ -60,6 +60,9 @@ class Net:
         self.dec_kv_pack = os.environ.get("REFTR_DEC_KV_PACK", "1") != "0"       # d memory as one K-concatenated product
         self._kv_cat = None
         self._dec_cus = None
+        # allocated (and zeroed) NOW, outside any stream capture: a zero-fill captured into a graph would reset the launch epoch on
+        # every replay and make the previous replay's hand-off tags look current
+        self._dec_handoff = H.decoder_handoff(store.device) if str(store.device).startswith("cuda") else None
         self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
         self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
         self._build_lins()
@@ -436,6 +439,11 @@ class Net:
         r.update(u3=u3, st3=(m3, r3))
         return t3_32, t3_16, t3q16, r
 
+    def _dec_handoff_buf(self, dev):
+        if self._dec_handoff is None or self._dec_handoff.device != dev:
+            self._dec_handoff = H.decoder_handoff(dev)          # this model's: its launches are ordered on its stream
+        return self._dec_handoff
+
     def dec_stack_coop_ok(self, N, T, S, n_layers, fold_sa):
         """Shapes rt_decoder_fwd covers: one query per image on the folded self-attention path, the reference's widths."""
         cfg = self.cfg
@@ -484,7 +492,8 @@ class Net:
             t16_in = t3_16
         dh = E // cfg.nheads
         drop_p = saved[0]["ad"][0]
-        self.dec_counters = H.decoder_fwd(layers, t32, t16, qpos, kpm, H=cfg.nheads, S=S, F=F, drop_p=drop_p, scale=dh ** -0.5)
+        self.dec_counters = H.decoder_fwd(layers, t32, t16, qpos, kpm, H=cfg.nheads, S=S, F=F, drop_p=drop_p, scale=dh ** -0.5,
+                                          handoff=self._dec_handoff_buf(dev))
         return saved
 
     def _wgrad_only(self, key, dy, x):
@@ -553,7 +562,8 @@ class Net:
         dta = torch.empty(N, E, dtype=f32, device=dev)
         dh = E // cfg.nheads
         self.dec_counters = H.decoder_bwd(layers, dta, dqpos_acc, kpm, H=cfg.nheads, S=S, F=F, drop_p=drop_p, scale=dh ** -0.5,
-                                          gate_scale=1.0 / (1.0 - p_dh) if p_dh > 0 else 1.0, ldkvp=NLd * E if pack else 0)
+                                          gate_scale=1.0 / (1.0 - p_dh) if p_dh > 0 else 1.0, ldkvp=NLd * E if pack else 0,
+                                          handoff=self._dec_handoff_buf(dev))
         for i in reversed(range(len(prefixes))):
             p, r = prefixes[i], saved[i]
             d16, dhdn, dkv, parts = outs[i]
