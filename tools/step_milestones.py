@@ -33,6 +33,15 @@ def last(pat, key=2):
     return v
 
 
+def first_of_last(pat):
+    """start of the last launch whose name contains `pat`"""
+    v = float("nan")
+    for r in step:
+        if pat in r[0]:
+            v = ms(r[1])
+    return v
+
+
 print("median step: %d kernels, wall %.3f ms" % (len(step), wall / 1e6))
 for label, v in (
         ("first AdamW launch starts", first("adamw_kernel")), ("last AdamW launch ends", last("adamw_kernel")),
@@ -41,11 +50,12 @@ for label, v in (
         ("input_proj GroupNorm stats (ResNet forward done)", first("gn_stats")),
         ("encoder forward: first dh=32 attention starts", first("attn_fwd_reg_kernel<32")),
         ("encoder forward: last dh=32 attention ends", last("attn_fwd_reg_kernel<32")),
-        ("decoder forward: first one-query attention", first("attn_q1_fwd")), ("decoder forward: last one-query attention", last("attn_q1_fwd")),
+        ("decoder forward: cooperative launch starts", first("decoder_fwd_kernel")), ("decoder forward: cooperative launch ends", last("decoder_fwd_kernel")),
         ("box loss", first("box_loss")),
-        ("decoder backward: first one-query attention bwd", first("attn_q1_bwd")), ("decoder backward: last", last("attn_q1_bwd")),
+        ("decoder backward: cooperative launch starts", first("decoder_bwd_kernel")), ("decoder backward: cooperative launch ends", last("decoder_bwd_kernel")),
         ("encoder backward: first attention bwd (dh=32)", first("attn_bwd_fused_kernel<32")), ("encoder backward: last", last("attn_bwd_fused_kernel<32")),
         ("GroupNorm backward (encoder chain done)", first("gn_bwd")),
         ("BERT backward: first dh=64 attention bwd", first("attn_bwd_fused_kernel<64")), ("BERT backward: last", last("attn_bwd_fused_kernel<64")),
-        ("last weight-gradient group ends", last("w2_grouped")), ("gradient norm ends (step end)", last("sqnorm_kernel"))):
+        ("last backward-data / forward product (conv_gemm_dma) ends", last("conv_gemm_dma_kernel")),
+        ("last weight-gradient group starts", first_of_last("w2_grouped")), ("last weight-gradient group ends", last("w2_grouped")), ("gradient norm ends (step end)", last("sqnorm_kernel"))):
     print("  %7.3f ms  %s" % (v, label))
