@@ -405,3 +405,24 @@ def test_stat_board_feeds_and_world2_reduction_shapes():
     assert "loss: 4" in str(b)
     b.synchronize_between_processes()          # no process group: a no-op
     assert b.global_avg()["loss"] == 2.0
+
+
+def test_cooperative_decoder_gating_and_failure_flag_on_the_host():
+    """Off the GPU the cooperative decoder launches are never chosen (no compute units to keep 80 workgroups resident), and the
+    epoch loops turn the launches' failure word into an error instead of returning numbers."""
+    import types
+    from reftr_amd.engine_vg import _check_cooperative
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.reftr_transformer import RefTR
+    model = RefTR(L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=1)), device="cpu")
+    assert not model.net.dec_stack_coop_ok(8, 1, 440, 6, True)          # shape would qualify; the device does not
+    assert model.net._dec_handoff is None
+    _check_cooperative(model)                                           # no launch has happened: nothing to report
+    fake = types.SimpleNamespace(net=types.SimpleNamespace(dec_counters=torch.tensor([7, 0])))
+    _check_cooperative(fake)
+    fake.net.dec_counters = torch.tensor([7, 1])
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        _check_cooperative(fake)
+    wrapped = types.SimpleNamespace(module=fake)                        # a DistributedDataParallel-style wrapper
+    with pytest.raises(RuntimeError):
+        _check_cooperative(wrapped)
