@@ -516,6 +516,27 @@ int rt_sgd_flat(const rt_adamw_desc* d, rt_stream_t stream);
 int rt_zero_chunks(float* base, const int64_t* table, int n, rt_stream_t stream);
 /* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */
 int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream);
+/* rt_counter_add_if_zero — the same, but only while the DEVICE word *cond is 0; otherwise *ctr is left alone (reset_else = 0) or
+ * cleared (reset_else = 1).  The engine advances the optimizer step counter (left alone) and the "update pending" word (cleared) of
+ * an iteration through it with cond = the cooperative decoder's failure word: an iteration whose launches reported a hand-off
+ * timeout never arms its AdamW update (engine_vg.py:55-58 of the reference stops BEFORE the update when an iteration is bad; here
+ * the decision is taken on the device, inside the captured graph). */
+int rt_counter_add_if_zero(int32_t* ctr, int32_t inc, const uint32_t* cond, int reset_else, rt_stream_t stream);
+/* rt_stamp — buf[idx] = the device's constant 100 MHz wall clock (s_memrealtime) when the stream reaches this point: a one-thread
+ * kernel the measurement tools capture into the step's graph at phase boundaries of every stream (tools/concurrent_timeline.py),
+ * because rocprofv3 serialises the graph's concurrent streams. */
+int rt_stamp(uint64_t* buf, int idx, rt_stream_t stream);
+/* rt_adamw_mat / rt_adamw_chunks — rt_adamw_flat's update (same descriptor, same arithmetic and rounding, same `active` / step /
+ * learning-rate device words), split into (a) the weight MATRICES, walked in 64 x 64 tiles so that the kernel also writes the bf16
+ * GEMM operands of the NEXT forward / backward from the registers that hold the new fp32 values -- what rt_weight_prep_batched
+ * produced in a second pass over the masters -- and (b) everything else (biases, norm parameters, embeddings), in chunks.
+ *   mat table (DEVICE int64 [njobs][8], static): {element offset of the matrix [N][T][C] in p / g / m / v, scale pointer | 0
+ *     (FrozenBN scale[n] folded into the bf16 copies only), dst bf16 [N][T][C] | 0, dst_t bf16 [C][T][N] | 0, N, T, C, first tile};
+ *     a job has ceil(N/64) * ceil(C/64) * T tiles; total_tiles = their sum; a matrix lies inside ONE learning-rate range.
+ *   chunk table (DEVICE int64 [nchunks][2], static): {element offset, element count <= 16384}, both multiples of 4.
+ * d->span_* are ignored (the tables say what is updated).  The caller makes jobs and chunks tile the parameters exactly once. */
+int rt_adamw_mat(const rt_adamw_desc* d, const int64_t* table, int njobs, int total_tiles, rt_stream_t stream);
+int rt_adamw_chunks(const rt_adamw_desc* d, const int64_t* table, int nchunks, rt_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Host input pipeline on the device — integer / byte work, bit-exact.
@@ -687,6 +708,13 @@ typedef struct rt_decoder_bwd_desc {
 int rt_decoder_bwd(const rt_decoder_bwd_desc* d, rt_stream_t stream);
 /* REFTR_DEC_TRACE=1 only: 1024 wall-clock stamps (100 MHz) of the last launch's stage boundaries, host buffer */
 int rt_decoder_trace(uint32_t* out1024);
+/* rt_decoder_supported — RT_OK when rt_decoder_fwd / rt_decoder_bwd may be used on the CURRENT device: their G spin-waiting
+ * workgroups must be co-resident, which is checked with the occupancy query (>= 1 workgroup of each kernel per compute unit at its
+ * LDS size) and a 2x margin of compute units over G; RT_ERR_UNSUPPORTED otherwise (the launchers answer the same, and the caller
+ * keeps the launched chain).  rt_decoder_set_spin — polls a consumer makes before it gives up and raises the failure word
+ * (<= 0: the default, 2^20 / REFTR_DEC_SPIN); tests force a timeout with 1. */
+int rt_decoder_supported(int F);
+int rt_decoder_set_spin(int spin);
 
 #ifdef __cplusplus
 }

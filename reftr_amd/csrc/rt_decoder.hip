@@ -906,9 +906,10 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const rt_decoder_bwd_d
     }
 }
 
+int g_spin_override = 0;              // rt_decoder_set_spin (tests force a hand-off timeout with 1)
 int dec_spin() {
     static const int v = getenv("REFTR_DEC_SPIN") ? atoi(getenv("REFTR_DEC_SPIN")) : (1 << 20);
-    return v;
+    return g_spin_override > 0 ? g_spin_override : v;
 }
 unsigned* dec_trace_buf() {           // REFTR_DEC_TRACE=1: 1024 words, read back by rt_decoder_trace
     static unsigned* buf = nullptr;
@@ -926,6 +927,33 @@ int dec_groups() {
     static const int g = getenv("REFTR_DEC_G") ? atoi(getenv("REFTR_DEC_G")) : 80;
     return g;
 }
+// Co-residency of the G spin-waiting workgroups is a REQUIREMENT of both kernels (a consumer polls a producer that must be running).
+// They are launched with plain launches (a cooperative launch costs +17-20 us per replay and applies no check under graph replay
+// anyway, MI355X_MICROARCH.md "Residency and cooperative launch"), so the check is made here, once per device: the occupancy query
+// must admit at least one workgroup of each kernel per compute unit at its dynamic LDS size, and the device must have at least 2 G
+// compute units (a margin of 2x against the query being one block per CU high and against other streams' resident workgroups:
+// the BERT branch runs beside the decoder).  Anything else answers RT_ERR_UNSUPPORTED and the caller keeps the launched chain.
+int dec_residency_ok(int F) {
+    static int cached_dev = -1, cached_F = 0, cached = RT_ERR_UNSUPPORTED;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RT_ERR_UNSUPPORTED;
+    if (dev == cached_dev && F == cached_F) return cached;
+    const int G = dec_groups();
+    hipDeviceProp_t prop;
+    int rc = RT_OK;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) rc = RT_ERR_UNSUPPORTED;
+    else {
+        const size_t smf = sizeof(DecSmem) + (size_t)16 * (F + 8) * 2, smb = sizeof(DecSmemB) + (size_t)16 * (F + 8) * 2;
+        int nf = 0, nb = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, decoder_fwd_kernel, 256, smf) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_bwd_kernel, 256, smb) != hipSuccess) { (void)hipGetLastError(); rc = RT_ERR_UNSUPPORTED; }
+        else if (nf < 1 || nb < 1 || prop.multiProcessorCount < 2 * G) rc = RT_ERR_UNSUPPORTED;
+    }
+    cached_dev = dev; cached_F = F; cached = rc;
+    return rc;
+}
 
 }  // namespace
 
@@ -941,6 +969,7 @@ extern "C" int rt_decoder_fwd(const rt_decoder_fwd_desc* d, rt_stream_t stream) 
         if (!L.Wv || !L.Wo || !L.Wq || !L.Wo2 || !L.W1 || !L.W2 || !L.k2 || !L.v2 || !L.o || !L.u || !L.q2 || !L.o2 || !L.u2 ||
             !L.hdn || !L.u3 || !L.lse2 || !L.t1q16 || !L.t2_16 || !L.t3_16) return RT_ERR_BADARG;
     }
+    if (dec_residency_ok(d->F) != RT_OK) return RT_ERR_UNSUPPORTED;
     const size_t smem = sizeof(DecSmem) + (size_t)16 * (d->F + 8) * 2;
     static bool attr = false;
     if (!attr) {
@@ -967,6 +996,7 @@ extern "C" int rt_decoder_bwd(const rt_decoder_bwd_desc* d, rt_stream_t stream) 
             !L.du3b || !L.dhdn || !L.du2b || !L.dq2 || !L.dub || !L.dv || !L.dk2 || !L.dv2 || (!L.dk2p != !L.dv2p) ||
             (L.dk2p && (d->ldkvp < DEC_E || (d->ldkvp & 7)))) return RT_ERR_BADARG;
     }
+    if (dec_residency_ok(d->F) != RT_OK) return RT_ERR_UNSUPPORTED;
     const size_t smem = sizeof(DecSmemB) + (size_t)16 * (d->F + 8) * 2;
     static bool attr = false;
     if (!attr) {
@@ -978,6 +1008,18 @@ extern "C" int rt_decoder_bwd(const rt_decoder_bwd_desc* d, rt_stream_t stream) 
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
+
+/* RT_OK when the cooperative decoder launches may be used on the current device (see dec_residency_ok), else RT_ERR_UNSUPPORTED. */
+extern "C" int rt_decoder_supported(int F) {
+    if (F != 2048) return RT_ERR_UNSUPPORTED;
+    const int G = dec_groups();
+    if (G <= DEC_CORE || G > 144 || (F >> 4) > DEC_NT * (G - DEC_CORE)) return RT_ERR_UNSUPPORTED;
+    return dec_residency_ok(F);
+}
+
+/* Overrides the number of polls a consumer makes before it gives up and raises the failure word (<= 0: back to REFTR_DEC_SPIN /
+   the default 2^20).  Tests use 1 to force a timeout. */
+extern "C" int rt_decoder_set_spin(int spin) { g_spin_override = spin; return RT_OK; }
 
 /* debugging aid (REFTR_DEC_TRACE=1): copies the 1024 stage time stamps of the last launch (100 MHz ticks; words 0.. = workgroup 0,
    words 512.. = the last workgroup) to `out`; returns RT_ERR_UNSUPPORTED when tracing is off. */

@@ -127,11 +127,227 @@ __global__ __launch_bounds__(256) void sgd_kernel(const rt_adamw_desc p) {
 
 __global__ void counter_add_kernel(int32_t* c, int32_t inc) { c[0] += inc; }
 
+// ------------------------------------------------------------------------------------------------
+// Matrix-aware AdamW (round 4): the same update, walked per WEIGHT MATRIX in 64(n) x 64(c) tiles per tap, so that the kernel that
+// produces the new fp32 master also emits the bf16 GEMM operands the next forward / backward read -- W [N][T][C] (x FrozenBN scale)
+// and its transpose [C][T][N] -- while the new values are still in registers.  The separate operand refresh (rt_weight_prep_batched:
+// re-reads 4 B per parameter, one more dependent launch at the head of the step) disappears; arithmetic and rounding points are
+// those of adamw_kernel followed by weight_prep_batched_kernel, bit for bit.  Everything that is not a matrix job (biases, norm
+// parameters, embeddings) is updated by adamw_chunks_kernel over a static chunk table (the complement of the jobs).
+struct AdamCoef { float gs, bc1, inv_sqrt_bc2; };
+__device__ __forceinline__ AdamCoef adam_coef(const rt_adamw_desc& p) {
+    const float total = sqrtf(p.gnorm_sq ? p.gnorm_sq[0] : 0.f) * p.grad_scale;
+    float coef = 1.f;
+    if (p.max_norm > 0.f) coef = fminf(1.f, p.max_norm / (total + 1e-6f));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.gnorm_out) p.gnorm_out[0] = total;
+    const int step = p.step_dev ? p.step_dev[0] : p.step;
+    AdamCoef c;
+    c.gs = p.grad_scale * coef;
+    c.bc1 = 1.f - powf(p.beta1, (float)step);
+    c.inv_sqrt_bc2 = rsqrtf(1.f - powf(p.beta2, (float)step));
+    return c;
+}
+__device__ __forceinline__ void adam_range(const rt_adamw_desc& p, size_t e, float& lr, float& wd) {
+    lr = 0.f; wd = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (r < p.n_ranges && e >= (size_t)p.range_begin[r] && e < (size_t)p.range_end[r]) {
+            lr = p.lr_dev ? p.lr_dev[r] : p.range_lr[r]; wd = p.range_wd[r];
+        }
+}
+// the update of one element, written exactly as in adamw_kernel (same operation order: the two kernels must round alike)
+__device__ __forceinline__ void adam_elem(const rt_adamw_desc& p, const AdamCoef& c, float lr, float wd, float graw, float& pv, float& mv, float& vv) {
+    const float g = graw * c.gs;
+    pv *= (1.f - lr * wd);
+    mv = p.beta1 * mv + (1.f - p.beta1) * g;
+    vv = p.beta2 * vv + (1.f - p.beta2) * g * g;
+    const float denom = sqrtf(vv) * c.inv_sqrt_bc2 + p.eps;
+    pv -= (lr / c.bc1) * (mv / denom);
+}
+
+// table: int64 [njobs][8] = {element offset of the matrix in p/g/m/v, scale ptr | 0, dst ptr | 0, dst_t ptr | 0, N, T, C, first tile}
+__global__ __launch_bounds__(256) void adamw_mat_kernel(const rt_adamw_desc p, const int64_t* __restrict__ table, int njobs) {
+    if (p.active && p.active[0] == 0) return;
+    __shared__ float tile[64][65];
+    const AdamCoef cf = adam_coef(p);
+    int lo = 0, hi = njobs - 1;                       // last job whose first_tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 7] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* j = table + lo * 8;
+    const size_t base = (size_t)j[0];
+    const float* scale = reinterpret_cast<const float*>(j[1]);
+    bf16_t* dst = reinterpret_cast<bf16_t*>(j[2]);
+    bf16_t* dst_t = reinterpret_cast<bf16_t*>(j[3]);
+    const int N = (int)j[4], T = (int)j[5], C = (int)j[6];
+    const int local = blockIdx.x - (int)j[7];
+    const int ct = (C + 63) >> 6, nt = (N + 63) >> 6;
+    const int tc = local % ct, tn = (local / ct) % nt, tap = local / (ct * nt);
+    float lr, wd;
+    adam_range(p, base, lr, wd);                      // a matrix lies inside one learning-rate range
+    float* P = p.p + base; float* Mo = p.m + base; float* Vo = p.v + base;
+    const float* G = p.g ? p.g + base : nullptr;
+    const bf16_t* G16 = p.g16 ? reinterpret_cast<const bf16_t*>(p.g16) + base : nullptr;
+    const bool vec_c = (C & 7) == 0 && (base & 3) == 0 && (!dst || ((uintptr_t)dst & 15) == 0);
+    const bool vec_n = (N & 7) == 0 && dst_t && ((uintptr_t)dst_t & 15) == 0;
+    if (vec_c) {
+        const int r0 = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;       // 32 rows x 8 pieces per pass
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int nl = r0 + 32 * rr, n = tn * 64 + nl, c = tc * 64 + c8;
+            float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (n < N && c < C) {
+                const size_t o = ((size_t)n * T + tap) * C + c;
+                float pv[8], gv[8], mv[8], vv[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + o + 4 * h));
+                    const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mo + o + 4 * h));
+                    const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vo + o + 4 * h));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pv[4 * h + e] = a[e]; mv[4 * h + e] = b[e]; vv[4 * h + e] = d[e]; }
+                    if (!G16) {
+                        const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + o + 4 * h));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gv[4 * h + e] = gg[e];
+                    }
+                }
+                if (G16) {
+                    const bf16x8 gg = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(G16 + o));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[e] = (float)gg[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) adam_elem(p, cf, lr, wd, gv[e], pv[e], mv[e], vv[e]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    *reinterpret_cast<f32x4*>(P + o + 4 * h) = f32x4{pv[4 * h], pv[4 * h + 1], pv[4 * h + 2], pv[4 * h + 3]};
+                    __builtin_nontemporal_store(f32x4{mv[4 * h], mv[4 * h + 1], mv[4 * h + 2], mv[4 * h + 3]}, reinterpret_cast<f32x4*>(Mo + o + 4 * h));
+                    __builtin_nontemporal_store(f32x4{vv[4 * h], vv[4 * h + 1], vv[4 * h + 2], vv[4 * h + 3]}, reinterpret_cast<f32x4*>(Vo + o + 4 * h));
+                }
+                const float sc = scale ? scale[n] : 1.f;
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { w[e] = scale ? pv[e] * sc : pv[e]; ov[e] = (bf16_t)w[e]; }
+                if (dst) *reinterpret_cast<bf16x8*>(dst + o) = ov;
+            }
+            if (dst_t) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tile[nl][c8 + e] = w[e];
+            }
+        }
+    } else {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int n = tn * 64 + ty + r * 4, c = tc * 64 + tx;
+            float w = 0.f;
+            if (n < N && c < C) {
+                const size_t o = ((size_t)n * T + tap) * C + c;
+                float pv = P[o], mv = Mo[o], vv = Vo[o];
+                const float gv = G16 ? (float)G16[o] : G[o];
+                adam_elem(p, cf, lr, wd, gv, pv, mv, vv);
+                P[o] = pv; Mo[o] = mv; Vo[o] = vv;
+                w = scale ? pv * scale[n] : pv;
+                if (dst) dst[o] = (bf16_t)w;
+            }
+            tile[ty + r * 4][tx] = w;
+        }
+    }
+    if (!dst_t) return;
+    __syncthreads();
+    if (vec_n) {
+        const int r0 = threadIdx.x >> 3, n8 = (threadIdx.x & 7) * 8;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int cl = r0 + 32 * rr, c = tc * 64 + cl, n = tn * 64 + n8;
+            if (c < C && n < N) {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)tile[n8 + e][cl];
+                *reinterpret_cast<bf16x8*>(dst_t + ((size_t)c * T + tap) * N + n) = ov;
+            }
+        }
+    } else {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int c = tc * 64 + ty + r * 4, n = tn * 64 + tx;
+            if (n < N && c < C) dst_t[((size_t)c * T + tap) * N + n] = (bf16_t)tile[tx][ty + r * 4];
+        }
+    }
+}
+
+// everything that is not a matrix job: table = nchunks x {int64 element offset (multiple of 4), int64 count (multiple of 4, <= 16384)}
+__global__ __launch_bounds__(256) void adamw_chunks_kernel(const rt_adamw_desc p, const int64_t* __restrict__ table) {
+    if (p.active && p.active[0] == 0) return;
+    const AdamCoef cf = adam_coef(p);
+    const size_t off = (size_t)table[2 * blockIdx.x], cnt = (size_t)table[2 * blockIdx.x + 1];
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    for (size_t i = threadIdx.x * 4; i < cnt; i += 1024) {
+        const size_t e = off + i;
+        float lr, wd;
+        adam_range(p, e, lr, wd);
+        f32x4 pv = *reinterpret_cast<const f32x4*>(p.p + e), mv = *reinterpret_cast<const f32x4*>(p.m + e), vv = *reinterpret_cast<const f32x4*>(p.v + e), gv;
+        if (p.g16) { const bf16x4_t h = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const bf16_t*>(p.g16) + e); gv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}; }
+        else gv = *reinterpret_cast<const f32x4*>(p.g + e);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { float a = pv[c], b = mv[c], d = vv[c]; adam_elem(p, cf, lr, wd, gv[c], a, b, d); pv[c] = a; mv[c] = b; vv[c] = d; }
+        *reinterpret_cast<f32x4*>(p.p + e) = pv; *reinterpret_cast<f32x4*>(p.m + e) = mv; *reinterpret_cast<f32x4*>(p.v + e) = vv;
+    }
+}
+
+__global__ void counter_add_if_zero_kernel(int32_t* c, int32_t inc, const uint32_t* cond, int reset_else) {
+    if (cond[0] == 0u) c[0] += inc; else if (reset_else) c[0] = 0;
+}
+__global__ void stamp_kernel(uint64_t* buf, int idx) { buf[idx] = wall_clock64(); }
+
 }  // namespace
 
 extern "C" int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream) {
     if (!ctr) return RT_ERR_BADARG;
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+
+extern "C" int rt_counter_add_if_zero(int32_t* ctr, int32_t inc, const uint32_t* cond, int reset_else, rt_stream_t stream) {
+    if (!ctr || !cond) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(counter_add_if_zero_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc, cond, reset_else);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_stamp(uint64_t* buf, int idx, rt_stream_t stream) {
+    if (!buf || idx < 0) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, buf, idx);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+static int adamw_desc_ok(const rt_adamw_desc* d) {
+    if (!d || !d->p || (!d->g && !d->g16) || !d->m || !d->v || d->n <= 0 || (d->n & 3) || d->n_ranges < 1 || d->n_ranges > 8 || (d->step < 1 && !d->step_dev))
+        return RT_ERR_BADARG;
+    for (int r = 0; r < d->n_ranges; ++r) if ((d->range_begin[r] & 3) || (d->range_end[r] & 3)) return RT_ERR_BADARG;
+    return RT_OK;
+}
+
+extern "C" int rt_adamw_mat(const rt_adamw_desc* d, const int64_t* table, int njobs, int total_tiles, rt_stream_t stream) {
+    const int rc = adamw_desc_ok(d);
+    if (rc != RT_OK) return rc;
+    if (!table || njobs <= 0 || total_tiles <= 0) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(adamw_mat_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, *d, table, njobs);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_adamw_chunks(const rt_adamw_desc* d, const int64_t* table, int nchunks, rt_stream_t stream) {
+    const int rc = adamw_desc_ok(d);
+    if (rc != RT_OK) return rc;
+    if (!table || nchunks <= 0) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(adamw_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, *d, table);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

@@ -80,9 +80,78 @@ def _zero_grad(optimizer):
         optimizer.zero_grad()
 
 
+def _inner(model):
+    return getattr(model, "module", model)
+
+
+def _seed_state(model):
+    """(device dropout step-seed word, host step count) BEFORE this iteration's forward advanced them (train_step reads them
+    after the forward: one step back)."""
+    inner = _inner(model)
+    if not hasattr(inner, "seed_dev"):
+        return None
+    return (1 if inner.training else 0, 1)
+
+
+def _restore_seed(model, back):
+    """Takes back the dropout-seed / step advance of an iteration that is run again."""
+    inner = _inner(model)
+    if back is None:
+        return
+    if back[0]:
+        inner.seed_dev.sub_(back[0])
+    inner._step -= back[1]
+
+
+def _cooperative_failed(model):
+    """True when a cooperative decoder launch of THIS process -- or, under data parallelism, of any rank (the choice to run the
+    iteration again must be collective) -- raised its failure word since it was last cleared.  One host read (eager loop only; the
+    replayed loop carries the word in its per-iteration stats vector)."""
+    inner = _inner(model)
+    fw = inner.coop_failure_word() if hasattr(inner, "coop_failure_word") else None
+    if fw is None or getattr(inner.net, "dec_counters", None) is None:
+        return False
+    if utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1:
+        f = fw.to(torch.int32).clone()
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
+        return int(f) != 0
+    return int(fw) != 0
+
+
+_COOP_LOGGED = False
+
+
+def _coop_fallback(model):
+    """Switches the cooperative decoder launches off for this process (the launched chain computes the same values), clears the
+    failure word, and drops every captured step / forward of the model: they contain the launches.  Pending (deferred) updates of
+    the dropped captures are discarded -- the caller runs the failed iteration again."""
+    global _COOP_LOGGED
+    inner = _inner(model)
+    net = inner.net
+    net.dec_coop = net.dec_coop_bwd = False
+    os.environ["REFTR_DEC_COOP"] = "0"; os.environ["REFTR_DEC_COOP_BWD"] = "0"
+    if net._dec_handoff is not None:
+        net._dec_handoff[1:2].zero_()
+    net.dec_counters = None
+    caps = inner.__dict__.get("_captured_steps") or {}
+    for cap in caps.values():
+        cap.reset_pending()
+        if getattr(cap.optimizer, "veto", None) is not None:
+            cap.optimizer.veto = None
+    caps.clear()
+    inner.__dict__["_staged_cap"] = None
+    inner.__dict__["_coop_generation"] = inner.__dict__.get("_coop_generation", 0) + 1     # CapturedForward drops its graphs
+    if not _COOP_LOGGED:
+        _COOP_LOGGED = True
+        print("[reftr_amd] rt_decoder_fwd / rt_decoder_bwd: a stage hand-off timed out (workgroups not co-resident?). The iteration "
+              "is discarded and run again; the decoder uses the launched chain (REFTR_DEC_COOP=0) from here on.", file=sys.stderr)
+
+
 def train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0):
     """The loop body, engine_vg.py:40-72.  Returns (loss_value, reduced scaled dict, reduced unscaled dict,
     grad_norm tensor)."""
+    if hasattr(optimizer, "veto") and hasattr(_inner(model), "coop_failure_word"):
+        optimizer.veto = _inner(model).coop_failure_word()
     outputs = model(samples)
     loss_dict = criterion(outputs, targets)
     weight_dict = criterion.weight_dict
@@ -96,7 +165,23 @@ def train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None,
         print(loss_dict_reduced)
         sys.exit(1)
     _zero_grad(optimizer)
+    seed0 = _seed_state(model)
     losses.backward()
+    if _cooperative_failed(model):
+        # a stage hand-off of the cooperative decoder launches timed out: this iteration's activations / gradients are void.
+        # The reference stops BEFORE the update when an iteration is bad (engine_vg.py:55-58); here the launches are switched
+        # off for the process and the iteration is run again on the launched chain (same dropout seeds), then updated as usual
+        _coop_fallback(model)
+        _restore_seed(model, seed0)
+        outputs = model(samples)
+        loss_dict = criterion(outputs, targets)
+        losses = _total(criterion, loss_dict)
+        loss_dict_reduced = utils.reduce_dict(loss_dict)
+        unscaled = {f"{k}_unscaled": v for k, v in loss_dict_reduced.items()}
+        scaled = {k: v * weight_dict[k] for k, v in loss_dict_reduced.items() if k in weight_dict}
+        loss_value = sum(scaled.values()).item()
+        _zero_grad(optimizer)
+        losses.backward()
     if hasattr(optimizer, "clip_grad_norm_"):
         grad_total_norm = optimizer.clip_grad_norm_(max_norm)
     elif max_norm > 0:
@@ -176,6 +261,10 @@ class CapturedTrainStep:
         self.key = self.shape_key(samples, targets)
         self._lrs = [g["lr"] for g in optimizer.param_groups]
         inner = self.inner
+        # the cooperative decoder's failure word vetoes an iteration's update on the device and travels in the stats vector
+        self.fail_word = inner.coop_failure_word() if hasattr(inner, "coop_failure_word") else None
+        if hasattr(optimizer, "veto"):
+            optimizer.veto = self.fail_word
         warmup = max(warmup, 2)          # the second step is the first one with the steady-state operand refresh
         # criterion.py:176-180 averages the box count over ranks: that collective runs eagerly before every replay and
         # the graph reads its result from a static device scalar
@@ -314,6 +403,8 @@ class CapturedTrainStep:
         try:
             out = self._fwd_bwd(zero=not inner._zero_grad_side)
             self.grad_norm = opt.finish_step(self.max_norm)
+            from . import hip as _H
+            _H.mark("gradient norm done (step end)")
         finally:
             inner._pre_update = None
             inner._zero_grad_side = False
@@ -328,9 +419,12 @@ class CapturedTrainStep:
             return
         self._pending = False
         self._set_flush(False)
-        self.optimizer.apply_pending()
+        emitted = self.optimizer.apply_pending()
         self.optimizer.clear_pending()
-        self.inner.mark_dirty()
+        if emitted:
+            self.inner.operands_emitted()
+        else:
+            self.inner.mark_dirty()
 
     def reset_pending(self):
         """Forgets the pending update (after the caller has restored weights / optimizer state by hand)."""
@@ -373,7 +467,9 @@ class CapturedTrainStep:
         copy per iteration instead of one .item() per meter (the reference: engine_vg.py:46-53,69-72, util/misc.py:156-160)."""
         ld = self._last[1]
         self.stat_names = tuple(sorted(ld))
-        self.stats = torch.stack([ld[k].reshape(()).float() for k in self.stat_names] + [self.grad_norm.reshape(()).float()])
+        # layout: [losses (sorted by name) | cooperative-launch failure word (when the model can raise one) | gradient norm]
+        fw = [self.fail_word.reshape(()).float()] if self.fail_word is not None else []
+        self.stats = torch.stack([ld[k].reshape(()).float() for k in self.stat_names] + fw + [self.grad_norm.reshape(()).float()])
 
     @staticmethod
     def _run(hooks):
@@ -411,6 +507,8 @@ class CapturedTrainStep:
         staged = self._staged is not None and self._staged[0] is samples and self._staged[1] is targets
         assert staged or (samples is self.s and targets is self.t) or self.shape_key(samples, targets) == self.key, \
             "captured for another input shape; use train_step"
+        if self.inner._operands_dirty:        # the masters were changed outside an optimizer step (load_state_dict, a restored
+            self.inner.refresh_now()          # snapshot): the graph no longer carries an operand refresh of its own
         if self.deferred:
             self._stage_in(samples, targets)
             self.g_fb.replay()                # applies iteration i-1's update with the rates synced at iteration i-1
@@ -444,7 +542,7 @@ class CapturedTrainStep:
         if self.deferred_dp:
             self._pending = True
             self._set_flush(True)
-        else:
+        elif not getattr(self.optimizer, "_last_emitted", False):
             self.inner.mark_dirty()      # eager forwards after a replay must rebuild the bf16 operands
         return self.out[0], self.out[1], self.grad_norm
 
@@ -493,14 +591,24 @@ class _EagerResult:
 class _ReplayInFlight:
     """A replayed step between its launch and its host read-out (`finish`)."""
 
-    def __init__(self, cap, criterion):
-        self.cap, self.criterion = cap, criterion
+    def __init__(self, cap, criterion, retry=None):
+        self.cap, self.criterion, self.retry = cap, criterion, retry
 
     def finish(self):
         cap = self.cap
         cap._stats_event.synchronize()
         host = cap._stats_host.tolist()
         k = len(cap.stat_names)
+        if cap.fail_word is not None and host[k] != 0:
+            # A stage hand-off of the cooperative decoder launches timed out in this iteration (under data parallelism: on any
+            # rank -- the word was summed with the losses).  Its AdamW update was never armed (optimizer.finish_step's device-side
+            # veto), so no parameter has changed; the launches are switched off, the captures dropped, and the SAME batch is run
+            # again on the launched chain with the dropout seeds and learning rates it had.
+            if self.retry is None:
+                _coop_fallback(cap.model)
+                raise RuntimeError("rt_decoder_fwd: a stage hand-off timed out and the iteration cannot be re-run from here "
+                                   "(replayed without begin_train_step); the launches are now off (REFTR_DEC_COOP=0)")
+            return self.retry()
         weight_dict = self.criterion.weight_dict
         unscaled = {f"{n}_unscaled": v for n, v in zip(cap.stat_names, host)}
         scaled = {n: v * weight_dict[n] for n, v in zip(cap.stat_names, host) if n in weight_dict}
@@ -509,7 +617,7 @@ class _ReplayInFlight:
             print("Loss is {}, stopping training".format(loss_value))
             print(unscaled)
             sys.exit(1)
-        return loss_value, scaled, unscaled, host[k]
+        return loss_value, scaled, unscaled, host[-1]
 
 
 def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4, lookahead=None):
@@ -577,12 +685,14 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
             st.flat_p.copy_(snap[0]); optimizer.m.copy_(snap[1]); optimizer.v.copy_(snap[2]); optimizer.step_dev.copy_(snap[3])
             optimizer.step_count = snap[4]
             inner.seed_dev.copy_(snap[5]); inner._step = snap[6]
-            inner.mark_dirty(full=True)
+            inner.mark_dirty(full=True)      # the replay's first act finds the operands dirty and rebuilds them from the restored masters
             del snap
         else:
             for other in caps.values():
                 if other is not cap:
                     other.flush()
+    lrs_now = [g["lr"] for g in optimizer.param_groups]
+    seed_back = (1 if model.training else 0, 1)
     cap(samples, targets)
     # ONE device -> host copy for everything the loop looks at (losses for the meters and the finite check, gradient norm);
     # under data parallelism the loss entries are first averaged over the ranks in one all-reduce (util/misc.py:136-160).
@@ -592,8 +702,9 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
     stats = cap.stats
     if dist_on:
         k = len(cap.stat_names)
+        kf = k + (1 if cap.fail_word is not None else 0)      # the failure word rides along: SUM over ranks, non-zero = some rank failed
         stats = stats.clone()
-        torch.distributed.all_reduce(stats[:k])
+        torch.distributed.all_reduce(stats[:kf])
         stats[:k] /= utils.get_world_size()
     if getattr(cap, "_stats_host", None) is None:
         cap._stats_host = torch.empty(stats.numel(), dtype=torch.float32).pin_memory()
@@ -607,7 +718,20 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
         nxt = lookahead()
         if nxt is not None and nxt[0] is not None and cap.stage(*nxt):
             inner.__dict__["_staged_cap"] = cap
-    return _ReplayInFlight(cap, criterion)
+    def _retry():
+        # what the failed iteration advanced: host step count (the device counter was vetoed), dropout seed / step, learning rates
+        _coop_fallback(model)
+        optimizer.step_count -= 1
+        _restore_seed(model, seed_back)
+        after = [g["lr"] for g in optimizer.param_groups]
+        for g, lr in zip(optimizer.param_groups, lrs_now):
+            g["lr"] = lr
+        try:
+            return begin_train_step(model, criterion, samples, targets, optimizer, None, max_norm, max_shapes, None).finish()
+        finally:
+            for g, lr in zip(optimizer.param_groups, after):
+                g["lr"] = lr
+    return _ReplayInFlight(cap, criterion, retry=_retry)
 
 
 def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4, lookahead=None):
@@ -660,6 +784,7 @@ class CapturedForward:
 
     def __init__(self, model, max_shapes=4):
         self.model, self.graphs, self.max_shapes = model, {}, max_shapes
+        self._gen = _inner(model).__dict__.get("_coop_generation", 0)
 
     @staticmethod
     def shape_key(samples):
@@ -670,6 +795,9 @@ class CapturedForward:
     def __call__(self, samples):
         if not isinstance(samples.get("img"), utils.NestedTensor):
             return self.model(samples)
+        gen = _inner(self.model).__dict__.get("_coop_generation", 0)
+        if gen != self._gen:                     # the cooperative launches were switched off: the graphs that contain them go
+            self.graphs, self._gen = {}, gen
         key = self.shape_key(samples)
         ent = self.graphs.get(key)
         if ent is None and len(self.graphs) >= self.max_shapes:      # variable-size data: eager launches
@@ -719,6 +847,9 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
     wvec = None
     for _ in board.log_every(range(len(data_loader)), 50, "Test:"):
         outputs = fwd(samples)
+        if _cooperative_failed(model):           # a hand-off timed out: the batch is run again on the launched chain
+            _coop_fallback(model)
+            outputs = fwd(samples)
         loss_dict = criterion(outputs, targets)
         weight_dict = criterion.weight_dict
         red = utils.reduce_dict(loss_dict)

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -324,6 +324,12 @@ _SIGNATURES = {
     "rt_decoder_fwd": (c_int, [POINTER(DecoderFwdDesc), c_void_p]),
     "rt_decoder_bwd": (c_int, [POINTER(DecoderBwdDesc), c_void_p]),
     "rt_decoder_trace": (c_int, [c_void_p]),
+    "rt_decoder_supported": (c_int, [c_int]),
+    "rt_decoder_set_spin": (c_int, [c_int]),
+    "rt_counter_add_if_zero": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p]),
+    "rt_stamp": (c_int, [c_void_p, c_int, c_void_p]),
+    "rt_adamw_mat": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_int, c_void_p]),
+    "rt_adamw_chunks": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_void_p]),
 }
 
 _lib = None
@@ -944,10 +950,13 @@ def sqnorm(g, out):
 
 
 def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_scale=1.0, max_norm=0.0,
-               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None, active=None, lr_dev=None, span=None, g16=None, sgd=False):
+               beta1=0.9, beta2=0.999, eps=1e-8, step_dev=None, active=None, lr_dev=None, span=None, g16=None, sgd=False,
+               mat=None, chunks=None):
     """ranges = [(begin, end, lr, wd), ...] element ranges of the flat buffers (multiples of 4); span = (begin, end)
     restricts the launch to that element span; active / lr_dev: device words (see rt_adamw_desc).  sgd=True: rt_sgd_flat
-    (m = momentum buffer, beta1 = momentum, v unused)."""
+    (m = momentum buffer, beta1 = momentum, v unused).  mat = (device job table, njobs, total tiles) and / or chunks = (device
+    chunk table, nchunks): the matrix-aware form (rt_adamw_mat + rt_adamw_chunks) that also emits the bf16 operands; the
+    tables say what is updated and `span` is ignored."""
     d = AdamWDesc()
     d.p, d.g, d.m, d.v, d.n = _p(p), _p(g), _p(m), _p(v), p.numel()
     d.gnorm_sq, d.gnorm_out = _p(gnorm_sq), _p(gnorm_out)
@@ -958,7 +967,13 @@ def adamw_flat(p, g, m, v, *, step, ranges, gnorm_sq=None, gnorm_out=None, grad_
     d.g16 = _p(g16)
     for i, (b, e, lr, wd) in enumerate(ranges):
         d.range_begin[i], d.range_end[i], d.range_lr[i], d.range_wd[i] = b, e, lr, wd
-    if sgd:
+    if mat is not None or chunks is not None:
+        assert not sgd
+        if mat is not None and mat[1] > 0:
+            _check(lib().rt_adamw_mat(ctypes.byref(d), _p(mat[0]), mat[1], mat[2], _stream()), "rt_adamw_mat")
+        if chunks is not None and chunks[1] > 0:
+            _check(lib().rt_adamw_chunks(ctypes.byref(d), _p(chunks[0]), chunks[1], _stream()), "rt_adamw_chunks")
+    elif sgd:
         _check(lib().rt_sgd_flat(ctypes.byref(d), _stream()), "rt_sgd_flat")
     else:
         _check(lib().rt_adamw_flat(ctypes.byref(d), _stream()), "rt_adamw_flat")
@@ -978,8 +993,57 @@ def pos_grad(dpos, d_lang_pos, d_type, d_level, B, S, L):
     _check(lib().rt_pos_grad(_p(dpos), _p(d_lang_pos), _p(d_type), _p(d_level), B, S, L, E, _stream()), "rt_pos_grad")
 
 
-def counter_add(ctr, inc=1):
-    _check(lib().rt_counter_add(_p(ctr), inc, _stream()), "rt_counter_add")
+def counter_add(ctr, inc=1, unless=None, reset_else=False):
+    """*ctr += inc on the device; `unless` (a device word): only while it is 0, else *ctr is left alone or -- reset_else --
+    cleared (rt_counter_add_if_zero)."""
+    if unless is not None:
+        _check(lib().rt_counter_add_if_zero(_p(ctr), inc, _p(unless), int(bool(reset_else)), _stream()), "rt_counter_add_if_zero")
+    else:
+        _check(lib().rt_counter_add(_p(ctr), inc, _stream()), "rt_counter_add")
+
+
+def stamp(buf, idx):
+    """buf[idx] (int64 device tensor) = the device's 100 MHz wall clock when the current stream gets here (rt_stamp)."""
+    assert buf.dtype == torch.int64 and 0 <= idx < buf.numel()
+    _check(lib().rt_stamp(_p(buf), idx, _stream()), "rt_stamp")
+
+
+# Measurement aid (tools/concurrent_timeline.py): wall-clock stamps at named points of a step, on whatever stream reaches them.
+# rocprofv3 serialises the concurrent streams of a replayed graph, so the step's real timeline is taken from inside the graph: with
+# stamping enabled BEFORE the step is captured, every `mark` is a one-thread kernel node writing the device's 100 MHz clock.
+_MARKS = None
+
+
+def enable_marks(device, capacity=256):
+    """Turns `mark` on: returns {'buf': int64 device tensor, 'names': {name: (slot, stream)}}.  Call before capturing the step."""
+    global _MARKS
+    _MARKS = {"buf": torch.zeros(capacity, dtype=torch.int64, device=device), "names": {}}
+    return _MARKS
+
+
+def disable_marks():
+    global _MARKS
+    _MARKS = None
+
+
+def mark(name):
+    """No-op unless enable_marks() was called (one global read)."""
+    m = _MARKS
+    if m is None:
+        return
+    ent = m["names"].get(name)
+    if ent is None:
+        ent = m["names"][name] = (len(m["names"]), torch.cuda.current_stream().cuda_stream)
+    stamp(m["buf"], ent[0])
+
+
+def decoder_supported(F=2048):
+    """True when the cooperative decoder launches may be used on the current device (co-residency check, rt_decoder_supported)."""
+    return lib().rt_decoder_supported(int(F)) == 0
+
+
+def decoder_set_spin(spin):
+    _check(lib().rt_decoder_set_spin(int(spin)), "rt_decoder_set_spin")
 
 
 class WgradBatch:

@@ -77,7 +77,10 @@ class ResNetBody:
             bns = [self.PFX + "bn1."] + [c.bn for c in self.all_convs]
             for bn in bns:
                 c = P[bn + "weight"].numel()
-                sc = torch.empty(c, dtype=torch.float32, device=dev); sh = torch.empty(c, dtype=torch.float32, device=dev)
+                if bn in self.bn and self.bn[bn][0].device == P[bn + "weight"].device:
+                    sc, sh = self.bn[bn]            # refilled in place: the optimizer's operand tables hold these pointers
+                else:
+                    sc = torch.empty(c, dtype=torch.float32, device=dev); sh = torch.empty(c, dtype=torch.float32, device=dev)
                 H.bn_fold(P[bn + "weight"], P[bn + "bias"], P[bn + "running_mean"], P[bn + "running_var"], 1e-5, sc, sh)
                 self.bn[bn] = (sc, sh)
             self.W["stem"] = torch.empty(64, 7, 8, 4, dtype=torch.bfloat16, device=dev)
@@ -119,6 +122,7 @@ class ResNetBody:
         xp = H.img_pack(img)
         y = H.stem_conv(xp, self.W["stem"], self.bn[self.PFX + "bn1."][1], Ho, Wo)
         y = H.maxpool3x3s2(y)
+        H.mark("ResNet forward: stem + max-pool done")
         shp = (B, y.shape[1], y.shape[2])
         x = y.view(-1, 64)
         feats, saved = [], []
@@ -139,6 +143,7 @@ class ResNetBody:
                     saved.append((b, rec))
                 x, shp = out, s3
             feats.append((x, shp))
+            H.mark(f"ResNet forward: layer{len(feats)} done")
         return feats, saved
 
     # ------------------------------------------------------------------ backward

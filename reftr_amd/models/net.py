@@ -447,9 +447,15 @@ class Net:
     def dec_stack_coop_ok(self, N, T, S, n_layers, fold_sa):
         """Shapes rt_decoder_fwd covers: one query per image on the folded self-attention path, the reference's widths."""
         cfg = self.cfg
-        if self._dec_cus is None:            # the launch needs its ~80 workgroups resident at once, one per compute unit
+        if self._dec_cus is None:
+            # the launches need their ~80 spin-waiting workgroups resident at once: the library answers from the occupancy query
+            # and the device's compute-unit count (rt_decoder_supported), per device, once
             dev = self.store.device
-            self._dec_cus = torch.cuda.get_device_properties(dev).multi_processor_count if str(dev).startswith("cuda") else 0
+            ok = False
+            if str(dev).startswith("cuda"):
+                with torch.cuda.device(dev):
+                    ok = H.decoder_supported(cfg.ffn)
+            self._dec_cus = 1 << 20 if ok else 0
         return (self.dec_coop and self._dec_cus >= 160 and T == 1 and fold_sa and self.trivial_sa and self.fold_sa and cfg.hidden == 256 and cfg.nheads == 8
                 and cfg.ffn == 2048 and N <= 16 and S <= 768 and 1 <= n_layers <= H.DEC_MAX_LAYERS)
 

@@ -160,6 +160,47 @@ class RefTR(nn.Module):
         self._operands_dirty = True
         self._full_refresh = self._full_refresh or full
 
+    def operand_jobs(self):
+        """Every trainable weight matrix as (element offset in the flat parameter buffer, N, T, C, FrozenBN scale | None, bf16
+        operand [N][T][C], bf16 transposed operand [C][T][N]): what the optimizer's matrix-aware pass (rt_adamw_mat) needs to write
+        the GEMM operands itself.  None until the operands exist (they are allocated by the first full refresh)."""
+        if self._full_refresh or not self.body.W:
+            return None
+        st, fp = self.store, self.store.flat_p
+
+        def off(t):
+            o = (t.data_ptr() - fp.data_ptr()) // 4
+            assert 0 <= o and o + t.numel() <= fp.numel() and t.is_contiguous()
+            return o
+        jobs = [(off(l.w32), l.N, 1, l.K, None, l.W, l.WT) for l in self.net.lins.values()]
+        for c in self.body.all_convs:
+            if c.trainable:
+                jobs.append((off(st.phys(c.name)), c.cout, c.k * c.k, c.cin, self.body.bn[c.bn][0], self.body.W[c.name],
+                             self.body.W[c.name + ".t"]))
+        if self.seg is not None:
+            jobs += [(off(c.w32), c.cop, c.k * c.k, c.cip, None, c.W, c.WT) for c in self.seg.convs.values()]
+        return jobs
+
+    def refresh_now(self):
+        """Rebuilds whatever is dirty on the current stream, now (callers that changed the masters outside an optimizer step and
+        then replay a captured graph: the graph itself no longer contains an operand refresh)."""
+        self.refresh_operands()
+        if self._lin_refresh_pending:
+            self.net.refresh()
+            self._lin_refresh_pending = False
+
+    def coop_failure_word(self):
+        """The device word the cooperative decoder launches raise when a stage hand-off timed out (1-element int32 view), or None
+        when this model cannot launch them."""
+        net = self.net
+        if not (net.dec_coop or net.dec_coop_bwd) or net._dec_handoff is None:
+            return None
+        return net._dec_handoff[1:2]
+
+    def operands_emitted(self):
+        """The optimizer's pass wrote every bf16 operand itself: nothing to rebuild except the K-concatenated copies."""
+        self.net._refresh_kv_cat()
+
     def refresh_operands(self):
         """fp32 masters -> bf16 GEMM operands (weights [N,K] and [K,N], BN-folded conv weights)."""
         if not self._operands_dirty:
@@ -199,6 +240,7 @@ class RefTR(nn.Module):
             self.seg = SegHead(self.store, self.cfg, self.net) if self.cfg.masks else None
             self._anchor = torch.zeros((), device=probe.device, requires_grad=True)
             self.seed_dev = self.seed_dev.to(probe.device)
+            self._operand_version = getattr(self, "_operand_version", 0) + 1      # the optimizer's operand tables point at the old tensors
             self.mark_dirty(full=True)
         return self
 
@@ -218,24 +260,27 @@ class RefTR(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, samples):
         self._bb_ready = None
+        H.mark("step start")
         if self._pre_update is not None:
             if self._pre_side and self.net.side.enabled and not self._full_refresh:
                 # Deferred optimizer: the pending AdamW pass over the main / mask / ResNet slices and the refresh of the trainable
                 # convolutions' operands go to the language stream (in front of the BERT slice's pass): the stem and layer1 are
                 # frozen, so the ResNet's forward starts at once and only its first trainable block waits (body.forward).
                 def _pre_main():
-                    self._pre_update[0]()
-                    self.mark_dirty()
+                    if not self._pre_update[0]():
+                        self.mark_dirty()
                     self.refresh_operands()
                 self.net.side.run(_pre_main)
                 self._bb_ready = torch.cuda.Event()
                 self._bb_ready.record(self.net.side.stream)
             else:
-                self._pre_update[0]()
-                self.mark_dirty()
+                # the pending AdamW pass; when it wrote the bf16 operands itself (rt_adamw_mat) nothing is dirty
+                if not self._pre_update[0]():
+                    self.mark_dirty()
         elif self._flush_pending is not None:
             self._flush_pending()
         self.refresh_operands()
+        H.mark("AdamW (main slice) + operands done")
         pred_masks = None
         if self.seg is not None:
             assert "phrase" not in samples, "RefTRSeg is single-phrase (reftr_segmentation.py:101-103)"
@@ -289,12 +334,15 @@ class RefTR(nn.Module):
         vt = "vl_transformer."
 
         def _lang_branch():
-            if self._pre_update is not None:
-                self._pre_update[1]()
+            H.mark("lang: branch starts")
+            if self._pre_update is not None and self._pre_update[1]():
+                net._refresh_kv_cat()          # operands written by the AdamW passes (this one and the main stream's, which is ordered in front of this branch)
             if self._lin_refresh_pending:
                 net.refresh()
                 self._lin_refresh_pending = False
+            H.mark("lang: AdamW (BERT slice) + operands done")
             r = net.bert_fwd(ids, smask_u8)
+            H.mark("lang: BERT forward done")
             pos = torch.empty(M, E, dtype=torch.float32, device=dev)
             kpm = torch.empty(B, S, dtype=torch.uint8, device=dev)
             kpm[:, :Lq] = (smask_u8 == 0)                                   # models/reftr.py:92
@@ -313,6 +361,7 @@ class RefTR(nn.Module):
                 col = st.P["img_backbone.1.col_embed.weight"][:w]; row = st.P["img_backbone.1.row_embed.weight"][:h]
                 pe = torch.cat([col.unsqueeze(0).expand(h, w, -1), row.unsqueeze(1).expand(h, w, -1)], dim=-1).reshape(HW, E) + addv
                 pos.view(B, S, E)[:, Lq:, :] = pe
+            H.mark("lang: positional / mask work done")
             return r + (pos, kpm)
         seq16, pooled16, bctx, pos, kpm = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
         feats, bb_saved = self.body.forward(x, ready=self._bb_ready)
@@ -321,7 +370,9 @@ class RefTR(nn.Module):
         x32 = torch.empty(M, E, dtype=torch.float32, device=dev)
         x16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
         xp16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
+        H.mark("ResNet forward done")
         net.side.join()
+        H.mark("forward join (language branch in)")
         if self._zero_grad_side:
             # 607 MB of zeros: off the critical path, under the (latency-bound) encoder / decoder forward; backward joins
             net.side.run(st.flat_g.zero_)
@@ -353,6 +404,7 @@ class RefTR(nn.Module):
             x32, x16, xp16, r = net.enc_layer_fwd(f"{vt}encoder.layers.{i}.", x32, x16, xp16, pos, kpm, B, S)
             enc.append(r)
         mem32, mem16, memp16 = x32, x16, xp16
+        H.mark("encoder forward done")
 
         # ---- QueryEncoder (models/reftr_transformer.py:41-66)
         qe = "query_encoder."
@@ -425,6 +477,7 @@ class RefTR(nn.Module):
             pred_masks, mask_att, seg_sv = self.seg.forward(hs16[(NL - 1) * N:], mem16, mem32, src32, pad_u8, feats, B, S, Lq, h, w)
             self._saved.update(pred_masks=pred_masks, mask_att=mask_att, seg=seg_sv)
         H.set_seed_dev(None)
+        H.mark("query encoder + decoder + head forward done")
         return logits.view(NL, B, Pn, cfg.n_q, 4)
 
     # ------------------------------------------------------------------ backward
@@ -511,6 +564,7 @@ class RefTR(nn.Module):
         M = B * S
         f32z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)     # noqa: E731
 
+        H.mark("loss done (backward starts)")
         # ---- bbox head (backbone.py:26-38)
         dl = dlogits.reshape(NL * N, 4)
         dl16 = torch.empty(NL * N, 4, dtype=torch.bfloat16, device=dev)
@@ -550,6 +604,7 @@ class RefTR(nn.Module):
             ga, gb = net.dec_layer_bwd(f"{vt}decoder.layers.{i}.", sv["dec"][i], dnorm, extra, sv["mem16"], sv["memp16"],
                                        sv["qmask"], sv["kpm"], B, T, S, dmem, dmemp, dqpos)
 
+        H.mark("head + decoder backward done")
         # ---- QueryEncoder backward
         nq, Nf = cfg.n_q, sv["Nf"]
         df = torch.empty(N, E, dtype=torch.float32, device=dev)
@@ -597,6 +652,7 @@ class RefTR(nn.Module):
 
         net.flush_wgrads_side(1)         # decoder / query-encoder / map_phrase / head weight gradients: grouped launches
 
+        H.mark("query encoder backward done")
         # ---- encoder
         H.rows_add(M, E, a_f32=dmemp, out_f32=dmem, accumulate=True)      # K-side input of every cross-attention = memory + pos
         dpos = dmemp
@@ -614,6 +670,7 @@ class RefTR(nn.Module):
             st.G["img_backbone.1.col_embed.weight"][:w5] += gi[..., :E // 2].sum(0)
             st.G["img_backbone.1.row_embed.weight"][:h5] += gi[..., E // 2:].sum(1)
 
+        H.mark("encoder backward done")
         # ---- sequence inputs: map_sentence (language rows) and input_proj + GroupNorm (image rows)
         d_seq = net.mlp_bwd(sv["ms_ctx"], dxa, "map_sentence.", dy_rowmap=(Lq, S, 0), dy2=dxb)
         if seg_dsrc is not None:
@@ -690,12 +747,14 @@ class RefTR(nn.Module):
             yield "bert"
         else:
             def _bert_bwd():
+                H.mark("lang: BERT backward starts")
                 if sv["pctx"] is None:
                     net.bert_bwd(sv["bctx"], d_seq, dpool)
                 else:
                     net.bert_bwd(sv["bctx"], d_seq, None)
                     net.bert_bwd(sv["pctx"], None, dpool)
                 net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
+                H.mark("lang: BERT backward (data + weight gradients) launched")
                 if self._norm_side:
                     # Every gradient of the BERT slice (63 % of the buffer) is final here, ~1.5 ms before the ResNet backward ends:
                     # its share of the clip norm is reduced on this stream now; the optimizer adds the rest (optim.finish_step).
@@ -703,17 +762,22 @@ class RefTR(nn.Module):
                     b0, b1 = st.group_range[L.GROUP_BERT]
                     H.sqnorm(st.flat_g[b0:b1], self._sq_bert)
                     self._norm_split = (b0, b1, self._sq_bert)
+                    H.mark("lang: BERT slice's squared norm done")
+            H.mark("input_proj backward done (ResNet backward starts)")
             net.flush_wgrads_side(4)     # encoder / map_sentence weight gradients: language stream, in front of the BERT branch
             net.side.run(_bert_bwd, d_seq, dpool)
         # ---- ResNet body (its gradients are the last to become final); data parallel: layer4's slice (64 % of the ResNet
         # bytes) is final -- and exchanged -- before layer3 / layer2 run
         for stage in (self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra) if cfg.train_backbone else ()):
+            H.mark(f"ResNet backward: layer{stage} launched")
             if dp and stage == 4:
                 net.flush_wgrads(); self.body.wgs.join()
                 yield "layer4"
         net.flush_wgrads()
+        H.mark("ResNet backward done")
         net.side.join()
         net.wg.join()
+        H.mark("backward join (language branch in)")
 
 
 def build_config(args):

@@ -12,6 +12,27 @@ from . import hip as H
 from .models import layout as L
 
 
+def cover_span(mats, b, e):
+    """`mats`: (element offset, N, T, C) of weight matrices inside [b, e), sorted by offset.  Returns (jobs, total tiles, chunks):
+    jobs = (offset, N, T, C, first tile) with ceil(N/64) * ceil(C/64) * T tiles each; chunks = flat [offset, count, ...] pairs
+    (count <= 16384) covering every element of [b, e) that no matrix covers.  Together they tile [b, e) exactly once."""
+    jobs, tiles, pos, chunks = [], 0, b, []
+
+    def fill(a, to):
+        while a < to:
+            c = min(16384, to - a)
+            chunks.extend((a, c)); a += c
+    for off, N, T, C in mats:
+        assert off >= pos and off + N * T * C <= e and off % 4 == 0 and (N * T * C) % 4 == 0, \
+            "weight matrices overlap, cross the span's end or are not 16-byte aligned"
+        fill(pos, off)
+        jobs.append((off, N, T, C, tiles))
+        tiles += ((N + 63) // 64) * ((C + 63) // 64) * T
+        pos = off + N * T * C
+    fill(pos, e)
+    return jobs, tiles, chunks
+
+
 class FusedAdamW(torch.optim.Optimizer):
     SGD = False
 
@@ -45,6 +66,14 @@ class FusedAdamW(torch.optim.Optimizer):
         self.active = None            # device word: != 0 while an update is pending
         self.lr_dev = None            # device learning rates (one per non-empty param group) read by the kernel
         self._flush_pending = None    # set by the engine: applies a pending update before anyone reads weights / state
+        # round 4: the AdamW pass walks the weight matrices in tiles and writes their bf16 GEMM operands itself (rt_adamw_mat +
+        # rt_adamw_chunks) -- no separate operand refresh after an update.  REFTR_OPT_EMIT=0: the flat pass + rt_weight_prep_batched.
+        import os
+        self._emit = os.environ.get("REFTR_OPT_EMIT", "1") != "0" and not self.SGD
+        self._emit_cache = {}
+        self._last_emitted = False
+        # device word that vetoes an iteration's update (the cooperative decoder's failure word): see finish_step / step
+        self.veto = None
 
     def zero_grad(self, set_to_none=False, fast=False):
         """One memset of the flat gradient buffer (param.grad views are kept).  fast=True (the training loops of
@@ -93,14 +122,42 @@ class FusedAdamW(torch.optim.Optimizer):
                 ranges.append((b, e, g["lr"], g["weight_decay"]))
         return ranges
 
+    def _emit_tables(self, span):
+        """((job table, njobs, tiles), (chunk table, nchunks)) covering `span` of the flat buffers exactly once: the model's weight
+        matrices as tile jobs (with the bf16 operand tensors they feed), everything else in <= 16384-element chunks.  None while
+        the model has not built its operands yet (before the first forward) or is not on a GPU."""
+        model = self.model
+        st = model.store
+        jobs = model.operand_jobs() if hasattr(model, "operand_jobs") else None
+        if not jobs or not st.flat_p.is_cuda:
+            return None
+        key = (span, getattr(model, "_operand_version", 0))
+        ent = self._emit_cache.get(key)
+        if ent is None:
+            b, e = span if span is not None else (0, st.flat_p.numel())
+            mine = sorted((j for j in jobs if b <= j[0] < e), key=lambda j: j[0])
+            geo, tiles, chunks = cover_span([j[:4] for j in mine], b, e)
+            rows = [[off, H._p(j[4]) or 0, H._p(j[5]) or 0, H._p(j[6]) or 0, N, T, C, first] for (off, N, T, C, first), j in zip(geo, mine)]
+            dev = st.device
+            mat = (torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None, len(rows), tiles)
+            chk = (torch.tensor(chunks, dtype=torch.int64).to(dev) if chunks else None, len(chunks) // 2)
+            ent = self._emit_cache[key] = (mat, chk, [j[4:] for j in mine])      # the tensors behind the raw pointers stay referenced
+        return ent[0], ent[1]
+
     def _launch(self, span=None):
+        """One AdamW pass over `span` (default: everything).  Returns True when the pass also wrote the bf16 operands of the
+        matrices it updated (the caller then skips the operand refresh)."""
         st = self.model.store
         b1, b2 = self.defaults["betas"]
+        tabs = self._emit_tables(span) if self._emit else None
+        kw = dict(mat=tabs[0], chunks=tabs[1]) if tabs is not None else {}
         H.adamw_flat(st.flat_p, st.flat_g, self.m, self.v, step=max(self.step_count, 1), ranges=self._ranges(), gnorm_sq=self.sq,
                      g16=getattr(st, "flat_g16", None),
                      gnorm_out=self.grad_norm, grad_scale=getattr(self.model, "_grad_scale", 1.0),
                      max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"], step_dev=self.step_dev,
-                     active=self.active, lr_dev=self.lr_dev, span=span, sgd=self.SGD)
+                     active=self.active, lr_dev=self.lr_dev, span=span, sgd=self.SGD, **kw)
+        self._last_emitted = tabs is not None
+        return self._last_emitted
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -111,13 +168,22 @@ class FusedAdamW(torch.optim.Optimizer):
         H.counter_add(self.step_dev, 1)
         if not self._have_sq:
             H.sqnorm(self._grad_buffer(), self.sq)
-        act, self.active = self.active, None          # an immediate step is never conditional
+        act, self.active = self.active, None          # an immediate step is never conditional ...
+        if self.veto is not None:                     # ... except on the cooperative decoder's failure word (see finish_step)
+            if getattr(self, "_ok", None) is None:
+                self._ok = torch.zeros(1, dtype=torch.int32, device=st.device)
+            self._ok.zero_()
+            H.counter_add(self._ok, 1, unless=self.veto)
+            self.active = self._ok
         try:
-            self._launch()
+            emitted = self._launch()
         finally:
             self.active = act
         self._have_sq = False
-        self.model.mark_dirty()
+        if emitted:
+            self.model.operands_emitted()
+        else:
+            self.model.mark_dirty()
 
     # ---- deferred mode: [finish_step at the end of iteration i] ... [apply_pending at the head of iteration i+1] ----
     def enable_device_lr(self):
@@ -164,8 +230,10 @@ class FusedAdamW(torch.optim.Optimizer):
         are NOT touched; grad_norm holds this iteration's (pre-clip) norm like clip_grad_norm_'s return value."""
         self._sqnorm_all()
         self._max_norm = float(max_norm)
-        H.counter_add(self.step_dev, 1)
-        H.counter_add(self.active, 1)
+        # `veto` (the cooperative decoder's failure word): an iteration whose launches reported a hand-off timeout neither advances
+        # the step counter nor arms its update -- decided on the device, so a replayed graph can never apply such an update
+        H.counter_add(self.step_dev, 1, unless=self.veto)
+        H.counter_add(self.active, 1, unless=self.veto, reset_else=True)     # `active` != 0 already (earlier iterations): a veto clears it
         torch.sqrt(self.sq, out=self.grad_norm)
         gs = getattr(self.model, "_grad_scale", 1.0)
         if gs != 1.0:
@@ -175,8 +243,8 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def apply_pending(self, span=None):
         """The AdamW pass over `span` (default: everything) for the pending update; a no-op kernel while nothing is
-        pending.  May be issued as several spans on different streams."""
-        self._launch(span)
+        pending.  May be issued as several spans on different streams.  Returns True when the pass wrote the bf16 operands too."""
+        return self._launch(span)
 
     def clear_pending(self):
         if self.active is not None:

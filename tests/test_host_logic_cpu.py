@@ -426,3 +426,54 @@ def test_cooperative_decoder_gating_and_failure_flag_on_the_host():
     wrapped = types.SimpleNamespace(module=fake)                        # a DistributedDataParallel-style wrapper
     with pytest.raises(RuntimeError):
         _check_cooperative(wrapped)
+
+
+def test_cover_span_tiles_a_span_exactly_once():
+    """The optimizer's matrix jobs + complement chunks (reftr_amd.optim.cover_span -> rt_adamw_mat / rt_adamw_chunks) cover every
+    element of a span once: no parameter is skipped or updated twice."""
+    import random
+    from reftr_amd.optim import cover_span
+    rnd = random.Random(0)
+    for _ in range(50):
+        b = rnd.randrange(0, 8) * 4096
+        pos, mats = b, []
+        for _ in range(rnd.randrange(0, 7)):
+            pos += rnd.randrange(0, 6000) * 4
+            N, T, C = rnd.choice([1, 4, 64, 70, 256]), rnd.choice([1, 9]), rnd.choice([4, 12, 64, 768])
+            mats.append((pos, N, T, C)); pos += N * T * C
+        e = pos + rnd.randrange(0, 9000) * 4
+        jobs, tiles, chunks = cover_span(mats, b, e)
+        seen = torch.zeros(e - b, dtype=torch.int32)
+        for off, N, T, C, first in jobs:
+            seen[off - b: off - b + N * T * C] += 1
+        for off, cnt in zip(chunks[0::2], chunks[1::2]):
+            assert 0 < cnt <= 16384 and off % 4 == 0 and cnt % 4 == 0
+            seen[off - b: off - b + cnt] += 1
+        assert bool((seen == 1).all())
+        assert tiles == sum(((N + 63) // 64) * ((C + 63) // 64) * T for _, N, T, C in mats)
+        firsts = [j[4] for j in jobs]
+        assert firsts == sorted(firsts) and (not firsts or firsts[0] == 0)
+    with pytest.raises(AssertionError):
+        cover_span([(0, 64, 1, 64), (1000, 64, 1, 64)], 0, 1 << 20)        # overlapping matrices
+
+
+def test_replayed_iteration_with_a_raised_failure_word_is_run_again_not_returned():
+    """_ReplayInFlight.finish(): the cooperative launches' failure word sits behind the losses in the stats vector; when it is
+    raised the handle hands back the result of the retry closure (the iteration on the launched chain) instead of the numbers of the
+    void iteration, and a handle without one raises."""
+    import types
+    from reftr_amd import engine_vg as E
+
+    class Ev:
+        def synchronize(self):
+            pass
+    crit = types.SimpleNamespace(weight_dict={"loss_bbox": 5.0, "loss_giou": 2.0})
+    cap = types.SimpleNamespace(_stats_event=Ev(), stat_names=("loss_bbox", "loss_giou"), fail_word=object(),
+                                _stats_host=torch.tensor([0.5, 0.25, 0.0, 3.0]), model=None)
+    loss, scaled, unscaled, gn = E._ReplayInFlight(cap, crit, retry=lambda: "again").finish()
+    assert abs(loss - 3.0) < 1e-6 and gn == 3.0 and scaled["loss_bbox"] == 2.5 and unscaled["loss_giou_unscaled"] == 0.25
+    cap._stats_host = torch.tensor([0.5, 0.25, 2.0, 3.0])                      # two ranks reported a timeout
+    assert E._ReplayInFlight(cap, crit, retry=lambda: "again").finish() == "again"
+    cap_nofail = types.SimpleNamespace(_stats_event=Ev(), stat_names=("loss_bbox", "loss_giou"), fail_word=None,
+                                       _stats_host=torch.tensor([0.5, 0.25, 3.0]), model=None)
+    assert E._ReplayInFlight(cap_nofail, crit).finish()[3] == 3.0             # models without the launches: [losses | norm]
