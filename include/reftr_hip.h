@@ -527,12 +527,12 @@ int rt_counter_add_if_zero(int32_t* ctr, int32_t inc, const uint32_t* cond, int 
  * because rocprofv3 serialises the graph's concurrent streams. */
 int rt_stamp(uint64_t* buf, int idx, rt_stream_t stream);
 /* rt_adamw_mat / rt_adamw_chunks — rt_adamw_flat's update (same descriptor, same arithmetic and rounding, same `active` / step /
- * learning-rate device words), split into (a) the weight MATRICES, walked in 64 x 64 tiles so that the kernel also writes the bf16
+ * learning-rate device words), split into (a) the weight MATRICES, walked in tiles of 32 rows x 256 columns of [N][T*C] so that the kernel also writes the bf16
  * GEMM operands of the NEXT forward / backward from the registers that hold the new fp32 values -- what rt_weight_prep_batched
  * produced in a second pass over the masters -- and (b) everything else (biases, norm parameters, embeddings), in chunks.
  *   mat table (DEVICE int64 [njobs][8], static): {element offset of the matrix [N][T][C] in p / g / m / v, scale pointer | 0
  *     (FrozenBN scale[n] folded into the bf16 copies only), dst bf16 [N][T][C] | 0, dst_t bf16 [C][T][N] | 0, N, T, C, first tile};
- *     a job has ceil(N/64) * ceil(C/64) * T tiles; total_tiles = their sum; a matrix lies inside ONE learning-rate range.
+ *     a job has ceil(N/32) * ceil(T*C/256) tiles; total_tiles = their sum; a matrix lies inside ONE learning-rate range.
  *   chunk table (DEVICE int64 [nchunks][2], static): {element offset, element count <= 16384}, both multiples of 4.
  * d->span_* are ignored (the tables say what is updated).  The caller makes jobs and chunks tile the parameters exactly once. */
 int rt_adamw_mat(const rt_adamw_desc* d, const int64_t* table, int njobs, int total_tiles, rt_stream_t stream);

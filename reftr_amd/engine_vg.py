@@ -427,8 +427,11 @@ class CapturedTrainStep:
             self.inner.mark_dirty()
 
     def reset_pending(self):
-        """Forgets the pending update (after the caller has restored weights / optimizer state by hand)."""
+        """Forgets the pending update (after / before the caller restores weights / optimizer state by hand).  The bf16 operands are
+        marked stale: the next replay rebuilds them from whatever the masters then hold (the graphs carry no operand refresh of
+        their own since the optimizer's pass writes the operands)."""
         self._pending = False
+        self.inner.mark_dirty()
         if self.deferred or self.deferred_dp:
             self.optimizer.clear_pending()
             self._set_flush(False)

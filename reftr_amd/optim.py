@@ -14,7 +14,7 @@ from .models import layout as L
 
 def cover_span(mats, b, e):
     """`mats`: (element offset, N, T, C) of weight matrices inside [b, e), sorted by offset.  Returns (jobs, total tiles, chunks):
-    jobs = (offset, N, T, C, first tile) with ceil(N/64) * ceil(C/64) * T tiles each; chunks = flat [offset, count, ...] pairs
+    jobs = (offset, N, T, C, first tile) with ceil(N/32) * ceil(T*C/256) tiles each (rt_adamw_mat's tiling); chunks = flat [offset, count, ...] pairs
     (count <= 16384) covering every element of [b, e) that no matrix covers.  Together they tile [b, e) exactly once."""
     jobs, tiles, pos, chunks = [], 0, b, []
 
@@ -27,7 +27,7 @@ def cover_span(mats, b, e):
             "weight matrices overlap, cross the span's end or are not 16-byte aligned"
         fill(pos, off)
         jobs.append((off, N, T, C, tiles))
-        tiles += ((N + 63) // 64) * ((C + 63) // 64) * T
+        tiles += ((N + 31) // 32) * ((T * C + 255) // 256)
         pos = off + N * T * C
     fill(pos, e)
     return jobs, tiles, chunks

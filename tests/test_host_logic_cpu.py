@@ -450,7 +450,7 @@ def test_cover_span_tiles_a_span_exactly_once():
             assert 0 < cnt <= 16384 and off % 4 == 0 and cnt % 4 == 0
             seen[off - b: off - b + cnt] += 1
         assert bool((seen == 1).all())
-        assert tiles == sum(((N + 63) // 64) * ((C + 63) // 64) * T for _, N, T, C in mats)
+        assert tiles == sum(((N + 31) // 32) * ((T * C + 255) // 256) for _, N, T, C in mats)
         firsts = [j[4] for j in jobs]
         assert firsts == sorted(firsts) and (not firsts or firsts[0] == 0)
     with pytest.raises(AssertionError):
