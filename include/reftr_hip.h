@@ -127,6 +127,8 @@ typedef struct rt_conv_wgrad_desc {
                              the gradient buffer was last consumed: no pre-zeroed memory is needed and the epilogue skips the read of
                              dw).  dbias always accumulates. */
     int32_t reserved;
+    float*  sqacc;        /* optional gradient-norm accumulator (RT_SQ_SLOTS x RT_SQ_STRIDE floats, see rt_sqnorm_finish): the launch adds
+                             |dw after|^2 - |dw before|^2, so that the clip norm (engine_vg.py:62-63) needs no pass over dw */
 } rt_conv_wgrad_desc;
 int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
 
@@ -136,6 +138,7 @@ int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
 typedef struct rt_small_wgrad_job {
     const void* dy; const void* x; float* dw; float* dbias;
     int32_t M, N, K, overwrite;      /* overwrite: as in rt_conv_wgrad_desc (dbias accumulates) */
+    float* sqacc;                    /* optional gradient-norm accumulator, as in rt_conv_wgrad_desc */
 } rt_small_wgrad_job;
 int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream);
 
@@ -514,6 +517,14 @@ int rt_sgd_flat(const rt_adamw_desc* d, rt_stream_t stream);
  * element count (<= 16384)}.  Used for the gradient tensors that are accumulated with atomics (biases, norm parameters,
  * embeddings) when the weight matrices are produced in overwrite mode and the full clear of the gradient buffer is skipped. */
 int rt_zero_chunks(float* base, const int64_t* table, int n, rt_stream_t stream);
+/* rt_sqnorm_finish — the clip norm without a pass over the weight gradients.  Every weight-gradient launch given `sqacc` has added
+ * |dw after|^2 - |dw before|^2 of what it wrote to the accumulator's slots (RT_SQ_SLOTS words, RT_SQ_STRIDE floats apart: the caller
+ * clears the RT_SQ_SLOTS * RT_SQ_STRIDE floats when it clears / re-arms the gradient buffer).  This call adds the squared norm of
+ * the tensors no such launch produces -- biases, norm parameters, embeddings, accumulated with atomics: the chunks of `table`
+ * (DEVICE int64 [nchunks][2] = {element offset in `base`, count <= 16384}) -- and writes out[0] = sum of the slots (+ extra[0]). */
+#define RT_SQ_SLOTS 256
+#define RT_SQ_STRIDE 32
+int rt_sqnorm_finish(const float* base, const int64_t* table, int nchunks, float* slots, const float* extra, float* out, rt_stream_t stream);
 /* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */
 int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream);
 /* rt_counter_add_if_zero — the same, but only while the DEVICE word *cond is 0; otherwise *ctr is left alone (reset_else = 0) or

@@ -90,4 +90,15 @@ __device__ __forceinline__ int rt_xcd_remap(int b, int n, int xcd_on) {
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
 }
 
+// Gradient-norm accumulator (round 4): the squared L2 norm of the weight gradients is collected WHERE THEY ARE PRODUCED -- every
+// epilogue that assigns or accumulates a piece of a weight gradient adds (new^2 - old^2) of that piece -- instead of by a second
+// pass over the 607 MB gradient buffer (engine_vg.py:62-63's clip_grad_norm_).  Contributions go to one of RT_SQ_SLOTS fp32 words
+// (a cache line apart, picked by workgroup / wave id) with fire-and-forget atomics; rt_sqnorm_finish adds the slots up.
+__device__ __forceinline__ void rt_sq_add(float* slots, unsigned who, float v) {
+    atomicAdd(slots + (size_t)(who & (RT_SQ_SLOTS - 1)) * RT_SQ_STRIDE, v);
+}
+// sign * |buf|^2 of up to 32 fp32 buffers into the slots (the producers without an in-kernel contribution: a pass with sign -1
+// in front of an accumulating launch, +1 behind every launch); rt_optim.hip
+int rt_sq_pass(float* const* bufs, const long long* counts, const float* signs, int n, float* slots, hipStream_t s);
+
 #define RT_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -296,6 +296,44 @@ __global__ __launch_bounds__(256) void adamw_chunks_kernel(const rt_adamw_desc p
     }
 }
 
+// ---- gradient-norm accumulator (rt_common.h): passes over whole buffers / chunk tables, and the final sum of the slots
+struct SqList { const float* buf[32]; long long cnt[32]; float sign[32]; int first[33]; int n; };
+__global__ __launch_bounds__(256) void sq_list_kernel(const SqList l, float* __restrict__ slots) {
+    __shared__ float sm[16];
+    int lo = 0, hi = l.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (l.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const float* g = l.buf[lo];
+    const size_t n = (size_t)l.cnt[lo];
+    const size_t b0 = (size_t)((int)blockIdx.x - l.first[lo]) * 4096;              // 4096 elements per workgroup
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t i = b0 + (size_t)j * 1024 + threadIdx.x * 4;
+        if (i + 4 <= n) { const f32x4 v = *reinterpret_cast<const f32x4*>(g + i); s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+        else for (size_t k = i; k < n; ++k) s += g[k] * g[k];
+    }
+    s = rt_block_sum(s, sm);
+    if (threadIdx.x == 0) rt_sq_add(slots, blockIdx.x, l.sign[lo] * s);
+}
+// the tensors that are accumulated with atomics (the complement of the weight matrices): table = n x {element offset, count <= 16384}
+__global__ __launch_bounds__(256) void sq_chunks_kernel(const float* __restrict__ base, const int64_t* __restrict__ table, float* __restrict__ slots) {
+    __shared__ float sm[16];
+    const size_t off = (size_t)table[2 * blockIdx.x], cnt = (size_t)table[2 * blockIdx.x + 1];
+    float s = 0.f;
+    for (size_t i = threadIdx.x * 4; i < cnt; i += 1024) {
+        if (i + 4 <= cnt && ((off + i) & 3) == 0) { const f32x4 v = *reinterpret_cast<const f32x4*>(base + off + i); s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+        else for (size_t k = i; k < cnt && k < i + 4; ++k) s += base[off + k] * base[off + k];
+    }
+    s = rt_block_sum(s, sm);
+    if (threadIdx.x == 0) rt_sq_add(slots, blockIdx.x, s);
+}
+__global__ __launch_bounds__(256) void sq_sum_kernel(const float* __restrict__ slots, float* __restrict__ out, const float* __restrict__ extra) {
+    __shared__ float sm[16];
+    float s = slots[(size_t)threadIdx.x * RT_SQ_STRIDE];
+    s = rt_block_sum(s, sm);
+    if (threadIdx.x == 0) out[0] = fmaxf(s, 0.f) + (extra ? extra[0] : 0.f);      // (new^2 - old^2 terms may leave -1 ulp when everything is zero)
+}
+
 __global__ void counter_add_if_zero_kernel(int32_t* c, int32_t inc, const uint32_t* cond, int reset_else) {
     if (cond[0] == 0u) c[0] += inc; else if (reset_else) c[0] = 0;
 }
@@ -346,6 +384,35 @@ extern "C" int rt_adamw_chunks(const rt_adamw_desc* d, const int64_t* table, int
     if (rc != RT_OK) return rc;
     if (!table || nchunks <= 0) return RT_ERR_BADARG;
     hipLaunchKernelGGL(adamw_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, *d, table);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+int rt_sq_pass(float* const* bufs, const long long* counts, const float* signs, int n, float* slots, hipStream_t s) {
+    for (int base = 0; base < n; base += 32) {
+        SqList l; l.n = 0; int blocks = 0;
+        for (int i = base; i < n && i < base + 32; ++i) {
+            if (!bufs[i] || counts[i] <= 0) continue;
+            l.buf[l.n] = bufs[i]; l.cnt[l.n] = counts[i]; l.sign[l.n] = signs[i]; l.first[l.n] = blocks; ++l.n;
+            blocks += (int)((counts[i] + 4095) / 4096);
+        }
+        if (!l.n) continue;
+        l.first[l.n] = blocks;
+        hipLaunchKernelGGL(sq_list_kernel, dim3((unsigned)blocks), dim3(256), 0, s, l, slots);
+        RT_CHECK_LAUNCH();
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_sqnorm_finish(const float* base, const int64_t* table, int nchunks, float* slots, const float* extra, float* out,
+                                rt_stream_t stream) {
+    if (!slots || !out || (nchunks > 0 && (!base || !table))) return RT_ERR_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(sq_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, base, table, slots);
+        RT_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(sq_sum_kernel, dim3(1), dim3(256), 0, s, slots, out, extra);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

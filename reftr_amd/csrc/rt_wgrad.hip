@@ -732,6 +732,32 @@ static bool groupable(const rt_conv_wgrad_desc& d) {
 }
 
 static int wgrad_grouped_v1(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes, rt_stream_t stream);
+static int conv_wgrad_impl(const rt_conv_wgrad_desc* d, rt_stream_t stream);
+
+// Gradient-norm accounting for the launches WITHOUT an in-kernel contribution (first-generation kernels, the M <= 16 kernels): a pass
+// with sign -1 over every dw that is accumulated onto (|before|^2) in front of the launches, +1 over every dw behind them.  Those
+// matrices are the small ones (decoder / query-encoder / head Linears, ragged channel counts) and were just written: L2 hits.
+static int sq_account(const rt_conv_wgrad_desc* descs, int n, bool after, hipStream_t s) {
+    float* bufs[32]; long long cnts[32]; float signs[32];
+    int m = 0;
+    float* slots = nullptr;
+    for (int i = 0; i <= n; ++i) {
+        const bool last = i == n;
+        if (!last) {
+            const rt_conv_wgrad_desc& d = descs[i];
+            if (!d.sqacc || (!after && d.overwrite)) continue;
+            if (slots && d.sqacc != slots) return RT_ERR_BADARG;     // one accumulator per call
+            slots = d.sqacc;
+            bufs[m] = d.dw; cnts[m] = (long long)d.N * d.KH * d.KW * d.SC; signs[m] = after ? 1.f : -1.f; ++m;
+        }
+        if (m == 32 || (last && m > 0)) {
+            const int rc = rt_sq_pass(bufs, cnts, signs, m, slots, s);
+            if (rc != RT_OK) return rc;
+            m = 0;
+        }
+    }
+    return RT_OK;
+}
 
 extern "C" int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes,
                                      rt_stream_t stream) {
@@ -753,9 +779,16 @@ extern "C" int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, flo
             if (rc != RT_OK) return rc;
         }
         // (the v2 launches above have consumed the workspace; the first-generation group below re-uses it -- same stream, in order)
-        return nr > 0 ? wgrad_grouped_v1(rest, nr, workspace, workspace_bytes, stream) : RT_OK;
+        if (nr == 0) return RT_OK;
+        int rc = sq_account(rest, nr, false, s);
+        if (rc == RT_OK) rc = wgrad_grouped_v1(rest, nr, workspace, workspace_bytes, stream);
+        if (rc == RT_OK) rc = sq_account(rest, nr, true, s);
+        return rc;
     }
-    return wgrad_grouped_v1(descs, n, workspace, workspace_bytes, stream);
+    int rc = sq_account(descs, n, false, s);
+    if (rc == RT_OK) rc = wgrad_grouped_v1(descs, n, workspace, workspace_bytes, stream);
+    if (rc == RT_OK) rc = sq_account(descs, n, true, s);
+    return rc;
 }
 
 static int wgrad_grouped_v1(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes, rt_stream_t stream) {
@@ -783,7 +816,7 @@ static int wgrad_grouped_v1(const rt_conv_wgrad_desc* descs, int n, float* works
     for (int i = 0; i < n; ++i) {
         const rt_conv_wgrad_desc& d = descs[i];
         if (!groupable(d)) {                               // anything else keeps its own launch
-            const int rc = rt_conv_wgrad(&d, stream);
+            const int rc = conv_wgrad_impl(&d, stream);
             if (rc != RT_OK) return rc;
             continue;
         }
@@ -848,6 +881,19 @@ static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a) {
 }
 
 extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
+    if (!d) return RT_ERR_BADARG;
+    if (!d->sqacc) return conv_wgrad_impl(d, stream);
+    const long long M = (long long)d->B * d->DH * d->DW;
+    const bool v2 = w2_enabled() && rt_w2_eligible(*d) && !getenv("REFTR_WGV") &&
+                    !(M <= 16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->SC & 3) == 0);
+    if (v2) return conv_wgrad_impl(d, stream);           // the second-generation kernels account in their epilogues
+    int rc = sq_account(d, 1, false, (hipStream_t)stream);
+    if (rc == RT_OK) rc = conv_wgrad_impl(d, stream);
+    if (rc == RT_OK) rc = sq_account(d, 1, true, (hipStream_t)stream);
+    return rc;
+}
+
+static int conv_wgrad_impl(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     WgradArgs a;
     const int frc = fill_wgrad_args(d, a);
     if (frc != RT_OK) return frc;
@@ -889,8 +935,31 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     return launch_wgrad<64, 64>(a, d->msplit, s);
 }
 
+static int sq_account_small(const rt_small_wgrad_job* jobs, int n, bool after, hipStream_t s) {
+    float* bufs[32]; long long cnts[32]; float signs[32];
+    int m = 0;
+    float* slots = nullptr;
+    for (int i = 0; i <= n; ++i) {
+        const bool last = i == n;
+        if (!last) {
+            const rt_small_wgrad_job& q = jobs[i];
+            if (!q.sqacc || (!after && q.overwrite)) continue;
+            if (slots && q.sqacc != slots) return RT_ERR_BADARG;
+            slots = q.sqacc;
+            bufs[m] = q.dw; cnts[m] = (long long)q.N * q.K; signs[m] = after ? 1.f : -1.f; ++m;
+        }
+        if (m == 32 || (last && m > 0)) {
+            const int rc = rt_sq_pass(bufs, cnts, signs, m, slots, s);
+            if (rc != RT_OK) return rc;
+            m = 0;
+        }
+    }
+    return RT_OK;
+}
+
 extern "C" int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream) {
     if (!jobs || njobs <= 0) return RT_ERR_BADARG;
+    { const int rc = sq_account_small(jobs, njobs, false, (hipStream_t)stream); if (rc != RT_OK) return rc; }
     for (int base = 0; base < njobs; base += 64) {
         SmallJobs p;
         p.n = njobs - base < 64 ? njobs - base : 64;
@@ -905,5 +974,5 @@ extern "C" int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs,
         hipLaunchKernelGGL(small_m_wgrad_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
         RT_CHECK_LAUNCH();
     }
-    return RT_OK;
+    return sq_account_small(jobs, njobs, true, (hipStream_t)stream);
 }

@@ -36,7 +36,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int w2_i32x4;
 
 struct W2Prob {
-    const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias; float* part;
+    const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias; float* part; float* sqacc;
     int SH, SW, SC, DH, DW, N, KH, KW, stride, pad, M;
     int n_tiles, c_tiles, tiles, splits, chunks_per_split, out_elems;
     unsigned dy_bytes, x_bytes;
@@ -400,6 +400,7 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * WTC);
     __syncthreads();                 // every wave is done reading the stages; the DMA tail is drained (vmcnt 0 above)
     const int er = lane / LPR, ec = (lane % LPR) * 4;
+    float ss = 0.f;                  // this thread's share of |dw after|^2 - |dw before|^2 (direct tiles only: the gradient norm)
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) {
     const int otap = FUSED ? tap * 3 + tp : tap;
@@ -427,13 +428,24 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
             if (direct && p.accumulate) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) old[i] = *reinterpret_cast<const f32x4*>(o[i]);
+                if (p.sqacc) {               // (a + b)^2 - a^2 = b (2a + b)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) if (ok[i]) { const f32x4 d = v[i] * (old[i] + old[i] + v[i]); ss += (d[0] + d[1]) + (d[2] + d[3]); }
+                }
 #pragma unroll
                 for (int i = 0; i < NB; ++i) v[i] += old[i];
+            } else if (direct && p.sqacc) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) if (ok[i]) { const f32x4 d = v[i] * v[i]; ss += (d[0] + d[1]) + (d[2] + d[3]); }
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) if (ok[i]) *reinterpret_cast<f32x4*>(o[i]) = v[i];
         }
     }
+    }
+    if (direct && p.sqacc) {
+        ss = rt_wave_sum(ss);
+        if (lane == 0) rt_sq_add(p.sqacc, (unsigned)blockIdx.x * 8u + (unsigned)wave, ss);
     }
 }
 
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(512, 1) void w2_grouped_kernel(const W2Group g) {
 }
 
 // dw[i] (+)= scale[i / row_elems] * sum_s part[s][i] for every split problem of a group (one launch)
-struct W2Reduce { const float* part[W2_MAXP]; float* dw[W2_MAXP]; const float* scale[W2_MAXP];
+struct W2Reduce { const float* part[W2_MAXP]; float* dw[W2_MAXP]; const float* scale[W2_MAXP]; float* sqacc[W2_MAXP];
                   int out_elems[W2_MAXP], row_elems[W2_MAXP], nsplit[W2_MAXP], accumulate[W2_MAXP], first[W2_MAXP + 1]; int n; };
 __global__ __launch_bounds__(256) void w2_reduce_kernel(const W2Reduce g) {
     int lo = 0, hi = g.n - 1;
@@ -494,7 +506,10 @@ __global__ __launch_bounds__(256) void w2_reduce_kernel(const W2Reduce g) {
     const float* part = g.part[lo]; float* dw = g.dw[lo]; const float* scale = g.scale[lo];
     const int out_elems = g.out_elems[lo], nsplit = g.nsplit[lo];
     const int i = (((int)blockIdx.x - g.first[lo]) * 256 + (int)threadIdx.x) * 4;
-    if (i >= out_elems) return;
+    float* const sq = g.sqacc[lo];
+    __shared__ float sm[16];
+    float ss = 0.f;
+    if (i < out_elems) {
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     int s = 0;
     for (; s + 4 <= nsplit; s += 4) {
@@ -507,7 +522,21 @@ __global__ __launch_bounds__(256) void w2_reduce_kernel(const W2Reduce g) {
     for (; s < nsplit; ++s) a += *reinterpret_cast<const f32x4*>(part + (size_t)s * out_elems + i);
     if (scale) a *= scale[i / g.row_elems[lo]];
     f32x4* o = reinterpret_cast<f32x4*>(dw + i);
-    *o = g.accumulate[lo] ? *o + a : a;
+    if (g.accumulate[lo]) {
+        const f32x4 old = *o;
+        const f32x4 d = a * (old + old + a);              // |old + a|^2 - |old|^2
+        ss = (d[0] + d[1]) + (d[2] + d[3]);
+        *o = old + a;
+    } else {
+        const f32x4 d = a * a;
+        ss = (d[0] + d[1]) + (d[2] + d[3]);
+        *o = a;
+    }
+    }
+    if (sq) {                                             // uniform per workgroup (one problem per workgroup)
+        ss = rt_block_sum(ss, sm);
+        if (threadIdx.x == 0) rt_sq_add(sq, blockIdx.x, ss);
+    }
 }
 
 template <int CR, int NS>
@@ -632,7 +661,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             W2Prob p;
             p.cfg = w2_cfg_of(d);
             const int BN = BNs[p.cfg], BC = BCs[p.cfg];
-            p.dy = (const bf16_t*)d.dy; p.x = (const bf16_t*)d.x; p.dw = d.dw; p.scale = d.scale; p.dbias = d.dbias; p.part = nullptr;
+            p.dy = (const bf16_t*)d.dy; p.x = (const bf16_t*)d.x; p.dw = d.dw; p.scale = d.scale; p.dbias = d.dbias; p.part = nullptr; p.sqacc = d.sqacc;
             p.SH = d.SH; p.SW = d.SW; p.SC = d.SC; p.DH = d.DH; p.DW = d.DW; p.N = d.N; p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
             const long long M = (long long)d.B * d.DH * d.DW;
             p.M = (int)M;
@@ -665,7 +694,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             p.splits = (total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
             if (p.splits > 1 && workspace) {
                 p.part = workspace + ws_off / 4;
-                r.part[r.n] = p.part; r.dw[r.n] = p.dw; r.scale[r.n] = p.scale; r.out_elems[r.n] = p.out_elems;
+                r.part[r.n] = p.part; r.dw[r.n] = p.dw; r.scale[r.n] = p.scale; r.sqacc[r.n] = p.sqacc; r.out_elems[r.n] = p.out_elems;
                 r.row_elems[r.n] = d.KH * d.KW * d.SC; r.nsplit[r.n] = p.splits; r.accumulate[r.n] = p.accumulate; r.first[r.n] = rblocks; ++r.n;
                 rblocks += (p.out_elems / 4 + 255) / 256;
                 ws_off += ((long long)p.splits * p.out_elems * 4 + 255) / 256 * 256;

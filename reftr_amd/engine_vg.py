@@ -399,7 +399,7 @@ class CapturedTrainStep:
         inner._zero_grad_side = os.environ.get("REFTR_ZERO_SIDE", "0") == "1" and inner.net.side.enabled
         # backward and clip norm are one unit here (nothing touches the gradient buffer in between): the BERT slice's share of the
         # norm may be taken on the language stream as soon as that slice is final (reftr_transformer._backward_gen)
-        inner._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0"
+        inner._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0" and not getattr(inner.store, "fused_norm", False)
         try:
             out = self._fwd_bwd(zero=not inner._zero_grad_side)
             self.grad_norm = opt.finish_step(self.max_norm)

@@ -41,6 +41,7 @@ class ConvWgradDesc(Structure):
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
         ("msplit", c_int32), ("dbias", c_void_p), ("variant", c_int32),
         ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64), ("overwrite", c_int32), ("reserved", c_int32),
+        ("sqacc", c_void_p),
     ]
 
 
@@ -174,7 +175,7 @@ class AdamWDesc(Structure):
 # (tests/test_abi.py cross-checks this table against the header).
 class SmallWgradJob(Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
-                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("overwrite", c_int32)]
+                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("overwrite", c_int32), ("sqacc", c_void_p)]
 
 
 class GnNhwcDesc(Structure):
@@ -300,6 +301,7 @@ _SIGNATURES = {
     "rt_pos_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_sqnorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "rt_sqnorm_finish": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_sgd_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_zero_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
@@ -528,6 +530,25 @@ def _wgrad_workspace(dev):
     return ws
 
 
+# Gradient-norm accumulators: {data_ptr of a registered weight-gradient matrix: its model's slot buffer} (ParamStore registers its
+# overwritable matrices here).  Every weight-gradient launch into such a matrix hands the slots to the library (`sqacc`), which adds
+# |dw after|^2 - |dw before|^2 -- the clip norm then needs no pass over the gradient buffer (rt_sqnorm_finish).
+SQ_SLOTS, SQ_STRIDE = 256, 32
+_SQACC_MAP = {}
+
+
+def _sqacc(dw):
+    t = _SQACC_MAP.get(dw.data_ptr())
+    return t.data_ptr() if t is not None else None
+
+
+def sqnorm_finish(flat_g, table, nchunks, slots, out, extra=None):
+    """out[0] = sum of the accumulator slots + |the chunks of flat_g listed in `table`|^2 (+ extra[0])."""
+    _req(flat_g, torch.float32, "flat_g"); _req(slots, torch.float32, "slots"); _req(out, torch.float32, "out")
+    assert slots.numel() == SQ_SLOTS * SQ_STRIDE
+    _check(lib().rt_sqnorm_finish(_p(flat_g), _p(table), int(nchunks), _p(slots), _p(extra), _p(out), _stream()), "rt_sqnorm_finish")
+
+
 def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, workspace=True, overwrite=False):
     """dw[N,KH,KW,SC] (fp32) += (overwrite: =) scale[n] * sum_m dy[m,n] * gather(x)[m,(kh,kw,c)]."""
     B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
@@ -537,7 +558,7 @@ def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, 
     _req(dbias, torch.float32, "dbias")
     ws = _wgrad_workspace(dy.device) if workspace else None
     d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit, _p(dbias), variant,
-                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0, int(bool(overwrite)), 0)
+                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0, int(bool(overwrite)), 0, _sqacc(dw))
     _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
            lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"), tag=("W",) + tuple(geom))
     return dw
@@ -1066,7 +1087,7 @@ class WgradBatch:
         K = x.shape[1]
         assert x.shape[0] == M and dw.numel() == N * K
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), None, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, _p(dbias), 0, None, 0,
-                                        int(bool(overwrite)), 0))
+                                        int(bool(overwrite)), 0, _sqacc(dw)))
         self.keep.append((dy, x))
         self._account((M, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
 
@@ -1075,7 +1096,7 @@ class WgradBatch:
         B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(scale, torch.float32, "scale")
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, 0, None, 0,
-                                        None, 0, int(bool(overwrite)), 0))
+                                        None, 0, int(bool(overwrite)), 0, _sqacc(dw)))
         self.keep.append((dy, x, scale))
         self._account(geom)
 
@@ -1112,7 +1133,7 @@ class SmallWgradBatch:
         M, N = dy.shape
         K = x.shape[1]
         assert M <= 16 and x.shape[0] == M and dw.numel() == N * K and K % 4 == 0
-        self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, int(bool(overwrite))))
+        self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, int(bool(overwrite)), _sqacc(dw)))
         self.keep.append((dy, x))
         self.flops += 2.0 * M * N * K; self.nbytes += 2.0 * M * (N + K) + 4.0 * N * K
 

@@ -83,6 +83,7 @@ class RefTR(nn.Module):
         assert self.dp_schedule in ("interleave", "serial")
         self._stops = frozenset()
         self._bwd_gen = None
+        self._slice_bounds = None         # set by the data-parallel wrapper: {boundary: slice(s) of flat_g that are final there}
         self._post_backward_hooks = []
         self._lin_refresh_pending = False
         # deferred optimizer (engine_vg.CapturedTrainStep): (main-stream fn, language-stream fn) that apply the previous
@@ -490,7 +491,9 @@ class RefTR(nn.Module):
 
     def active_boundaries(self):
         """The boundaries this model's backward actually passes (serial schedule: BERT is cut in thirds only from 3 layers up)."""
-        return tuple(b for b in self.BOUNDARIES if self.cfg.bert.layers >= 3 or b not in ("bert_hi", "bert_mid"))
+        return tuple(b for b in self.BOUNDARIES
+                     if (self.cfg.bert.layers >= 3 or b not in ("bert_hi", "bert_mid"))
+                     and (self.cfg.train_backbone or b != "layer4"))       # frozen ResNet (--lr_backbone 0): its backward never runs
 
     def bert_cuts(self):
         """{BERT layer index: boundary reached right after that layer's backward} of the interleaved schedule
@@ -532,6 +535,11 @@ class RefTR(nn.Module):
         if gen is None:
             return None
         for name in gen:
+            # data parallel: the slices that are final at this boundary are about to be exchanged -- their registered matrices
+            # that this step never wrote are cleared NOW (ParamStore.finish_overwrite_range), not at the end of backward
+            sb = self._slice_bounds
+            if sb is not None and name in sb:
+                self.store.finish_overwrite_range(sb[name] if isinstance(sb[name], list) else [sb[name]])
             for hook in self._phase_hooks.get(name, ()):
                 hook()
             if name in self._stops:
@@ -755,7 +763,7 @@ class RefTR(nn.Module):
                     net.bert_bwd(sv["pctx"], None, dpool)
                 net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
                 H.mark("lang: BERT backward (data + weight gradients) launched")
-                if self._norm_side:
+                if self._norm_side and not net.wg.enabled:      # (REFTR_STREAMS=3: the weight gradients run on their own stream -- not ordered in front of this one)
                     # Every gradient of the BERT slice (63 % of the buffer) is final here, ~1.5 ms before the ResNet backward ends:
                     # its share of the clip norm is reduced on this stream now; the optimizer adds the rest (optim.finish_step).
                     net.flush_wgrads()   # the slice's queued LayerNorm-parameter / grouped weight gradients (nothing else is queued)

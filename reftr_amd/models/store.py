@@ -83,6 +83,14 @@ class ParamStore:
         # overwrite-mode bookkeeping (see the module docstring): registered matrices {data_ptr: (offset, numel)}
         self._ow, self._ow_table, self._armed, self._written, self._stale_tables = {}, None, False, set(), {}
         self.last_stale = ()
+        # gradient-norm accumulator (hip._SQACC_MAP, rt_sqnorm_finish): the weight-gradient launches into the registered matrices add
+        # |after|^2 - |before|^2 to these slots; `norm_valid` = the slots were cleared together with the gradients (optimizer.zero_grad)
+        # and nothing consumed them since.  REFTR_FUSED_NORM=0: the norm is a pass over the buffer again (rt_sqnorm).
+        import os
+        from .. import hip as H
+        self.fused_norm = os.environ.get("REFTR_FUSED_NORM", "1") != "0" and self.device.type == "cuda"
+        self.sq_slots = torch.zeros(H.SQ_SLOTS * H.SQ_STRIDE, dtype=torch.float32, device=device) if self.fused_norm else None
+        self.norm_valid = False
 
     # ------------------------------------------------------------------ overwrite-mode gradient production
     def register_overwritable(self, gw):
@@ -92,6 +100,9 @@ class ParamStore:
         assert 0 <= off and off + gw.numel() <= self.flat_g.numel()
         self._ow[gw.data_ptr()] = (off, gw.numel())
         self._ow_table, self._stale_tables = None, {}
+        if self.fused_norm:
+            from .. import hip as H
+            H._SQACC_MAP[gw.data_ptr()] = self.sq_slots
 
     def _complement_table(self):
         """Static device table of <= 16384-element chunks covering everything that is NOT a registered matrix."""
@@ -106,6 +117,12 @@ class ParamStore:
             self._ow_table = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
         return self._ow_table
 
+    def begin_norm(self):
+        """The gradients are (about to be) cleared / re-armed: clear the norm accumulator with them."""
+        if self.fused_norm:
+            self.sq_slots.zero_()
+            self.norm_valid = True
+
     def arm_overwrite(self):
         """Start of a training backward: clear the atomically-accumulated tensors only; until `finish_overwrite` the first
         `claim` of every registered matrix answers True (its producer overwrites)."""
@@ -114,6 +131,7 @@ class ParamStore:
         if n:
             H.zero_chunks(self.flat_g, table, n)
         self._armed, self._written = True, set()
+        self._range_stale = ()
 
     def claim(self, gw):
         if not self._armed:
@@ -129,6 +147,41 @@ class ParamStore:
         the caller clears the whole buffer, nothing may stay in overwrite mode."""
         self._armed, self._written = False, set()
 
+    def finish_overwrite_range(self, bounds):
+        """Data parallel: the slices `bounds` = [(a, b), ...] of the gradient buffer are final NOW -- their exchange is the next thing
+        that happens -- so the registered matrices inside them that no producer has written in this step are cleared here, in front
+        of the exchange, instead of at the end of backward (where the clear would come after the slice was copied / all-reduced:
+        the previous step's gradient of such a matrix would be exchanged and applied, and with the fp32 exchange the late clear
+        would race the in-place all-reduce).  They count as written from here on: finish_overwrite leaves them alone."""
+        if not self._armed:
+            return
+        merged = []
+        for a, b in sorted((a, b) for a, b in bounds if b > a):
+            if merged and a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        missing = frozenset(k for k, (off, n) in self._ow.items()
+                            if k not in self._written and any(a <= off < b for a, b in merged))
+        if not missing:
+            return
+        self._zero_matrices(missing)
+        self._written |= missing
+        self._range_stale = getattr(self, "_range_stale", ()) + tuple(self._ow[k] for k in missing)
+
+    def _zero_matrices(self, keys):
+        ent = self._stale_tables.get(keys)
+        if ent is None:
+            chunks = []
+            for off, n in sorted(self._ow[k] for k in keys):
+                a = off
+                while a < off + n:
+                    c = min(16384, off + n - a)
+                    chunks += [a, c]; a += c
+            ent = self._stale_tables[keys] = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
+        from .. import hip as H
+        H.zero_chunks(self.flat_g, ent[0], ent[1])
+
     def finish_overwrite(self):
         """End of backward: EVERY registered matrix that no producer wrote in this step is cleared -- unconditionally, by one
         launch that depends on this step's written set only, never on what earlier steps did.  (A matrix that an input kind
@@ -140,19 +193,11 @@ class ParamStore:
         if not self._armed:
             return
         missing = frozenset(self._ow) - self._written
-        self.last_stale = tuple(self._ow[k] for k in missing)          # (offset, numel) of what this step left unwritten
+        # (offset, numel) of what this step left unwritten (including what finish_overwrite_range already cleared at a boundary)
+        self.last_stale = tuple(self._ow[k] for k in missing) + getattr(self, "_range_stale", ())
+        self._range_stale = ()
         if missing:
-            ent = self._stale_tables.get(missing)
-            if ent is None:
-                chunks = []
-                for off, n in sorted(self._ow[k] for k in missing):
-                    a = off
-                    while a < off + n:
-                        c = min(16384, off + n - a)
-                        chunks += [a, c]; a += c
-                ent = self._stale_tables[missing] = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
-            from .. import hip as H
-            H.zero_chunks(self.flat_g, ent[0], ent[1])
+            self._zero_matrices(missing)
         self._armed, self._written = False, set()
 
     def _view(self, buf, name, off):

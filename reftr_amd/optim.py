@@ -86,6 +86,7 @@ class FusedAdamW(torch.optim.Optimizer):
         else:
             self.model.store.disarm()         # a backward that was abandoned half-way must not leave overwrite mode armed
             self.model.store.flat_g.zero_()
+        self.model.store.begin_norm()         # the producers' epilogues collect the clip norm from here on (rt_sqnorm_finish)
 
     def _grad_buffer(self):
         """The buffer the update reads: the fp32 gradients, or -- in a data-parallel run that exchanges bf16 -- the bf16 copy
@@ -99,7 +100,14 @@ class FusedAdamW(torch.optim.Optimizer):
         g = self._grad_buffer()
         split = getattr(self.model, "_norm_split", None)
         st = self.model.store
-        if split is not None and g is st.flat_g and split[1] == st.flat_g.numel() and split[0] > 0:
+        if getattr(st, "norm_valid", False) and g is st.flat_g and not getattr(self.model, "dp_mode", False):
+            # the weight-gradient launches of this backward have left |dw|^2 of every registered matrix in the accumulator slots
+            # (hip._SQACC_MAP); what they do not produce -- biases, norm parameters, embeddings: 4 % of the buffer -- is read here
+            table, n = st._complement_table()
+            H.sqnorm_finish(st.flat_g, table, n, st.sq_slots, self.sq)
+            st.norm_valid = False
+            self.model._norm_split = None
+        elif split is not None and g is st.flat_g and split[1] == st.flat_g.numel() and split[0] > 0:
             H.sqnorm(g[:split[0]], self.sq)
             self.sq.add_(split[2])
             self.model._norm_split = None

@@ -77,6 +77,8 @@ class DistributedDataParallel(nn.Module):
         if not self.active:
             return
         if overlap:
+            module._slice_bounds = self.slice_bounds()     # backward clears never-written matrices of a slice in front of its exchange
+        if overlap:
             # REFTR_DDP_PHASES: comma list of the boundaries to exchange at (default: all); a boundary that is left out hands
             # its slice to the next one that is kept (the end if none)
             want = os.environ.get("REFTR_DDP_PHASES")

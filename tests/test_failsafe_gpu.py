@@ -248,3 +248,73 @@ def test_training_with_emitted_operands_matches_the_refresh_path(hip, monkeypatc
             w = (m1.store.phys(c.name) * m1.body.bn[c.bn][0].view(-1, 1, 1)).to(torch.bfloat16)
             assert torch.equal(m1.body.W[c.name], w), c.name
             assert torch.equal(m1.body.W[c.name + ".t"], w.permute(2, 1, 0).contiguous()), c.name
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+def _norm_case(kind):
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase, CriterionVGOnePhraseSeg
+    from reftr_amd.models.reftr_transformer import RefTR
+    from reftr_amd.optim import FusedAdamW
+    masks = kind == "seg"
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=masks, aux_loss=not masks)
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), masks=masks)
+    model = RefTR(cfg, device="cuda", aux_loss=not masks)
+    model.load_state_dict(formula_state(param_shapes(ocfg)), strict=True)
+    torch.manual_seed(3)
+    model.store.P["bbox_embed.layers.2.weight"].normal_(0, 0.02)
+    model.mark_dirty()
+    model.train()
+    if masks:
+        crit = CriterionVGOnePhraseSeg(O.weight_dict(ocfg), ["masks", "boxes"])
+        samples, targets = make_inputs("seg_single", B=2, H=96, W=128, L=12)
+        g = torch.Generator().manual_seed(1)
+        targets = [dict(t, masks=(torch.rand(1, 96, 128, generator=g) > 0.5)) for t in targets]
+    else:
+        crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+        samples, targets = make_inputs("norm_" + kind, B=3, H=96, W=128, L=12, n_phrase=3 if kind == "multi" else 0)
+    s, tg = to_cuda(samples, targets)
+    return model, crit, s, tg, FusedAdamW(model)
+
+
+@pytest.mark.parametrize("kind", ["single", "multi", "seg"])
+@pytest.mark.parametrize("fast", [True, False])
+def test_clip_norm_collected_in_the_weight_gradient_epilogues_equals_the_norm_of_the_buffer(hip, kind, fast):
+    """engine_vg.py:62-63's total norm without a pass over the 607 MB buffer: the weight-gradient launches add |dw after|^2 -
+    |dw before|^2 of what they write (in-kernel for the second-generation kernels and their reduction, a pass over the freshly
+    written matrix for the small first-generation / M <= 16 ones), rt_sqnorm_finish adds the atomically accumulated tensors.
+    Cases: one contribution per matrix (single phrase), two BERT passes + real decoder self-attention (multi-phrase: accumulating
+    second writes), the RES head (unregistered convolution gradients: counted with the complement); overwrite mode and the full
+    clear; a second backward onto the same gradients (accumulation) keeps the accumulator exact."""
+    from reftr_amd.engine_vg import _total, _zero_grad
+    model, crit, s, tg, opt = _norm_case(kind)
+    st = model.store
+    assert st.fused_norm and st.sq_slots is not None
+    st.flat_g.normal_()                                   # stale garbage the step must not count
+    for rep in range(2):
+        out = model(s)
+        total = _total(crit, crit(out, tg))
+        if rep == 0:
+            _zero_grad(opt) if fast else opt.zero_grad()
+            assert st.norm_valid
+        total.backward()                                  # rep 1: accumulates onto rep 0's gradients, no zero_grad in between
+    gn = opt.clip_grad_norm_(0.1)
+    assert not st.norm_valid                              # consumed: a second clip without a new zero_grad reads the buffer again
+    fused = float(opt.sq)
+    ref = float(st.flat_g.double().pow(2).sum())
+    assert ref > 0 and abs(fused - ref) <= 2e-5 * ref, (kind, fast, fused, ref)
+    opt._sqnorm_all()
+    assert abs(float(opt.sq) - ref) <= 2e-5 * ref          # the old path, for reference
+
+
+def test_replayed_step_reports_the_same_gradient_norm_with_and_without_the_fused_norm(hip, monkeypatch):
+    from reftr_amd.engine_vg import captured_train_step
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("REFTR_FUSED_NORM", on)
+        model, crit, s, tg, opt = build()
+        assert model.store.fused_norm == (on == "1")
+        res.append([float(captured_train_step(model, crit, s, tg, opt, None, 0.1)[3]) for _ in range(3)])
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * res[1][0], res
+    for a, b in zip(res[0], res[1]):
+        assert abs(a - b) <= 2e-2 * b, res

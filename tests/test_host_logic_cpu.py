@@ -477,3 +477,45 @@ def test_replayed_iteration_with_a_raised_failure_word_is_run_again_not_returned
     cap_nofail = types.SimpleNamespace(_stats_event=Ev(), stat_names=("loss_bbox", "loss_giou"), fail_word=None,
                                        _stats_host=torch.tensor([0.5, 0.25, 3.0]), model=None)
     assert E._ReplayInFlight(cap_nofail, crit).finish()[3] == 3.0             # models without the launches: [losses | norm]
+
+
+def test_data_parallel_boundary_clears_never_written_matrices_before_the_exchange(monkeypatch):
+    """ParamStore.finish_overwrite_range: a registered matrix that this step never writes must be cleared
+    BEFORE its slice is exchanged at a data-parallel boundary, and the end-of-backward clear must leave it (and the in-flight
+    exchange buffer) alone afterwards.  rt_zero_chunks is replaced by a torch stand-in (host logic under test, no GPU here)."""
+    from reftr_amd import hip as H
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.store import ParamStore
+    log = []
+
+    def zero_chunks(base, table, n):
+        t = table.view(-1, 2).tolist()
+        log.append([tuple(r) for r in t[:n]])
+        for off, cnt in t[:n]:
+            base[off:off + cnt] = 0
+    monkeypatch.setattr(H, "zero_chunks", zero_chunks)
+    st = ParamStore(L.ModelConfig(enc_layers=1, dec_layers=1, bert=L.BertConfig(layers=1)), "cpu")
+    a = st.G["vl_transformer.encoder.layers.0.linear1.weight"]
+    b = st.G["vl_transformer.encoder.layers.0.linear2.weight"]
+    c = st.G["lang_backbone.encoder.layer.0.output.dense.weight"]
+    for t in (a, b, c):
+        st.register_overwritable(t)
+    st.flat_g.fill_(3.0)                                   # "the previous step's gradients"
+    st.arm_overwrite()
+    assert st.claim(a) and not st.claim(a)                 # a is produced (overwritten) in this step; b and c are not
+    a.fill_(1.0)
+    ma, mb = st.group_range[L.GROUP_MAIN]
+    log.clear()
+    st.finish_overwrite_range([(ma, mb // 2), (mb // 2, mb)])        # the main slice is final: split in two pieces like the exchange
+    assert float(b.abs().sum()) == 0 and float(a.min()) == 1.0 and float(c.min()) == 3.0     # b cleared now, c is not in this slice
+    assert len(log) == 1
+    exchanged = st.flat_g[ma:mb].clone()                   # what the all-reduce would read
+    b.fill_(9.0)                                            # stands for the in-place all-reduce result landing in the buffer
+    st.finish_overwrite()                                   # end of backward: only c is left to clear
+    assert float(b.min()) == 9.0 and float(c.abs().sum()) == 0
+    assert float(exchanged.view(-1)[(st.offset["vl_transformer.encoder.layers.0.linear2.weight"][1] - ma)]) == 0
+    offs = {o for o, _ in st.last_stale}
+    assert offs == {st.offset["vl_transformer.encoder.layers.0.linear2.weight"][1],
+                    st.offset["lang_backbone.encoder.layer.0.output.dense.weight"][1]}
+    # not armed (plain zero_grad): nothing to do
+    log.clear(); st.finish_overwrite_range([(ma, mb)]); assert not log

@@ -7,8 +7,8 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
                   "on d.kernel_id = s.id order by d.start").fetchall()
-ad = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0]]
-ad = [i for n, i in enumerate(ad) if n + 1 == len(ad) or any("adamw_kernel" in r[0] for r in rows[i + 1:ad[n + 1]])]   # the step-ending one of a run
+ad = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0] or "sq_sum_kernel" in r[0]]      # rt_sqnorm / rt_sqnorm_finish (fused norm, round 4)
+ad = [i for n, i in enumerate(ad) if n + 1 == len(ad) or any("adamw_" in r[0] for r in rows[i + 1:ad[n + 1]])]   # the step-ending one of a run
 cands = [(rows[ad[i + 1]][2] - rows[ad[i]][2], ad[i] + 1, ad[i + 1] + 1) for i in range(len(ad) - 1)
          if not any("spin_kernel" in r[0] for r in rows[ad[i] + 1:ad[i + 1] + 1])]
 cands.sort()
@@ -44,7 +44,7 @@ def first_of_last(pat):
 
 print("median step: %d kernels, wall %.3f ms" % (len(step), wall / 1e6))
 for label, v in (
-        ("first AdamW launch starts", first("adamw_kernel")), ("last AdamW launch ends", last("adamw_kernel")),
+        ("first AdamW launch starts", first("adamw_")), ("last AdamW launch ends", last("adamw_")),
         ("weight prep (last) ends", last("weight_prep")), ("stem conv starts (ResNet forward)", first("stem_conv")),
         ("BERT forward: last dh=64 attention ends", last("attn_fwd_reg_kernel<64")),
         ("input_proj GroupNorm stats (ResNet forward done)", first("gn_stats")),
@@ -57,5 +57,5 @@ for label, v in (
         ("GroupNorm backward (encoder chain done)", first("gn_bwd")),
         ("BERT backward: first dh=64 attention bwd", first("attn_bwd_fused_kernel<64")), ("BERT backward: last", last("attn_bwd_fused_kernel<64")),
         ("last backward-data / forward product (conv_gemm_dma) ends", last("conv_gemm_dma_kernel")),
-        ("last weight-gradient group starts", first_of_last("w2_grouped")), ("last weight-gradient group ends", last("w2_grouped")), ("gradient norm ends (step end)", last("sqnorm_kernel"))):
+        ("last weight-gradient group starts", first_of_last("w2_grouped")), ("last weight-gradient group ends", last("w2_grouped")), ("gradient norm ends (step end)", (last("sq_sum_kernel") if last("sq_sum_kernel") == last("sq_sum_kernel") else last("sqnorm_kernel")))):
     print("  %7.3f ms  %s" % (v, label))

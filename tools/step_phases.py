@@ -3,17 +3,19 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
 # the gradient-norm kernel ends an iteration in both schedules (deferred: [AdamW of i-1 | fwd | bwd | norm]; eager: [... norm | AdamW])
-ad = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0]]
+def is_norm(n):      # the launch that ends an iteration: rt_sqnorm (rounds 1-3) or rt_sqnorm_finish's slot sum (round 4: fused norm)
+    return "sqnorm_kernel" in n or "sq_sum_kernel" in n
+ad = [i for i, r in enumerate(rows) if is_norm(r[0])]
 # (round 3: the BERT slice's share of the norm is a second, earlier sqnorm launch -- the iteration ends at the one that is followed by
 # the next iteration's AdamW, i.e. the last of each run of sqnorm launches without an adamw_kernel in between)
-ad = [i for n, i in enumerate(ad) if n + 1 == len(ad) or any("adamw_kernel" in r[0] for r in rows[i + 1:ad[n + 1]])]
+ad = [i for n, i in enumerate(ad) if n + 1 == len(ad) or any("adamw_" in r[0] for r in rows[i + 1:ad[n + 1]])]
 # the shortest step of the run (skips warm-up and bench.py's backlogged roofline pass behind a spin kernel)
 cands = [(rows[ad[i + 1]][2] - rows[ad[i] + 1][1], ad[i] + 1, ad[i + 1] + 1) for i in range(len(ad) - 1)
          if not any("spin_kernel" in r[0] for r in rows[ad[i] + 1:ad[i + 1] + 1])]
 _, a, b = min(cands)
 step = rows[a:b]
 t0 = step[0][1]
-marks = [("AdamW of the previous step (deferred) + weight prep + pack", "adamw_kernel"), ("pack", "img_pack"), ("stem", "stem_conv"), ("ResNet fwd (+BERT if 1 stream)", "maxpool"), ("input_proj+GN", "gn_stats_kernel"),
+marks = [("AdamW of the previous step (deferred) + weight prep + pack", "adamw_"), ("pack", "img_pack"), ("stem", "stem_conv"), ("ResNet fwd (+BERT if 1 stream)", "maxpool"), ("input_proj+GN", "gn_stats_kernel"),
          ("encoder fwd", "gn_apply"), ("query encoder + decoder fwd + head", "qenc_attn_fwd"), ("loss", "box_loss"),
          ("head + decoder bwd", "box_loss"), ("qenc bwd + encoder bwd", "qenc_attn_bwd"), ("GN/input_proj bwd", "gn_bwd_stats"),
          ("ResNet bwd (+BERT bwd)", "gn_bwd_apply"), ("gradient norm", "sqnorm")]
@@ -21,7 +23,7 @@ idx, pos = [], 0
 for label, key in marks:
     rng = range(pos, len(step)) if key != "sqnorm" else range(len(step) - 1, pos - 1, -1)      # the step-ending norm launch
     for i in rng:
-        if key in step[i][0]:
+        if (is_norm(step[i][0]) if key == "sqnorm" else key in step[i][0]):
             idx.append((label, i)); pos = i + 1; break
 print("step: %d kernels, %.2f ms (kernel-busy %.2f ms)" % (len(step), (step[-1][2] - t0) / 1e6, sum(r[2] - r[1] for r in step) / 1e6))
 for n, (label, i) in enumerate(idx):

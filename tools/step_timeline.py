@@ -9,8 +9,8 @@ db = sqlite3.connect(sys.argv[1])
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 rows = db.execute("select s.display_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
                   "on d.kernel_id = s.id order by d.start").fetchall()
-ad = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0]]
-ad = [i for n, i in enumerate(ad) if n + 1 == len(ad) or any("adamw_kernel" in r[0] for r in rows[i + 1:ad[n + 1]])]   # the step-ending one of a run
+ad = [i for i, r in enumerate(rows) if "sqnorm_kernel" in r[0] or "sq_sum_kernel" in r[0]]      # rt_sqnorm / rt_sqnorm_finish (fused norm, round 4)
+ad = [i for n, i in enumerate(ad) if n + 1 == len(ad) or any("adamw_" in r[0] for r in rows[i + 1:ad[n + 1]])]   # the step-ending one of a run
 cands = [(rows[ad[i + 1]][2] - rows[ad[i]][2], ad[i] + 1, ad[i + 1] + 1) for i in range(len(ad) - 1)
          if not any("spin_kernel" in r[0] for r in rows[ad[i] + 1:ad[i + 1] + 1])]
 cands.sort()
