@@ -1,0 +1,157 @@
+"""GPU: rt_enc_tail_fwd / rt_enc_tail_bwd -- the row-local part of a TransformerEncoderLayer (models/modeling/transformer.py:168-181,
+forward_post) as one launch per direction -- against (1) a plain PyTorch fp32 restatement with the kernels' rounding points (bf16 GEMM
+operands, fp32 accumulation / residual stream / LayerNorm), and (2) the launched chain it replaces inside the model, dropout on (the
+dropout sites and masks are the chain's, so forward tensors and gradients must agree to a flipped bf16 rounding)."""
+import os
+
+import pytest
+import torch
+
+from oracle import reftr_oracle as O
+from oracle.shapes import param_shapes
+from oracle.synth import make_inputs
+from oracle.weights import formula_state
+
+pytestmark = pytest.mark.gpu
+E = 256
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__ as g
+    g.build()
+    from reftr_amd import hip as H
+    return H
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def ln(x, g, b, eps=1e-5):
+    mean = x.mean(-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(-1, keepdim=True)
+    rstd = (var + eps).rsqrt()
+    return (x - mean) * rstd * g + b, mean.squeeze(-1), rstd.squeeze(-1)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,F,proj", [(3520, 2048, True), (72, 512, False), (33, 256, True)])
+def test_fused_forward_and_backward_against_fp32_torch(hip, M, F, proj):
+    H = hip
+    g = torch.Generator(device="cpu").manual_seed(M + F)
+    dev = "cuda"
+
+    def rn(*s, sc=1.0):
+        return (torch.randn(*s, generator=g) * sc).to(dev)
+    o = bf(rn(M, E)); x32 = rn(M, E); pos = rn(M, E)
+    Wo, W1, W2 = bf(rn(E, E, sc=E ** -0.5)), bf(rn(F, E, sc=E ** -0.5)), bf(rn(E, F, sc=F ** -0.5))
+    Wqk, Wv = bf(rn(2 * E, E, sc=E ** -0.5)), bf(rn(E, E, sc=E ** -0.5))
+    bo, b1, b2, bqk, bv = rn(E, sc=0.1), rn(F, sc=0.1), rn(E, sc=0.1), rn(2 * E, sc=0.1), rn(E, sc=0.1)
+    g1, be1, g2, be2 = 1 + rn(E, sc=0.1), rn(E, sc=0.1), 1 + rn(E, sc=0.1), rn(E, sc=0.1)
+    f32, b16 = torch.float32, torch.bfloat16
+    out32 = torch.empty(3, M, E, dtype=f32, device=dev); out16 = torch.empty(3, M, E, dtype=b16, device=dev)
+    stats = torch.empty(4, M, dtype=f32, device=dev); hdn = torch.empty(M, F, dtype=b16, device=dev)
+    kw = {}
+    if proj:
+        qk = torch.empty(M, 2 * E, dtype=b16, device=dev); v = torch.empty(M, E, dtype=b16, device=dev)
+        kw = dict(Wqk=Wqk, Wv=Wv, bqk=bqk, bv=bv, qk=qk, v=v)
+    H.enc_tail_fwd(M=M, F=F, eps=1e-5, drop_p=0.0, seeds=(1, 2, 3), o=o, x32=x32, Wo=Wo, W1=W1, W2=W2, bo=bo, b1=b1, b2=b2, g1=g1,
+                   be1=be1, g2=g2, be2=be2, pos=pos, t=out32[0], mean1=stats[0], rstd1=stats[1], x1_16=out16[0], hdn=hdn,
+                   t2=out32[1], mean2=stats[2], rstd2=stats[3], x2_32=out32[2], x2_16=out16[1], x2p16=out16[2], **kw)
+    torch.cuda.synchronize()
+    # ---- reference forward (fp32 torch on the bf16-rounded operands)
+    t = x32 + (o.float() @ Wo.float().t() + bo)
+    x1, m1, r1 = ln(t, g1, be1)
+    h = bf(torch.relu(bf(x1).float() @ W1.float().t() + b1))
+    t2 = x1 + (h.float() @ W2.float().t() + b2)
+    x2, m2, r2 = ln(t2, g2, be2)
+    assert rel(out32[0], t) < 2e-5 and rel(stats[0], m1) < 2e-4 and rel(stats[1], r1) < 2e-5
+    assert rel(out16[0], bf(x1)) < 3e-3 and rel(hdn, h) < 4e-3
+    assert rel(out32[1], t2) < 1e-3                      # a flipped bf16 rounding of a hidden unit moves t2 by ~1e-4
+    assert rel(out32[2], x2) < 1e-3 and rel(out16[1], bf(x2)) < 3e-3 and rel(out16[2], bf(x2 + pos)) < 3e-3
+    if proj:
+        assert rel(qk, bf(out16[2].float() @ Wqk.float().t() + bqk)) < 3e-3
+        assert rel(v, bf(out16[1].float() @ Wv.float().t() + bv)) < 3e-3
+    # ---- backward on the tensors the forward saved
+    dy, dy2 = rn(M, E), rn(M, E, sc=0.3)
+    nb = (M + 31) // 32
+    g16 = torch.empty(3, M, E, dtype=b16, device=dev); dhdn = torch.empty(M, F, dtype=b16, device=dev)
+    dt = torch.empty(M, E, dtype=f32, device=dev); parts = torch.zeros(2, nb, 2, E, dtype=f32, device=dev)
+    H.enc_tail_bwd(M=M, F=F, drop_p=0.0, gate_scale=1.0, seeds=(1, 3), dy=dy, dy2=dy2, t2=out32[1], mean2=stats[2], rstd2=stats[3],
+                   g2=g2, hdn=hdn, WT2=W2.t().contiguous(), WT1=W1.t().contiguous(), WTo=Wo.t().contiguous(), t=out32[0],
+                   mean1=stats[0], rstd1=stats[1], g1=g1, dt2b=g16[0], dhdn=dhdn, dtb=g16[1], d_o=g16[2], dt=dt, part2=parts[0],
+                   part1=parts[1])
+    torch.cuda.synchronize()
+
+    def ln_bwd(gin, x, mean, rstd, gam):
+        xh = (x - mean[:, None]) * rstd[:, None]
+        gh = gin * gam
+        dx = rstd[:, None] * (gh - gh.mean(-1, keepdim=True) - xh * (gh * xh).mean(-1, keepdim=True))
+        return dx, (gin * xh).sum(0), gin.sum(0)
+    gsum = dy + dy2
+    dt2, dg2, db2 = ln_bwd(gsum, out32[1], stats[2], stats[3], g2)
+    dt2b = bf(dt2)
+    dh = bf((hdn.float() > 0) * (dt2b.float() @ W2.float()))
+    dx1 = dh.float() @ W1.float() + dt2
+    dt_ref, dg1, db1 = ln_bwd(dx1, out32[0], stats[0], stats[1], g1)
+    do = bf(bf(dt_ref).float() @ Wo.float())
+    assert rel(g16[0], dt2b) < 3e-3 and rel(dhdn, dh) < 5e-3
+    assert rel(dt, dt_ref) < 2e-3 and rel(g16[1], bf(dt_ref)) < 4e-3 and rel(g16[2], do) < 6e-3
+    assert rel(parts[0].sum(0)[0], dg2) < 1e-4 and rel(parts[0].sum(0)[1], db2) < 1e-4
+    assert rel(parts[1].sum(0)[0], dg1) < 3e-3 and rel(parts[1].sum(0)[1], db1) < 3e-3
+
+
+def to_cuda(samples, targets):
+    from reftr_amd.util.misc import NestedTensor
+    s = {k: v.cuda() for k, v in samples.items() if k not in ("img", "img_mask")}
+    s["img"] = NestedTensor(samples["img"].cuda(), samples["img_mask"].cuda())
+    return s, [{k: v.cuda() for k, v in t.items()} for t in targets]
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, monkeypatch, train):
+    """Three encoder layers (the last one without next-layer projections) inside RefTR, B = 3 with ragged padding (M = 72: a partial
+    row block), dropout on: forward tensors, the encoder memory, the loss and every gradient against REFTR_ENC_FUSE=0."""
+    from reftr_amd.engine_vg import _total
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    ocfg = O.Cfg(enc_layers=3, dec_layers=2, bert=O.BertCfg(layers=1))
+    cfg = L.ModelConfig(enc_layers=3, dec_layers=2, bert=L.BertConfig(layers=1))
+    model = RefTR(cfg, device="cuda")
+    model.load_state_dict(formula_state(param_shapes(ocfg)), strict=True)
+    torch.manual_seed(3)
+    model.store.P["bbox_embed.layers.2.weight"].normal_(0, 0.02)
+    model.mark_dirty()
+    model.train(train)
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    s, tg = to_cuda(*make_inputs("encfuse", B=3, H=96, W=128, L=12))
+    res = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("REFTR_ENC_FUSE", fuse)
+        model.seed_dev.fill_(11)
+        out = model(s)
+        sv = model._saved
+        assert all(bool(r.get("fused")) == (fuse == "1") for r in sv["enc"])
+        enc = [{k: r[k].detach().clone() for k in ("t", "x1_16", "hdn", "t2", "qk", "v", "o")} for r in sv["enc"]]
+        total = _total(crit, crit(out, tg))
+        model.store.flat_g.zero_()
+        total.backward()
+        res.append(dict(mem=sv["mem32"].detach().clone(), logits=out["pred_logits"].detach().clone(), enc=enc, loss=float(total),
+                        grad=model.store.flat_g.detach().clone()))
+    a, b = res
+    for i, (ra, rb) in enumerate(zip(a["enc"], b["enc"])):
+        for k in ra:
+            tol = 2e-5 if ra[k].dtype == torch.float32 and i == 0 and k == "t" else 4e-3
+            assert rel(rb[k], ra[k]) < tol, (i, k, rel(rb[k], ra[k]))
+    assert rel(b["mem"], a["mem"]) < 2e-3, rel(b["mem"], a["mem"])
+    assert abs(b["loss"] - a["loss"]) < 2e-3 * abs(a["loss"])
+    d = rel(b["grad"], a["grad"])
+    assert d < 3e-2, d                                    # bf16 rounding flips of the hidden units / operands, nothing systematic
+    cos = float((a["grad"] * b["grad"]).sum() / (a["grad"].norm() * b["grad"].norm()))
+    assert cos > 0.9995, cos
