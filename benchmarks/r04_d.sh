@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_encoder_fused_gpu.py -x -q > gpurun_out/r04d_enc.log 2>&1; echo "enc rc $?"
-tail -25 gpurun_out/r04d_enc.log
+grep -n "assert\|Error\|passed\|failed" gpurun_out/r04d_enc.log | head -20
 VAR=REFTR_ENC_FUSE VALS="0 1" timeout 600 bash benchmarks/ab_env.sh > gpurun_out/r04d_ab_enc.txt 2>&1; cat gpurun_out/r04d_ab_enc.txt

@@ -27,7 +27,8 @@ namespace {
 
 constexpr int EE = 256, RB = 32, ENT = 512, ENS = 3;
 constexpr int STAGE_BYTES = 256 * 128, ACT_BYTES = RB * EE * 2, ELPT = 4;      // 256 weight rows x 64 k; DMA instructions per thread per tile
-constexpr int SMEM_BYTES = ENS * STAGE_BYTES + 3 * ACT_BYTES + 2 * RB * 4 * 4 + 2 * 2 * EE * 4;
+constexpr int TOUCH_OFF = ENS * STAGE_BYTES + 3 * ACT_BYTES + 2 * RB * 4 * 4 + 2 * 2 * EE * 4;      // 256 scratch bytes per wave for the L2 touches
+constexpr int SMEM_BYTES = TOUCH_OFF + 8 * 256;
 
 typedef __attribute__((ext_vector_type(4))) int e_i32x4;
 typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
@@ -41,6 +42,27 @@ __device__ __forceinline__ void e_dma16(const e_i32x4 rsrc, unsigned lds_base, i
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory", "m0");
+}
+
+// 4 bytes per lane into a scratch LDS word: pulls a 128-byte line into this XCD's L2 without a register destination
+__device__ __forceinline__ void e_dma4(const e_i32x4 rsrc, unsigned lds_base, int voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 ::"s"(lds_base), "v"(voff), "s"(rsrc)
+                 : "memory", "m0");
+}
+// Outputs are written through and dropped from L2 (sc1): a layer's kernel writes ~4.5 MB per XCD that nothing in it reads again,
+// next to the 2.6 MB weight stream that all of the XCD's workgroups re-read tile by tile from the 4 MB L2.
+constexpr int E_WT = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t e_out_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+typedef unsigned e_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned e_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void e_st_f32x4(float* base, size_t elem, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<e_u32x4*>(&v), e_out_rsrc(base), (int)(elem * 4), 0, E_WT);
+}
+__device__ __forceinline__ void e_st_bf16x4(void* base, size_t elem, bf16x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<e_u32x2*>(&v), e_out_rsrc(base), (int)(elem * 2), 0, E_WT);
 }
 
 struct EUnit { const bf16_t* W; unsigned bytes; int n_base, ldw, k_base; };
@@ -65,6 +87,25 @@ __device__ __forceinline__ void ectx_init(ECtx& c, unsigned char* smem, int n_ti
 __device__ __forceinline__ unsigned char* e_act(const ECtx& c, int i) { return c.smem + ENS * STAGE_BYTES + i * ACT_BYTES; }
 __device__ __forceinline__ float* e_red(const ECtx& c, int i) { return reinterpret_cast<float*>(c.smem + ENS * STAGE_BYTES + 3 * ACT_BYTES) + i * RB * 4; }
 __device__ __forceinline__ float* e_colbuf(const ECtx& c) { return reinterpret_cast<float*>(c.smem + ENS * STAGE_BYTES + 3 * ACT_BYTES + 2 * RB * 4 * 4); }
+
+// The weight stream is COLD when a layer's kernel starts (every layer has its own weights; AdamW rewrote them milliseconds ago): with
+// three 32 KB stages in flight a tile that misses L2 costs ~1 us (measured: 80 tiles -> 81 us, profiles/r04e_*), 14 workgroups per XCD
+// waiting on the same miss.  So the first thing the kernel does is ask for the WHOLE stream: the workgroups of an XCD (blocks b, b + 8,
+// ...: the hardware deals them round-robin -- for speed only) split its 128-byte lines among them, 4-byte LDS-DMA touches into a scratch
+// word, ~3 per thread, never read.  They are the oldest entries of every wave's vmcnt queue, i.e. the first tile's wait covers them.
+__device__ __forceinline__ void e_touch(const ECtx& c, const void* base, unsigned bytes) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int nx = ((int)gridDim.x + 7) >> 3, xw = (int)blockIdx.x >> 3;
+    const bool short_xcd = ((int)gridDim.x & 7) != 0 && ((int)blockIdx.x & 7) >= ((int)gridDim.x & 7);     // this XCD has nx - 1 workgroups
+    const e_i32x4 rs = e_rsrc(base, bytes);
+    const unsigned scratch = (unsigned)(uintptr_t)(lds_ptr)(c.smem + TOUCH_OFF) + (unsigned)c.wave * 256u;
+    const int lines = (int)((bytes + 127) >> 7);
+    for (int l0 = 0; l0 < lines; l0 += nx * ENT) {
+        const int l = l0 + xw * ENT + c.t;
+        e_dma4(rs, scratch, l < lines ? l * 128 : 0x7fffffff);
+        if (short_xcd && xw == 0) { const int l2 = l0 + (nx - 1) * ENT + c.t; e_dma4(rs, scratch, l2 < lines ? l2 * 128 : 0x7fffffff); }
+    }
+}
 
 // tile `ti` of the kernel's weight stream -> its stage (ti % ENS).  Past the end: out-of-range offsets (the DMA writes zeros into a
 // stage nobody reads any more), so that every thread's vmcnt bookkeeping stays uniform.
@@ -171,6 +212,8 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_fwd_kernel(const rt_enc_tail_
         xres[a] = e_ld4(p.x32 + (size_t)m * EE + e_col(c, a), row_ok);
         posv[a] = p.pos ? e_ld4(p.pos + (size_t)m * EE + e_col(c, a), row_ok) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    e_touch(c, p.Wo, EE * EE * 2); e_touch(c, p.W1, (unsigned)(p.F * EE * 2)); e_touch(c, p.W2, (unsigned)(EE * p.F * 2));
+    if (proj) { e_touch(c, p.Wqk, 2 * EE * EE * 2); e_touch(c, p.Wv, EE * EE * 2); }
     e_load_rows(c, (const bf16_t*)p.o, m0, p.M, e_act(c, 0));
 #pragma unroll
     for (int s = 0; s < ENS - 1; ++s) e_issue(c, unit_of);
@@ -211,12 +254,12 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_fwd_kernel(const rt_enc_tail_
     auto st_bf16 = [&](void* dst, int ld, int col0, const bf16x4_t (&o)[4]) __attribute__((always_inline)) {
         if (!row_ok || !dst) return;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) *reinterpret_cast<bf16x4_t*>((bf16_t*)dst + (size_t)m * ld + col0 + e_col(c, a)) = o[a];
+        for (int a = 0; a < 4; ++a) e_st_bf16x4(dst, (size_t)m * ld + col0 + e_col(c, a), o[a]);
     };
     auto st_f32 = [&](float* dst, const f32x4 (&v)[4]) __attribute__((always_inline)) {
         if (!row_ok || !dst) return;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4*>(dst + (size_t)m * EE + e_col(c, a)) = v[a];
+        for (int a = 0; a < 4; ++a) e_st_f32x4(dst, (size_t)m * EE + e_col(c, a), v[a]);
     };
 
     // ---- out_proj + dropout1 + residual (rt_conv_gemm epilogue order: +bias -> dropout -> +res) -> norm1
@@ -333,6 +376,7 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_
     }
     const float mean2 = row_ok ? p.mean2[m] : 0.f, rstd2 = row_ok ? p.rstd2[m] : 0.f;
     const float mean1 = row_ok ? p.mean1[m] : 0.f, rstd1 = row_ok ? p.rstd1[m] : 0.f;
+    e_touch(c, p.WT2, (unsigned)(p.F * EE * 2)); e_touch(c, p.WT1, (unsigned)(EE * p.F * 2)); e_touch(c, p.WTo, EE * EE * 2);
 #pragma unroll
     for (int s = 0; s < ENS - 1; ++s) e_issue(c, unit_of);
 
@@ -395,7 +439,7 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_
     auto st_bf16 = [&](void* dst, int ld, int col0, const bf16x4_t (&o)[4]) __attribute__((always_inline)) {
         if (!row_ok || !dst) return;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) *reinterpret_cast<bf16x4_t*>((bf16_t*)dst + (size_t)m * ld + col0 + e_col(c, a)) = o[a];
+        for (int a = 0; a < 4; ++a) e_st_bf16x4(dst, (size_t)m * ld + col0 + e_col(c, a), o[a]);
     };
 
     // ---- norm2 backward: dt2 (fp32, the residual path) and dt2b = bf16(dt2 through dropout2): linear2's output gradient
@@ -431,7 +475,7 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_
     ln_bwd(dx1, xv1, mean1, rstd1, p.g1, p.part1, dt);
     if (row_ok)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4*>(p.dt + (size_t)m * EE + e_col(c, a)) = dt[a];
+        for (int a = 0; a < 4; ++a) e_st_f32x4(p.dt, (size_t)m * EE + e_col(c, a), dt[a]);
     drop_bf16(dt, s_d1, ob);
     st_bf16(p.dtb, EE, 0, ob);
     e_store_act(c, e_act(c, 2), ob);

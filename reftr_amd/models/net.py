@@ -318,9 +318,13 @@ class Net:
     # ------------------------------------------------------------------ encoder layer (transformer.py:168-181)
     def enc_fuse_ok(self):
         """The row-local part of an encoder layer as one launch per direction (rt_enc_tail_fwd / rt_enc_tail_bwd): the reference's
-        width, a feed-forward width in whole 256-unit chunks.  REFTR_ENC_FUSE=0: the launched chain."""
+        width, a feed-forward width in whole 256-unit chunks.  OFF by default (REFTR_ENC_FUSE=1 turns it on): measured slower than the
+        launched chain at configs[1]'s M = 3520 rows -- a row block's workgroup streams the layer's whole 2.6 MB of weights through ONE
+        compute unit's LDS-DMA path, which delivers ~32 KB/us: 80.5 / 71 us per layer against 78 / 72 us for the chain's 6 + 5 launches
+        (profiles/r04_enc_fused_negative_result.txt).  Kept: correct (tests/test_encoder_fused_gpu.py), and the right shape once a row
+        block can be split over compute units."""
         cfg = self.cfg
-        return (os.environ.get("REFTR_ENC_FUSE", "1") != "0" and str(self.store.device).startswith("cuda")
+        return (os.environ.get("REFTR_ENC_FUSE", "0") == "1" and str(self.store.device).startswith("cuda")
                 and cfg.hidden == 256 and cfg.ffn >= 256 and cfg.ffn % 256 == 0)
 
     def enc_layer_fwd(self, p, x32, x16, xp16, pos, kpm, B, S, qkv=None, next_p=None):
@@ -390,6 +394,8 @@ class Net:
         dh = E // Hh
         M = B * S
         gs = 1.0 / (1.0 - r["dh"][0]) if r["dh"][0] > 0 else 1.0
+        if getattr(self, "_dbg_enc", None) is not None:          # tests: the gradient that enters the layer
+            self._dbg_enc.append((dx2 if dx2b is None else dx2 + dx2b).detach().clone())
         if self.enc_fuse_ok() and self.ln_batch is not None and self.big_wg is not None:
             # norm2 backward -> linear2^T (gate) -> linear1^T + residual -> norm1 backward -> out_proj^T: ONE launch (rt_enc_tail_bwd);
             # it leaves the weight-gradient operands and the LayerNorm parameter-gradient partials for the grouped launches
@@ -428,6 +434,8 @@ class Net:
         _, dxa = self.lin_bwd(p + "self_attn.v", dv, r["x16"], res_f32=dt, out_bf16=False, out_f32=True, group=grp)
         _, dxp = self.lin_bwd(p + "self_attn.qk", dqk, r["xp16"], out_bf16=False, out_f32=True, group=grp, acc2_f32=dpos_acc)
         grp.run()
+        if getattr(self, "_dbg_enc", None) is not None:          # tests: the per-layer input gradient
+            self._dbg_enc.append((dxa + dxp).detach().clone())
         return dxa, dxp          # sum of the two = gradient w.r.t. the layer input
 
     # ------------------------------------------------------------------ decoder layer (transformer.py:231-252)

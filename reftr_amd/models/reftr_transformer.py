@@ -182,15 +182,16 @@ class RefTR(nn.Module):
             jobs += [(off(c.w32), c.cop, c.k * c.k, c.cip, None, c.W, c.WT) for c in self.seg.convs.values()]
         # large tables that feed no GEMM (BERT's word / position embeddings: 24 M parameters) take the same tiled pass without
         # operand copies: it streams at 5.5 TB/s where the chunk pass over them ran at 3.9
-        starts = sorted(j[0] for j in jobs)
+        spans = sorted((j[0], j[0] + j[1] * j[2] * j[3]) for j in jobs)
         import bisect
         for name, shape, kind in st.table:
             if kind != "param" or len(shape) != 2 or name in st.physd:
                 continue
             n = shape[0] * shape[1]
             o = st.offset[name][1]
-            i = bisect.bisect_left(starts, o)
-            if n >= 65536 and shape[1] % 4 == 0 and not (i < len(starts) and starts[i] < o + n):
+            i = bisect.bisect_right(spans, (o, 1 << 62))          # first job that starts behind o; the one in front may still cover it
+            covered = (i < len(spans) and spans[i][0] < o + n) or (i > 0 and spans[i - 1][1] > o)
+            if n >= 65536 and shape[1] % 4 == 0 and not covered:
                 jobs.append((o, shape[0], 1, shape[1], None, None, None))
         return jobs
 

@@ -116,11 +116,16 @@ def to_cuda(samples, targets):
 @pytest.mark.parametrize("train", [False, True])
 def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, monkeypatch, train):
     """Three encoder layers (the last one without next-layer projections) inside RefTR, B = 3 with ragged padding (M = 72: a partial
-    row block), dropout on: forward tensors, the encoder memory, the loss and every gradient against REFTR_ENC_FUSE=0."""
+    row block), dropout on.  Forward: every saved tensor, the encoder memory and the loss against REFTR_ENC_FUSE=0 (same dropout
+    sites, same masks).  Backward: each layer's backward is run BOTH ways on the same saved state and the same incoming gradient --
+    the end-to-end gradient of this 3-box fixture moves by 11 % when the memory moves by 2e-3 (loss kinks in the head, measured:
+    what enters the last encoder layer already differs by 0.109 between the two runs and leaves the first one at 0.114), so only
+    a per-layer comparison on identical inputs says anything about the kernels."""
     from reftr_amd.engine_vg import _total
     from reftr_amd.models import layout as L
     from reftr_amd.models.criterion import CriterionVGMultiPhrase
     from reftr_amd.models.reftr_transformer import RefTR
+    H = hip
     ocfg = O.Cfg(enc_layers=3, dec_layers=2, bert=O.BertCfg(layers=1))
     cfg = L.ModelConfig(enc_layers=3, dec_layers=2, bert=L.BertConfig(layers=1))
     model = RefTR(cfg, device="cuda")
@@ -139,11 +144,7 @@ def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, mon
         sv = model._saved
         assert all(bool(r.get("fused")) == (fuse == "1") for r in sv["enc"])
         enc = [{k: r[k].detach().clone() for k in ("t", "x1_16", "hdn", "t2", "qk", "v", "o")} for r in sv["enc"]]
-        total = _total(crit, crit(out, tg))
-        model.store.flat_g.zero_()
-        total.backward()
-        res.append(dict(mem=sv["mem32"].detach().clone(), logits=out["pred_logits"].detach().clone(), enc=enc, loss=float(total),
-                        grad=model.store.flat_g.detach().clone()))
+        res.append(dict(mem=sv["mem32"].detach().clone(), enc=enc, loss=float(_total(crit, crit(out, tg)).detach())))
     a, b = res
     for i, (ra, rb) in enumerate(zip(a["enc"], b["enc"])):
         for k in ra:
@@ -151,7 +152,29 @@ def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, mon
             assert rel(rb[k], ra[k]) < tol, (i, k, rel(rb[k], ra[k]))
     assert rel(b["mem"], a["mem"]) < 2e-3, rel(b["mem"], a["mem"])
     assert abs(b["loss"] - a["loss"]) < 2e-3 * abs(a["loss"])
-    d = rel(b["grad"], a["grad"])
-    assert d < 3e-2, d                                    # bf16 rounding flips of the hidden units / operands, nothing systematic
-    cos = float((a["grad"] * b["grad"]).sum() / (a["grad"].norm() * b["grad"].norm()))
-    assert cos > 0.9995, cos
+    # ---- backward, layer by layer, on the fused forward's saved state (interchangeable with the chain's) and identical inputs
+    sv, net, st = model._saved, model.net, model.store
+    B, S = sv["B"], sv["S"]
+    M = B * S
+    g = torch.Generator(device="cpu").manual_seed(9)
+    H.set_seed_dev(model.seed_dev)
+    for i in reversed(range(cfg.enc_layers)):
+        dx2 = torch.randn(M, E, generator=g).cuda(); dx2b = (torch.randn(M, E, generator=g) * 0.3).cuda() if i != 1 else None
+        outs = []
+        for fuse in ("0", "1"):
+            monkeypatch.setenv("REFTR_ENC_FUSE", fuse)
+            st.flat_g.zero_()
+            dpos = torch.zeros(M, E, device="cuda")
+            dxa, dxp = net.enc_layer_bwd(f"vl_transformer.encoder.layers.{i}.", sv["enc"][i], dx2, dx2b, sv["kpm"], B, S, dpos)
+            net.flush_wgrads()
+            torch.cuda.synchronize()
+            outs.append((dxa.clone(), dxp.clone(), dpos.clone(), st.flat_g.clone()))
+        (xa0, xp0, dp0, g0), (xa1, xp1, dp1, g1) = outs
+        # bf16 operands inside (dt2b, dhdn, dtb, do): the fused launch may round a value the other way where its fp32 input differs in the
+        # last bit; measured <= 3e-3 on every output
+        assert rel(xa1, xa0) < 6e-3 and rel(xp1, xp0) < 6e-3 and rel(dp1, dp0) < 6e-3, (i, rel(xa1, xa0), rel(xp1, xp0))
+        assert float(g0.norm()) > 0 and rel(g1, g0) < 6e-3, (i, rel(g1, g0))
+        for nm in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "linear1.weight", "linear2.bias", "self_attn.out_proj.weight"):
+            n = f"vl_transformer.encoder.layers.{i}.{nm}"
+            assert rel(st.view_of(g1, n), st.view_of(g0, n)) < 6e-3, (n, rel(st.view_of(g1, n), st.view_of(g0, n)))
+    H.set_seed_dev(None)
