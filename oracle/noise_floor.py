@@ -116,5 +116,65 @@ def grad_floor(multi=False):
     return res
 
 
-if __name__ == "__main__" and os.environ.get("GRAD_FLOOR"):
+if __name__ == "__main__" and os.environ.get("GRAD_FLOOR") == "1":
     print(json.dumps({"grad_floor_single": grad_floor(False), "grad_floor_multi": grad_floor(True)}, indent=1))
+
+
+def grad_floor_samples(multi=False, seeds=tuple(range(1, 17))):
+    """VERDICT r03 item 8(ii): the gradient order floor as a DISTRIBUTION.  The test's quantity (tests/test_parity_fullsize_gpu.py::
+    test_cfg1_full_depth_backward_of_a_linear_functional_vs_oracle: gradients of sum(logits * W), W = the test's formula tensor, masked
+    to the valid phrase slots) under the q=True oracle in torch's fp32 order (the baseline the HIP path is compared with) against
+    the SAME computation in other summation orders: `accumulate_permuted(seed)` for every seed, and fp64 accumulation.  Returns the
+    samples and their mean / standard deviation; the test's gates are mean + 3 sigma (cosine: mean - 3 sigma)."""
+    from oracle.weights import formula_tensor
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ocfg = O.Cfg()
+    samples, targets = make_inputs("e2e_multi" if multi else "e2e_single", B=2, H=320, W=320, L=40, n_phrase=3 if multi else 0)
+    P = formula_state(param_shapes(ocfg))
+    names = [k for k in P if O.is_trainable(k) and torch.is_floating_point(P[k])]
+    Wf = None
+
+    def run(ctx):
+        nonlocal Wf
+        Pq = {k: v.clone() for k, v in P.items()}
+        leaves = [Pq[k].requires_grad_(True) for k in names]
+        if ctx:
+            ctx.__enter__()
+        try:
+            o = O.reftr_forward(Pq, samples, ocfg, q=True)
+            if Wf is None:
+                Wf = formula_tensor("functional.w", tuple(o["logits"].shape), 1.0, bf16=False)
+                if multi:
+                    Wf = Wf * o["phrase_mask"].view(1, *o["phrase_mask"].shape, 1, 1).float()
+            scalar = (o["logits"] * Wf).sum()
+            inter = [o["hs"], o["memory"], o["c5"]]
+            allg = torch.autograd.grad(scalar, leaves + inter, allow_unused=True)
+        finally:
+            if ctx:
+                ctx.__exit__()
+        pg = torch.cat([(a if a is not None else torch.zeros_like(P[k])).reshape(-1) for k, a in zip(names, allg[:len(names)])])
+        c5mask = (o["c5"] > 0).float()          # the HIP path hands on dL/d(pre-ReLU): the test compares d_c5 * (c5 > 0)
+        return dict(d_hs=allg[len(names)], d_memory=allg[len(names) + 1], d_c5=allg[len(names) + 2] * c5mask, params=pg)
+    base = run(None)
+    rows = []
+    for tag, ctx in [(f"perm{s}", O.accumulate_permuted(s)) for s in seeds] + [("fp64acc", O.accumulate_fp64())]:
+        t0 = time.time()
+        g = run(ctx)
+        r = {k: rel(g[k], base[k]) for k in base}
+        r["params_cosine"] = float((g["params"].double() * base["params"].double()).sum() / (g["params"].double().norm() * base["params"].double().norm()))
+        r["order"] = tag; r["seconds"] = round(time.time() - t0, 1)
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+    keys = ("d_hs", "d_memory", "d_c5", "params", "params_cosine")
+    n = len(rows)
+    mean = {k: sum(r[k] for r in rows) / n for k in keys}
+    std = {k: (sum((r[k] - mean[k]) ** 2 for r in rows) / max(n - 1, 1)) ** 0.5 for k in keys}
+    gate = {k: (mean[k] - 3 * std[k] if k == "params_cosine" else mean[k] + 3 * std[k]) for k in keys}
+    return {"samples": rows, "mean": mean, "std": std, "gate_mean_3sigma": gate}
+
+
+if __name__ == "__main__" and os.environ.get("GRAD_FLOOR") == "samples":
+    out = {"workload": "configs[0] size: 320x320, B = 2, L = 40, 12 + 6 + 6 layers, q=True oracle, gradient of sum(logits * W)",
+           "single": grad_floor_samples(False), "multi": grad_floor_samples(True)}
+    json.dump(out, open(os.environ.get("OUT", "profiles/r04_noise_floor_gradients.json"), "w"), indent=1)
+    print(json.dumps({k: out[k]["gate_mean_3sigma"] for k in ("single", "multi")}, indent=1))

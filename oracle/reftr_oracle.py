@@ -72,7 +72,7 @@ class Cfg:
 # around it when q=True.  The distance between the two `q=True` forwards is the floor any bf16-operand implementation with its
 # own accumulation order (the MFMA path) can be expected to sit at (tests/test_oracle_golden.py).
 # ----------------------------------------------------------------------------------------------
-_ACC = {"fp64": False, "fp32_trunk_from": 0}      # fp32_trunk_from = L > 0: experiment, see `fp32_trunk`
+_ACC = {"fp64": False, "fp32_trunk_from": 0, "perm": 0, "site": 0}      # fp32_trunk_from = L > 0: experiment, see `fp32_trunk`
 
 
 class fp32_trunk:
@@ -100,6 +100,40 @@ class accumulate_fp64:
         _ACC["fp64"] = self._old
 
 
+class accumulate_permuted:
+    """Yet another summation order of the same computation, in fp32: every contraction is cut into 2..5 chunks along its
+    reduction axis and the chunk products are added in an order that depends on `seed` (and on the call site, so that no two
+    contractions of a forward use the same cut).  Many seeds = many samples of the order floor (the
+    gradient gates must come from a distribution of floor samples, not from one).  seed = 0: off."""
+
+    def __init__(self, seed):
+        self.seed = int(seed)
+
+    def __enter__(self):
+        self._old = (_ACC["perm"], _ACC["site"])
+        _ACC["perm"], _ACC["site"] = self.seed, 0
+
+    def __exit__(self, *a):
+        _ACC["perm"], _ACC["site"] = self._old
+
+
+def _perm_chunks(K):
+    """[(begin, end), ...] of the reduction axis in the order the chunk products are added, or None (axis too short / off)."""
+    seed = _ACC["perm"]
+    if not seed or K < 32:
+        return None
+    _ACC["site"] += 1
+    h = (seed * 2654435761 + _ACC["site"] * 40503) & 0xFFFFFFFF
+    n = 2 + (h >> 3) % 4
+    edges = [K * i // n for i in range(n + 1)]
+    order = list(range(n))
+    rot = (h >> 7) % n
+    order = order[rot:] + order[:rot]
+    if (h >> 11) & 1:
+        order.reverse()
+    return [(edges[i], edges[i + 1]) for i in order]
+
+
 def _d(t):
     return None if t is None else t.double()
 
@@ -107,21 +141,46 @@ def _d(t):
 def conv2d_acc(x, w, b=None, *a, **k):
     if _ACC["fp64"]:
         return F.conv2d(_d(x), _d(w), _d(b), *a, **k).float()
+    ch = _perm_chunks(x.shape[1]) if k.get("groups", 1) == 1 and (len(a) < 4 or a[3] == 1) else None
+    if ch is not None:
+        y = None
+        for lo, hi in ch:
+            part = F.conv2d(x[:, lo:hi], w[:, lo:hi], None, *a, **k)
+            y = part if y is None else y + part
+        return y if b is None else y + b.view(1, -1, 1, 1)
     return F.conv2d(x, w, b, *a, **k)
 
 
 def linear_acc(x, w, b=None):
     if _ACC["fp64"]:
         return F.linear(_d(x), _d(w), _d(b)).float()
+    ch = _perm_chunks(x.shape[-1])
+    if ch is not None:
+        y = None
+        for lo, hi in ch:
+            part = F.linear(x[..., lo:hi], w[:, lo:hi])
+            y = part if y is None else y + part
+        return y if b is None else y + b
     return F.linear(x, w, b)
 
 
+def _mm_perm(fn, a, b):
+    ch = _perm_chunks(a.shape[-1])
+    if ch is None:
+        return fn(a, b)
+    y = None
+    for lo, hi in ch:
+        part = fn(a[..., lo:hi], b[..., lo:hi, :])
+        y = part if y is None else y + part
+    return y
+
+
 def bmm_acc(a, b):
-    return torch.bmm(a.double(), b.double()).float() if _ACC["fp64"] else torch.bmm(a, b)
+    return torch.bmm(a.double(), b.double()).float() if _ACC["fp64"] else _mm_perm(torch.bmm, a, b)
 
 
 def matmul_acc(a, b):
-    return torch.matmul(a.double(), b.double()).float() if _ACC["fp64"] else torch.matmul(a, b)
+    return torch.matmul(a.double(), b.double()).float() if _ACC["fp64"] else _mm_perm(torch.matmul, a, b)
 
 
 class _Round(torch.autograd.Function):
@@ -276,6 +335,9 @@ def mha(P, pfx, query, key, value, key_padding_mask, nheads, p_drop=0.0, train=F
         scores = scores.view(B, nheads, Lq, Lk).masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
         scores = scores.view(B * nheads, Lq, Lk)
     attn = drop(F.softmax(scores, dim=-1), p_drop, train)
+    # q-mode: the MFMA attention kernels (rt_attn_fwd / rt_attn_bwd) hand the probabilities to the P V product as bf16 operands;
+    # the one-query kernels (a single query row per image: the single-phrase decoder) keep them in fp32 (csrc/rt_attention.hip)
+    attn = rq(attn, q and Lq > 1)
     out = bmm_acc(attn, vh).transpose(0, 1).reshape(Lq, B, E)
     return linear_acc(rq(out, q), rq_fwd(P[pfx + "out_proj.weight"], q), P[pfx + "out_proj.bias"])
 
@@ -325,7 +387,7 @@ def bert_forward(P, ids, attn_mask, bc: BertCfg, pfx="lang_backbone.", train=Fal
         kh = rq(linear(h, P, lp + "attention.self.key.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
         vh = rq(linear(h, P, lp + "attention.self.value.", q), q).view(B, L, bc.heads, dh).transpose(1, 2)
         s = matmul_acc(qh, kh.transpose(-1, -2)) / math.sqrt(dh) + add_mask
-        a = drop(F.softmax(s, dim=-1), bc.dropout, train)
+        a = rq(drop(F.softmax(s, dim=-1), bc.dropout, train), q)          # bf16 operand of the P V product (rt_attn_fwd)
         ctx = matmul_acc(a, vh).transpose(1, 2).reshape(B, L, bc.hidden)
         o = drop(linear(ctx, P, lp + "attention.output.dense.", q), bc.dropout, train)
         h = layer_norm(h + o, P, lp + "attention.output.LayerNorm.", bc.eps)
@@ -484,7 +546,9 @@ def mask_head(P, x, bbox_mask, fpns, pfx="mask_head.", q=False):
         cur = conv(f, f"adapter{i + 1}", 0)
         if cur.shape[0] != x.shape[0]:
             cur = expand(cur, x.shape[0] // cur.shape[0])
-        x = cur + F.interpolate(x, size=cur.shape[-2:], mode="nearest")
+        # q-mode: GroupNorm + ReLU leaves its output as a bf16 operand in the HIP path (rt_gn_nhwc_fwd), also where the next consumer
+        # is the FPN's upsample + add (rt_upsample_add) rather than a convolution
+        x = cur + F.interpolate(rq(x, q), size=cur.shape[-2:], mode="nearest")
         x = gn(conv(x, f"lay{i + 3}", 1), f"gn{i + 3}")
     return conv(x, "out_lay", 1), x
 

@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256) void small_m_wgrad_kernel(const bf16_t* __rest
 // B*n_q token rows produce ~50 of these per step; none of them is on the backward-data dependency chain.
 struct SmallJobs { rt_small_wgrad_job j[64]; int first[65]; int n; };
 __global__ __launch_bounds__(256) void small_m_wgrad_grouped_kernel(const SmallJobs p) {
+    __shared__ float sm[16];
     int lo = 0, hi = p.n - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (p.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const rt_small_wgrad_job& q = p.j[lo];
@@ -593,29 +594,42 @@ __global__ __launch_bounds__(256) void small_m_wgrad_grouped_kernel(const SmallJ
     const int k4 = q.K >> 2;
     const size_t total = (size_t)q.N * k4;
     const size_t i = (size_t)(blockIdx.x - p.first[lo]) * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int kk = (int)(i % k4) * 4, n = (int)(i / k4);
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    float gs = 0.f;
-    // all <= 16 rows' loads are requested before the first use (rows past M re-read the last row: cache hits, masked out below):
-    // the launch is a few thousand workgroups of one load round trip each, not M of them
-    float gv[16]; bf16x4 xv[16];
+    float ss = 0.f;                          // |dw after|^2 - |dw before|^2 of this thread's four elements (the clip norm, rt_sqnorm_finish)
+    if (i < total) {
+        const int kk = (int)(i % k4) * 4, n = (int)(i / k4);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        float gs = 0.f;
+        // all <= 16 rows' loads are requested before the first use (rows past M re-read the last row: cache hits, masked out below):
+        // the launch is a few thousand workgroups of one load round trip each, not M of them
+        float gv[16]; bf16x4 xv[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int mm = m < q.M ? m : q.M - 1;
-        gv[m] = (float)dy[(size_t)mm * q.N + n];
-        xv[m] = *reinterpret_cast<const bf16x4*>(x + (size_t)mm * q.K + kk);
+        for (int m = 0; m < 16; ++m) {
+            const int mm = m < q.M ? m : q.M - 1;
+            gv[m] = (float)dy[(size_t)mm * q.N + n];
+            xv[m] = *reinterpret_cast<const bf16x4*>(x + (size_t)mm * q.K + kk);
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m >= q.M) continue;
+            gs += gv[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += gv[m] * (float)xv[m][r];
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(q.dw + (size_t)n * q.K + kk);
+        if (q.overwrite) {
+            const f32x4 d = a * a; ss = (d[0] + d[1]) + (d[2] + d[3]);
+            *o = a;
+        } else {
+            const f32x4 old = *o;
+            const f32x4 d = a * (old + old + a); ss = (d[0] + d[1]) + (d[2] + d[3]);
+            *o = old + a;
+        }
+        if (q.dbias && kk == 0) q.dbias[n] += gs;
     }
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        if (m >= q.M) continue;
-        gs += gv[m];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] += gv[m] * (float)xv[m][r];
+    if (q.sqacc) {                           // uniform per workgroup: a workgroup belongs to one job
+        ss = rt_block_sum(ss, sm);
+        if (threadIdx.x == 0) rt_sq_add(q.sqacc, blockIdx.x, ss);
     }
-    f32x4* o = reinterpret_cast<f32x4*>(q.dw + (size_t)n * q.K + kk);
-    *o = q.overwrite ? a : *o + a;
-    if (q.dbias && kk == 0) q.dbias[n] += gs;
 }
 
 // overwrite semantics for launches whose tiles are accumulated with atomics by several workgroups: clear dw, then accumulate
@@ -935,31 +949,8 @@ static int conv_wgrad_impl(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     return launch_wgrad<64, 64>(a, d->msplit, s);
 }
 
-static int sq_account_small(const rt_small_wgrad_job* jobs, int n, bool after, hipStream_t s) {
-    float* bufs[32]; long long cnts[32]; float signs[32];
-    int m = 0;
-    float* slots = nullptr;
-    for (int i = 0; i <= n; ++i) {
-        const bool last = i == n;
-        if (!last) {
-            const rt_small_wgrad_job& q = jobs[i];
-            if (!q.sqacc || (!after && q.overwrite)) continue;
-            if (slots && q.sqacc != slots) return RT_ERR_BADARG;
-            slots = q.sqacc;
-            bufs[m] = q.dw; cnts[m] = (long long)q.N * q.K; signs[m] = after ? 1.f : -1.f; ++m;
-        }
-        if (m == 32 || (last && m > 0)) {
-            const int rc = rt_sq_pass(bufs, cnts, signs, m, slots, s);
-            if (rc != RT_OK) return rc;
-            m = 0;
-        }
-    }
-    return RT_OK;
-}
-
 extern "C" int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream) {
     if (!jobs || njobs <= 0) return RT_ERR_BADARG;
-    { const int rc = sq_account_small(jobs, njobs, false, (hipStream_t)stream); if (rc != RT_OK) return rc; }
     for (int base = 0; base < njobs; base += 64) {
         SmallJobs p;
         p.n = njobs - base < 64 ? njobs - base : 64;
@@ -974,5 +965,5 @@ extern "C" int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs,
         hipLaunchKernelGGL(small_m_wgrad_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
         RT_CHECK_LAUNCH();
     }
-    return sq_account_small(jobs, njobs, true, (hipStream_t)stream);
+    return RT_OK;                           // (the gradient-norm contribution is taken inside the kernel)
 }
