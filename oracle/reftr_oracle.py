@@ -525,6 +525,9 @@ def mh_attention_map(P, qv, k, mask, nheads, pfx="bbox_attention.", q=False):
     return F.softmax(w.flatten(2), dim=-1).view_as(w)
 
 
+MASK_HEAD_TRACE = None      # debugging aid (benchmarks/debug_seg_floor.py): a dict that receives the head's intermediate tensors
+
+
 def mask_head(P, x, bbox_mask, fpns, pfx="mask_head.", q=False):
     """MaskHeadSmallConv.forward (reftr_segmentation.py:240-280).  x [B,2E,h,w], bbox_mask [B,Q,n,h,w],
     fpns = [stride16, stride8, stride4 features].  Returns (mask logits [B*Q,1,4h',4w'..], last feature)."""
@@ -539,17 +542,22 @@ def mask_head(P, x, bbox_mask, fpns, pfx="mask_head.", q=False):
     def gn(t, name):
         return F.relu(F.group_norm(t, 8, P[pfx + name + ".weight"], P[pfx + name + ".bias"], 1e-5))
 
+    tr = MASK_HEAD_TRACE if MASK_HEAD_TRACE is not None else {}
     x = torch.cat([expand(x, Q), bbox_mask.flatten(0, 1)], 1)
-    x = gn(conv(x, "lay1", 1), "gn1")
-    x = gn(conv(x, "lay2", 1), "gn2")
+    tr["X0"] = x
+    tr["u1"] = conv(x, "lay1", 1); x = gn(tr["u1"], "gn1"); tr["a1"] = x
+    tr["u2"] = conv(x, "lay2", 1); x = gn(tr["u2"], "gn2"); tr["a2"] = x
     for i, f in enumerate(fpns):
         cur = conv(f, f"adapter{i + 1}", 0)
+        tr[f"fo{i}"] = cur
         if cur.shape[0] != x.shape[0]:
             cur = expand(cur, x.shape[0] // cur.shape[0])
         # q-mode: GroupNorm + ReLU leaves its output as a bf16 operand in the HIP path (rt_gn_nhwc_fwd), also where the next consumer
         # is the FPN's upsample + add (rt_upsample_add) rather than a convolution
         x = cur + F.interpolate(rq(x, q), size=cur.shape[-2:], mode="nearest")
-        x = gn(conv(x, f"lay{i + 3}", 1), f"gn{i + 3}")
+        tr[f"x{i}"] = x
+        tr[f"u{i + 3}"] = conv(x, f"lay{i + 3}", 1)
+        x = gn(tr[f"u{i + 3}"], f"gn{i + 3}"); tr[f"a{i + 3}"] = x
     return conv(x, "out_lay", 1), x
 
 
