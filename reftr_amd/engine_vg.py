@@ -436,8 +436,11 @@ class CapturedTrainStep:
             self.optimizer.clear_pending()
             self._set_flush(False)
 
-    def _refresh_num_boxes(self, targets):
+    def _refresh_num_boxes(self, targets, reduced=None):
         if self.nb is None:
+            return
+        if reduced is not None:               # already averaged over the ranks by the iteration's capture decision (one collective)
+            self.nb.copy_(reduced)
             return
         self.nb.fill_(float(sum(len(t["labels"]) for t in targets)))
         torch.distributed.all_reduce(self.nb)
@@ -506,7 +509,7 @@ class CapturedTrainStep:
         if staged is None or staged[0] is not samples or staged[1] is not targets:
             _copy_batch(self.s, self.t, samples, targets)
 
-    def __call__(self, samples, targets):
+    def __call__(self, samples, targets, nb_reduced=None):
         staged = self._staged is not None and self._staged[0] is samples and self._staged[1] is targets
         assert staged or (samples is self.s and targets is self.t) or self.shape_key(samples, targets) == self.key, \
             "captured for another input shape; use train_step"
@@ -531,7 +534,7 @@ class CapturedTrainStep:
             else:
                 self.refresh_lr()
         self._stage_in(samples, targets)
-        self._refresh_num_boxes(targets)
+        self._refresh_num_boxes(targets, reduced=nb_reduced)
         self.g_fb.replay()                # deferred: applies iteration i-1's update with the rates synced at iteration i-1
         if self.deferred_dp and lrs != self._lrs:
             self._lrs = lrs
@@ -558,14 +561,19 @@ class CapturedTrainStep:
         self.optimizer.step_count = sc
 
 
-def dp_capture_decision(can_replay, can_capture, device):
+def dp_capture_decision(can_replay, can_capture, device, num_boxes=None):
     """The collective choice between replaying, capturing and the eager loop body under data parallelism: 'replay' only if
-    EVERY rank can replay its batch, 'capture' only if every rank would capture, else 'eager' on every rank (one MIN all-reduce
-    of two words)."""
-    flags = torch.tensor([int(bool(can_replay)), int(bool(can_capture))], dtype=torch.int32, device=device)
-    torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MIN)
-    all_replay, all_capture = (bool(v) for v in flags.tolist())
-    return "replay" if all_replay else ("capture" if all_capture else "eager")
+    EVERY rank can replay its batch, 'capture' only if every rank would capture, else 'eager' on every rank.  ONE all-reduce per
+    iteration: with `num_boxes` (this rank's box count) the same collective also carries the criterion's box-count average
+    (criterion.py:176-180), which a replay would otherwise have to all-reduce on its own right behind this one -- returns
+    (decision, device tensor [1] = world-average box count) then, the decision alone otherwise."""
+    v = torch.tensor([0.0 if can_replay else 1.0, 0.0 if can_capture else 1.0, float(num_boxes or 0.0)], dtype=torch.float32, device=device)
+    torch.distributed.all_reduce(v)                       # SUM: a rank that cannot contributes 1
+    no_replay, no_capture, _ = v.tolist()
+    decision = "replay" if no_replay == 0 else ("capture" if no_capture == 0 else "eager")
+    if num_boxes is None:
+        return decision
+    return decision, v[2:3] / utils.get_world_size()
 
 
 class Lookahead:
@@ -638,6 +646,7 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
     inner = getattr(model, "module", model)
     caps = inner.__dict__.setdefault("_captured_steps", {})
     dist_on = utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1
+    nb_reduced = None
     cap = inner.__dict__.get("_staged_cap")
     if cap is not None and not dist_on and cap._staged is not None and cap._staged[0] is samples and cap._staged[1] is targets \
             and cap.criterion is criterion and cap.optimizer is optimizer and cap.max_norm == max_norm and cap.training == model.training:
@@ -659,7 +668,11 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
             # otherwise every rank runs the eager step.  One 2-word MIN all-reduce per iteration, issued while the device is
             # idle behind the previous iteration's read-out.
             mine = ok
-            ok = dp_capture_decision(ok and key in caps, ok and key not in caps, inner.store.device) != "eager"
+            decision, nb_reduced = dp_capture_decision(ok and key in caps, ok and key not in caps, inner.store.device,
+                                                       num_boxes=sum(len(t["labels"]) for t in targets))
+            ok = decision != "eager"
+            if decision != "replay":
+                nb_reduced = None                   # the capture / eager paths reduce the box count themselves
             if mine and not ok:
                 # this rank could have replayed / captured, another one could not (its capture budget is spent, or its batch has a
                 # shape this rank already holds while the other must still capture): the whole job runs this iteration eagerly.
@@ -696,7 +709,7 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
                     other.flush()
     lrs_now = [g["lr"] for g in optimizer.param_groups]
     seed_back = (1 if model.training else 0, 1)
-    cap(samples, targets)
+    cap(samples, targets, nb_reduced)
     # ONE device -> host copy for everything the loop looks at (losses for the meters and the finite check, gradient norm);
     # under data parallelism the loss entries are first averaged over the ranks in one all-reduce (util/misc.py:136-160).
     # The copy is enqueued right behind the replay, into pinned memory; the host then spends the step's run time on the

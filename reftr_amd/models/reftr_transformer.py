@@ -96,6 +96,8 @@ class RefTR(nn.Module):
         # measured (profiles/r03_side_stream_probes.txt): the main-slice AdamW pass beside the frozen stem / layer1 instead of in
         # front of them changes nothing (7.295 vs 7.295 ms over four interleaved pairs) -- both are HBM-bound; off by default
         self._pre_side = os.environ.get("REFTR_PRE_SIDE", "0") != "0"
+        self._opt_serial = os.environ.get("REFTR_OPT_SERIAL", "0") != "0"
+        self._adam_done = None
         self._bb_ready = None
         self._norm_side = False          # switched on by engine_vg.CapturedTrainStep around its own backward + clip-norm unit only
         self._norm_split = None
@@ -351,6 +353,12 @@ class RefTR(nn.Module):
             H.mark("lang: branch starts")
             if self._pre_update is not None and self._pre_update[1]():
                 net._refresh_kv_cat()          # operands written by the AdamW passes (this one and the main stream's, which is ordered in front of this branch)
+            if self._pre_update is not None and self._opt_serial:
+                # the BERT slice's AdamW pass (3.5 GB) and the frozen stem / layer1 (HBM-bound too) do not share the memory system
+                # well: side by side they took 1080 + 1075 us against ~600 + ~85 us alone (profiles/r04a_concurrent_timeline.txt).
+                # The ResNet forward waits for this event; BERT's forward then runs beside it instead.
+                self._adam_done = torch.cuda.Event()
+                self._adam_done.record()
             if self._lin_refresh_pending:
                 net.refresh()
                 self._lin_refresh_pending = False
@@ -377,7 +385,10 @@ class RefTR(nn.Module):
                 pos.view(B, S, E)[:, Lq:, :] = pe
             H.mark("lang: positional / mask work done")
             return r + (pos, kpm)
+        self._adam_done = None
         seq16, pooled16, bctx, pos, kpm = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
+        if self._adam_done is not None and net.side.enabled:
+            torch.cuda.current_stream().wait_event(self._adam_done)
         feats, bb_saved = self.body.forward(x, ready=self._bb_ready)
         c5, (_, h5, w5) = feats[-1]
         assert (h5, w5) == (h, w)

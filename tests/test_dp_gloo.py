@@ -118,6 +118,9 @@ def _collectives_worker(rank, world, port, q):
         d2 = dp_capture_decision(False, True, torch.device("cpu"))
         d3 = dp_capture_decision(True, False, torch.device("cpu"))
         d4 = dp_capture_decision(False, rank == 0, torch.device("cpu"))       # rank 1 is out of capture budget
+        # the same collective carries the box-count average of the iteration (one all-reduce instead of two per replay)
+        d5, nb5 = dp_capture_decision(True, False, torch.device("cpu"), num_boxes=sum(counts))
+        assert d5 == "replay" and abs(float(nb5) - 4.0) < 1e-6, (d5, nb5)
         q.put((rank, float(nb), nb_static, float(nb0), float(red["loss_giou"]), float(red["loss_bbox"]), float(summed["a"]),
                (d1, d2, d3, d4)))
     finally:
