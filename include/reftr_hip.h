@@ -129,6 +129,9 @@ typedef struct rt_conv_wgrad_desc {
     int32_t reserved;
     float*  sqacc;        /* optional gradient-norm accumulator (RT_SQ_SLOTS x RT_SQ_STRIDE floats, see rt_sqnorm_finish): the launch adds
                              |dw after|^2 - |dw before|^2, so that the clip norm (engine_vg.py:62-63) needs no pass over dw */
+    void*   g16;          /* optional bf16 twin of dw (same shape): every value written to dw is also written there, rounded -- the
+                             data-parallel exchange buffer (bf16 on the xGMI links, main_vg.py:290-296's all-reduce), which otherwise
+                             costs a 607 MB read + 304 MB write rounding pass per step */
 } rt_conv_wgrad_desc;
 int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream);
 
@@ -139,6 +142,7 @@ typedef struct rt_small_wgrad_job {
     const void* dy; const void* x; float* dw; float* dbias;
     int32_t M, N, K, overwrite;      /* overwrite: as in rt_conv_wgrad_desc (dbias accumulates) */
     float* sqacc;                    /* optional gradient-norm accumulator, as in rt_conv_wgrad_desc */
+    void*  g16;                      /* optional bf16 twin of dw, as in rt_conv_wgrad_desc */
 } rt_small_wgrad_job;
 int rt_small_wgrad_grouped(const rt_small_wgrad_job* jobs, int njobs, rt_stream_t stream);
 
@@ -525,6 +529,10 @@ int rt_zero_chunks(float* base, const int64_t* table, int n, rt_stream_t stream)
 #define RT_SQ_SLOTS 256
 #define RT_SQ_STRIDE 32
 int rt_sqnorm_finish(const float* base, const int64_t* table, int nchunks, float* slots, const float* extra, float* out, rt_stream_t stream);
+/* rt_round_chunks — twin[i] = bf16(base[i]) over `n` chunks {element offset, count <= 16384} (DEVICE int64 table): the tensors of a
+ * gradient slice that no weight-gradient launch writes (biases, norm parameters, embeddings) on their way into the bf16 exchange
+ * buffer; the weight matrices arrive there through rt_conv_wgrad_desc.g16. */
+int rt_round_chunks(const float* base, void* twin, const int64_t* table, int n, rt_stream_t stream);
 /* rt_counter_add — *ctr += inc on the device (step / dropout-seed counters that must advance inside a captured graph). */
 int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream);
 /* rt_counter_add_if_zero — the same, but only while the DEVICE word *cond is 0; otherwise *ctr is left alone (reset_else = 0) or

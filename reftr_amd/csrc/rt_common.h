@@ -100,5 +100,8 @@ __device__ __forceinline__ void rt_sq_add(float* slots, unsigned who, float v) {
 // sign * |buf|^2 of up to 32 fp32 buffers into the slots (the producers without an in-kernel contribution: a pass with sign -1
 // in front of an accumulating launch, +1 behind every launch); rt_optim.hip
 int rt_sq_pass(float* const* bufs, const long long* counts, const float* signs, int n, float* slots, hipStream_t s);
+// twin[i] = bf16(buf[i]) for up to any number of fp32 buffers (the bf16 exchange twins of weight gradients whose producer has no
+// in-kernel twin store); rt_optim.hip
+int rt_round_pass(float* const* bufs, void* const* twins, const long long* counts, int n, hipStream_t s);
 
 #define RT_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

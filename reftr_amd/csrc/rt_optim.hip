@@ -334,6 +334,34 @@ __global__ __launch_bounds__(256) void sq_sum_kernel(const float* __restrict__ s
     if (threadIdx.x == 0) out[0] = fmaxf(s, 0.f) + (extra ? extra[0] : 0.f);      // (new^2 - old^2 terms may leave -1 ulp when everything is zero)
 }
 
+struct RoundList { const float* buf[32]; bf16_t* twin[32]; long long cnt[32]; int first[33]; int n; };
+__global__ __launch_bounds__(256) void round_list_kernel(const RoundList l) {
+    int lo = 0, hi = l.n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (l.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const float* g = l.buf[lo]; bf16_t* tw = l.twin[lo];
+    const size_t n = (size_t)l.cnt[lo];
+    const size_t b0 = (size_t)((int)blockIdx.x - l.first[lo]) * 4096;
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t i = b0 + (size_t)j * 1024 + threadIdx.x * 4;
+        if (i + 4 <= n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+            *reinterpret_cast<bf16x4_t*>(tw + i) = bf16x4_t{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        } else for (size_t k = i; k < n; ++k) tw[k] = (bf16_t)g[k];
+    }
+}
+__global__ __launch_bounds__(256) void round_chunks_kernel(const float* __restrict__ base, bf16_t* __restrict__ twin, const int64_t* __restrict__ table) {
+    const size_t off = (size_t)table[2 * blockIdx.x], cnt = (size_t)table[2 * blockIdx.x + 1];
+    typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+    for (size_t i = threadIdx.x * 4; i < cnt; i += 1024) {
+        if (i + 4 <= cnt && ((off + i) & 3) == 0) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + off + i);
+            *reinterpret_cast<bf16x4_t*>(twin + off + i) = bf16x4_t{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        } else for (size_t k = i; k < cnt && k < i + 4; ++k) twin[off + k] = (bf16_t)base[off + k];
+    }
+}
+
 __global__ void counter_add_if_zero_kernel(int32_t* c, int32_t inc, const uint32_t* cond, int reset_else) {
     if (cond[0] == 0u) c[0] += inc; else if (reset_else) c[0] = 0;
 }
@@ -401,6 +429,29 @@ int rt_sq_pass(float* const* bufs, const long long* counts, const float* signs, 
         hipLaunchKernelGGL(sq_list_kernel, dim3((unsigned)blocks), dim3(256), 0, s, l, slots);
         RT_CHECK_LAUNCH();
     }
+    return RT_OK;
+}
+
+int rt_round_pass(float* const* bufs, void* const* twins, const long long* counts, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += 32) {
+        RoundList l; l.n = 0; int blocks = 0;
+        for (int i = base; i < n && i < base + 32; ++i) {
+            if (!bufs[i] || !twins[i] || counts[i] <= 0) continue;
+            l.buf[l.n] = bufs[i]; l.twin[l.n] = (bf16_t*)twins[i]; l.cnt[l.n] = counts[i]; l.first[l.n] = blocks; ++l.n;
+            blocks += (int)((counts[i] + 4095) / 4096);
+        }
+        if (!l.n) continue;
+        l.first[l.n] = blocks;
+        hipLaunchKernelGGL(round_list_kernel, dim3((unsigned)blocks), dim3(256), 0, s, l);
+        RT_CHECK_LAUNCH();
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_round_chunks(const float* base, void* twin, const int64_t* table, int n, rt_stream_t stream) {
+    if (!base || !twin || !table || n <= 0) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(round_chunks_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, base, (bf16_t*)twin, table);
+    RT_CHECK_LAUNCH();
     return RT_OK;
 }
 

@@ -616,14 +616,17 @@ __global__ __launch_bounds__(256) void small_m_wgrad_grouped_kernel(const SmallJ
             for (int r = 0; r < 4; ++r) a[r] += gv[m] * (float)xv[m][r];
         }
         f32x4* o = reinterpret_cast<f32x4*>(q.dw + (size_t)n * q.K + kk);
+        f32x4 fin;
         if (q.overwrite) {
             const f32x4 d = a * a; ss = (d[0] + d[1]) + (d[2] + d[3]);
-            *o = a;
+            fin = a;
         } else {
             const f32x4 old = *o;
             const f32x4 d = a * (old + old + a); ss = (d[0] + d[1]) + (d[2] + d[3]);
-            *o = old + a;
+            fin = old + a;
         }
+        *o = fin;
+        if (q.g16) *reinterpret_cast<bf16x4*>((bf16_t*)q.g16 + (size_t)n * q.K + kk) = bf16x4{(bf16_t)fin[0], (bf16_t)fin[1], (bf16_t)fin[2], (bf16_t)fin[3]};
         if (q.dbias && kk == 0) q.dbias[n] += gs;
     }
     if (q.sqacc) {                           // uniform per workgroup: a workgroup belongs to one job
@@ -772,6 +775,21 @@ static int sq_account(const rt_conv_wgrad_desc* descs, int n, bool after, hipStr
     }
     return RT_OK;
 }
+// the bf16 exchange twins of the same launches (behind them): one rounding pass over what they wrote
+static int twin_account(const rt_conv_wgrad_desc* descs, int n, hipStream_t s) {
+    float* bufs[32]; void* twins[32]; long long cnts[32];
+    int m = 0;
+    for (int i = 0; i <= n; ++i) {
+        const bool last = i == n;
+        if (!last && descs[i].g16) { bufs[m] = descs[i].dw; twins[m] = descs[i].g16; cnts[m] = (long long)descs[i].N * descs[i].KH * descs[i].KW * descs[i].SC; ++m; }
+        if (m == 32 || (last && m > 0)) {
+            const int rc = rt_round_pass(bufs, twins, cnts, m, s);
+            if (rc != RT_OK) return rc;
+            m = 0;
+        }
+    }
+    return RT_OK;
+}
 
 extern "C" int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, float* workspace, int64_t workspace_bytes,
                                      rt_stream_t stream) {
@@ -797,11 +815,13 @@ extern "C" int rt_conv_wgrad_grouped(const rt_conv_wgrad_desc* descs, int n, flo
         int rc = sq_account(rest, nr, false, s);
         if (rc == RT_OK) rc = wgrad_grouped_v1(rest, nr, workspace, workspace_bytes, stream);
         if (rc == RT_OK) rc = sq_account(rest, nr, true, s);
+        if (rc == RT_OK) rc = twin_account(rest, nr, s);
         return rc;
     }
     int rc = sq_account(descs, n, false, s);
     if (rc == RT_OK) rc = wgrad_grouped_v1(descs, n, workspace, workspace_bytes, stream);
     if (rc == RT_OK) rc = sq_account(descs, n, true, s);
+    if (rc == RT_OK) rc = twin_account(descs, n, s);
     return rc;
 }
 
@@ -896,7 +916,7 @@ static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a) {
 
 extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (!d) return RT_ERR_BADARG;
-    if (!d->sqacc) return conv_wgrad_impl(d, stream);
+    if (!d->sqacc && !d->g16) return conv_wgrad_impl(d, stream);
     const long long M = (long long)d->B * d->DH * d->DW;
     const bool v2 = w2_enabled() && rt_w2_eligible(*d) && !getenv("REFTR_WGV") &&
                     !(M <= 16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->SC & 3) == 0);
@@ -904,6 +924,7 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     int rc = sq_account(d, 1, false, (hipStream_t)stream);
     if (rc == RT_OK) rc = conv_wgrad_impl(d, stream);
     if (rc == RT_OK) rc = sq_account(d, 1, true, (hipStream_t)stream);
+    if (rc == RT_OK) rc = twin_account(d, 1, (hipStream_t)stream);
     return rc;
 }
 

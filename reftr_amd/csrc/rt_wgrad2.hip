@@ -36,7 +36,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int w2_i32x4;
 
 struct W2Prob {
-    const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias; float* part; float* sqacc;
+    const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias; float* part; float* sqacc; bf16_t* g16;
     int SH, SW, SC, DH, DW, N, KH, KW, stride, pad, M;
     int n_tiles, c_tiles, tiles, splits, chunks_per_split, out_elems;
     unsigned dy_bytes, x_bytes;
@@ -440,6 +440,12 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) if (ok[i]) *reinterpret_cast<f32x4*>(o[i]) = v[i];
+            if (direct && p.g16) {           // the bf16 exchange twin of the same elements
+                typedef bf16_t w2_bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (ok[i]) *reinterpret_cast<w2_bf16x4*>(p.g16 + (o[i] - p.dw)) = w2_bf16x4{(bf16_t)v[i][0], (bf16_t)v[i][1], (bf16_t)v[i][2], (bf16_t)v[i][3]};
+            }
         }
     }
     }
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void w2_grouped_kernel(const W2Group g) {
 }
 
 // dw[i] (+)= scale[i / row_elems] * sum_s part[s][i] for every split problem of a group (one launch)
-struct W2Reduce { const float* part[W2_MAXP]; float* dw[W2_MAXP]; const float* scale[W2_MAXP]; float* sqacc[W2_MAXP];
+struct W2Reduce { const float* part[W2_MAXP]; float* dw[W2_MAXP]; const float* scale[W2_MAXP]; float* sqacc[W2_MAXP]; bf16_t* g16[W2_MAXP];
                   int out_elems[W2_MAXP], row_elems[W2_MAXP], nsplit[W2_MAXP], accumulate[W2_MAXP], first[W2_MAXP + 1]; int n; };
 __global__ __launch_bounds__(256) void w2_reduce_kernel(const W2Reduce g) {
     int lo = 0, hi = g.n - 1;
@@ -522,15 +528,21 @@ __global__ __launch_bounds__(256) void w2_reduce_kernel(const W2Reduce g) {
     for (; s < nsplit; ++s) a += *reinterpret_cast<const f32x4*>(part + (size_t)s * out_elems + i);
     if (scale) a *= scale[i / g.row_elems[lo]];
     f32x4* o = reinterpret_cast<f32x4*>(dw + i);
+    f32x4 fin;
     if (g.accumulate[lo]) {
         const f32x4 old = *o;
         const f32x4 d = a * (old + old + a);              // |old + a|^2 - |old|^2
         ss = (d[0] + d[1]) + (d[2] + d[3]);
-        *o = old + a;
+        fin = old + a;
     } else {
         const f32x4 d = a * a;
         ss = (d[0] + d[1]) + (d[2] + d[3]);
-        *o = a;
+        fin = a;
+    }
+    *o = fin;
+    if (g.g16[lo]) {
+        typedef bf16_t w2_bf16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<w2_bf16x4*>(g.g16[lo] + i) = w2_bf16x4{(bf16_t)fin[0], (bf16_t)fin[1], (bf16_t)fin[2], (bf16_t)fin[3]};
     }
     }
     if (sq) {                                             // uniform per workgroup (one problem per workgroup)
@@ -661,7 +673,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             W2Prob p;
             p.cfg = w2_cfg_of(d);
             const int BN = BNs[p.cfg], BC = BCs[p.cfg];
-            p.dy = (const bf16_t*)d.dy; p.x = (const bf16_t*)d.x; p.dw = d.dw; p.scale = d.scale; p.dbias = d.dbias; p.part = nullptr; p.sqacc = d.sqacc;
+            p.dy = (const bf16_t*)d.dy; p.x = (const bf16_t*)d.x; p.dw = d.dw; p.scale = d.scale; p.dbias = d.dbias; p.part = nullptr; p.sqacc = d.sqacc; p.g16 = (bf16_t*)d.g16;
             p.SH = d.SH; p.SW = d.SW; p.SC = d.SC; p.DH = d.DH; p.DW = d.DW; p.N = d.N; p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
             const long long M = (long long)d.B * d.DH * d.DW;
             p.M = (int)M;
@@ -694,7 +706,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             p.splits = (total_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
             if (p.splits > 1 && workspace) {
                 p.part = workspace + ws_off / 4;
-                r.part[r.n] = p.part; r.dw[r.n] = p.dw; r.scale[r.n] = p.scale; r.sqacc[r.n] = p.sqacc; r.out_elems[r.n] = p.out_elems;
+                r.part[r.n] = p.part; r.dw[r.n] = p.dw; r.scale[r.n] = p.scale; r.sqacc[r.n] = p.sqacc; r.g16[r.n] = p.g16; r.out_elems[r.n] = p.out_elems;
                 r.row_elems[r.n] = d.KH * d.KW * d.SC; r.nsplit[r.n] = p.splits; r.accumulate[r.n] = p.accumulate; r.first[r.n] = rblocks; ++r.n;
                 rblocks += (p.out_elems / 4 + 255) / 256;
                 ws_off += ((long long)p.splits * p.out_elems * 4 + 255) / 256 * 256;

@@ -41,7 +41,7 @@ class ConvWgradDesc(Structure):
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
         ("msplit", c_int32), ("dbias", c_void_p), ("variant", c_int32),
         ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64), ("overwrite", c_int32), ("reserved", c_int32),
-        ("sqacc", c_void_p),
+        ("sqacc", c_void_p), ("g16", c_void_p),
     ]
 
 
@@ -175,7 +175,7 @@ class AdamWDesc(Structure):
 # (tests/test_abi.py cross-checks this table against the header).
 class SmallWgradJob(Structure):
     _fields_ = [("dy", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("dbias", c_void_p),
-                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("overwrite", c_int32), ("sqacc", c_void_p)]
+                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("overwrite", c_int32), ("sqacc", c_void_p), ("g16", c_void_p)]
 
 
 class GnNhwcDesc(Structure):
@@ -317,6 +317,7 @@ _SIGNATURES = {
     "rt_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_sqnorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rt_sqnorm_finish": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rt_round_chunks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rt_adamw_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_sgd_flat": (c_int, [POINTER(AdamWDesc), c_void_p]),
     "rt_zero_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
@@ -554,9 +555,37 @@ SQ_SLOTS, SQ_STRIDE = 256, 32
 _SQACC_MAP = {}
 
 
+def _owned(table, dw):
+    """Entry of a {data_ptr: (weakref to the owning ParamStore, value)} map, valid only while the owner is alive (its gradient
+    buffer still occupies that address: nothing else can); entries of dead owners are dropped."""
+    ent = table.get(dw.data_ptr())
+    if ent is None:
+        return None
+    if ent[0]() is None:
+        del table[dw.data_ptr()]
+        return None
+    return ent[1]
+
+
 def _sqacc(dw):
-    t = _SQACC_MAP.get(dw.data_ptr())
+    t = _owned(_SQACC_MAP, dw)
     return t.data_ptr() if t is not None else None
+
+
+# bf16 exchange twins (data parallel): {data_ptr of a registered weight-gradient matrix: data_ptr of its bf16 twin} -- the launches
+# that write the matrix write the rounded copy as well (rt_conv_wgrad_desc.g16); reftr_amd.parallel fills the map
+_G16_MAP = {}
+
+
+def _g16(dw):
+    return _owned(_G16_MAP, dw)
+
+
+def round_chunks(base, twin, table, n):
+    """twin[i] = bf16(base[i]) over n chunks {offset, count} of a static device table (rt_round_chunks)."""
+    _req(base, torch.float32, "base"); _req(twin, torch.bfloat16, "twin"); _req(table, torch.int64, "table")
+    if n > 0:
+        _check(lib().rt_round_chunks(_p(base), _p(twin), _p(table), int(n), _stream()), "rt_round_chunks")
 
 
 def sqnorm_finish(flat_g, table, nchunks, slots, out, extra=None):
@@ -575,7 +604,7 @@ def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, 
     _req(dbias, torch.float32, "dbias")
     ws = _wgrad_workspace(dy.device) if workspace else None
     d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit, _p(dbias), variant,
-                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0, int(bool(overwrite)), 0, _sqacc(dw))
+                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0, int(bool(overwrite)), 0, _sqacc(dw), _g16(dw))
     _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
            lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"), tag=("W",) + tuple(geom))
     return dw
@@ -1135,7 +1164,7 @@ class WgradBatch:
         K = x.shape[1]
         assert x.shape[0] == M and dw.numel() == N * K
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), None, M, 1, 1, K, 1, 1, N, 1, 1, 1, 0, 0, _p(dbias), 0, None, 0,
-                                        int(bool(overwrite)), 0, _sqacc(dw)))
+                                        int(bool(overwrite)), 0, _sqacc(dw), _g16(dw)))
         self.keep.append((dy, x))
         self._account((M, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
 
@@ -1144,7 +1173,7 @@ class WgradBatch:
         B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(scale, torch.float32, "scale")
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, 0, None, 0,
-                                        None, 0, int(bool(overwrite)), 0, _sqacc(dw)))
+                                        None, 0, int(bool(overwrite)), 0, _sqacc(dw), _g16(dw)))
         self.keep.append((dy, x, scale))
         self._account(geom)
 
@@ -1181,7 +1210,7 @@ class SmallWgradBatch:
         M, N = dy.shape
         K = x.shape[1]
         assert M <= 16 and x.shape[0] == M and dw.numel() == N * K and K % 4 == 0
-        self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, int(bool(overwrite)), _sqacc(dw)))
+        self.jobs.append(SmallWgradJob(_p(dy), _p(x), _p(dw), _p(dbias), M, N, K, int(bool(overwrite)), _sqacc(dw), _g16(dw)))
         self.keep.append((dy, x))
         self.flops += 2.0 * M * N * K; self.nbytes += 2.0 * M * (N + K) + 4.0 * N * K
 

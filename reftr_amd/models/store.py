@@ -69,6 +69,10 @@ class ParamStore:
 
     def allocate(self, device, src=None):
         self.device = torch.device(device)
+        from .. import hip as _H
+        for tab in (_H._SQACC_MAP, _H._G16_MAP):          # entries of this store's previous buffers (device move): their addresses are void
+            for k in [k for k, v in tab.items() if v[0]() is self]:
+                del tab[k]
         new = {"p": torch.zeros(self.n_train, dtype=torch.float32, device=device),
                "f": torch.zeros(max(self.n_frozen, 4), dtype=torch.float32, device=device),
                "b": torch.zeros(max(self.n_buffer, 4), dtype=torch.float32, device=device)}
@@ -102,7 +106,8 @@ class ParamStore:
         self._ow_table, self._stale_tables = None, {}
         if self.fused_norm:
             from .. import hip as H
-            H._SQACC_MAP[gw.data_ptr()] = self.sq_slots
+            import weakref
+            H._SQACC_MAP[gw.data_ptr()] = (weakref.ref(self), self.sq_slots)
 
     def _complement_table(self):
         """Static device table of <= 16384-element chunks covering everything that is NOT a registered matrix."""
@@ -181,6 +186,9 @@ class ParamStore:
             ent = self._stale_tables[keys] = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
         from .. import hip as H
         H.zero_chunks(self.flat_g, ent[0], ent[1])
+        g16 = getattr(self, "flat_g16", None)
+        if g16 is not None and g16.is_cuda:          # the bf16 exchange twins of the cleared matrices (their producers never ran)
+            H.round_chunks(self.flat_g, g16, ent[0], ent[1])
 
     def finish_overwrite(self):
         """End of backward: EVERY registered matrix that no producer wrote in this step is cleared -- unconditionally, by one

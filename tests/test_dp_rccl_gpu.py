@@ -205,3 +205,35 @@ def test_dp_wrapper_on_the_c_abi_exchange_matches_the_torch_distributed_one(hip,
     (lt, gt, pt), (la, ga, pa) = out["torch"], out["abi"]
     assert abs(lt[0] - la[0]) < 1e-6 * abs(lt[0]) and abs(gt - ga) < 2e-3 * gt      # atomics-order noise of two backward runs: 4e-4
     assert abs(lt[2] - la[2]) < 5e-2 * abs(lt[2]) and rel(pa, pt) < 2e-4
+
+
+@pytest.mark.parametrize("kind", ["single", "multi"])
+def test_bf16_exchange_twin_is_written_by_the_gradient_producers(hip, single_rank_group, monkeypatch, kind):
+    """Round 4: the bf16 exchange buffer is filled by the weight-gradient launches themselves (rt_conv_wgrad_desc.g16:
+    second-generation epilogues and reduction, the M <= 16 kernel, a rounding pass behind the first-generation launches) plus one
+    chunk pass per slice over what they do not produce -- not by a 607 MB -> 304 MB copy.  After a backward through the wrapper (single
+    rank: the all-reduce is the identity) the twin must be the bf16 image of the fp32 gradients, bit for bit, everywhere: matrices
+    written once, matrices accumulated twice (multi-phrase: two BERT passes), matrices never written (cleared), biases / norms /
+    embeddings."""
+    from reftr_amd.engine_vg import _total, _zero_grad
+    from reftr_amd.optim import FusedAdamW
+    from reftr_amd.parallel import DistributedDataParallel
+    monkeypatch.setenv("REFTR_DDP_DTYPE", "bf16")
+    samples, targets = make_inputs("e2e_" + kind, B=2, H=96, W=128, L=12, n_phrase=3 if kind == "multi" else 0)
+    s, tg = to_cuda(samples, targets)
+    model, crit, P, ocfg = build(small=True)
+    model.train()
+    opt = FusedAdamW(model)
+    runner = DistributedDataParallel(model)
+    assert runner.active and runner.bf16 and runner.twin
+    st = model.store
+    st.flat_g.normal_(); st.flat_g16.normal_()                  # garbage from "the previous step" on both sides
+    out = runner(s)
+    total = _total(crit, crit(out, tg))
+    _zero_grad(opt)
+    total.backward()
+    torch.cuda.synchronize()
+    want = st.flat_g.to(torch.bfloat16)
+    bad = (st.flat_g16 != want)
+    assert int(bad.sum()) == 0, ("first mismatch at", int(bad.nonzero()[0]), "of", int(bad.sum()))
+    assert float(st.flat_g.abs().sum()) > 0
