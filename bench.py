@@ -290,7 +290,7 @@ def main():
         tm = sum(r["start"].elapsed_time(r["end"]) for r in recs) * 1e-3
         ach = fl / tm / 1e12
         if rank == 0:
-            roof = {"bound": "mfma", "kernel": "rt_conv_gemm / rt_conv_wgrad(+_grouped) kernels (conv_gemm_dma_kernel, w2_grouped_kernel + w2_reduce_kernel, conv_wgrad*_kernel, skinny / small-M)",
+            roof = {"bound": "mfma", "kernel": "rt_conv_gemm / rt_conv_wgrad(+_grouped) kernels (conv_gemm_dma_kernel, w2_grouped_kernel + w2_reduce_kernel, conv_wgrad*_kernel, skinny / small-M; rt_enc_tail_* when REFTR_ENC_FUSE=1)",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
                     "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3,
