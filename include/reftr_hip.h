@@ -767,6 +767,10 @@ typedef struct rt_enc_tail_fwd_desc {
     float   eps, drop_p;
     uint32_t seed_d1, seed_dh, seed_d2;
     const uint32_t* seed_dev;             /* optional, see rt_conv_gemm_desc */
+    int32_t mode;                         /* 0: the whole tail; 1: out_proj + dropout1 + residual -> norm1 only (writes t, mean1, rstd1,
+                                             x1_16 and x1_32; the feed-forward pair stays with the caller's launches) */
+    int32_t reserved;
+    float*  x1_32;                        /* mode 1: norm1's fp32 output [M,256] (linear2's residual) */
 } rt_enc_tail_fwd_desc;
 int rt_enc_tail_fwd(const rt_enc_tail_fwd_desc* d, rt_stream_t stream);
 typedef struct rt_enc_tail_bwd_desc {
@@ -782,6 +786,9 @@ typedef struct rt_enc_tail_bwd_desc {
     float   drop_p, gate_scale;
     uint32_t seed_d1, seed_d2;
     const uint32_t* seed_dev;
+    int32_t mode;                         /* 0: the whole tail; 1: norm1 backward -> out_proj^T only, from dx1 */
+    int32_t reserved;
+    const float* dx1;                     /* mode 1: fp32 [M,256] gradient w.r.t. norm1's output (linear1^T's result + the residual path) */
 } rt_enc_tail_bwd_desc;
 int rt_enc_tail_bwd(const rt_enc_tail_bwd_desc* d, rt_stream_t stream);
 

@@ -188,9 +188,9 @@ __device__ __forceinline__ void e_load_rows(const ECtx& c, const bf16_t* src, in
 __global__ __launch_bounds__(ENT, 1) void enc_tail_fwd_kernel(const rt_enc_tail_fwd_desc p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = p.F >> 8;                             // chunks of 256 hidden units
-    const bool proj = p.qk != nullptr;
+    const bool proj = p.qk != nullptr && p.mode == 0;
     ECtx c;
-    ectx_init(c, smem, 4 * (1 + 2 * C + (proj ? 3 : 0)));
+    ectx_init(c, smem, p.mode == 1 ? 4 : 4 * (1 + 2 * C + (proj ? 3 : 0)));
     auto unit_of = [&](int u) __attribute__((always_inline)) -> EUnit {
         if (u == 0) return EUnit{(const bf16_t*)p.Wo, (unsigned)(EE * EE * 2), 0, EE, 0};
         if (u <= 2 * C) {
@@ -212,7 +212,8 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_fwd_kernel(const rt_enc_tail_
         xres[a] = e_ld4(p.x32 + (size_t)m * EE + e_col(c, a), row_ok);
         posv[a] = p.pos ? e_ld4(p.pos + (size_t)m * EE + e_col(c, a), row_ok) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    e_touch(c, p.Wo, EE * EE * 2); e_touch(c, p.W1, (unsigned)(p.F * EE * 2)); e_touch(c, p.W2, (unsigned)(EE * p.F * 2));
+    e_touch(c, p.Wo, EE * EE * 2);
+    if (p.mode == 0) { e_touch(c, p.W1, (unsigned)(p.F * EE * 2)); e_touch(c, p.W2, (unsigned)(EE * p.F * 2)); }
     if (proj) { e_touch(c, p.Wqk, 2 * EE * EE * 2); e_touch(c, p.Wv, EE * EE * 2); }
     e_load_rows(c, (const bf16_t*)p.o, m0, p.M, e_act(c, 0));
 #pragma unroll
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_fwd_kernel(const rt_enc_tail_
     bf16x4_t hb[4];
     to_bf16(x1, hb);
     st_bf16(p.x1_16, EE, 0, hb);
+    if (p.mode == 1) { st_f32(p.x1_32, x1); e_wait_vmcnt<0>(); return; }
     e_store_act(c, e_act(c, 1), hb);                    // linear1's operand (read behind the first barrier of the next unit)
 
     // ---- feed-forward, 256 hidden units at a time: h_c = dropout(relu(x1 W1_c^T + b1_c)); t2 += h_c W2[:, c]^T
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_fwd_kernel(const rt_enc_tail_
 // ------------------------------------------------------------------------------------------------------------------ backward
 __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_bwd_desc p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int C = p.F >> 8;
+    const int C = p.mode == 1 ? 0 : p.F >> 8;
     ECtx c;
     ectx_init(c, smem, 4 * (2 * C + 1));
     auto unit_of = [&](int u) __attribute__((always_inline)) -> EUnit {
@@ -365,18 +367,20 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_
     const int m = m0 + c.wm * 16 + c.li;
     const bool row_ok = m < p.M;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool full = p.mode == 0;
     f32x4 dy[4], xv2[4], xv1[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const size_t o = (size_t)m * EE + e_col(c, a);
-        dy[a] = e_ld4(p.dy + o, row_ok);
-        if (p.dy2) dy[a] += e_ld4(p.dy2 + o, row_ok);
-        xv2[a] = e_ld4(p.t2 + o, row_ok);
+        dy[a] = e_ld4((full ? p.dy : p.dx1) + o, row_ok);            // mode 1: dy carries dx1
+        if (full && p.dy2) dy[a] += e_ld4(p.dy2 + o, row_ok);
+        xv2[a] = full ? e_ld4(p.t2 + o, row_ok) : z4;
         xv1[a] = e_ld4(p.t + o, row_ok);
     }
-    const float mean2 = row_ok ? p.mean2[m] : 0.f, rstd2 = row_ok ? p.rstd2[m] : 0.f;
+    const float mean2 = row_ok && full ? p.mean2[m] : 0.f, rstd2 = row_ok && full ? p.rstd2[m] : 0.f;
     const float mean1 = row_ok ? p.mean1[m] : 0.f, rstd1 = row_ok ? p.rstd1[m] : 0.f;
-    e_touch(c, p.WT2, (unsigned)(p.F * EE * 2)); e_touch(c, p.WT1, (unsigned)(EE * p.F * 2)); e_touch(c, p.WTo, EE * EE * 2);
+    if (full) { e_touch(c, p.WT2, (unsigned)(p.F * EE * 2)); e_touch(c, p.WT1, (unsigned)(EE * p.F * 2)); }
+    e_touch(c, p.WTo, EE * EE * 2);
 #pragma unroll
     for (int s = 0; s < ENS - 1; ++s) e_issue(c, unit_of);
 
@@ -442,15 +446,16 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_
         for (int a = 0; a < 4; ++a) e_st_bf16x4(dst, (size_t)m * ld + col0 + e_col(c, a), o[a]);
     };
 
-    // ---- norm2 backward: dt2 (fp32, the residual path) and dt2b = bf16(dt2 through dropout2): linear2's output gradient
-    f32x4 dt2[4];
-    ln_bwd(dy, xv2, mean2, rstd2, p.g2, p.part2, dt2);
     bf16x4_t ob[4];
+    f32x4 dx1[4] = {z4, z4, z4, z4};
+    f32x4 dt2[4] = {z4, z4, z4, z4};
+    if (full) {
+    // ---- norm2 backward: dt2 (fp32, the residual path) and dt2b = bf16(dt2 through dropout2): linear2's output gradient
+    ln_bwd(dy, xv2, mean2, rstd2, p.g2, p.part2, dt2);
     drop_bf16(dt2, s_d2, ob);
     st_bf16(p.dt2b, EE, 0, ob);
     e_store_act(c, e_act(c, 0), ob);
     // ---- feed-forward backward, chunk by chunk: dhdn_c = gate(dt2b W2[:, c]) ; dx1 += dhdn_c W1_c
-    f32x4 dx1[4] = {z4, z4, z4, z4};
 #pragma unroll 1
     for (int cc = 0; cc < C; ++cc) {
         bf16x4_t gate[4];
@@ -470,6 +475,10 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) dx1[a] += dt2[a];           // linear1's input gradient + the residual path
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dx1[a] = dy[a];          // mode 1: the caller's launches produced it
+    }
     // ---- norm1 backward -> dt (fp32, passed on: the layer input's residual path) and dtb = out_proj's output gradient
     f32x4 dt[4];
     ln_bwd(dx1, xv1, mean1, rstd1, p.g1, p.part1, dt);
@@ -494,8 +503,10 @@ __global__ __launch_bounds__(ENT, 1) void enc_tail_bwd_kernel(const rt_enc_tail_
 static int enc_common_ok(int M, int F) { return (M > 0 && F >= 256 && (F & 255) == 0 && (long long)M * F < 0x3fffffffLL) ? RT_OK : RT_ERR_UNSUPPORTED; }
 
 extern "C" int rt_enc_tail_fwd(const rt_enc_tail_fwd_desc* d, rt_stream_t stream) {
-    if (!d || !d->o || !d->x32 || !d->Wo || !d->W1 || !d->W2 || !d->bo || !d->b1 || !d->b2 || !d->g1 || !d->be1 || !d->g2 || !d->be2 ||
-        !d->t || !d->mean1 || !d->rstd1 || !d->x1_16 || !d->hdn || !d->t2 || !d->mean2 || !d->rstd2 || !d->x2_32 || !d->x2_16)
+    if (!d || !d->o || !d->x32 || !d->Wo || !d->bo || !d->g1 || !d->be1 || !d->t || !d->mean1 || !d->rstd1 || !d->x1_16) return RT_ERR_BADARG;
+    if (d->mode != 0 && d->mode != 1) return RT_ERR_BADARG;
+    if (d->mode == 1 && !d->x1_32) return RT_ERR_BADARG;
+    if (d->mode == 0 && (!d->W1 || !d->W2 || !d->b1 || !d->b2 || !d->g2 || !d->be2 || !d->hdn || !d->t2 || !d->mean2 || !d->rstd2 || !d->x2_32 || !d->x2_16))
         return RT_ERR_BADARG;
     if ((d->qk != nullptr) != (d->v != nullptr) || (d->qk && (!d->Wqk || !d->Wv || !d->bqk || !d->bv))) return RT_ERR_BADARG;
     if (d->x2p16 && !d->pos) return RT_ERR_BADARG;
@@ -513,8 +524,10 @@ extern "C" int rt_enc_tail_fwd(const rt_enc_tail_fwd_desc* d, rt_stream_t stream
 }
 
 extern "C" int rt_enc_tail_bwd(const rt_enc_tail_bwd_desc* d, rt_stream_t stream) {
-    if (!d || !d->dy || !d->t2 || !d->mean2 || !d->rstd2 || !d->g2 || !d->hdn || !d->WT2 || !d->WT1 || !d->t || !d->mean1 || !d->rstd1 ||
-        !d->g1 || !d->WTo || !d->dt2b || !d->dhdn || !d->dt || !d->dtb || !d->d_o) return RT_ERR_BADARG;
+    if (!d || !d->t || !d->mean1 || !d->rstd1 || !d->g1 || !d->WTo || !d->dt || !d->dtb || !d->d_o) return RT_ERR_BADARG;
+    if (d->mode != 0 && d->mode != 1) return RT_ERR_BADARG;
+    if (d->mode == 1 && !d->dx1) return RT_ERR_BADARG;
+    if (d->mode == 0 && (!d->dy || !d->t2 || !d->mean2 || !d->rstd2 || !d->g2 || !d->hdn || !d->WT2 || !d->WT1 || !d->dt2b || !d->dhdn)) return RT_ERR_BADARG;
     const int rc = enc_common_ok(d->M, d->F);
     if (rc != RT_OK) return rc;
     static bool attr = false;

@@ -269,14 +269,15 @@ class EncTailFwdDesc(Structure):
              "t", "mean1", "rstd1", "x1_16", "hdn", "t2", "mean2", "rstd2", "x2_32", "x2_16", "x2p16", "qk", "v")
     _fields_ = [(n, c_void_p) for n in _PTRS] + [("M", c_int32), ("F", c_int32), ("eps", c_float), ("drop_p", c_float),
                                                  ("seed_d1", c_uint32), ("seed_dh", c_uint32), ("seed_d2", c_uint32),
-                                                 ("seed_dev", c_void_p)]
+                                                 ("seed_dev", c_void_p), ("mode", c_int32), ("reserved", c_int32), ("x1_32", c_void_p)]
 
 
 class EncTailBwdDesc(Structure):
     _PTRS = ("dy", "dy2", "t2", "mean2", "rstd2", "g2", "hdn", "WT2", "WT1", "WTo", "t", "mean1", "rstd1", "g1",
              "dt2b", "dhdn", "dtb", "d_o", "dt", "part2", "part1")
     _fields_ = [(n, c_void_p) for n in _PTRS] + [("M", c_int32), ("F", c_int32), ("drop_p", c_float), ("gate_scale", c_float),
-                                                 ("seed_d1", c_uint32), ("seed_d2", c_uint32), ("seed_dev", c_void_p)]
+                                                 ("seed_d1", c_uint32), ("seed_d2", c_uint32), ("seed_dev", c_void_p),
+                                                 ("mode", c_int32), ("reserved", c_int32), ("dx1", c_void_p)]
 
 
 _SIGNATURES = {
@@ -1104,34 +1105,39 @@ def mark(name):
     stamp(m["buf"], ent[0])
 
 
-def enc_tail_fwd(*, M, F, eps, drop_p, seeds, **t):
-    """rt_enc_tail_fwd: keyword tensors = EncTailFwdDesc._PTRS (missing / None = NULL); seeds = (d1, dh, d2) dropout sites."""
+def enc_tail_fwd(*, M, F, eps, drop_p, seeds, mode=0, x1_32=None, **t):
+    """rt_enc_tail_fwd: keyword tensors = EncTailFwdDesc._PTRS (missing / None = NULL); seeds = (d1, dh, d2) dropout sites;
+    mode 1: out_proj + residual + norm1 only (x1_32 = norm1's fp32 output)."""
     d = EncTailFwdDesc()
     for n in EncTailFwdDesc._PTRS:
         setattr(d, n, _p(t.get(n)))
     assert not (set(t) - set(EncTailFwdDesc._PTRS)), set(t) - set(EncTailFwdDesc._PTRS)
+    d.mode, d.x1_32 = mode, _p(x1_32)
     d.M, d.F, d.eps, d.drop_p = M, F, eps, drop_p
     d.seed_d1, d.seed_dh, d.seed_d2 = (x & 0xFFFFFFFF for x in seeds)
     d.seed_dev = _seedp(drop_p)
-    nproj = 3 if t.get("qk") is not None else 0
+    nproj = 3 if (t.get("qk") is not None and mode == 0) else 0
     # the launch belongs to the GEMM family of bench.py's roofline: out_proj + linear1 + linear2 (+ the next layer's projections);
     # compulsory bytes = the weights once + the row tensors it reads / writes once
-    flops = 2.0 * M * 256 * (256 * (1 + nproj) + 2 * F)
-    nbytes = 2.0 * (256 * 256 * (1 + nproj) + 2 * 256 * F) + M * (2 * 256 + 4 * 256 + 2 * F + 3 * 2 * 256 + 3 * 4 * 256 + nproj * 2 * 256)
+    Fe = F if mode == 0 else 0
+    flops = 2.0 * M * 256 * (256 * (1 + nproj) + 2 * Fe)
+    nbytes = 2.0 * (256 * 256 * (1 + nproj) + 2 * 256 * Fe) + M * (2 * 256 + 4 * 256 + 2 * Fe + 3 * 2 * 256 + 3 * 4 * 256 + nproj * 2 * 256)
     _timed("enc_tail_fwd", flops, lambda: _check(lib().rt_enc_tail_fwd(ctypes.byref(d), _stream()), "rt_enc_tail_fwd"), nbytes=nbytes)
 
 
-def enc_tail_bwd(*, M, F, drop_p, gate_scale, seeds, **t):
-    """rt_enc_tail_bwd: keyword tensors = EncTailBwdDesc._PTRS; seeds = (d1, d2)."""
+def enc_tail_bwd(*, M, F, drop_p, gate_scale, seeds, mode=0, dx1=None, **t):
+    """rt_enc_tail_bwd: keyword tensors = EncTailBwdDesc._PTRS; seeds = (d1, d2); mode 1: norm1 backward + out_proj^T from dx1."""
     d = EncTailBwdDesc()
     for n in EncTailBwdDesc._PTRS:
         setattr(d, n, _p(t.get(n)))
     assert not (set(t) - set(EncTailBwdDesc._PTRS)), set(t) - set(EncTailBwdDesc._PTRS)
+    d.mode, d.dx1 = mode, _p(dx1)
     d.M, d.F, d.drop_p, d.gate_scale = M, F, drop_p, gate_scale
     d.seed_d1, d.seed_d2 = (x & 0xFFFFFFFF for x in seeds)
     d.seed_dev = _seedp(drop_p)
-    flops = 2.0 * M * 256 * (256 + 2 * F)
-    nbytes = 2.0 * (256 * 256 + 2 * 256 * F) + M * (3 * 4 * 256 + 2 * 2 * F + 3 * 2 * 256 + 4 * 256)
+    Fe = F if mode == 0 else 0
+    flops = 2.0 * M * 256 * (256 + 2 * Fe)
+    nbytes = 2.0 * (256 * 256 + 2 * 256 * Fe) + M * (3 * 4 * 256 + 2 * 2 * Fe + 3 * 2 * 256 + 4 * 256)
     _timed("enc_tail_bwd", flops, lambda: _check(lib().rt_enc_tail_bwd(ctypes.byref(d), _stream()), "rt_enc_tail_bwd"), nbytes=nbytes)
 
 

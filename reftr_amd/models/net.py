@@ -327,6 +327,11 @@ class Net:
         return (os.environ.get("REFTR_ENC_FUSE", "0") == "1" and str(self.store.device).startswith("cuda")
                 and cfg.hidden == 256 and cfg.ffn >= 256 and cfg.ffn % 256 == 0)
 
+    def enc_fuse_attn_tail(self):
+        """REFTR_ENC_FUSE=2: only out_proj + residual + norm1 (forward) and norm1' + out_proj^T (backward) go through the fused launch
+        (mode 1: 128 KB of weights per row block instead of 2.6 MB); the feed-forward pair, norm2 and the projections stay launches."""
+        return (os.environ.get("REFTR_ENC_FUSE", "0") == "2" and str(self.store.device).startswith("cuda") and self.cfg.hidden == 256)
+
     def enc_layer_fwd(self, p, x32, x16, xp16, pos, kpm, B, S, qkv=None, next_p=None):
         """One TransformerEncoderLayer (transformer.py:168-181).  `qkv`: this layer's (q|k, v) projections when the previous layer's
         launch already produced them; `next_p`: the next layer's prefix, whose projections this layer's fused launch may produce.
@@ -372,9 +377,20 @@ class Net:
                            hdn=hdn, t2=out32[1], mean2=stats[2], rstd2=stats[3], x2_32=out32[2], x2_16=out16[1], x2p16=out16[2], **kw)
             r.update(t=out32[0], st1=(stats[0], stats[1]), x1_16=out16[0], hdn=hdn, t2=out32[1], st2=(stats[2], stats[3]), fused=True)
             return out32[2], out16[1], out16[2], r, nxt
-        _, t = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=x32,
-                            out_bf16=False, out_f32=True)
-        x1_32, x1_16, _, m1, r1 = self.ln_fwd(t, p + "norm1.")
+        if self.enc_fuse_attn_tail():
+            M, dev = B * S, x32.device
+            o32 = torch.empty(2, M, E, dtype=torch.float32, device=dev); x1_16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
+            st = torch.empty(2, M, dtype=torch.float32, device=dev)
+            L = self.lins
+            H.enc_tail_fwd(M=M, F=cfg.ffn, eps=1e-5, drop_p=r["d1"][0], seeds=(r["d1"][1], 0, 0), mode=1, o=o, x32=x32,
+                           Wo=L[p + "self_attn.out_proj."].W, bo=L[p + "self_attn.out_proj."].b32, g1=self.P(p + "norm1.weight"),
+                           be1=self.P(p + "norm1.bias"), t=o32[0], mean1=st[0], rstd1=st[1], x1_16=x1_16, x1_32=o32[1])
+            t, x1_32, m1, r1 = o32[0], o32[1], st[0], st[1]
+            r["fused_attn_tail"] = True
+        else:
+            _, t = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=x32,
+                                out_bf16=False, out_f32=True)
+            x1_32, x1_16, _, m1, r1 = self.ln_fwd(t, p + "norm1.")
         r.update(t=t, st1=(m1, r1), x1_16=x1_16)
         r["dh"] = self._drop(cfg.dropout)
         hdn, _ = self.lin_fwd(p + "linear1.", x1_16, act=RELU, drop_p=r["dh"][0], drop_seed=r["dh"][1])
@@ -424,8 +440,22 @@ class Net:
             dt2, dt2b = self.ln_bwd(dx2, r["t2"], p + "norm2.", *r["st2"], dy2=dx2b, drop2_p=r["d2"][0], drop2_seed=r["d2"][1])
             dhdn, _ = self.lin_bwd(p + "linear2.", dt2b, r["hdn"], gate=r["hdn"], gate_scale=gs)
             _, dx1 = self.lin_bwd(p + "linear1.", dhdn, r["x1_16"], res_f32=dt2, out_bf16=False, out_f32=True)
-            dt, dtb = self.ln_bwd(dx1, r["t"], p + "norm1.", *r["st1"], drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
-            do, _ = self.lin_bwd(p + "self_attn.out_proj.", dtb, r["o"])
+            if self.enc_fuse_attn_tail() and self.ln_batch is not None and self.big_wg is not None:
+                nb = (M + 31) // 32
+                g16 = torch.empty(2, M, E, dtype=torch.bfloat16, device=dx1.device)               # dtb, do
+                dt = torch.empty(M, E, dtype=torch.float32, device=dx1.device)
+                part = torch.empty(nb, 2, E, dtype=torch.float32, device=dx1.device)
+                H.enc_tail_bwd(M=M, F=cfg.ffn, drop_p=r["d1"][0], gate_scale=1.0, seeds=(r["d1"][1], 0), mode=1, dx1=dx1, t=r["t"],
+                               mean1=r["st1"][0], rstd1=r["st1"][1], g1=self.P(p + "norm1.weight"),
+                               WTo=self.lins[p + "self_attn.out_proj."].WT, dtb=g16[0], d_o=g16[1], dt=dt, part1=part)
+                self._wgrad_only(p + "self_attn.out_proj.", g16[0], r["o"])
+                self.ln_batch.jobs.append(H.LnPgJob(part.data_ptr(), self.G(p + "norm1.weight").data_ptr(),
+                                                    self.G(p + "norm1.bias").data_ptr(), nb, E))
+                self.ln_batch.keep.append(part)
+                do = g16[1]
+            else:
+                dt, dtb = self.ln_bwd(dx1, r["t"], p + "norm1.", *r["st1"], drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
+                do, _ = self.lin_bwd(p + "self_attn.out_proj.", dtb, r["o"])
         qk, v = r["qk"], r["v"]
         dqk = torch.empty_like(qk)
         _, _, dv = H.attn_bwd(qk[:, :E], qk[:, E:], v, r["o"], do, r["lse"], kpm, B=B, H=Hh, Sq=S, Sk=S, dh=dh,

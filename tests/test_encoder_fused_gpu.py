@@ -113,8 +113,9 @@ def to_cuda(samples, targets):
     return s, [{k: v.cuda() for k, v in t.items()} for t in targets]
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("train", [False, True])
-def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, monkeypatch, train):
+def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, monkeypatch, train, mode):
     """Three encoder layers (the last one without next-layer projections) inside RefTR, B = 3 with ragged padding (M = 72: a partial
     row block), dropout on.  Forward: every saved tensor, the encoder memory and the loss against REFTR_ENC_FUSE=0 (same dropout
     sites, same masks).  Backward: each layer's backward is run BOTH ways on the same saved state and the same incoming gradient --
@@ -137,12 +138,13 @@ def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, mon
     crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
     s, tg = to_cuda(*make_inputs("encfuse", B=3, H=96, W=128, L=12))
     res = []
-    for fuse in ("0", "1"):
+    flag = "fused" if mode == "1" else "fused_attn_tail"        # REFTR_ENC_FUSE=2: only out_proj + norm1 / norm1' + out_proj^T are fused
+    for fuse in ("0", mode):
         monkeypatch.setenv("REFTR_ENC_FUSE", fuse)
         model.seed_dev.fill_(11)
         out = model(s)
         sv = model._saved
-        assert all(bool(r.get("fused")) == (fuse == "1") for r in sv["enc"])
+        assert all(bool(r.get(flag)) == (fuse != "0") for r in sv["enc"])
         enc = [{k: r[k].detach().clone() for k in ("t", "x1_16", "hdn", "t2", "qk", "v", "o")} for r in sv["enc"]]
         res.append(dict(mem=sv["mem32"].detach().clone(), enc=enc, loss=float(_total(crit, crit(out, tg)).detach())))
     a, b = res
@@ -161,7 +163,7 @@ def test_fused_encoder_layers_match_the_launched_chain_inside_the_model(hip, mon
     for i in reversed(range(cfg.enc_layers)):
         dx2 = torch.randn(M, E, generator=g).cuda(); dx2b = (torch.randn(M, E, generator=g) * 0.3).cuda() if i != 1 else None
         outs = []
-        for fuse in ("0", "1"):
+        for fuse in ("0", mode):
             monkeypatch.setenv("REFTR_ENC_FUSE", fuse)
             st.flat_g.zero_()
             dpos = torch.zeros(M, E, device="cuda")
