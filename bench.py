@@ -271,7 +271,7 @@ def main():
         model.net.side.enabled = False          # one stream for this pass: per-launch durations must be additive
         if mode == "hipgraph" and not dp:
             torch.cuda.synchronize()
-            torch.cuda._sleep(int(2.4e9 * 0.12))
+            torch.cuda._sleep(int(2.4e9 * 0.4))       # longer than the host needs to enqueue the whole eager step (~0.1-0.15 s of Python)
             hip.set_launch_timer(recs)
             cap._fwd_bwd(); cap._opt()
         else:
@@ -280,7 +280,7 @@ def main():
             torch.cuda.synchronize()
             if dp:
                 dist.barrier()
-            torch.cuda._sleep(int(2.4e9 * 0.12))
+            torch.cuda._sleep(int(2.4e9 * 0.4))       # longer than the host needs to enqueue the whole eager step (~0.1-0.15 s of Python)
             hip.set_launch_timer(recs)
             eager_step()
         torch.cuda.synchronize()

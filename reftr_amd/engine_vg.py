@@ -379,6 +379,9 @@ class CapturedTrainStep:
                 self.out = self._step_deferred()
             self.g_bb = self.g_opt = None
             self.grad_norm = opt.grad_norm
+            if getattr(opt, "_emit", False):
+                opt._emit_tables(None)                 # flush() applies the update over the WHOLE buffer: its job / chunk tables are built
+                                                       # now (a pageable host -> device copy later would stall the host behind queued work)
             self._pending = True                       # the last warm-up iteration's update
             self._set_flush(True)
         finally:
