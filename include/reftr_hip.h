@@ -390,6 +390,26 @@ int rt_stem_conv(const void* xp, const void* w, const float* bias, void* out,
                  int B, int Hp, int Wp, int Ho, int Wo, rt_stream_t stream);
 int rt_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, rt_stream_t stream);
 int rt_weight_prep(const float* src, const float* scale, void* dst, void* dst_t, int N, int T, int C, rt_stream_t stream);
+
+/* rt_bottleneck_fwd — one FROZEN stride-1 bottleneck of layer1 in ONE launch (models/modeling/backbone.py:87-89 freezes conv1 and
+ * layer1; torchvision Bottleneck v1.5 with FrozenBatchNorm2d :43-80): conv1 1x1 + BN + ReLU -> conv2 3x3 pad 1 + BN + ReLU ->
+ * conv3 1x1 + BN (+ x | + downsample 1x1 + BN) -> ReLU.  The 64-channel intermediates never leave LDS.  NHWC bf16 activations;
+ * weights bf16 with the BN scale folded (rt_weight_prep layout [N][T][C]), b* = BN shifts.  planes must be 64;
+ * cin = 256 with wd = bd = NULL (identity shortcut) or cin = 64 with the downsample operands.  B*H*W*256 < 2^31. */
+typedef struct rt_bottleneck_desc {
+    const void*  x;        /* bf16 [B,H,W,cin] */
+    const void*  w1;       /* bf16 [64][cin] */
+    const void*  w2;       /* bf16 [64][9][64] */
+    const void*  w3;       /* bf16 [256][64] */
+    const void*  wd;       /* bf16 [256][cin] or NULL */
+    const float* b1;       /* [64] */
+    const float* b2;       /* [64] */
+    const float* b3;       /* [256] */
+    const float* bd;       /* [256] or NULL */
+    void*        out;      /* bf16 [B,H,W,256] */
+    int32_t B, H, W, cin, planes;
+} rt_bottleneck_desc;
+int rt_bottleneck_fwd(const rt_bottleneck_desc* d, rt_stream_t stream);
 /* rt_weight_prep_batched — every per-step operand refresh in ONE launch.  table: DEVICE int64 [njobs][8] =
  * {src, scale|0, dst|0, dst_t|0, N, T, C, first_tile}; a job's tiles are 32(n) x 32(c) per tap, tiles numbered
  * consecutively over jobs (total_tiles = sum).  Both outputs are written coalesced (LDS tile transpose). */

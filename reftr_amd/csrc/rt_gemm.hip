@@ -386,7 +386,10 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
             static const int pipe = getenv("REFTR_PIPE") ? atoi(getenv("REFTR_PIPE")) : 3;         // bit 0: 128x128 / 3 stages, bit 1: 64x64 / 3 stages
             const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
             const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-            if (dense && smallt && a.M <= 1024 && t64 < 256 && (a.N & 7) == 0) hint = t64 <= 96 ? 281 : 33;
+            // round 4 (profiles/r04o_deep_stage_cold.txt): at <= 1 workgroup per CU the 32 x 32 form is bound by the K tiles it keeps in
+            // flight -- 6 stages instead of 3 take the cold K >= 768 products from 17.3 / 14.6 / 7.8 us to 11.1 / 9.9 / 5.8 (8 stages: no better)
+            static const int deep = getenv("REFTR_DEEP") ? atoi(getenv("REFTR_DEEP")) : 1;
+            if (dense && smallt && a.M <= 1024 && t64 < 256 && (a.N & 7) == 0) hint = t64 <= 96 ? ((deep && a.K >= 512) ? 285 : 281) : 33;
             else if (a.K < 1024) hint = (a.N >= 128 && t128 >= 384 && t128 <= 512) ? 51 : 31;
             else if (dense && a.K >= 2048 && a.N >= 128 && t256 >= 512) hint = 262;     // big products only; none in the step
             else if (a.N > 64 && (t128 >= 384 || (a.K >= 2048 && t128 >= 192))) hint = (!dense && (pipe & 1) && a.K >= 2048 && t128 <= 256) ? 252 : 51;
@@ -437,7 +440,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         case 62: return launch_gemm_dma<256, 128, 3, 1, 8>(a, s);
         case 63: return launch_gemm_dma<128, 256, 2, 1, 8>(a, s);
         case 211: case 221: case 231: case 233: case 251: case 252: case 261: case 262:
-        case 81: case 281: case 282: case 283: case 284: return rt_launch_gemm_pipe(a, hint, s);
+        case 81: case 281: case 282: case 283: case 284: case 285: case 286: case 287: case 288: case 234: case 236: return rt_launch_gemm_pipe(a, hint, s);
         default: return RT_ERR_BADARG;
     }
 }
@@ -472,7 +475,7 @@ extern "C" int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_st
     return RT_OK;
 }
 
-extern "C" int rt_abi_version(void) { return 27; }
+extern "C" int rt_abi_version(void) { return 28; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

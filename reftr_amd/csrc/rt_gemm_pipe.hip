@@ -21,6 +21,14 @@ int rt_launch_gemm_pipe(const GemmArgs& a, int hint, hipStream_t s) {
         case 282: return launch_gemm_dma_dense<32, 64, 3, 4, 4, 1>(a, s);
         case 283: return launch_gemm_dma_dense<64, 32, 3, 4, 4, 1>(a, s);
         case 284: return launch_gemm_dma_dense<32, 64, 2, 4, 4, 1>(a, s);
+        // deep-stage forms (round 4): at <= 1 workgroup per CU the K loop of a few-tile product is bound by the bytes one workgroup
+        // keeps in flight ((NS - 1) K tiles), not by its MFMAs
+        case 285: return launch_gemm_dma_dense<32, 32, 6, 2, 4, 1>(a, s);
+        case 286: return launch_gemm_dma_dense<32, 32, 8, 2, 4, 1>(a, s);
+        case 287: return launch_gemm_dma_dense<32, 64, 6, 2, 4, 1>(a, s);
+        case 288: return launch_gemm_dma_dense<64, 32, 6, 2, 4, 1>(a, s);
+        case 234: return launch_gemm_dma_dense<64, 64, 4, 2, 4, 1>(a, s);
+        case 236: return launch_gemm_dma_dense<64, 64, 6, 1, 4, 1>(a, s);
         default: return RT_ERR_BADARG;
     }
 }

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -114,6 +114,14 @@ class MaskPosencDesc(Structure):
         ("mask", c_void_p), ("kpm_out", c_void_p), ("pos_out", c_void_p), ("add_vec", c_void_p),
         ("B", c_int32), ("H", c_int32), ("W", c_int32), ("h", c_int32), ("w", c_int32), ("C", c_int32),
         ("kpm_stride", c_int32), ("kpm_off", c_int32), ("pos_rows_per_img", c_int32), ("pos_row_off", c_int32),
+    ]
+
+
+class BottleneckDesc(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("w1", c_void_p), ("w2", c_void_p), ("w3", c_void_p), ("wd", c_void_p),
+        ("b1", c_void_p), ("b2", c_void_p), ("b3", c_void_p), ("bd", c_void_p), ("out", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("cin", c_int32), ("planes", c_int32),
     ]
 
 
@@ -295,6 +303,7 @@ _SIGNATURES = {
     "rt_img_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_stem_conv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_bottleneck_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p]),
     "rt_weight_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rt_weight_prep_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rt_stem_weight_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -840,6 +849,17 @@ def maxpool3x3s2(x):
     y = _new((B, Ho, Wo, C), torch.bfloat16, x)
     _check(lib().rt_maxpool3x3s2(_p(x), _p(y), B, H, W, C, Ho, Wo, _stream()), "rt_maxpool3x3s2")
     return y
+
+
+def bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out=None):
+    """One frozen stride-1 layer1 bottleneck (planes 64) in one launch: x bf16 [B,H,W,cin] -> bf16 [B,H,W,256]."""
+    _req(x, torch.bfloat16, "x")
+    B, Hh, Ww, cin = x.shape
+    if out is None:
+        out = _new((B, Hh, Ww, 256), torch.bfloat16, x)
+    d = BottleneckDesc(_p(x), _p(w1), _p(w2), _p(w3), _p(wd), _p(b1), _p(b2), _p(b3), _p(bd), _p(out), B, Hh, Ww, cin, w1.shape[0])
+    _check(lib().rt_bottleneck_fwd(ctypes.byref(d), _stream()), "rt_bottleneck_fwd")
+    return out
 
 
 def weight_prep(src, N, T, C, *, scale=None, dst=None, dst_t=None):

@@ -56,6 +56,7 @@ class ResNetBody:
             self.blocks.append(stage)
         self.wg = H.SideStream(False)     # conv weight gradients stay inline (they fill the chip on their own)
         import os
+        self.fuse_frozen = os.environ.get("REFTR_L1_FUSE", "1") == "1" and str(store.device).startswith("cuda")
         gc = int(os.environ.get("REFTR_GROUP_CONV", "1")) if str(store.device).startswith("cuda") else 0
         self.batch = H.WgradBatch(workspace_mb=1024) if gc else None
         self.wgs = H.SideStream(gc == 2)
@@ -131,6 +132,15 @@ class ResNetBody:
                 if ready is not None and b.trainable:
                     torch.cuda.current_stream().wait_event(ready)
                     ready = None
+                if self.fuse_frozen and not b.trainable and b.conv1.cout == 64 and b.conv2.stride == 1 and (b.down is None or b.conv1.cin == 64):
+                    # frozen layer1 block: one launch, h1 / h2 never reach HBM (nothing of it is read by a backward)
+                    Bn, Hh, Ww = shp
+                    c1, c2, c3, cd = b.conv1, b.conv2, b.conv3, b.down
+                    out = H.bottleneck_fwd(x.view(Bn, Hh, Ww, c1.cin), self.W[c1.name], self.bn[c1.bn][1], self.W[c2.name], self.bn[c2.bn][1],
+                                           self.W[c3.name], self.bn[c3.bn][1],
+                                           wd=self.W[cd.name] if cd is not None else None, bd=self.bn[cd.bn][1] if cd is not None else None)
+                    x = out.view(-1, c3.cout)
+                    continue
                 rec = {"x": x, "shp": shp}
                 idt = x
                 if b.down is not None:

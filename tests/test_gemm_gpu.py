@@ -51,6 +51,9 @@ def hash_keep(seed, idx, p):
     (129, 64, 68, 231), (200, 256, 256, 231), (3520, 2048, 256, 233), (320, 768, 3072, 233), (333, 192, 72, 221), (333, 320, 72, 221),
     (320, 768, 3072, 81), (320, 3072, 768, 281), (333, 192, 72, 281), (129, 64, 68, 282), (320, 768, 768, 282), (333, 320, 72, 283),
     (320, 3072, 768, 284), (50, 128, 40, 281),
+    # deep-stage forms: fewer K tiles than stages (64, 192), as many, and many more
+    (320, 3072, 768, 285), (333, 192, 72, 285), (50, 64, 40, 285), (320, 384, 768, 285), (320, 768, 768, 286), (129, 64, 68, 286),
+    (333, 320, 72, 287), (320, 2304, 768, 288), (3520, 2048, 256, 234), (129, 64, 68, 234), (3520, 2048, 256, 236), (200, 256, 256, 236),
     (700, 256, 264, 261), (3520, 2048, 256, 262),
     (200, 256, 256, 211), (700, 320, 264, 251), (3520, 2048, 256, 252), (129, 64, 68, 251), (12800, 256, 1024, 251),
 ])
