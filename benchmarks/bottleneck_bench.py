@@ -25,11 +25,13 @@ for flush in (True, False):
             h1, _ = hip.conv_gemm(xf, w1, geom=g1, bias=b1, act=hip.ACT_RELU)
             h2, _ = hip.conv_gemm(h1, w2, geom=g2, bias=b2, act=hip.ACT_RELU)
             hip.conv_gemm(h2, w3, geom=g3, bias=b3, res_bf16=idt, res_first=True, act=hip.ACT_RELU)
+        def fused1():
+            hip.bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=wd, bd=bd, out=out, form=1)
         def fused():
-            hip.bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=wd, bd=bd, out=out)
-        tc, tf = TS.graph_time(chain), TS.graph_time(fused)
+            hip.bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=wd, bd=bd, out=out, form=2)
+        tc, t1, tf = TS.graph_time(chain), TS.graph_time(fused1), TS.graph_time(fused)
         M = B * Hh * Hh
         fl = 2.0 * M * (cin * 64 + 576 * 64 + 64 * 256 + (cin * 256 if down else 0))
         io = M * (cin + 256) * 2
-        print("%s cin %3d %s  launches %6.1f us   fused %6.1f us (%4.0f TF useful, %4.2f TB/s of block input + output)" % (
-            "cold" if flush else "warm", cin, "downsample" if down else "identity  ", tc, tf, fl / tf / 1e6, io / tf / 1e6), flush=True)
+        print("%s cin %3d %s  launches %6.1f us   one-tile form %6.1f us   persistent form %6.1f us (%4.0f TF useful, %4.2f TB/s of block input + output)" % (
+            "cold" if flush else "warm", cin, "downsample" if down else "identity  ", tc, t1, tf, fl / tf / 1e6, io / tf / 1e6), flush=True)

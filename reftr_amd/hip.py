@@ -121,7 +121,7 @@ class BottleneckDesc(Structure):
     _fields_ = [
         ("x", c_void_p), ("w1", c_void_p), ("w2", c_void_p), ("w3", c_void_p), ("wd", c_void_p),
         ("b1", c_void_p), ("b2", c_void_p), ("b3", c_void_p), ("bd", c_void_p), ("out", c_void_p),
-        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("cin", c_int32), ("planes", c_int32),
+        ("B", c_int32), ("H", c_int32), ("W", c_int32), ("cin", c_int32), ("planes", c_int32), ("form", c_int32),
     ]
 
 
@@ -851,13 +851,13 @@ def maxpool3x3s2(x):
     return y
 
 
-def bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out=None):
+def bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out=None, form=0):
     """One frozen stride-1 layer1 bottleneck (planes 64) in one launch: x bf16 [B,H,W,cin] -> bf16 [B,H,W,256]."""
     _req(x, torch.bfloat16, "x")
     B, Hh, Ww, cin = x.shape
     if out is None:
         out = _new((B, Hh, Ww, 256), torch.bfloat16, x)
-    d = BottleneckDesc(_p(x), _p(w1), _p(w2), _p(w3), _p(wd), _p(b1), _p(b2), _p(b3), _p(bd), _p(out), B, Hh, Ww, cin, w1.shape[0])
+    d = BottleneckDesc(_p(x), _p(w1), _p(w2), _p(w3), _p(wd), _p(b1), _p(b2), _p(b3), _p(bd), _p(out), B, Hh, Ww, cin, w1.shape[0], form)
     _check(lib().rt_bottleneck_fwd(ctypes.byref(d), _stream()), "rt_bottleneck_fwd")
     return out
 

@@ -51,15 +51,16 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("B,H,W,cin,down", CASES)
-def test_fused_bottleneck_vs_torch(hip, B, H, W, cin, down):
+def test_fused_bottleneck_vs_torch(hip, B, H, W, cin, down, form):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + cin)
     x = bf(torch.relu(torch.randn(B, H, W, cin, generator=g)))           # a block input is a ReLU output
     blk = make_block(cin, down, seed=cin + H)
     ref = torch_block(x, *blk)
     dev = [t.cuda() if t is not None else None for t in blk]
     w1, b1, w2, b2, w3, b3, wd, bd = dev
-    out = hip.bottleneck_fwd(x.cuda(), w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd)
+    out = hip.bottleneck_fwd(x.cuda(), w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=form)
     torch.cuda.synchronize()
     o = out.float().cpu()
     assert o.shape == ref.shape
@@ -75,12 +76,14 @@ def test_fused_bottleneck_vs_torch(hip, B, H, W, cin, down):
     assert float((o[:, ring] - ref[:, ring]).norm() / ref[:, ring].norm()) < 4e-3
 
 
-@pytest.mark.parametrize("B,H,W,cin,down", [(2, 24, 40, 256, False), (2, 24, 40, 64, True), (8, 160, 160, 256, False), (8, 160, 160, 64, True)])
-def test_fused_bottleneck_vs_the_launches_it_replaces(hip, B, H, W, cin, down):
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("B,H,W,cin,down", [(2, 24, 40, 256, False), (2, 24, 40, 64, True), (8, 160, 160, 256, False), (8, 160, 160, 64, True),
+                                            (5, 100, 100, 256, False), (5, 100, 100, 64, True)])
+def test_fused_bottleneck_vs_the_launches_it_replaces(hip, B, H, W, cin, down, form):
     g = torch.Generator(device="cuda").manual_seed(7 + cin)
     x = torch.relu(torch.randn(B, H, W, cin, generator=g, device="cuda")).bfloat16()
     w1, b1, w2, b2, w3, b3, wd, bd = [t.cuda() if t is not None else None for t in make_block(cin, down, seed=3)]
-    fused = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd)
+    fused = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=form)
     g1 = (B, H, W, cin, H, W, 64, 1, 1, 1, 0)
     g2 = (B, H, W, 64, H, W, 64, 3, 3, 1, 1)
     g3 = (B, H, W, 64, H, W, 256, 1, 1, 1, 0)
@@ -111,3 +114,18 @@ def test_fused_bottleneck_rejects_what_it_does_not_implement(hip):
     x64 = torch.zeros(1, 8, 16, 64, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         hip.bottleneck_fwd(x64, torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16), b, w2, b, w3, b)     # cin = 64 needs the downsample
+
+
+@pytest.mark.parametrize("B,H,W,cin,down", [(3, 37, 53, 256, False), (3, 37, 53, 64, True)])
+def test_the_two_forms_agree(hip, B, H, W, cin, down):
+    """Same MFMA shapes, same K order per output element, same rounding points: the persistent form and the one-tile form are
+    bit-identical (a tile's result does not depend on which workgroup computed it, nor on what the workgroup computed before)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.relu(torch.randn(B, H, W, cin, generator=g, device="cuda")).bfloat16()
+    w1, b1, w2, b2, w3, b3, wd, bd = [t.cuda() if t is not None else None for t in make_block(cin, down, seed=5)]
+    a = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=1)
+    b = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=2)
+    c = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=2)
+    torch.cuda.synchronize()
+    assert torch.equal(b, c)
+    assert torch.equal(a, b)
