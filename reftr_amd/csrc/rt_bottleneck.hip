@@ -16,8 +16,8 @@
 // MFMA-tile order of a PERMUTED feature order -- LDS row a*16 + i holds feature (i>>2)*16 + a*4 + (i&3) -- so that after the
 // four 16-feature MFMAs a lane holds 16 CONSECUTIVE features of its pixel: h1 / h2 go to LDS as two 16-B writes per pixel, and
 // the output / residual as two 16-B global accesses per lane, 128 contiguous bytes per pixel and wave instruction, without an
-// LDS staging pass.  Rounding points are those of the three rt_conv_gemm launches (bf16 h1, h2, out; fp32 accumulate, bias,
-// residual, ReLU) except that the downsample branch is accumulated in fp32 with conv3 instead of being rounded to bf16 first.
+// LDS staging pass.  Rounding points are those of the rt_conv_gemm launches it replaces (bf16 h1, h2, downsample output, out;
+// fp32 accumulate, bias, residual, ReLU): the two paths differ by summation order only.
 #include "rt_common.h"
 #include <stdlib.h>
 
@@ -271,11 +271,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
         bk_wait(issued - w_mark[pc]);
         __syncthreads();                                 // (q = 0: h2 complete)
         if (pc + 3 < NP) { issue_w(pc + 3); issued += BK_LW; w_mark[pc + 3] = issued; }
-        f32x4 bq[4];                                     // younger than every piece waited for so far: they can only make a wait longer
+        f32x4 bq[4], bdq[4];                             // younger than every piece waited for so far: they can only make a wait longer
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             bq[a] = *reinterpret_cast<const f32x4*>(p.b3 + q * 64 + lg * 16 + a * 4);
-            if (DOWN) bq[a] += *reinterpret_cast<const f32x4*>(p.bd + q * 64 + lg * 16 + a * 4);
+            if (DOWN) bdq[a] = *reinterpret_cast<const f32x4*>(p.bd + q * 64 + lg * 16 + a * 4);
         }
         if (q == 0) {
 #pragma unroll
@@ -290,11 +290,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
                     }
                 }
         }
-        f32x4 acc3[4][2];
-#pragma unroll
+        f32x4 acc3[4][2], accd[4][2];                    // the downsample branch keeps accumulators of its own: it is rounded to bf16
+#pragma unroll                                           // before it joins (the identity tensor of the unfused launches)
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) acc3[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int bb = 0; bb < 2; ++bb) { acc3[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f}; accd[a][bb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         {
             bf16x8 wf[2][4];
             w_frags(pc, wf);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int bb = 0; bb < 2; ++bb)
-                        acc3[a][bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][a], cf[kk][bb], acc3[a][bb], 0, 0, 0);
+                        accd[a][bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][a], cf[kk][bb], accd[a][bb], 0, 0, 0);
         }
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
                     const int e = a * 4 + r;
                     float v = acc3[a][bb][r] + bq[a][r];
                     if (!DOWN) v += (float)(e < 8 ? res[q][bb][0][e & 7] : res[q][bb][1][e & 7]);
+                    else v += (float)(bf16_t)(accd[a][bb][r] + bdq[a][r]);
                     v = fmaxf(v, 0.f);
                     if (e < 8) lo[e] = (bf16_t)v; else hi[e - 8] = (bf16_t)v;
                 }
@@ -386,13 +387,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_persist_kernel(const BnkArg
         }
     }
     const f32x4 b1v = *reinterpret_cast<const f32x4*>(p.b1 + 16 * wave + lg * 4), b2v = *reinterpret_cast<const f32x4*>(p.b2 + 16 * wave + lg * 4);
-    float b3v[16];
+    float b3v[16], bdv[16];
 #pragma unroll
     for (int e = 0; e < 16; e += 4) {
-        f32x4 u = *reinterpret_cast<const f32x4*>(p.b3 + 64 * wave + lg * 16 + e);
-        if (DOWN) u += *reinterpret_cast<const f32x4*>(p.bd + 64 * wave + lg * 16 + e);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(p.b3 + 64 * wave + lg * 16 + e);
+        const f32x4 ud = DOWN ? *reinterpret_cast<const f32x4*>(p.bd + 64 * wave + lg * 16 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b3v[e + r] = u[r];
+        for (int r = 0; r < 4; ++r) { b3v[e + r] = u[r]; bdv[e + r] = ud[r]; }
     }
 
     const int srow = t >> 3, chunk = (t & 7) ^ (srow & 7);
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_persist_kernel(const BnkArg
                     res[bb][1] = *reinterpret_cast<const bf16x8*>(rp + 8);
                 }
             }
-            f32x4 acc3[4][2];
+            f32x4 acc3[4][2], accd[4][2];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -539,11 +540,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck_persist_kernel(const BnkArg
                     f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[a][kk], hf[bb][kk], c, 0, 0, 0);
-                    if (DOWN) {                            // conv3 first, then the downsample: the summation order of the one-tile form
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdf[a][kk], cf[bb][kk], c, 0, 0, 0);
-                    }
                     acc3[a][bb] = c;
+                    if (DOWN) {                            // accumulators of its own: rounded to bf16 before it joins, like the one-tile form
+                        f32x4 dd = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdf[a][kk], cf[bb][kk], dd, 0, 0, 0);
+                        accd[a][bb] = dd;
+                    }
                 }
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck_persist_kernel(const BnkArg
                         const int e = a * 4 + r;
                         float v = acc3[a][bb][r] + b3v[e];
                         if (!DOWN) v += (float)(e < 8 ? res[bb][0][e & 7] : res[bb][1][e & 7]);
+                        else v += (float)(bf16_t)(accd[a][bb][r] + bdv[e]);
                         v = fmaxf(v, 0.f);
                         if (e < 8) lo[e] = (bf16_t)v; else hi[e - 8] = (bf16_t)v;
                     }

@@ -348,6 +348,18 @@ class CapturedTrainStep:
         assert be == inner.store.flat_p.numel() or be > bb, "BERT is the last group of the flat buffers"
         self._hooks = ((lambda: opt.apply_pending(span=(0, bb)) if bb > 0 else None),
                        (lambda: opt.apply_pending(span=(bb, be))))
+        # pipelined schedule (REFTR_OPT_PIPE, reftr_transformer.forward): the BERT slice in pieces of three layers on a stream of its
+        # own, each piece gating only the BERT layers that read it -- BERT's forward starts behind the embeddings + layers 0-2
+        # instead of behind the whole 3.5 GB slice, the ResNet starts at once (stem / layer1 are frozen)
+        cuts = inner.bert_layer_offsets() if hasattr(inner, "bert_layer_offsets") else None
+        if cuts and bb > 0 and getattr(opt, "_emit", False):
+            step = int(os.environ.get("REFTR_OPT_PIPE_LAYERS", "3"))
+            marks = [bb] + [cuts[i] for i in range(step, len(cuts) - 1, step)] + [be]     # cuts[-1] = the pooler, kept with the last piece
+            pieces = [((lambda: opt.apply_pending(span=(0, bb))), "main")]
+            for k in range(len(marks) - 1):
+                sp = (marks[k], marks[k + 1])
+                pieces.append(((lambda sp=sp: opt.apply_pending(span=sp)), k * step))          # tag = first BERT layer that reads the piece
+            self._hooks = self._hooks + (pieces,)
 
     def _head_deferred(self):
         """[AdamW of the previous iteration | forward | loss | backward up to the first boundary]"""

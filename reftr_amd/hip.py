@@ -858,7 +858,13 @@ def bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out=None, form=0
     if out is None:
         out = _new((B, Hh, Ww, 256), torch.bfloat16, x)
     d = BottleneckDesc(_p(x), _p(w1), _p(w2), _p(w3), _p(wd), _p(b1), _p(b2), _p(b3), _p(bd), _p(out), B, Hh, Ww, cin, w1.shape[0], form)
-    _check(lib().rt_bottleneck_fwd(ctypes.byref(d), _stream()), "rt_bottleneck_fwd")
+    # a member of the GEMM family of bench.py's roofline: the algorithmic FLOPs of the convolutions it replaces (the conv1 halo
+    # recomputation is not counted), compulsory bytes = block input + output + weights once
+    M = B * Hh * Ww
+    macs = cin * 64 + 576 * 64 + 64 * 256 + (cin * 256 if wd is not None else 0)
+    nbytes = 2.0 * (M * (cin + 256) + macs)
+    _timed("bottleneck_fwd", 2.0 * M * macs, lambda: _check(lib().rt_bottleneck_fwd(ctypes.byref(d), _stream()), "rt_bottleneck_fwd"),
+           nbytes=nbytes)
     return out
 
 

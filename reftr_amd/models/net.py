@@ -203,13 +203,17 @@ class Net:
                                self.G(pfx + "weight"), self.G(pfx + "bias"), pg_batch=self.ln_batch, **kw)
 
     # ------------------------------------------------------------------ BERT
-    def bert_fwd(self, ids, mask_u8):
+    def bert_fwd(self, ids, mask_u8, gates=None):
         """ids int64 [B, L], mask uint8 [B, L] (1 = token).  Returns (seq bf16 [B*L, Hd], pooled bf16 [B, Hd], ctx)."""
         bc = self.cfg.bert
         B, L = ids.shape
         M, Hd = B * L, bc.hidden
         pfx = "lang_backbone."
         e = pfx + "embeddings."
+        # gates {first layer: event}: the pipelined optimizer's piece that holds layers [i, next key) (and, for 0, the embeddings;
+        # for the last, the pooler) has been applied once the event has passed
+        if gates and 0 in gates:
+            torch.cuda.current_stream().wait_event(gates[0])
         kpm = (mask_u8 == 0).to(torch.uint8)
         pos_ids = H.roberta_pos_ids(ids, bc.pad_idx) if bc.pad_idx >= 0 else None
         emb = H.bert_embed_fwd(ids, self.P(e + "word_embeddings.weight"), self.P(e + "position_embeddings.weight"),
@@ -221,6 +225,8 @@ class Net:
         scale = 1.0 / math.sqrt(dh)
         for i in range(bc.layers):
             lp = f"{pfx}encoder.layer.{i}."
+            if gates and i > 0 and i in gates:
+                torch.cuda.current_stream().wait_event(gates[i])
             r = {"h16": h16}
             qkv, _ = self.lin_fwd(lp + "qkv", h16)
             r["qkv"] = qkv

@@ -97,6 +97,12 @@ class RefTR(nn.Module):
         # front of them changes nothing (7.295 vs 7.295 ms over four interleaved pairs) -- both are HBM-bound; off by default
         self._pre_side = os.environ.get("REFTR_PRE_SIDE", "0") != "0"
         self._opt_serial = os.environ.get("REFTR_OPT_SERIAL", "0") != "0"
+        # pipelined deferred optimizer: every AdamW piece on a third stream, consumers wait per piece (forward).  Measured
+        # (profiles/r04s_opt_pipe_negative_result.txt): BERT's forward then ends 0.5 ms earlier and the ResNet's 0.4 ms LATER (three
+        # streams share the chip; layer2 alone goes 469 -> 1004 us beside BERT's forward): 7.28-7.33 vs 7.01-7.04 ms.  Off.
+        self._opt_pipe = os.environ.get("REFTR_OPT_PIPE", "0") != "0"
+        self.opt_side = H.SideStream(self._opt_pipe)
+        self._bert_gates = None
         self._adam_done = None
         self._bb_ready = None
         self._norm_side = False          # switched on by engine_vg.CapturedTrainStep around its own backward + clip-norm unit only
@@ -213,6 +219,25 @@ class RefTR(nn.Module):
             return None
         return net._dec_handoff[1:2]
 
+    def bert_layer_offsets(self):
+        """Flat-buffer offsets at which BERT encoder layer 0, 1, ... start, then the pooler's: piece boundaries of the pipelined
+        optimizer pass.  None when the layout is not layer-contiguous."""
+        st, nl = self.store, self.cfg.bert.layers
+        firsts = []
+        for pfx in [f"lang_backbone.encoder.layer.{i}." for i in range(nl)] + ["lang_backbone.pooler."]:
+            offs = [o for n, (b, o) in st.offset.items() if b == "p" and n.startswith(pfx)]
+            if not offs:
+                return None
+            firsts.append(min(offs))
+        bb, be = st.group_range[L.GROUP_BERT]
+        ok = all(a < b for a, b in zip(firsts, firsts[1:])) and bb < firsts[0] and firsts[-1] < be
+        # every parameter of layer i lies in [firsts[i], firsts[i+1])
+        for i, pfx in enumerate([f"lang_backbone.encoder.layer.{i}." for i in range(nl)]):
+            for n, (b, o) in st.offset.items():
+                if b == "p" and n.startswith(pfx) and not (firsts[i] <= o < firsts[i + 1]):
+                    ok = False
+        return firsts if ok else None
+
     def operands_emitted(self):
         """The optimizer's pass wrote every bf16 operand itself: nothing to rebuild except the K-concatenated copies."""
         self.net._refresh_kv_cat()
@@ -277,7 +302,29 @@ class RefTR(nn.Module):
     def forward(self, samples):
         self._bb_ready = None
         H.mark("step start")
-        if self._pre_update is not None:
+        self._bert_gates = None
+        if self._pre_update is not None and self._opt_pipe and len(self._pre_update) > 2 and self.net.side.enabled \
+                and self.opt_side.enabled and not self._full_refresh and not self._operands_dirty:
+            # Deferred optimizer, pipelined: [main slice | BERT embeddings + layers 0-2 | 3-5 | 6-8 | 9-11 + pooler] on the optimizer
+            # stream.  Nothing on the main stream waits here: the frozen stem / layer1 start at once, the first trainable
+            # convolution waits for the main piece (body.forward `ready`), BERT layer i for the piece that holds it (_bert_gates).
+            gates, state = {}, {"ok": True}
+            def _chain():
+                for fn, tag in self._pre_update[2]:
+                    state["ok"] = bool(fn()) and state["ok"]
+                    if tag == "main":
+                        self.net._refresh_kv_cat()
+                    ev = torch.cuda.Event(); ev.record()
+                    gates[tag] = ev
+                    H.mark("opt: main slice done" if tag == "main" else f"opt: BERT piece from layer {tag} done")
+            self.opt_side.run(_chain)
+            if not state["ok"]:                 # a piece did not write its operands (not expected here): refresh behind the whole chain
+                self.opt_side.join()
+                self.mark_dirty()
+            else:
+                self._bb_ready = gates.pop("main")
+                self._bert_gates = gates
+        elif self._pre_update is not None:
             if self._pre_side and self.net.side.enabled and not self._full_refresh:
                 # Deferred optimizer: the pending AdamW pass over the main / mask / ResNet slices and the refresh of the trainable
                 # convolutions' operands go to the language stream (in front of the BERT slice's pass): the stem and layer1 are
@@ -351,7 +398,9 @@ class RefTR(nn.Module):
 
         def _lang_branch():
             H.mark("lang: branch starts")
-            if self._pre_update is not None and self._pre_update[1]():
+            if self._bert_gates is not None:
+                pass                           # the optimizer stream holds every piece; bert_fwd waits per piece
+            elif self._pre_update is not None and self._pre_update[1]():
                 net._refresh_kv_cat()          # operands written by the AdamW passes (this one and the main stream's, which is ordered in front of this branch)
             if self._pre_update is not None and self._opt_serial:
                 # the BERT slice's AdamW pass (3.5 GB) and the frozen stem / layer1 (HBM-bound too) do not share the memory system
@@ -363,7 +412,7 @@ class RefTR(nn.Module):
                 net.refresh()
                 self._lin_refresh_pending = False
             H.mark("lang: AdamW (BERT slice) + operands done")
-            r = net.bert_fwd(ids, smask_u8)
+            r = net.bert_fwd(ids, smask_u8, gates=self._bert_gates)
             H.mark("lang: BERT forward done")
             pos = torch.empty(M, E, dtype=torch.float32, device=dev)
             kpm = torch.empty(B, S, dtype=torch.uint8, device=dev)
@@ -396,6 +445,10 @@ class RefTR(nn.Module):
         x16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
         xp16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
         H.mark("ResNet forward done")
+        if self._bert_gates is not None:
+            if self._bb_ready is not None:     # nothing trainable in the ResNet waited for the main piece (--lr_backbone 0)
+                torch.cuda.current_stream().wait_event(self._bb_ready)
+            self.opt_side.join()
         net.side.join()
         H.mark("forward join (language branch in)")
         if self._zero_grad_side:

@@ -100,10 +100,13 @@ def main():
     say("%10s  %-6s %s" % ("t [us]", "stream", "mark"))
     order = sorted(names, key=lambda n: med[n])
     for n in order:
-        st = "main" if names[n][1] == main_stream else "lang"
+        st = "main" if names[n][1] == main_stream else ("opt" if n.startswith("opt:") else "lang")
         say("%10.1f  %-6s %s" % (med[n], st, n))
-    for label, pick in (("main", lambda st: st == main_stream), ("lang", lambda st: st != main_stream)):
-        seq = [n for n in order if pick(names[n][1])]
+    for label, pick in (("main", lambda n: names[n][1] == main_stream), ("lang", lambda n: names[n][1] != main_stream and not n.startswith("opt:")),
+                        ("opt", lambda n: n.startswith("opt:"))):
+        seq = [n for n in order if pick(n)]
+        if len(seq) < 2:
+            continue
         say()
         say(f"phases on the {label} stream (between consecutive marks of that stream):")
         for a, b in zip(seq, seq[1:]):
