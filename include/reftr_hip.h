@@ -574,6 +574,11 @@ int rt_stamp(uint64_t* buf, int idx, rt_stream_t stream);
  *   mat table (DEVICE int64 [njobs][8], static): {element offset of the matrix [N][T][C] in p / g / m / v, scale pointer | 0
  *     (FrozenBN scale[n] folded into the bf16 copies only), dst bf16 [N][T][C] | 0, dst_t bf16 [C][T][N] | 0, N, T, C, first tile};
  *     a job has ceil(N/32) * ceil(T*C/256) tiles; total_tiles = their sum; a matrix lies inside ONE learning-rate range.
+ *     A job with dst = dst_t = 0 (an embedding table) may carry, in the scale slot, a DEVICE uint8 array [N][ceil(T*C/256)] of
+ *     state bytes (0 = "m and v of this 256-column piece of row n are all zero"; start it at 1 = unknown; the kernel maintains
+ *     it; reset it to 1 whenever m / v are written by anyone else).  A piece with byte 0 AND an all-zero gradient is skipped
+ *     without reading p / m / v whenever (1 - lr * wd) rounds to 1.0f: with g = m = v = 0 the update is exactly that factor
+ *     (torch.optim.AdamW's own fp32 no-op at the reference's lr_bert * weight_decay = 1e-9), so results are bit-identical.
  *   chunk table (DEVICE int64 [nchunks][2], static): {element offset, element count <= 16384}, both multiples of 4.
  * d->span_* are ignored (the tables say what is updated).  The caller makes jobs and chunks tile the parameters exactly once. */
 int rt_adamw_mat(const rt_adamw_desc* d, const int64_t* table, int njobs, int total_tiles, rt_stream_t stream);

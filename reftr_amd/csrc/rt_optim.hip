@@ -183,9 +183,15 @@ __global__ __launch_bounds__(256) void adamw_mat_kernel(const rt_adamw_desc p, c
     }
     const int64_t* j = table + lo * 8;
     const size_t base = (size_t)j[0];
-    const float* scale = reinterpret_cast<const float*>(j[1]);
     bf16_t* dst = reinterpret_cast<bf16_t*>(j[2]);
     bf16_t* dst_t = reinterpret_cast<bf16_t*>(j[3]);
+    // Sparse-state jobs (round 4): a matrix WITHOUT bf16 operands (the embedding tables: 24 M of BERT's parameters, of which a step
+    // touches <= B * L rows) may carry, in the otherwise unused scale slot, one byte per KB row piece: 0 = "m and v of this piece
+    // are all zero".  A piece whose gradient is all zero too is then left alone WITHOUT reading p / m / v -- bit-exact, because with
+    // g = m = v = 0 the update is p *= (1 - lr * wd) and nothing else, and the skip is only taken when that factor rounds to 1.0f
+    // (lr_bert * wd = 1e-9 in every reference config: models the reference's own fp32 no-op).  4 B instead of 32 B per element.
+    uint8_t* flags = (!dst && !dst_t && j[1]) ? reinterpret_cast<uint8_t*>(j[1]) : nullptr;
+    const float* scale = flags ? nullptr : reinterpret_cast<const float*>(j[1]);
     const int N = (int)j[4], T = (int)j[5], C = (int)j[6];
     const int K = T * C;
     const int local = blockIdx.x - (int)j[7];
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(256) void adamw_mat_kernel(const rt_adamw_desc p, c
     const bool vec = (K & 3) == 0 && (base & 3) == 0 && (!dst || ((uintptr_t)dst & 7) == 0);
     if (vec) {
         const int r = t >> 6, q = (t & 63) * 4, k = k0 + q;
+        const bool may_skip = flags && (1.f - lr * wd) == 1.f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 pv[4], gv[4], mv[4], vv[4];
@@ -212,13 +219,30 @@ __global__ __launch_bounds__(256) void adamw_mat_kernel(const rt_adamw_desc p, c
                 ok[jj] = n < N && k < K;
                 if (ok[jj]) {
                     const size_t o = (size_t)n * K + k;
-                    pv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + o));
-                    mv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mo + o));
-                    vv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vo + o));
                     if (G16) {
                         const bf16x4_t h = __builtin_nontemporal_load(reinterpret_cast<const bf16x4_t*>(G16 + o));
                         gv[jj] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
                     } else gv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + o));
+                }
+            }
+            if (flags) {
+                // a wave = one KB row piece (row n, column tile tk): the decisions below are wave-uniform
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int n = n0 + (half * 4 + jj) * 4 + r;
+                    const bool nz = ok[jj] && (gv[jj][0] != 0.f || gv[jj][1] != 0.f || gv[jj][2] != 0.f || gv[jj][3] != 0.f);
+                    const bool g_zero = __ballot(nz) == 0;
+                    if (n < N && may_skip && g_zero && flags[(size_t)n * kt + tk] == 0) ok[jj] = false;      // nothing to do for this piece
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int n = n0 + (half * 4 + jj) * 4 + r;
+                if (ok[jj]) {
+                    const size_t o = (size_t)n * K + k;
+                    pv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + o));
+                    mv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Mo + o));
+                    vv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Vo + o));
                 }
             }
 #pragma unroll
@@ -232,6 +256,13 @@ __global__ __launch_bounds__(256) void adamw_mat_kernel(const rt_adamw_desc p, c
                     *reinterpret_cast<f32x4*>(P + o) = pv[jj];
                     __builtin_nontemporal_store(mv[jj], reinterpret_cast<f32x4*>(Mo + o));
                     __builtin_nontemporal_store(vv[jj], reinterpret_cast<f32x4*>(Vo + o));
+                    if (flags) {                       // the state of this piece after the update (wave-uniform: ok[jj] is, within a row piece, except past K)
+                        bool live = false;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) live = live || mv[jj][e] != 0.f || vv[jj][e] != 0.f;
+                        const bool any_live = __ballot(live) != 0;
+                        if ((t & 63) == 0) flags[(size_t)n * kt + tk] = any_live ? 1 : 0;
+                    }
                     const float sc = scale ? scale[n] : 1.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[e] = (bf16_t)(scale ? pv[jj][e] * sc : pv[jj][e]);

@@ -530,6 +530,8 @@ class CapturedTrainStep:
             "captured for another input shape; use train_step"
         if self.inner._operands_dirty:        # the masters were changed outside an optimizer step (load_state_dict, a restored
             self.inner.refresh_now()          # snapshot): the graph no longer carries an operand refresh of its own
+        if hasattr(self.optimizer, "check_sparse_state"):
+            self.optimizer.check_sparse_state()      # moments restored from outside: the sparse-state bytes go back to 'unknown'
         if self.deferred:
             self._stage_in(samples, targets)
             self.g_fb.replay()                # applies iteration i-1's update with the rates synced at iteration i-1

@@ -864,7 +864,7 @@ def bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out=None, form=0
     macs = cin * 64 + 576 * 64 + 64 * 256 + (cin * 256 if wd is not None else 0)
     nbytes = 2.0 * (M * (cin + 256) + macs)
     _timed("bottleneck_fwd", 2.0 * M * macs, lambda: _check(lib().rt_bottleneck_fwd(ctypes.byref(d), _stream()), "rt_bottleneck_fwd"),
-           nbytes=nbytes)
+           tag=("BNK", B, Hh, Ww, cin, Hh, Ww, 256, 3, 3, 1, 1), nbytes=nbytes)
     return out
 
 

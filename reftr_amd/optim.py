@@ -72,6 +72,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._emit = os.environ.get("REFTR_OPT_EMIT", "1") != "0" and not self.SGD
         self._emit_cache = {}
         self._last_emitted = False
+        # sparse optimizer state (rt_adamw_mat, matrices without bf16 operands = the embedding tables): one byte per KB row piece,
+        # 0 = "m and v of the piece are zero"; such a piece with an all-zero gradient is skipped without reading p / m / v (exact: see
+        # the kernel).  The bytes describe m / v as THIS optimizer's kernels left them: any write to them from outside (a restored
+        # snapshot, load_state_dict) is noticed through the tensors' version counters and resets every byte to "unknown" (1).
+        self._sparse = os.environ.get("REFTR_OPT_SPARSE", "1") != "0"
+        self._sparse_flags = {}
+        self._mv_version = None
         # device word that vetoes an iteration's update (the cooperative decoder's failure word): see finish_step / step
         self.veto = None
 
@@ -146,11 +153,33 @@ class FusedAdamW(torch.optim.Optimizer):
             mine = sorted((j for j in jobs if b <= j[0] < e), key=lambda j: j[0])
             geo, tiles, chunks = cover_span([j[:4] for j in mine], b, e)
             rows = [[off, H._p(j[4]) or 0, H._p(j[5]) or 0, H._p(j[6]) or 0, N, T, C, first] for (off, N, T, C, first), j in zip(geo, mine)]
+            if self._sparse:
+                for row, j in zip(rows, mine):
+                    if j[4] is None and j[5] is None and j[6] is None:          # no operands: the scale slot carries the state bytes
+                        row[1] = self._sparse_flag(row[0], row[4], row[5] * row[6]).data_ptr()
             dev = st.device
             mat = (torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None, len(rows), tiles)
             chk = (torch.tensor(chunks, dtype=torch.int64).to(dev) if chunks else None, len(chunks) // 2)
             ent = self._emit_cache[key] = (mat, chk, [j[4:] for j in mine])      # the tensors behind the raw pointers stay referenced
         return ent[0], ent[1]
+
+    def _sparse_flag(self, off, N, K):
+        f = self._sparse_flags.get(off)
+        if f is None:
+            f = self._sparse_flags[off] = torch.ones(N * ((K + 255) // 256), dtype=torch.uint8, device=self.model.store.device)
+        return f
+
+    def check_sparse_state(self):
+        """Host-side, before a launch / a graph replay: m or v written from outside since the last look -> every state byte back to
+        'unknown'.  (The kernels write through raw pointers and do not move the version counters.)"""
+        if not self._sparse_flags:
+            return
+        ver = (self.m._version, self.v._version)
+        if ver != self._mv_version:
+            if not torch.cuda.is_current_stream_capturing():
+                for f in self._sparse_flags.values():
+                    f.fill_(1)
+                self._mv_version = ver
 
     def _launch(self, span=None):
         """One AdamW pass over `span` (default: everything).  Returns True when the pass also wrote the bf16 operands of the
@@ -159,6 +188,7 @@ class FusedAdamW(torch.optim.Optimizer):
         b1, b2 = self.defaults["betas"]
         tabs = self._emit_tables(span) if self._emit else None
         kw = dict(mat=tabs[0], chunks=tabs[1]) if tabs is not None else {}
+        self.check_sparse_state()
         H.adamw_flat(st.flat_p, st.flat_g, self.m, self.v, step=max(self.step_count, 1), ranges=self._ranges(), gnorm_sq=self.sq,
                      g16=getattr(st, "flat_g16", None),
                      gnorm_out=self.grad_norm, grad_scale=getattr(self.model, "_grad_scale", 1.0),

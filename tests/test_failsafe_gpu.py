@@ -318,3 +318,84 @@ def test_replayed_step_reports_the_same_gradient_norm_with_and_without_the_fused
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * res[1][0], res
     for a, b in zip(res[0], res[1]):
         assert abs(a - b) <= 2e-2 * b, res
+
+
+def test_sparse_state_adamw_is_bit_exact_and_skips_untouched_pieces(hip):
+    """rt_adamw_mat with state bytes (matrices without bf16 operands = the embedding tables): a KB row piece whose m / v are zero and
+    whose gradient is zero is left alone without reading p / m / v.  The mat job WITH the bytes must equal the same job WITHOUT them
+    bit for bit -- over several steps, with rows entering the touched set late, with weight decay that rounds to a no-op (the skip
+    is taken) and with one that does not (the skip is never taken)."""
+    H = hip
+    dev = "cuda"
+    N, K = 100, 768
+    n = N * K
+    g0 = torch.Generator(device="cpu").manual_seed(3)
+    kt = (K + 255) // 256
+    tiles = ((N + 31) // 32) * kt
+    for lr, wd, expect_skip in ((1e-5, 1e-4, True), (1e-2, 0.1, False)):
+        p = torch.randn(n, generator=g0).to(dev)
+        pa, ma, va = p.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        pb, mb, vb = p.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        flags = torch.ones(N * kt, dtype=torch.uint8, device=dev)
+        tab_a = torch.tensor([[0, 0, 0, 0, N, 1, K, 0]], dtype=torch.int64).to(dev)
+        tab_b = torch.tensor([[0, flags.data_ptr(), 0, 0, N, 1, K, 0]], dtype=torch.int64).to(dev)
+        touched = set()
+        for step, rows in enumerate(([3, 50], [3], [], [77, 50]), start=1):
+            gr = torch.zeros(N, K)
+            for r in rows:
+                gr[r] = torch.randn(K, generator=g0) * 0.1
+            if step == 4:
+                gr[12, 300:310] = 0.5                     # a single piece of a row
+            gr = gr.reshape(-1).to(dev)
+            touched |= set(rows)
+            sq = (gr.double() ** 2).sum().float().reshape(1)
+            kw = dict(step=step, ranges=[(0, n, lr, wd)], gnorm_sq=sq, max_norm=0.1)
+            H.adamw_flat(pa, gr, ma, va, mat=(tab_a, 1, tiles), **kw)
+            H.adamw_flat(pb, gr, mb, vb, mat=(tab_b, 1, tiles), **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), (lr, step)
+        f = flags.view(N, kt).cpu()
+        live = (mb.view(N, K) != 0) | (vb.view(N, K) != 0)
+        want = torch.stack([live[:, c * 256:(c + 1) * 256].any(dim=1) for c in range(kt)], dim=1)
+        assert torch.equal(f.bool(), want.cpu())          # the bytes say exactly which pieces hold state
+        assert int(f.sum()) == 3 * len(touched) + 1       # rows 3, 50, 77 whole + one piece of row 12
+        if expect_skip:
+            assert torch.equal(pb.view(N, K)[0], p.view(N, K)[0])        # an untouched row never moved (decay rounds to a no-op)
+        else:
+            assert not torch.equal(pb.view(N, K)[0], p.view(N, K)[0])    # real weight decay: every row moves, nothing was skipped
+
+
+def test_sparse_state_bytes_follow_moments_written_from_outside(hip):
+    """FusedAdamW notices m / v written from outside (a restored snapshot, load_state_dict) through the tensors' version counters
+    and resets the state bytes to 'unknown' before the next launch: a trajectory restored from a snapshot -- with the bytes
+    deliberately falsified to 'no state anywhere' -- equals the original one bit for bit."""
+    from reftr_amd.engine_vg import train_step
+    model, crit, s, tg, opt = build(dec_layers=2, B=2)
+    model.eval()                                           # no dropout: the two passes see the same masks (none)
+    train_step(model, crit, s, tg, opt, None, max_norm=0.1)
+    assert opt._sparse_flags, "the embedding tables run as sparse-state jobs"
+    f = max(opt._sparse_flags.values(), key=lambda t: t.numel())          # the word embeddings
+    torch.cuda.synchronize()
+    assert 0 < int(f.sum()) < f.numel() // 8                              # only the batch's tokens hold state
+    st = model.store
+    snap = (st.flat_p.clone(), opt.m.clone(), opt.v.clone(), opt.step_count)
+    for _ in range(2):
+        train_step(model, crit, s, tg, opt, None, max_norm=0.1)
+    torch.cuda.synchronize()
+    end = (st.flat_p.clone(), opt.m.clone(), opt.v.clone())
+    st.flat_p.copy_(snap[0]); opt.m.copy_(snap[1]); opt.v.copy_(snap[2]); opt.step_count = snap[3]; opt.step_dev.fill_(snap[3])
+    model.mark_dirty(full=True)
+    for t in opt._sparse_flags.values():
+        t.zero_()                                          # a lie the version check must override
+    for _ in range(2):
+        train_step(model, crit, s, tg, opt, None, max_norm=0.1)
+    torch.cuda.synchronize()
+    # the backward has fp32 atomics (bias / LayerNorm / embedding gradients): run to run 1 ulp, not bit-equal -- the moments of the
+    # embedding rows that hold state must be there again, which a skipped piece would have left at the snapshot's values
+    emb = "lang_backbone.embeddings.word_embeddings.weight"
+    m_end, m_now, m_snap = st.view_of(end[1], emb), st.view_of(opt.m, emb), st.view_of(snap[1], emb)
+    rows = (m_end != 0).any(dim=1)
+    assert int(rows.sum()) > 0
+    assert float((m_now[rows] - m_end[rows]).abs().max()) <= 1e-3 * float(m_end[rows].abs().max())
+    assert float((m_now[rows] - m_snap[rows]).abs().max()) > 10 * float((m_now[rows] - m_end[rows]).abs().max())
+    assert float((st.flat_p - end[0]).abs().max()) <= 1e-5
