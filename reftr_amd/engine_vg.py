@@ -348,6 +348,7 @@ class CapturedTrainStep:
         assert be == inner.store.flat_p.numel() or be > bb, "BERT is the last group of the flat buffers"
         self._hooks = ((lambda: opt.apply_pending(span=(0, bb)) if bb > 0 else None),
                        (lambda: opt.apply_pending(span=(bb, be))))
+        inner._late_ok = bool(getattr(opt, "_emit", False)) and bb > 0      # the late main-slice pass relies on the pass writing the operands
         # pipelined schedule (REFTR_OPT_PIPE, reftr_transformer.forward): the BERT slice in pieces of three layers on a stream of its
         # own, each piece gating only the BERT layers that read it -- BERT's forward starts behind the embeddings + layers 0-2
         # instead of behind the whole 3.5 GB slice, the ResNet starts at once (stem / layer1 are frozen)

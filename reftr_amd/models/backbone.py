@@ -115,7 +115,7 @@ class ResNetBody:
                            act=H.ACT_RELU if relu else H.ACT_NONE)
         return y, (B, Ho, Wo), geom
 
-    def forward(self, img, ready=None):
+    def forward(self, img, ready=None, before_trainable=None):
         """img fp32 [B,3,H,W] -> (list of the 4 stage outputs as ([M, C] bf16, (B,h,w))), saved-for-backward).
         `ready`: event after which the TRAINABLE convolutions' operands are current (the frozen stem / layer1 do not wait)."""
         B, _, Hh, Ww = img.shape
@@ -129,6 +129,9 @@ class ResNetBody:
         feats, saved = [], []
         for stage in self.blocks:
             for b in stage:
+                if before_trainable is not None and b.trainable:
+                    before_trainable()              # the deferred optimizer pass over the main slice, behind the frozen prefix
+                    before_trainable = None
                 if ready is not None and b.trainable:
                     torch.cuda.current_stream().wait_event(ready)
                     ready = None
@@ -154,6 +157,8 @@ class ResNetBody:
                 x, shp = out, s3
             feats.append((x, shp))
             H.mark(f"ResNet forward: layer{len(feats)} done")
+        if before_trainable is not None:            # nothing trainable in the body (--lr_backbone 0)
+            before_trainable()
         return feats, saved
 
     # ------------------------------------------------------------------ backward

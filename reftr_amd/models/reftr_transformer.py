@@ -97,6 +97,12 @@ class RefTR(nn.Module):
         # front of them changes nothing (7.295 vs 7.295 ms over four interleaved pairs) -- both are HBM-bound; off by default
         self._pre_side = os.environ.get("REFTR_PRE_SIDE", "0") != "0"
         self._opt_serial = os.environ.get("REFTR_OPT_SERIAL", "0") != "0"
+        # the main slice's deferred AdamW pass BEHIND the frozen stem / layer1 (in front of the first trainable convolution) instead
+        # of in front of the stem: the frozen prefix shares the memory system with the BERT slice's pass from t = 0.  Measured
+        # (profiles/r04z_opt_late_negative_result.txt): layer1 is done at 0.92 instead of 1.15 ms, but the pass then takes 0.33 ms
+        # beside BERT's forward and layer2 starts at 1.25 ms: 6.76-6.81 vs 6.66-6.72 ms.  Off.
+        self._opt_late = os.environ.get("REFTR_OPT_LATE", "0") != "0"
+        self._late_hook = None
         # pipelined deferred optimizer: every AdamW piece on a third stream, consumers wait per piece (forward).  Measured
         # (profiles/r04s_opt_pipe_negative_result.txt): BERT's forward then ends 0.5 ms earlier and the ResNet's 0.4 ms LATER (three
         # streams share the chip; layer2 alone goes 469 -> 1004 us beside BERT's forward): 7.28-7.33 vs 7.01-7.04 ms.  Off.
@@ -301,6 +307,7 @@ class RefTR(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, samples):
         self._bb_ready = None
+        self._late_hook = None
         H.mark("step start")
         self._bert_gates = None
         if self._pre_update is not None and self._opt_pipe and len(self._pre_update) > 2 and self.net.side.enabled \
@@ -324,6 +331,9 @@ class RefTR(nn.Module):
             else:
                 self._bb_ready = gates.pop("main")
                 self._bert_gates = gates
+        elif self._pre_update is not None and self._opt_late and self.net.side.enabled and not self._full_refresh \
+                and not self._operands_dirty and getattr(self, "_late_ok", True):
+            self._late_hook = self._pre_update[0]          # issued by body.forward in front of the first trainable block
         elif self._pre_update is not None:
             if self._pre_side and self.net.side.enabled and not self._full_refresh:
                 # Deferred optimizer: the pending AdamW pass over the main / mask / ResNet slices and the refresh of the trainable
@@ -343,7 +353,8 @@ class RefTR(nn.Module):
         elif self._flush_pending is not None:
             self._flush_pending()
         self.refresh_operands()
-        H.mark("AdamW (main slice) + operands done")
+        if self._late_hook is None:
+            H.mark("AdamW (main slice) + operands done")
         pred_masks = None
         if self.seg is not None:
             assert "phrase" not in samples, "RefTRSeg is single-phrase (reftr_segmentation.py:101-103)"
@@ -401,7 +412,8 @@ class RefTR(nn.Module):
             if self._bert_gates is not None:
                 pass                           # the optimizer stream holds every piece; bert_fwd waits per piece
             elif self._pre_update is not None and self._pre_update[1]():
-                net._refresh_kv_cat()          # operands written by the AdamW passes (this one and the main stream's, which is ordered in front of this branch)
+                if self._late_hook is None:
+                    net._refresh_kv_cat()      # operands written by the AdamW passes (this one and the main stream's, which is ordered in front of this branch)
             if self._pre_update is not None and self._opt_serial:
                 # the BERT slice's AdamW pass (3.5 GB) and the frozen stem / layer1 (HBM-bound too) do not share the memory system
                 # well: side by side they took 1080 + 1075 us against ~600 + ~85 us alone (profiles/r04a_concurrent_timeline.txt).
@@ -414,6 +426,11 @@ class RefTR(nn.Module):
             H.mark("lang: AdamW (BERT slice) + operands done")
             r = net.bert_fwd(ids, smask_u8, gates=self._bert_gates)
             H.mark("lang: BERT forward done")
+            if self._late_hook is not None:
+                return r                       # the positional work reads main-slice parameters: it is forked behind their update
+            return r + _pos_work()
+
+        def _pos_work():
             pos = torch.empty(M, E, dtype=torch.float32, device=dev)
             kpm = torch.empty(B, S, dtype=torch.uint8, device=dev)
             kpm[:, :Lq] = (smask_u8 == 0)                                   # models/reftr.py:92
@@ -433,12 +450,23 @@ class RefTR(nn.Module):
                 pe = torch.cat([col.unsqueeze(0).expand(h, w, -1), row.unsqueeze(1).expand(h, w, -1)], dim=-1).reshape(HW, E) + addv
                 pos.view(B, S, E)[:, Lq:, :] = pe
             H.mark("lang: positional / mask work done")
-            return r + (pos, kpm)
+            return (pos, kpm)
         self._adam_done = None
-        seq16, pooled16, bctx, pos, kpm = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
+        late = self._late_hook
+        lang_out = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
         if self._adam_done is not None and net.side.enabled:
             torch.cuda.current_stream().wait_event(self._adam_done)
-        feats, bb_saved = self.body.forward(x, ready=self._bb_ready)
+        late_out = []
+        def _late_main():
+            # main stream, behind the frozen stem / layer1: the main slice's pending AdamW pass (it writes the bf16 operands), the
+            # K-concatenated copies, then the positional work -- forked here, it queues on the language stream behind BERT's forward
+            if not late():
+                raise RuntimeError("the deferred AdamW pass did not write the bf16 operands (REFTR_OPT_EMIT=0?): run with REFTR_OPT_LATE=0")
+            net._refresh_kv_cat()
+            H.mark("AdamW (main slice) + operands done")
+            late_out.append(net.side.run(_pos_work, mask_u8, smask_u8))
+        feats, bb_saved = self.body.forward(x, ready=self._bb_ready, before_trainable=_late_main if late is not None else None)
+        seq16, pooled16, bctx, pos, kpm = lang_out + late_out[0] if late is not None else lang_out
         c5, (_, h5, w5) = feats[-1]
         assert (h5, w5) == (h, w)
         x32 = torch.empty(M, E, dtype=torch.float32, device=dev)
