@@ -29,9 +29,11 @@ for flush in (True, False):
             hip.bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=wd, bd=bd, out=out, form=1)
         def fused():
             hip.bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=wd, bd=bd, out=out, form=2)
-        tc, t1, tf = TS.graph_time(chain), TS.graph_time(fused1), TS.graph_time(fused)
+        def fused3():
+            hip.bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=wd, bd=bd, out=out, form=3)
+        tc, t1, tf, t3 = TS.graph_time(chain), TS.graph_time(fused1), TS.graph_time(fused), TS.graph_time(fused3)
         M = B * Hh * Hh
         fl = 2.0 * M * (cin * 64 + 576 * 64 + 64 * 256 + (cin * 256 if down else 0))
         io = M * (cin + 256) * 2
-        print("%s cin %3d %s  launches %6.1f us   one-tile form %6.1f us   persistent form %6.1f us (%4.0f TF useful, %4.2f TB/s of block input + output)" % (
-            "cold" if flush else "warm", cin, "downsample" if down else "identity  ", tc, t1, tf, fl / tf / 1e6, io / tf / 1e6), flush=True)
+        print("%s cin %3d %s  launches %6.1f us   form 1 (8x16, 2 WG/CU) %6.1f us   form 3 (8x32, 8 waves) %6.1f us   form 2 (persistent) %6.1f us (%4.0f TF useful, %4.2f TB/s of block input + output: form 2)" % (
+            "cold" if flush else "warm", cin, "downsample" if down else "identity  ", tc, t1, t3, tf, fl / tf / 1e6, io / tf / 1e6), flush=True)

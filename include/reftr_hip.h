@@ -409,7 +409,7 @@ typedef struct rt_bottleneck_desc {
     void*        out;      /* bf16 [B,H,W,256] */
     int32_t B, H, W, cin, planes;
     int32_t form;          /* 0 = library default (REFTR_BNK_V, 1); 1 = one tile per workgroup, weights through an LDS ring;
-                              2 = persistent workgroups, weights in registers */
+                              2 = persistent workgroups, weights in registers; 3 = one 8-wave workgroup per CU on an 8 x 32 tile, 8-slot ring */
 } rt_bottleneck_desc;
 int rt_bottleneck_fwd(const rt_bottleneck_desc* d, rt_stream_t stream);
 /* rt_weight_prep_batched — every per-step operand refresh in ONE launch.  table: DEVICE int64 [njobs][8] =

@@ -60,14 +60,22 @@ constexpr int BK_LX = BK_XROWS / 32, BK_LW = 2;            // DMA instructions p
 // persistent form: h1 row pitch (pixels), bytes of h1, LDS of a workgroup
 constexpr int BKP_PITCH = 24, BKP_T1_BYTES = (BK_TH + 2) * BKP_PITCH * 128, BKP_LDS = 4 * BK_XSLOT + BKP_T1_BYTES + BK_TH * BK_TW * 128;
 
-template <int CIN, bool DOWN>
-__global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p) {
+// TW / NW / R: tile width in pixels, waves, ring slots.  (16, 4, 4) = the first form: 8 x 16 tile, 80 KB of LDS, two workgroups per CU.
+// (32, 8, 8) = the third form: ONE 8-wave workgroup per CU on an 8 x 32 tile, all 160 KB -- the weight pieces are pulled once per 256
+// pixels instead of per 128, the halo is 1.33x instead of 1.41x, and the ring runs SEVEN pieces ahead instead of three (the first
+// form's workgroups spend most of their 23 us parked on ring pieces: an L2 round trip is longer than three pieces of compute).
+template <int CIN, bool DOWN, int TW = 16, int NW = 4, int R = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bottleneck_fwd_kernel(const BnkArgs p) {
+    static_assert((R & (R - 1)) == 0 && R >= 4 && TW % 16 == 0 && NW * 2 == BK_TH * TW / 16, "8 rows x TW / 16 pixel tiles, two per wave");
+    constexpr int HWD = TW + 2, HALO = (BK_TH + 2) * HWD, XROWS = NW * 48, XSLOT = XROWS * 128, RPP = NW * 8, LX = XROWS / RPP, LW = 64 / RPP,
+                  PASS = RPP * 128, CT = TW / 16;
+    static_assert(HALO <= XROWS && BK_TH * TW * 128 <= XSLOT, "the haloed tile / h2 fit an X slot");
     constexpr int NK1 = CIN / 64;                         // conv1 K chunks
     constexpr int NP = NK1 + 9 + (DOWN ? 8 : 4);          // weight pieces in order of use: conv1 chunks, conv2 taps, conv3 (+downsample) quarters
     static_assert(NK1 == 1 || !DOWN, "the downsample variant keeps the whole input tile resident: cin = 64");
-    constexpr unsigned T1_OFF = DOWN ? BK_XSLOT : 0;      // h1 [192 x 64] bf16: over X slot 0 once conv1 is done (identity variant)
-    constexpr unsigned T2_OFF = BK_XSLOT;                 // h2 [128 x 64] bf16: X slot 1 (identity) / over h1 after a barrier (downsample)
-    constexpr unsigned WR_OFF = 2 * BK_XSLOT;             // weight ring, 4 x 8 KB
+    constexpr unsigned T1_OFF = DOWN ? XSLOT : 0;      // h1 [192 x 64] bf16: over X slot 0 once conv1 is done (identity variant)
+    constexpr unsigned T2_OFF = XSLOT;                 // h2 [128 x 64] bf16: X slot 1 (identity) / over h1 after a barrier (downsample)
+    constexpr unsigned WR_OFF = 2 * XSLOT;             // weight ring, 4 x 8 KB
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -75,23 +83,23 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
     // vertically adjacent tiles share two haloed rows, horizontally adjacent ones two columns: contiguous runs per XCD
     const int bid = rt_xcd_remap((int)blockIdx.x, (int)gridDim.x, 1);
     const int tx = bid % p.tiles_x, tyb = bid / p.tiles_x, ty = tyb % p.tiles_y, b = tyb / p.tiles_y;
-    const int oy0 = ty * BK_TH, ox0 = tx * BK_TW;
+    const int oy0 = ty * BK_TH, ox0 = tx * TW;
 
     const int srow = t >> 3;
     const int chunk = (t & 7) ^ (srow & 7);               // source-side swizzle (see rt_gemm_dma.h)
     constexpr int OOB = 0x7fffffff;
-    int x_off[BK_LX];
+    int x_off[LX];
 #pragma unroll
-    for (int j = 0; j < BK_LX; ++j) {
-        const int hp = srow + 32 * j, hr = hp / BK_HW, hc = hp - hr * BK_HW;
+    for (int j = 0; j < LX; ++j) {
+        const int hp = srow + RPP * j, hr = hp / HWD, hc = hp - hr * HWD;
         const int y = oy0 - 1 + hr, x = ox0 - 1 + hc;
-        const bool ok = hp < BK_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const bool ok = hp < HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         x_off[j] = ok ? (((b * p.H + y) * p.W + x) * CIN + chunk * 8) * 2 : OOB;
     }
-    int w1_off[BK_LW], w2_off[BK_LW], w3_off[BK_LW];
+    int w1_off[LW], w2_off[LW], w3_off[LW];
 #pragma unroll
-    for (int j = 0; j < BK_LW; ++j) {
-        const int r = srow + 32 * j, a = r >> 4, i = r & 15;
+    for (int j = 0; j < LW; ++j) {
+        const int r = srow + RPP * j, a = r >> 4, i = r & 15;
         const int ch = (i >> 2) * 16 + a * 4 + (i & 3);  // permuted feature order
         w1_off[j] = (ch * CIN + chunk * 8) * 2;
         w2_off[j] = (ch * 576 + chunk * 8) * 2;
@@ -102,28 +110,28 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
 
     auto issue_x = [&](int kc) __attribute__((always_inline)) {
-        const unsigned base = lds0 + (kc & 1) * BK_XSLOT;
+        const unsigned base = lds0 + (kc & 1) * XSLOT;
 #pragma unroll
-        for (int j = 0; j < BK_LX; ++j) bk_dma16(rs_x, base + j * 4096, x_off[j], kc * 128);
+        for (int j = 0; j < LX; ++j) bk_dma16(rs_x, base + j * PASS, x_off[j], kc * 128);
     };
     auto issue_w = [&](int pc) __attribute__((always_inline)) {      // pc is a compile-time constant at every call site
-        const unsigned base = lds0 + WR_OFF + (pc & 3) * BK_WSLOT;
+        const unsigned base = lds0 + WR_OFF + (pc & (R - 1)) * BK_WSLOT;
         if (pc < NK1) {
 #pragma unroll
-            for (int j = 0; j < BK_LW; ++j) bk_dma16(rs_w1, base + j * 4096, w1_off[j], pc * 128);
+            for (int j = 0; j < LW; ++j) bk_dma16(rs_w1, base + j * PASS, w1_off[j], pc * 128);
         } else if (pc < NK1 + 9) {
 #pragma unroll
-            for (int j = 0; j < BK_LW; ++j) bk_dma16(rs_w2, base + j * 4096, w2_off[j], (pc - NK1) * 128);
+            for (int j = 0; j < LW; ++j) bk_dma16(rs_w2, base + j * PASS, w2_off[j], (pc - NK1) * 128);
         } else {
             const int i = pc - NK1 - 9, q = DOWN ? i >> 1 : i;
             const bool dn = DOWN && (i & 1);
 #pragma unroll
-            for (int j = 0; j < BK_LW; ++j) bk_dma16(dn ? rs_wd : rs_w3, base + j * 4096, w3_off[j], q * 8192);
+            for (int j = 0; j < LW; ++j) bk_dma16(dn ? rs_wd : rs_w3, base + j * PASS, w3_off[j], q * 8192);
         }
     };
     // A fragments (weights) of piece pc: 4 feature tiles x 2 K halves
     auto w_frags = [&](int pc, bf16x8 (&wf)[2][4]) __attribute__((always_inline)) {
-        const unsigned char* base = smem + WR_OFF + (pc & 3) * BK_WSLOT;
+        const unsigned char* base = smem + WR_OFF + (pc & (R - 1)) * BK_WSLOT;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
     bool oin[2];
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
-        const int r = wave * 2 + bb, oy = oy0 + r, ox = ox0 + li;
+        const int mt = wave * 2 + bb, oy = oy0 + mt / CT, ox = ox0 + (mt % CT) * 16 + li;
         oin[bb] = oy < p.H && ox < p.W;
         opix[bb] = (b * p.H + oy) * p.W + ox;
     }
@@ -173,11 +181,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
     // ---- prologue: pieces 0 .. 2 and the first two X chunks in flight.  `marks`: DMA instructions issued so far / when an
     // operand was issued (all compile-time after unrolling): the wait for an operand allows exactly the younger ones outstanding.
     int issued = 0, x_mark[NK1 > 1 ? NK1 : 2], w_mark[NP];
-    issue_x(0); issued += BK_LX; x_mark[0] = issued;
-    issue_w(0); issued += BK_LW; w_mark[0] = issued;
-    if (NK1 > 1) { issue_x(1); issued += BK_LX; x_mark[1] = issued; }
-    issue_w(1); issued += BK_LW; w_mark[1] = issued;
-    issue_w(2); issued += BK_LW; w_mark[2] = issued;
+    issue_x(0); issued += LX; x_mark[0] = issued;
+    issue_w(0); issued += LW; w_mark[0] = issued;
+    if (NK1 > 1) { issue_x(1); issued += LX; x_mark[1] = issued; }
+#pragma unroll
+    for (int pc = 1; pc < R - 1; ++pc) { issue_w(pc); issued += LW; w_mark[pc] = issued; }
 
     // ---- stage 1: conv1 on the haloed tile
     f32x4 acc1[4][3];
@@ -190,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
         const int need = x_mark[kc] > w_mark[kc] ? x_mark[kc] : w_mark[kc];
         bk_wait(issued - need);
         __syncthreads();                                 // chunk kc / piece kc visible; everyone is done with chunk kc-1 / piece kc-1
-        if (kc >= 1 && kc + 1 < NK1) { issue_x(kc + 1); issued += BK_LX; x_mark[kc + 1] = issued; }
-        if (kc + 3 < NP) { issue_w(kc + 3); issued += BK_LW; w_mark[kc + 3] = issued; }
+        if (kc >= 1 && kc + 1 < NK1) { issue_x(kc + 1); issued += LX; x_mark[kc + 1] = issued; }
+        if (kc + R - 1 < NP) { issue_w(kc + R - 1); issued += LW; w_mark[kc + R - 1] = issued; }
         bf16x8 wf[2][4];
         w_frags(kc, wf);
-        const unsigned char* xs = smem + (kc & 1) * BK_XSLOT;
+        const unsigned char* xs = smem + (kc & 1) * XSLOT;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 xf[3];
@@ -211,10 +219,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
     if (!DOWN) __syncthreads();                          // h1 goes over X slot 0: every wave is done with the last chunk held there
 #pragma unroll
     for (int bb = 0; bb < 3; ++bb) {
-        const int hp = (wave * 3 + bb) * 16 + li, hr = hp / BK_HW, hc = hp - hr * BK_HW;
+        const int hp = (wave * 3 + bb) * 16 + li, hr = hp / HWD, hc = hp - hr * HWD;
         const int y = oy0 - 1 + hr, x = ox0 - 1 + hc;
         // conv2 pads h1 with ZEROS outside the image (not with conv1 of zeros)
-        const bool in = hp < BK_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const bool in = hp < HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         float v[16];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
         const int pc = NK1 + tp, kh = tp / 3, kw = tp % 3;
         bk_wait(issued - w_mark[pc]);
         __syncthreads();                                 // (tp = 0: h1 complete)
-        if (pc + 3 < NP) { issue_w(pc + 3); issued += BK_LW; w_mark[pc + 3] = issued; }
+        if (pc + R - 1 < NP) { issue_w(pc + R - 1); issued += LW; w_mark[pc + R - 1] = issued; }
         bf16x8 wf[2][4];
         w_frags(pc, wf);
 #pragma unroll
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
             bf16x8 xf[2];
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
-                const int row = (wave * 2 + bb + kh) * BK_HW + kw + li;
+                const int mt = wave * 2 + bb, row = (mt / CT + kh) * HWD + kw + (mt % CT) * 16 + li;
                 xf[bb] = *reinterpret_cast<const bf16x8*>(smem + T1_OFF + row * 128 + (((kk * 4 + lg) ^ (row & 7)) << 4));
             }
 #pragma unroll
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
         const int pc = NK1 + 9 + (DOWN ? 2 * q : q);
         bk_wait(issued - w_mark[pc]);
         __syncthreads();                                 // (q = 0: h2 complete)
-        if (pc + 3 < NP) { issue_w(pc + 3); issued += BK_LW; w_mark[pc + 3] = issued; }
+        if (pc + R - 1 < NP) { issue_w(pc + R - 1); issued += LW; w_mark[pc + R - 1] = issued; }
         f32x4 bq[4], bdq[4];                             // younger than every piece waited for so far: they can only make a wait longer
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
                     const int m = (wave * 2 + bb) * 16 + li;
                     hf[kk][bb] = *reinterpret_cast<const bf16x8*>(smem + T2_OFF + m * 128 + (((kk * 4 + lg) ^ (m & 7)) << 4));
                     if (DOWN) {
-                        const int hp = (wave * 2 + bb + 1) * BK_HW + 1 + li;
+                        const int mt = wave * 2 + bb, hp = (mt / CT + 1) * HWD + 1 + (mt % CT) * 16 + li;
                         cf[kk][bb] = *reinterpret_cast<const bf16x8*>(smem + hp * 128 + (((kk * 4 + lg) ^ (hp & 7)) << 4));
                     }
                 }
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fwd_kernel(const BnkArgs p)
         if (DOWN) {
             bk_wait(issued - w_mark[pc + 1]);
             __syncthreads();
-            if (pc + 4 < NP) { issue_w(pc + 4); issued += BK_LW; w_mark[pc + 4] = issued; }
+            if (pc + R < NP) { issue_w(pc + R); issued += LW; w_mark[pc + R] = issued; }
             bf16x8 wf[2][4];
             w_frags(pc + 1, wf);
 #pragma unroll
@@ -600,6 +608,20 @@ int launch_bottleneck(const BnkArgs& a, int want, hipStream_t s) {
         RT_CHECK_LAUNCH();
         return RT_OK;
     }
+    if (form == 3) {
+        constexpr int LDS3 = 2 * (8 * 48 * 128) + 8 * BK_WSLOT;        // all 160 KB
+        static bool attr3 = false;
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute((const void*)bottleneck_fwd_kernel<CIN, DOWN, 32, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
+            if (e != hipSuccess) return (int)e;
+            attr3 = true;
+        }
+        BnkArgs a3 = a;
+        a3.tiles_x = (a.W + 31) / 32;
+        hipLaunchKernelGGL((bottleneck_fwd_kernel<CIN, DOWN, 32, 8, 8>), dim3((unsigned)(a.B * a3.tiles_x * a.tiles_y)), dim3(512), LDS3, s, a3);
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
     hipLaunchKernelGGL((bottleneck_fwd_kernel<CIN, DOWN>), dim3(grid), dim3(256), BK_LDS, s, a);
     RT_CHECK_LAUNCH();
     return RT_OK;
@@ -609,7 +631,7 @@ int launch_bottleneck(const BnkArgs& a, int want, hipStream_t s) {
 
 extern "C" int rt_bottleneck_fwd(const rt_bottleneck_desc* d, rt_stream_t stream) {
     if (!d || !d->x || !d->w1 || !d->w2 || !d->w3 || !d->b1 || !d->b2 || !d->b3 || !d->out) return RT_ERR_BADARG;
-    if (d->planes != 64 || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->form < 0 || d->form > 2) return RT_ERR_UNSUPPORTED;
+    if (d->planes != 64 || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->form < 0 || d->form > 3) return RT_ERR_UNSUPPORTED;
     const long long in_bytes = (long long)d->B * d->H * d->W * d->cin * 2, out_elems = (long long)d->B * d->H * d->W * 256;
     if (in_bytes >= (1ll << 31) || out_elems >= (1ll << 31)) return RT_ERR_UNSUPPORTED;      // 32-bit buffer offsets / pixel indices
     BnkArgs a;
