@@ -90,6 +90,9 @@ typedef struct rt_conv_gemm_desc {
     float* acc2_f32;          /* optional second fp32 destination [M, N] that the result is ADDED to (out_f32 / out_bf16 still receive
                                  the result itself): the q/k-side input gradient of an attention layer is both passed on and summed into
                                  the gradient of `pos` / `query_pos`, which every layer re-adds (transformer.py:154-156,168-175) */
+    int32_t dil;              /* dilation of the taps (0 / 1 = none): tap (kh, kw) reads the source pixel kh * dil, kw * dil away (`--dilation`,
+                                 models/modeling/backbone.py:117-125: layer4's 3x3 convolutions with dilation 2, pad 2, stride 1).
+                                 dil > 1 needs stride 1 and the LDS-DMA tiles (every tile_hint but 1-3). */
 } rt_conv_gemm_desc;
 int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream);
 /* rt_conv_gemm_grouped — n independent rt_conv_gemm problems (HOST array of descriptors).  Dense products with K < 1024 and
@@ -126,7 +129,7 @@ typedef struct rt_conv_wgrad_desc {
     int32_t overwrite;    /* 1: dw = result instead of dw += result (the caller guarantees this is the first contribution to dw since
                              the gradient buffer was last consumed: no pre-zeroed memory is needed and the epilogue skips the read of
                              dw).  dbias always accumulates. */
-    int32_t reserved;
+    int32_t dil;          /* dilation of the taps (0 / 1 = none; > 1 needs stride 1), as in rt_conv_gemm_desc */
     float*  sqacc;        /* optional gradient-norm accumulator (RT_SQ_SLOTS x RT_SQ_STRIDE floats, see rt_sqnorm_finish): the launch adds
                              |dw after|^2 - |dw before|^2, so that the clip norm (engine_vg.py:62-63) needs no pass over dw */
     void*   g16;          /* optional bf16 twin of dw (same shape): every value written to dw is also written there, rounded -- the

@@ -57,6 +57,7 @@ class Cfg:
     resnet_layers: tuple = (3, 4, 6, 3)
     bert: BertCfg = field(default_factory=BertCfg)
     pos_learned: bool = False     # --position_embedding learned (position_encoding.py:59-84)
+    dilation: bool = False        # --dilation: layer4's stride replaced by dilation (backbone.py:117-125, torchvision resnet._make_layer)
     masks: bool = False           # RefTRSeg (reftr_segmentation.py): RES head on top of the single-phrase REC model
     cem: bool = False             # --ablation cem_loss: the CEM block + loss_cem (reftr_segmentation.py:16-41, 62-64, 146-147)
     mask_loss_coef: float = 1.0   # main_vg.py (default 1)
@@ -214,13 +215,13 @@ def frozen_bn_affine(P, pfx, eps=1e-5):
     return scale.detach(), shift.detach()
 
 
-def conv_bn(x, P, conv, bn, stride=1, padding=0, q=False, relu=True, residual=None, round_out=True):
+def conv_bn(x, P, conv, bn, stride=1, padding=0, q=False, relu=True, residual=None, round_out=True, dilation=1):
     w = P[conv + "weight"]
     scale, shift = frozen_bn_affine(P, bn)
     if q:   # HIP path: scale folded into the bf16 weight, output stored as bf16
-        y = conv2d_acc(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, stride, padding) + shift.view(1, -1, 1, 1)
+        y = conv2d_acc(rq(x, q), rq_fwd(w * scale.view(-1, 1, 1, 1), q), None, stride, padding, dilation) + shift.view(1, -1, 1, 1)
     else:
-        y = conv2d_acc(x, w, None, stride, padding) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        y = conv2d_acc(x, w, None, stride, padding, dilation) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if residual is not None:
         y = y + residual
     if relu:
@@ -228,19 +229,21 @@ def conv_bn(x, P, conv, bn, stride=1, padding=0, q=False, relu=True, residual=No
     return rq(y, q and round_out)
 
 
-def bottleneck(x, P, pfx, stride, q=False, trunk_round=True):
-    """ResNet v1.5 bottleneck (stride on the 3x3), SURVEY.md A1."""
+def bottleneck(x, P, pfx, stride, q=False, trunk_round=True, dilation=1):
+    """ResNet v1.5 bottleneck (stride on the 3x3; its padding = its dilation, torchvision conv3x3), SURVEY.md A1."""
     idt = x
     if (pfx + "downsample.0.weight") in P:
         idt = conv_bn(x, P, pfx + "downsample.0.", pfx + "downsample.1.", stride, 0, q, relu=False, round_out=trunk_round)
     y = conv_bn(x, P, pfx + "conv1.", pfx + "bn1.", 1, 0, q)
-    y = conv_bn(y, P, pfx + "conv2.", pfx + "bn2.", stride, 1, q)
+    y = conv_bn(y, P, pfx + "conv2.", pfx + "bn2.", stride, dilation, q, dilation=dilation)
     return conv_bn(y, P, pfx + "conv3.", pfx + "bn3.", 1, 0, q, relu=True, residual=idt, round_out=trunk_round)
 
 
-def resnet_body(x, P, pfx="img_backbone.0.body.", layers=(3, 4, 6, 3), q=False):
+def resnet_body(x, P, pfx="img_backbone.0.body.", layers=(3, 4, 6, 3), q=False, dilation=False):
     """conv1 7x7/2 + FrozenBN + ReLU + maxpool 3x3/2, then layer1..4 (backbone.py:99,119-121).
-    Returns the four stage outputs (strides 4, 8, 16, 32)."""
+    Returns the four stage outputs (strides 4, 8, 16, 32).  dilation (backbone.py:117-125 -> torchvision's
+    replace_stride_with_dilation=[False, False, True]): layer4's first block runs at stride 1 with dilation 1, its other blocks
+    dilate their 3x3 by 2 -- the last output keeps stride 16."""
     scale, shift = frozen_bn_affine(P, pfx + "bn1.")
     w = P[pfx + "conv1.weight"]
     if q:
@@ -253,8 +256,11 @@ def resnet_body(x, P, pfx="img_backbone.0.body.", layers=(3, 4, 6, 3), q=False):
     for li, n in enumerate(layers):
         for bi in range(n):
             stride = 2 if (bi == 0 and li > 0) else 1
+            dl = 1
+            if dilation and li == 3:
+                stride, dl = 1, (1 if bi == 0 else 2)
             t32 = _ACC["fp32_trunk_from"]
-            y = bottleneck(y, P, f"{pfx}layer{li + 1}.{bi}.", stride, q, trunk_round=not (t32 and li + 1 >= t32))
+            y = bottleneck(y, P, f"{pfx}layer{li + 1}.{bi}.", stride, q, trunk_round=not (t32 and li + 1 >= t32), dilation=dl)
         outs.append(y)
     return outs
 
@@ -447,7 +453,7 @@ def reftr_forward(P, samples, cfg: Cfg, train=False, q=False):
     img, img_mask = samples["img"], samples["img_mask"]
     B = img.shape[0]
     E = cfg.hidden
-    feats = resnet_body(img, P, layers=cfg.resnet_layers, q=q)
+    feats = resnet_body(img, P, layers=cfg.resnet_layers, q=q, dilation=cfg.dilation)
     c5 = feats[-1]
     m5 = mask_downsample(img_mask, c5.shape[-2:])
     pos5 = learned_pos(P, m5.shape[0], m5.shape[1], m5.shape[2]) if cfg.pos_learned else sine_pos(m5, E // 2)

@@ -320,6 +320,8 @@ static int fill_gemm_args(const rt_conv_gemm_desc* d, GemmArgs& a) {
     a.act = d->act; a.res_first = d->res_first; a.gate_scale = d->gate_scale; a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.seed_dev = d->seed_dev;
     a.drop_shift = d->drop_shift;
     a.acc2_f32 = d->acc2_f32;
+    a.dil = d->dil > 1 ? d->dil : 1;
+    if (a.dil > 1 && d->stride != 1) return RT_ERR_UNSUPPORTED;
     if (a.drop_shift < 0 || a.drop_shift > 16) return RT_ERR_BADARG;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
@@ -361,6 +363,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         return RT_OK;
     }
     int hint = d->tile_hint;
+    if (a.dil > 1 && hint >= 1 && hint <= 3) return RT_ERR_UNSUPPORTED;      // the register-staged tiles have no dilation
     if (hint == 0) {
         // Tile choice from the in-step sweeps (benchmarks/tile_sweep.py, profiles/r01e_tile_sweep.txt): small K streams
         // best through many 64x64 workgroups; 128x128 needs >= 1.5 waves of tiles over the 256 CUs to pay off.
@@ -418,6 +421,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
             else hint = a.K >= 1024 ? 33 : 31;
         }
     }
+    if (a.dil > 1 && hint >= 1 && hint <= 3) return RT_ERR_UNSUPPORTED;      // (REFTR_DMA=0)
     switch (hint) {
         case 1: return launch_gemm<128, 128>(a, s);
         case 2: return launch_gemm<128, 64>(a, s);

@@ -9,7 +9,7 @@ struct GemmArgs {
     const float* bias; const float* res_f32; const bf16_t* res_bf16; const bf16_t* gate; const bf16_t* preact; const bf16_t* dtanh;
     int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, transposed, act, res_first;
     float gate_scale, drop_p; uint32_t drop_seed; int drop_shift;
-    int M, K, sshift, xcd, early, epi_lds, abl, prefetch, mfast;
+    int M, K, sshift, xcd, early, epi_lds, abl, prefetch, mfast, dil;
     unsigned src_bytes, wgt_bytes;
     const uint32_t* seed_dev;
 };

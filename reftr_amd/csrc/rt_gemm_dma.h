@@ -137,13 +137,13 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
             } else {
                 bool ok;
                 int sy, sx;
-                if (MODE == 1) { sy = b_y[j] + kh; sx = b_x[j] + kw; ok = true; }
+                if (MODE == 1) { sy = b_y[j] + kh * p.dil; sx = b_x[j] + kw * p.dil; ok = true; }
                 else if (MODE == 3) {
                     const int ny_ = b_y[j] - kh, nx_ = b_x[j] - kw;      // even by construction of the class
                     ok = (ny_ | nx_) >= 0;
                     sy = ny_ >> 1; sx = nx_ >> 1;
                 } else {
-                    const int ny = b_y[j] - kh, nx = b_x[j] - kw;
+                    const int ny = b_y[j] - kh * p.dil, nx = b_x[j] - kw * p.dil;
                     const int msk = p.stride - 1;
                     ok = ((ny | nx) >= 0) && (((ny | nx) & msk) == 0);
                     sy = ny >> p.sshift; sx = nx >> p.sshift;

@@ -18,7 +18,7 @@ namespace {
 
 struct WgradArgs {
     const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias;
-    int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad;
+    int B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, dil;
     int M, chunks_per_block, c_tiles;
     float* part; int out_elems; int xcd, early, epi_lds;      // split partials workspace ([split][N*taps*SC]) or NULL -> atomics
     int overwrite;            // single-writer launches (one split, no workspace) store instead of accumulating
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const bf16_t* __rest
             int pix;
             if (SIMPLE) pix = m;
             else {
-                const int sy = gy[j] * p.stride - p.pad + kh, sx = gx[j] * p.stride - p.pad + kw;
+                const int sy = gy[j] * p.stride - p.pad + kh * p.dil, sx = gx[j] * p.stride - p.pad + kw * p.dil;
                 ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
                 pix = (gb[j] * p.SH + sy) * p.SW + sx;
                 if (!last) {
@@ -336,7 +336,7 @@ __device__ __forceinline__ void wgrad_dma_body(const bf16_t* __restrict__ dyp, c
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int m = lc * CR + b_r[j];
-                const int sy = gy[j] * p.stride - p.pad + kh, sx = gx[j] * p.stride - p.pad + kw;
+                const int sy = gy[j] * p.stride - p.pad + kh * p.dil, sx = gx[j] * p.stride - p.pad + kw * p.dil;
                 const bool ok = m < p.M && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW && voff_b[j] != OOB;
                 const int pix = (gb[j] * p.SH + sy) * p.SW + sx;
                 wg_dma16(rs_x_abs, bB + j * 4096, ok ? pix * p.SC * 2 + voff_b[j] : OOB);
@@ -896,9 +896,10 @@ static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a) {
     if (!d || !d->dy || !d->x || !d->dw) return RT_ERR_BADARG;
     if (d->SC <= 0 || (d->SC & 15) || (d->N & 3) || d->N <= 0) return RT_ERR_UNSUPPORTED;
     if (d->KH <= 0 || d->KW <= 0 || d->B <= 0 || d->DH <= 0 || d->DW <= 0 || d->stride <= 0) return RT_ERR_BADARG;
+    if (d->dil > 1 && d->stride != 1) return RT_ERR_UNSUPPORTED;
     a.dy = (const bf16_t*)d->dy; a.x = (const bf16_t*)d->x; a.dw = d->dw; a.scale = d->scale; a.dbias = d->dbias;
     a.B = d->B; a.SH = d->SH; a.SW = d->SW; a.SC = d->SC; a.DH = d->DH; a.DW = d->DW; a.N = d->N;
-    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil > 1 ? d->dil : 1;
     const long long M = (long long)d->B * d->DH * d->DW;
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     if (M * d->N >= 0x3fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;

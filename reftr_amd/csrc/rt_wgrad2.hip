@@ -37,7 +37,7 @@ typedef __attribute__((ext_vector_type(4))) int w2_i32x4;
 
 struct W2Prob {
     const bf16_t* dy; const bf16_t* x; float* dw; const float* scale; float* dbias; float* part; float* sqacc; bf16_t* g16;
-    int SH, SW, SC, DH, DW, N, KH, KW, stride, pad, M;
+    int SH, SW, SC, DH, DW, N, KH, KW, stride, pad, M, dil;
     int n_tiles, c_tiles, tiles, splits, chunks_per_split, out_elems;
     unsigned dy_bytes, x_bytes;
     int simple, accumulate, xrot, cfg;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
             if (col < p.SC * 2 && (SIMPLE || p.stride == 1)) voff_pf = r * p.SC * 2 + col;
         }
     }
-    const int pf_shift = SIMPLE ? 0 : ((kh - p.pad) * p.SW + (kw - p.pad)) * p.SC * 2;       // bytes
+    const int pf_shift = SIMPLE ? 0 : ((kh * p.dil - p.pad) * p.SW + (kw * p.dil - p.pad)) * p.SC * 2;       // bytes
 
     f32x16 acc[TAPS][TN][TC];
 #pragma unroll
@@ -236,7 +236,7 @@ __device__ __forceinline__ void w2_body(const W2Prob& p, const int split, const 
 #pragma unroll
             for (int j = 0; j < BJ; ++j) {
                 const int m = lc * CR + b_r[j];
-                const int sy = gy[j] * p.stride - p.pad + kh, sx = gx[j] * p.stride - p.pad + kw;
+                const int sy = gy[j] * p.stride - p.pad + kh * p.dil, sx = gx[j] * p.stride - p.pad + kw * p.dil;
                 const bool ok = m < p.M && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW && voff_b[j] != OOB;
                 const int pix = (gb[j] * p.SH + sy) * p.SW + sx;
                 w2_dma16(rs_x_abs, bB + j * 4096, ok ? pix * p.SC * 2 + voff_b[j] : OOB);
@@ -585,7 +585,7 @@ static int w2_cfg_of(const rt_conv_wgrad_desc& d) {       // 0: 256x256, 1: 128x
     // fused taps where the per-tap tile could not be wider than 128 x 128 anyway (layer2, the RES head): 2.3x on those; with 256
     // channels a side the per-tap 256 x 256 tile is as good (layer3: equal), and at W = 20 the row masks cost more than the taps
     // save (layer4: 150 -> 169 us) -- REFTR_W2_FUSE3_MAXC / _MINW widen the choice
-    if (fuse_env && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.SH == d.DH && d.SW == d.DW && d.DW >= fuse_minw &&
+    if (fuse_env && d.dil <= 1 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.SH == d.DH && d.SW == d.DW && d.DW >= fuse_minw &&
         d.N <= fuse_maxc && d.SC <= fuse_maxc && (long long)d.B * d.SH * d.SW * d.SC * 2 < 0x3fffffffLL) return 4;
     const bool n_big = d.N > 128, c_big = d.SC > 128;
     return n_big ? (c_big ? 0 : 2) : (c_big ? 1 : 3);
@@ -674,7 +674,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
             p.cfg = w2_cfg_of(d);
             const int BN = BNs[p.cfg], BC = BCs[p.cfg];
             p.dy = (const bf16_t*)d.dy; p.x = (const bf16_t*)d.x; p.dw = d.dw; p.scale = d.scale; p.dbias = d.dbias; p.part = nullptr; p.sqacc = d.sqacc; p.g16 = (bf16_t*)d.g16;
-            p.SH = d.SH; p.SW = d.SW; p.SC = d.SC; p.DH = d.DH; p.DW = d.DW; p.N = d.N; p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad;
+            p.SH = d.SH; p.SW = d.SW; p.SC = d.SC; p.DH = d.DH; p.DW = d.DW; p.N = d.N; p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad = d.pad; p.dil = d.dil > 1 ? d.dil : 1;
             const long long M = (long long)d.B * d.DH * d.DW;
             p.M = (int)M;
             p.n_tiles = (d.N + BN - 1) / BN; p.c_tiles = (d.SC + BC - 1) / BC;

@@ -29,7 +29,7 @@ class ConvGemmDesc(Structure):
         ("transposed", c_int32), ("act", c_int32),
         ("gate_scale", c_float), ("drop_p", c_float), ("drop_seed", c_uint32), ("tile_hint", c_int32),
         ("out_preact", c_void_p), ("dtanh", c_void_p), ("res_first", c_int32), ("seed_dev", c_void_p),
-        ("drop_shift", c_int32), ("acc2_f32", c_void_p),
+        ("drop_shift", c_int32), ("acc2_f32", c_void_p), ("dil", c_int32),
     ]
 
 
@@ -40,7 +40,7 @@ class ConvWgradDesc(Structure):
         ("DH", c_int32), ("DW", c_int32), ("N", c_int32),
         ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
         ("msplit", c_int32), ("dbias", c_void_p), ("variant", c_int32),
-        ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64), ("overwrite", c_int32), ("reserved", c_int32),
+        ("workspace", c_void_p), ("workspace_bytes", ctypes.c_int64), ("overwrite", c_int32), ("dil", c_int32),
         ("sqacc", c_void_p), ("g16", c_void_p),
     ]
 
@@ -464,7 +464,7 @@ def _req(t, dtype, name):
 # --------------------------------------------------------------------------------------------
 def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=None, gate_scale=1.0,
               preact=None, dtanh=None, res_first=False, act=ACT_NONE, drop_p=0.0, drop_seed=0, transposed=False,
-              out_bf16=True, out_f32=False, out_preact=False, tile_hint=0, group=None, drop_shift=0, acc2_f32=None):
+              out_bf16=True, out_f32=False, out_preact=False, tile_hint=0, group=None, drop_shift=0, acc2_f32=None, dil=1):
     """out[B,DH,DW,N] = epilogue(implicit_gemm(src[B,SH,SW,SC], wgt[N,KH,KW,SC])).
 
     geom = (B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad).  Returns (out_bf16 | None, out_f32 | None)
@@ -488,7 +488,7 @@ def conv_gemm(src, wgt, *, geom, bias=None, res_f32=None, res_bf16=None, gate=No
     d = ConvGemmDesc(_p(src), _p(wgt), _p(ob), _p(of), _p(bias), _p(res_f32), _p(res_bf16), _p(gate),
                      _p(preact), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad,
                      1 if transposed else 0, act, gate_scale, drop_p, drop_seed & 0xFFFFFFFF, tile_hint, None, _p(dtanh), 1 if res_first else 0, _seedp(drop_p),
-                     drop_shift, _p(acc2_f32))
+                     drop_shift, _p(acc2_f32), int(dil))
     op = None
     if out_preact:
         op = torch.empty((M, N), dtype=torch.bfloat16, device=src.device)
@@ -605,7 +605,7 @@ def sqnorm_finish(flat_g, table, nchunks, slots, out, extra=None):
     _check(lib().rt_sqnorm_finish(_p(flat_g), _p(table), int(nchunks), _p(slots), _p(extra), _p(out), _stream()), "rt_sqnorm_finish")
 
 
-def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, workspace=True, overwrite=False):
+def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, workspace=True, overwrite=False, dil=1):
     """dw[N,KH,KW,SC] (fp32) += (overwrite: =) scale[n] * sum_m dy[m,n] * gather(x)[m,(kh,kw,c)]."""
     B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
     _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw")
@@ -614,7 +614,7 @@ def conv_wgrad(dy, x, dw, *, geom, scale=None, msplit=0, dbias=None, variant=0, 
     _req(dbias, torch.float32, "dbias")
     ws = _wgrad_workspace(dy.device) if workspace else None
     d = ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, msplit, _p(dbias), variant,
-                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0, int(bool(overwrite)), 0, _sqacc(dw), _g16(dw))
+                      _p(ws), WGRAD_WS_BYTES if ws is not None else 0, int(bool(overwrite)), int(dil), _sqacc(dw), _g16(dw))
     _timed("conv_wgrad", 2.0 * B * DH * DW * N * KH * KW * SC,
            lambda: _check(lib().rt_conv_wgrad(ctypes.byref(d), _stream()), "rt_conv_wgrad"), tag=("W",) + tuple(geom))
     return dw
@@ -1200,12 +1200,12 @@ class WgradBatch:
         self.keep.append((dy, x))
         self._account((M, 1, 1, K, 1, 1, N, 1, 1, 1, 0))
 
-    def add_conv(self, dy, x, dw, geom, scale=None, overwrite=False):
+    def add_conv(self, dy, x, dw, geom, scale=None, overwrite=False, dil=1):
         """A convolution weight gradient (any geometry: the non-groupable ones are forwarded to rt_conv_wgrad at run())."""
         B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad = geom
         _req(dy, torch.bfloat16, "dy"); _req(x, torch.bfloat16, "x"); _req(dw, torch.float32, "dw"); _req(scale, torch.float32, "scale")
         self.descs.append(ConvWgradDesc(_p(dy), _p(x), _p(dw), _p(scale), B, SH, SW, SC, DH, DW, N, KH, KW, stride, pad, 0, None, 0,
-                                        None, 0, int(bool(overwrite)), 0, _sqacc(dw), _g16(dw)))
+                                        None, 0, int(bool(overwrite)), int(dil), _sqacc(dw), _g16(dw)))
         self.keep.append((dy, x, scale))
         self._account(geom)
 

@@ -16,11 +16,12 @@ from . import layout as L
 
 
 class ConvSpec:
-    __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "pad", "trainable")
+    __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "pad", "trainable", "dil")
 
-    def __init__(self, name, bn, cin, cout, k, stride, trainable):
+    def __init__(self, name, bn, cin, cout, k, stride, trainable, dil=1):
         self.name, self.bn, self.cin, self.cout, self.k, self.stride = name, bn, cin, cout, k, stride
-        self.pad = k // 2
+        self.dil = dil
+        self.pad = (k // 2) * dil
         self.trainable = trainable
 
 
@@ -36,6 +37,9 @@ class ResNetBody:
         self.cfg = cfg
         self.blocks = []          # list of stages, each a list of BlockSpec
         inpl = 64
+        # --dilation (torchvision replace_stride_with_dilation=[False, False, True], backbone.py:117-125): layer4's stride becomes a
+        # dilation -- its first block runs at stride 1 with the PREVIOUS dilation (1), the following blocks dilate their 3x3 by 2
+        dilate = bool(getattr(cfg, "dilation", False))
         for li, n in enumerate(cfg.resnet_layers):
             planes = 64 * 2 ** li
             tr = li > 0 and getattr(cfg, "train_backbone", True)     # lr_backbone 0: nothing trains, nothing is saved for backward
@@ -43,9 +47,12 @@ class ResNetBody:
             for bi in range(n):
                 p = f"{self.PFX}layer{li + 1}.{bi}."
                 s = 2 if (bi == 0 and li > 0) else 1
+                dl = 1
+                if dilate and li == 3:
+                    s, dl = 1, (1 if bi == 0 else 2)
                 b = BlockSpec()
                 b.conv1 = ConvSpec(p + "conv1.weight", p + "bn1.", inpl, planes, 1, 1, tr)
-                b.conv2 = ConvSpec(p + "conv2.weight", p + "bn2.", planes, planes, 3, s, tr)
+                b.conv2 = ConvSpec(p + "conv2.weight", p + "bn2.", planes, planes, 3, s, tr, dil=dl)
                 b.conv3 = ConvSpec(p + "conv3.weight", p + "bn3.", planes, planes * 4, 1, 1, tr)
                 b.down = ConvSpec(p + "downsample.0.weight", p + "downsample.1.", inpl, planes * 4, 1, s, tr) if bi == 0 else None
                 b.trainable = tr
@@ -108,11 +115,11 @@ class ResNetBody:
     # ------------------------------------------------------------------ forward
     def _conv(self, x, shp, c, relu, res=None):
         B, Hh, Ww = shp
-        Ho = (Hh + 2 * c.pad - c.k) // c.stride + 1
-        Wo = (Ww + 2 * c.pad - c.k) // c.stride + 1
+        Ho = (Hh + 2 * c.pad - c.dil * (c.k - 1) - 1) // c.stride + 1
+        Wo = (Ww + 2 * c.pad - c.dil * (c.k - 1) - 1) // c.stride + 1
         geom = (B, Hh, Ww, c.cin, Ho, Wo, c.cout, c.k, c.k, c.stride, c.pad)
         y, _ = H.conv_gemm(x, self.W[c.name], geom=geom, bias=self.bn[c.bn][1], res_bf16=res, res_first=True,
-                           act=H.ACT_RELU if relu else H.ACT_NONE)
+                           act=H.ACT_RELU if relu else H.ACT_NONE, dil=c.dil)
         return y, (B, Ho, Wo), geom
 
     def forward(self, img, ready=None, before_trainable=None):
@@ -166,14 +173,14 @@ class ResNetBody:
         dw, sc = self.store.phys(c.name, grad=True), self.bn[c.bn][0]
         ow = self.store.claim(dw)
         if self.batch is not None:
-            self.batch.add_conv(g, x, dw, geom, scale=sc, overwrite=ow)
+            self.batch.add_conv(g, x, dw, geom, scale=sc, overwrite=ow, dil=c.dil)
         else:
-            self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc, overwrite=ow), g, x)
+            self.wg.run(lambda: H.conv_wgrad(g, x, dw, geom=geom, scale=sc, overwrite=ow, dil=c.dil), g, x)
 
     def _dgrad(self, g, c, geom, res=None, gate=None, res_f32=None):
         B, SH, SW, SC, DH, DW, N, KH, KW, s, p = geom
         geom_t = (B, DH, DW, N, SH, SW, SC, KH, KW, s, p)
-        y, _ = H.conv_gemm(g, self.W[c.name + ".t"], geom=geom_t, transposed=True, res_bf16=res, res_f32=res_f32, gate=gate)
+        y, _ = H.conv_gemm(g, self.W[c.name + ".t"], geom=geom_t, transposed=True, res_bf16=res, res_f32=res_f32, gate=gate, dil=c.dil)
         return y
 
     def backward(self, saved, g_out, extra=None):

@@ -46,6 +46,7 @@ class ModelConfig:
     masks: bool = False                   # RefTRSeg: RES head (bbox_attention + mask_head), single phrase, no aux loss
     pos_learned: bool = False             # --position_embedding learned: PositionEmbeddingLearned (position_encoding.py:59-84)
     train_backbone: bool = True           # False: --lr_backbone 0 freezes the whole ResNet (backbone.py:87-89,150)
+    dilation: bool = False                # --dilation (DC5): layer4 keeps stride 16, its 3x3 convolutions dilate by 2 (backbone.py:117-125)
     cem: bool = False                     # --ablation cem_loss: CEM block + loss_cem (reftr_segmentation.py:16-41, 62-64)
     bert: BertConfig = field(default_factory=BertConfig)
 

@@ -399,7 +399,7 @@ class RefTR(nn.Module):
         # c5 geometry from the image size (stem 7x7/2, maxpool 3x3/2, three stride-2 stages): the positional / mask work below
         # only needs the padding mask, so it rides on the language side stream behind BERT
         h, w = x.shape[2], x.shape[3]
-        for _ in range(5):
+        for _ in range(4 if cfg.dilation else 5):                            # --dilation: layer4 keeps stride 16
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         HW = h * w
         assert Lq <= cfg.max_lang_seq                                       # models/reftr.py:81
@@ -905,9 +905,9 @@ def build_config(args):
     # main_vg.py but have NO effect in the reference either: freeze_lang_backbone is stored and never used,
     # reftr_transformer.py:128,152-157; freeze_backbone is never read; build_reftr_seg hard-codes freeze_reftr=False,
     # reftr_segmentation.py:375.  They are accepted and ignored here for the same behaviour.)
-    if getattr(args, "dilation", False):
-        raise NotImplementedError("--dilation (layer4 stride replaced by dilation, models/modeling/backbone.py:120-125) is not "
-                                  "built: no reference config uses it")
+    if getattr(args, "dilation", False) and bool(getattr(args, "masks", False)):
+        raise NotImplementedError("--dilation with --masks: the RES head's FPN assumes the stride-32 layer4 output "
+                                  "(models/reftr_segmentation.py:196-227); not built")
     pe = getattr(args, "position_embedding", "sine")
     if pe not in ("v2", "sine"):
         raise ValueError(f"not supported {pe}")                     # as position_encoding.py:95
@@ -928,6 +928,7 @@ def build_config(args):
                          # lr_backbone <= 0 freezes the whole ResNet (train_backbone = False, models/modeling/backbone.py:87-89,150):
                          # its parameters leave the optimizer and the clip norm, its backward is not run
                          train_backbone=float(getattr(args, "lr_backbone", 1e-5)) > 0,
+                         dilation=bool(getattr(args, "dilation", False)),            # backbone.py:117-125 (DC5)
                          pos_learned=pe in ("v3", "learned"),          # position_encoding.py:91-92
                          cem=bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss")
 

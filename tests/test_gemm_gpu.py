@@ -413,3 +413,39 @@ def test_wgrad_v2_fused_taps_3x3(hip, B, H, W, Ci, Co, overwrite):
     assert e1 < TOL_F32 and e2 < TOL_F32
     for xa, da, dwa in keep:
         assert rel(dwa, da.float().T @ xa.float()) < TOL_F32
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,dil", [(2, 12, 16, 512, 512, 2), (1, 13, 9, 64, 128, 2), (2, 20, 20, 128, 64, 3)])
+def test_dilated_conv_fwd_dgrad_wgrad(hip, B, H, W, Ci, Co, dil):
+    """`dil` of rt_conv_gemm / rt_conv_wgrad (--dilation: layer4's 3x3 convolutions, stride 1, padding = dilation) against
+    torch fp32: forward gather, transposed (backward-data) gather and the weight-gradient gather (both generations' paths)."""
+    g = torch.Generator().manual_seed(B * 100 + H + Ci + dil)
+    x = bf(torch.randn(B, Ci, H, W, generator=g)).float().requires_grad_(True)
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).float().requires_grad_(True)
+    bias = torch.randn(Co, generator=g)
+    y = F.conv2d(x, w, bias, stride=1, padding=dil, dilation=dil)
+    assert y.shape[-2:] == (H, W)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy.float())
+    x_nhwc = nhwc(x.detach()).bfloat16().cuda()
+    w_k = w.detach().permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    geom = (B, H, W, Ci, H, W, Co, 3, 3, 1, dil)
+    ob, of = hip.conv_gemm(x_nhwc, w_k, geom=geom, bias=bias.cuda(), out_bf16=True, out_f32=True, dil=dil)
+    ref = nhwc(y.detach()).reshape(-1, Co)
+    assert rel(of, ref) < TOL_F32 and rel(ob, ref) < TOL_BF16
+    w_t = w.detach().permute(1, 2, 3, 0).contiguous().bfloat16().cuda()
+    dy_nhwc = nhwc(dy).cuda()
+    _, dxf = hip.conv_gemm(dy_nhwc, w_t, geom=(B, H, W, Co, H, W, Ci, 3, 3, 1, dil), transposed=True, out_bf16=False, out_f32=True, dil=dil)
+    assert rel(dxf, nhwc(x.grad).reshape(-1, Ci)) < TOL_F32
+    dw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+    hip.conv_wgrad(dy_nhwc.view(-1, Co), x_nhwc, dw, geom=geom, dil=dil)
+    assert rel(dw, w.grad.permute(0, 2, 3, 1)) < 5e-5
+    # the grouped second-generation launch (what the training step uses)
+    dw2 = torch.zeros(Co, 3, 3, Ci, device="cuda")
+    batch = hip.WgradBatch(workspace_mb=64)
+    batch.add_conv(dy_nhwc.view(-1, Co), x_nhwc, dw2, geom, dil=dil)
+    batch.run()
+    assert rel(dw2, w.grad.permute(0, 2, 3, 1)) < 5e-5
+    # a hint that names a register-staged tile has no dilation: refused, not silently wrong
+    with pytest.raises(RuntimeError):
+        hip.conv_gemm(x_nhwc, w_k, geom=geom, bias=bias.cuda(), tile_hint=3, dil=dil)

@@ -94,6 +94,13 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         build_reftr(ref_args(num_feature_levels=4))
     assert build_reftr(ref_args(bert_model="roberta-base"))[0].cfg.bert.pad_idx == 1
+    # --dilation is built (backbone.py:117-125): layer4 at stride 1, its later 3x3 convolutions dilated by 2 with padding 2
+    m = build_reftr(ref_args(dilation=True))[0]
+    l4 = m.body.blocks[3]
+    assert m.cfg.dilation and [(b.conv2.stride, b.conv2.dil, b.conv2.pad) for b in l4] == [(1, 1, 1), (1, 2, 2), (1, 2, 2)]
+    assert l4[0].down.stride == 1 and all(b.conv2.dil == 1 for st in m.body.blocks[:3] for b in st)
+    with pytest.raises(NotImplementedError):
+        build_reftr(ref_args(dilation=True, masks=True, aux_loss=False, reftr_type="transformer_single_phrase", dice_loss_coef=1.0, mask_loss_coef=1.0))
 
 
 def test_oracle_post_process_segm_matches_reference_golden_exactly():

@@ -453,6 +453,49 @@ def test_learned_position_embedding_vs_reference_golden(hip):
     assert rel(model.store.G["bbox_embed.layers.2.weight"], g["grad_bbox2_w"]) < 3e-2
 
 
+def test_dilation_vs_reference_golden(hip):
+    """--dilation (models/modeling/backbone.py:117-125): layer4 at stride 1 with its 3x3 convolutions dilated by 2 from the second
+    block on (rt_conv_gemm / rt_conv_wgrad `dil`), c5 at stride 16 -- forward, loss and the convolution gradients of layer4 against
+    the fixture minted from the reference built with that flag, with the q-oracle (the HIP path's bf16 rounding points) as the
+    yardstick for the gradients."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    g = np.load(os.path.join(GOLD, "e2e_dilation.npz"))
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), dilation=True)
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), dilation=True)
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda")
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    samples, targets = make_inputs("e2e_dilation", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    assert rel(out["pred_logits"].sigmoid(), g["boxes"]) < 5e-3
+    ld = crit(out, tg)
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    assert abs(float(total) - float(g["total_loss"])) < 5e-3 * float(g["total_loss"])
+    model.store.flat_g.zero_()
+    total.backward()
+    keys = [k[5:] for k in g.files if k.startswith("grad.")]
+    Pq = {k: v.clone() for k, v in P.items()}
+    leaves = [Pq[k].requires_grad_(True) for k in keys]
+    oq = O.reftr_forward(Pq, samples, ocfg, q=True)
+    gq = torch.autograd.grad(O.total_loss(O.criterion(oq, targets), O.weight_dict(ocfg)), leaves)
+    for name, q_ in zip(keys, gq):
+        mine = model.store.G[name].float().cpu()
+        ref = torch.from_numpy(g["grad." + name])
+        samp = (lambda t: t.reshape(-1)[::97]) if mine.numel() > 100000 else (lambda t: t)
+        floor = rel(samp(q_), ref)
+        got = rel(samp(mine).reshape(ref.shape), ref)
+        assert got < max(2.0 * floor, 3e-2), (name, got, floor)
+        a, b, c = samp(mine).reshape(-1), ref.reshape(-1), samp(q_).reshape(-1)
+        cos = lambda u, v: float((u * v).sum() / (u.norm() * v.norm()))
+        assert 1 - cos(a, b) < max(4.0 * (1 - cos(c, b)), 1e-3), (name, cos(a, b), cos(c, b))     # (1 - cos ~ rel^2 / 2: twice the floor's rel)
+        assert abs(float(mine.norm()) / float(g["gnorm." + name]) - 1) < max(2.0 * abs(float(q_.norm()) / float(g["gnorm." + name]) - 1), 2e-2), name
+
+
 def test_clip_norm_with_the_bert_share_taken_on_the_language_stream(hip):
     """Single process: the BERT slice's squared gradient norm is reduced on the language stream right after BERT's backward
     (reftr_transformer._backward_gen), the optimizer reads only the rest of the buffer (optim._sqnorm_all): the total equals

@@ -186,6 +186,29 @@ def test_learned_position_embedding_golden():
     assert float(gr[3:].abs().sum()) == 0 and float(gc[4:].abs().sum()) == 0 and float(gr[:3].abs().min()) > 0
 
 
+def test_dilation_golden():
+    """--dilation (models/modeling/backbone.py:117-125 -> torchvision replace_stride_with_dilation=[False, False, True]): layer4 at
+    stride 1, its 3x3 convolutions dilated by 2 from the second block on, c5 at stride 16; fixture minted from the reference
+    built with that flag (oracle/gen_golden_dilation.py: boxes, losses, sampled convolution gradients + their norms)."""
+    g = gold("e2e_dilation")
+    cfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), dilation=True)
+    P = formula_state(param_shapes(cfg))
+    samples, targets = make_inputs("e2e_dilation", B=2, H=96, W=128, L=12)
+    keys = [k[5:] for k in g.files if k.startswith("grad.")]
+    leaves = {k: P[k].requires_grad_(True) for k in keys}
+    out = O.reftr_forward(P, samples, cfg)
+    assert tuple(out["c5"].shape[-2:]) == tuple(int(v) for v in g["c5_hw"]) == (6, 8)          # stride 16, not 32
+    assert rel(out["logits"].sigmoid(), g["boxes"]) < 1e-5
+    total = O.total_loss(O.criterion(out, targets), O.weight_dict(cfg))
+    assert abs(float(total) - float(g["total_loss"])) < 1e-5 * float(g["total_loss"])
+    grads = torch.autograd.grad(total, [leaves[k] for k in keys])
+    for k, gr in zip(keys, grads):
+        ref = torch.from_numpy(g["grad." + k])
+        mine = gr.reshape(-1)[::97] if gr.numel() > 100000 else gr
+        assert rel(mine, ref) < 1e-4, k
+        assert abs(float(gr.norm()) - float(g["gnorm." + k])) < 1e-4 * float(g["gnorm." + k]), k
+
+
 def test_roberta_backbone_golden():
     """RefTR with a HF RobertaModel language backbone (configs/flickr30k/RefTR_flickr_roberta.sh): position ids from the
     padding index, one token type, eps 1e-5."""
