@@ -412,7 +412,12 @@ class CapturedTrainStep:
         inner, opt = self.inner, self.optimizer
         self._set_flush(False)
         inner._pre_update = self._hooks
-        inner._zero_grad_side = os.environ.get("REFTR_ZERO_SIDE", "0") == "1" and inner.net.side.enabled
+        # REFTR_ZERO_SIDE: 0 = the clear between loss and backward on the main stream; 1 = a FULL clear on the language stream under
+        # the encoder (measured neutral in round 1); 2 = the fast clear (atomics' 4 % + norm slots: ~20 us of launches on the
+        # loss -> backward chain) there: 6.67-6.69 vs 6.66-6.68 ms over four interleaved pairs (profiles/r04ai_zero_side_ab.txt): the
+        # fork / join edges cost what the launches did.  0.
+        zs = int(os.environ.get("REFTR_ZERO_SIDE", "0"))
+        inner._zero_grad_side = zs if (zs in (1, 2) and inner.net.side.enabled) else 0
         # backward and clip norm are one unit here (nothing touches the gradient buffer in between): the BERT slice's share of the
         # norm may be taken on the language stream as soon as that slice is final (reftr_transformer._backward_gen)
         inner._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0" and not getattr(inner.store, "fused_norm", False)

@@ -479,7 +479,11 @@ class RefTR(nn.Module):
             self.opt_side.join()
         net.side.join()
         H.mark("forward join (language branch in)")
-        if self._zero_grad_side:
+        if self._zero_grad_side == 2:
+            # the clear in front of backward (the 4 % of the buffer that is accumulated with atomics + the norm slots: ~20 us of
+            # launches between the loss and the first backward kernel) on the idle language stream instead; backward joins
+            net.side.run(st.zero_for_backward)
+        elif self._zero_grad_side:
             # 607 MB of zeros: off the critical path, under the (latency-bound) encoder / decoder forward; backward joins
             net.side.run(st.flat_g.zero_)
         _, ms_ctx = net.mlp_fwd(seq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos, rowmap=(Lq, S, 0))

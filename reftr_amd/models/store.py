@@ -122,6 +122,19 @@ class ParamStore:
             self._ow_table = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
         return self._ow_table
 
+    def zero_for_backward(self, fast=True):
+        """What optimizer.zero_grad does to the gradient buffer in front of a backward (fast: only the atomically-accumulated tensors
+        are cleared, the weight matrices are overwritten by their first producer; REFTR_OVERWRITE=0 / a CPU store: the full clear),
+        plus the clip-norm accumulator.  A method of the store so that the model can issue it on the language stream at the forward
+        join (engine_vg: REFTR_ZERO_SIDE=2), off the loss -> backward chain."""
+        import os
+        if fast and os.environ.get("REFTR_OVERWRITE", "1") != "0" and self.flat_g.is_cuda:
+            self.arm_overwrite()
+        else:
+            self.disarm()                     # a backward that was abandoned half-way must not leave overwrite mode armed
+            self.flat_g.zero_()
+        self.begin_norm()                     # the producers' epilogues collect the clip norm from here on (rt_sqnorm_finish)
+
     def begin_norm(self):
         """The gradients are (about to be) cleared / re-armed: clear the norm accumulator with them."""
         if self.fused_norm:

@@ -87,13 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
         reftr_amd.engine_vg, right in front of backward): only the atomically-accumulated tensors are cleared and the weight
         matrices -- 96 % of the 607 MB -- are overwritten by their first weight-gradient launch (ParamStore.arm_overwrite);
         REFTR_OVERWRITE=0 keeps the full clear."""
-        import os
-        if fast and os.environ.get("REFTR_OVERWRITE", "1") != "0" and self.model.store.flat_g.is_cuda:
-            self.model.store.arm_overwrite()
-        else:
-            self.model.store.disarm()         # a backward that was abandoned half-way must not leave overwrite mode armed
-            self.model.store.flat_g.zero_()
-        self.model.store.begin_norm()         # the producers' epilogues collect the clip norm from here on (rt_sqnorm_finish)
+        self.model.store.zero_for_backward(fast)
 
     def _grad_buffer(self):
         """The buffer the update reads: the fp32 gradients, or -- in a data-parallel run that exchanges bf16 -- the bf16 copy

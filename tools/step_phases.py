@@ -31,6 +31,10 @@ for n, (label, i) in enumerate(idx):
     seg = step[i:j]
     print("  %-40s %4d kernels  %7.3f ms  (busy %7.3f)" % (label, len(seg), (seg[-1][2] - seg[0][1]) / 1e6, sum(r[2] - r[1] for r in seg) / 1e6))
 print("  %-40s %4d kernels  %7.3f ms" % ("(before first marker: zero-fill, prep)", idx[0][1], (step[idx[0][1]][1] - t0) / 1e6))
+if len(sys.argv) > 2 and sys.argv[2] == "head":      # the kernels in front of the first marker (zero-fill, staging, counters)
+    for k in range(idx[0][1]):
+        nm, st, en = step[k]
+        print("  %9.1f us  %6.1f us  %s" % ((st - t0) / 1e3, (en - st) / 1e3, nm.replace("(anonymous namespace)::", "").replace("void ", "")[:110]))
 if len(sys.argv) > 2:               # dump the kernel sequence of the phases whose label contains argv[2]: start offset, duration, gap, name
     for n, (label, i) in enumerate(idx):
         if sys.argv[2] not in label:
