@@ -383,6 +383,9 @@ int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream);
  *                    (8 taps x 4 channels); w bf16 [64][7][8][4] (BN scale folded), bias = BN shift;
  *                    out bf16 NHWC [B,Ho,Wo,64]; needs Wp >= 32*ceil(Wo/16)+6, Hp >= 2*Ho+5
  * rt_maxpool3x3s2    nn.MaxPool2d(3, 2, 1) on NHWC bf16
+ * rt_stem_pool       rt_stem_conv + rt_maxpool3x3s2 in one launch (torchvision ResNet.forward: conv1, bn1, relu, maxpool; all
+ *                    frozen, backbone.py:87-89): out bf16 NHWC [B,(Ho-1)/2+1,(Wo-1)/2+1,64], bit-identical to the two launches;
+ *                    the stem output itself is never written; needs Wp >= 2*Wo+6, Hp >= 2*Ho+5
  * rt_weight_prep     fp32 master weight [N][T][C] (T = KH*KW, channels-last) -> bf16 [N][T][C] (dst) and/or
  *                    bf16 [C][T][N] (dst_t, the backward-data operand), times scale[n] (FrozenBN) if given
  * rt_stem_weight_prep fp32 [64][7][7][3] -> bf16 [64][7][8][4]
@@ -392,6 +395,8 @@ int rt_img_pack(const float* img, void* out, int B, int H, int W, int Hp, int Wp
 int rt_stem_conv(const void* xp, const void* w, const float* bias, void* out,
                  int B, int Hp, int Wp, int Ho, int Wo, rt_stream_t stream);
 int rt_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, rt_stream_t stream);
+int rt_stem_pool(const void* xp, const void* w, const float* bias, void* out,
+                 int B, int Hp, int Wp, int Ho, int Wo, rt_stream_t stream);
 int rt_weight_prep(const float* src, const float* scale, void* dst, void* dst_t, int N, int T, int C, rt_stream_t stream);
 
 /* rt_bottleneck_fwd — one FROZEN stride-1 bottleneck of layer1 in ONE launch (models/modeling/backbone.py:87-89 freezes conv1 and

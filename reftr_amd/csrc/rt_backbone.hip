@@ -2,6 +2,7 @@
 //   rt_img_pack      NCHW fp32 image -> zero-haloed NHWC4 bf16 (the stem's input layout)
 //   rt_stem_conv     7x7/2 conv + FrozenBN + ReLU on MFMA (K = 7 rows x (8 taps x 4 ch) = 7 x 32)
 //   rt_maxpool3x3s2  NHWC bf16 max-pool 3x3 / stride 2 / pad 1
+//   rt_stem_pool     the two above in one launch (the stem output never reaches HBM)
 //   rt_weight_prep   fp32 master weight -> bf16 GEMM operand(s): [N][T][C] (x FrozenBN scale) and [C][T][N]
 //   rt_mask_posenc   pad-mask nearest downsample + DETR sine position encoding (+ level / token-type embeds)
 #include "rt_common.h"
@@ -110,6 +111,114 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)m[e];
         *reinterpret_cast<bf16x8*>(y + i * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------- stem conv + max pool in one launch
+// A workgroup owns an 8 x 16 tile of POOLED pixels: its four waves compute the 17 x 33 stem pixels under it (36 MFMA pixel tiles
+// of 16, nine per wave, weights in registers exactly as in stem_conv_kernel; the next tile's seven 16-byte loads are in flight
+// under the 28 MFMAs of the current one), round them to bf16 into LDS (72 KB, 16-byte slots XOR-swizzled by the pixel), and pool
+// from there: the 105 MB stem output of a 640 x 640 batch of 8 is neither written nor read back.  Same products, same K order,
+// same rounding point as the two launches it replaces, and max commutes with the (monotonic) rounding: bit-identical.
+// Values behind the ReLU are non-negative, so the maximum is taken on the bf16 bit patterns as signed 16-bit integers
+// (a -0.0, pattern 0x8000, loses against everything else, as it may in fmaxf).
+constexpr int SP_PH = 8, SP_PW = 16, SP_SH = 2 * SP_PH + 1, SP_SW = 2 * SP_PW + 1, SP_NPIX = SP_SH * SP_SW;     // 17 x 33 = 561
+constexpr int SP_TILES = (SP_NPIX + 15) / 16;                                                                   // 36
+
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restrict__ xp, const bf16_t* __restrict__ w,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                           int B, int Hp, int Wp, int Ho, int Wo, int Po, int Qo, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    bf16_t* sm = reinterpret_cast<bf16_t*>(sp_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    // neighbouring tiles share a one-pixel stem halo and six input rows / columns: contiguous runs of blocks per XCD
+    int blk = rt_xcd_remap((int)blockIdx.x, (int)gridDim.x, 1);
+    const int tx = blk % tiles_x; blk /= tiles_x;
+    const int ty = blk % tiles_y;
+    const int b = blk / tiles_y;
+    const int py0 = ty * SP_PH, px0 = tx * SP_PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;                    // stem pixel of tile-local (0, 0)
+    bf16x8 wf[7][4];
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            wf[kh][nt] = *reinterpret_cast<const bf16x8*>(w + ((size_t)(nt * 16 + li) * 7 + kh) * 32 + lg * 8);
+    f32x4 bv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const f32x4*>(bias + nt * 16 + lg * 4);
+    const bf16_t* ximg = xp + (size_t)b * Hp * Wp * 4;
+    // stem pixels outside the image (the pool's padding, tile overhang) are computed at a clamped position and never read back
+    auto src = [&](int t) -> const bf16_t* {
+        int p = (wave + 4 * t) * 16 + li; p = p < SP_NPIX ? p : SP_NPIX - 1;
+        int sy = sy0 + p / SP_SW, sx = sx0 + p % SP_SW;
+        sy = sy < 0 ? 0 : (sy >= Ho ? Ho - 1 : sy);
+        sx = sx < 0 ? 0 : (sx >= Wo ? Wo - 1 : sx);
+        return ximg + ((size_t)(2 * sy) * Wp + 2 * sx + 2 * lg) * 4;
+    };
+    auto load = [&](bf16x8 (&x)[7], int t) {
+        const bf16_t* s0 = src(t);
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) x[kh] = *reinterpret_cast<const bf16x8*>(s0 + (size_t)kh * Wp * 4);
+    };
+    auto compute = [&](const bf16x8 (&x)[7], int t) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][nt], x[kh], acc[nt], 0, 0, 0);
+        const int p = (wave + 4 * t) * 16 + li;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)fmaxf(acc[nt][r] + bv[nt][r], 0.f);
+            const int slot = (nt * 2 + (lg >> 1)) ^ (p & 7);
+            *reinterpret_cast<bf16x4*>(sm + (size_t)p * 64 + slot * 8 + (lg & 1) * 4) = ov;
+        }
+    };
+    static_assert(SP_TILES % 4 == 0 && (SP_TILES / 4) % 2 == 1, "nine tiles per wave: four pairs and one");
+    bf16x8 xa[7], xb[7];
+    load(xa, 0);
+#pragma unroll 1
+    for (int t = 0; t < SP_TILES / 4 - 1; t += 2) {
+        load(xb, t + 1);
+        compute(xa, t);
+        load(xa, t + 2);
+        compute(xb, t + 1);
+    }
+    compute(xa, SP_TILES / 4 - 1);
+    __syncthreads();
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int it = 0; it < SP_PH * SP_PW * 8 / 256; ++it) {
+        const int item = it * 256 + (int)threadIdx.x;
+        const int cs = item & 7, pp = item >> 3;
+        const int pyl = pp / SP_PW, pxl = pp % SP_PW;
+        const int py = py0 + pyl, px = px0 + pxl;
+        if (py >= Po || px >= Qo) continue;
+        // tile-local stem centre (2 pyl + 1, 2 pxl + 1) = stem pixel (2 py, 2 px): always inside the image
+        const int cy = 2 * pyl + 1, cx = 2 * pxl + 1;
+        const int pc = cy * SP_SW + cx;
+        s16x8 m = *reinterpret_cast<const s16x8*>(sm + (size_t)pc * 64 + ((cs ^ (pc & 7)) * 8));
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int sy = 2 * py + dy;
+            if (sy < 0 || sy >= Ho) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int sx = 2 * px + dx;
+                if (sx < 0 || sx >= Wo || (dy == 0 && dx == 0)) continue;
+                const int q = (cy + dy) * SP_SW + cx + dx;
+                const s16x8 v = *reinterpret_cast<const s16x8*>(sm + (size_t)q * 64 + ((cs ^ (q & 7)) * 8));
+                m = __builtin_elementwise_max(m, v);
+            }
+        }
+        *reinterpret_cast<s16x8*>(out + (((size_t)b * Po + py) * Qo + px) * 64 + cs * 8) = m;
     }
 }
 
@@ -298,6 +407,25 @@ extern "C" int rt_stem_conv(const void* xp, const void* w, const float* bias, vo
     if (Wp < 2 * (((Wo + 15) / 16) * 16) + 6 || Hp < 2 * (Ho - 1) + 7) return RT_ERR_BADARG;
     hipLaunchKernelGGL(stem_conv_kernel, dim3((B * Ho + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)xp, (const bf16_t*)w, bias, (bf16_t*)out, B, Hp, Wp, Ho, Wo);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_stem_pool(const void* xp, const void* w, const float* bias, void* out,
+                            int B, int Hp, int Wp, int Ho, int Wo, rt_stream_t stream) {
+    if (!xp || !w || !bias || !out || B <= 0 || Ho <= 0 || Wo <= 0) return RT_ERR_BADARG;
+    if (Wp < 2 * Wo + 6 || Hp < 2 * (Ho - 1) + 7) return RT_ERR_BADARG;
+    const int Po = (Ho - 1) / 2 + 1, Qo = (Wo - 1) / 2 + 1;
+    const int tiles_x = (Qo + SP_PW - 1) / SP_PW, tiles_y = (Po + SP_PH - 1) / SP_PH;
+    constexpr int lds = SP_TILES * 16 * 64 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(B * tiles_x * tiles_y), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16_t*)xp, (const bf16_t*)w, bias, (bf16_t*)out, B, Hp, Wp, Ho, Wo, Po, Qo, tiles_x, tiles_y);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

@@ -866,11 +866,59 @@ class CapturedForward:
         return out
 
 
+def _vis_dirs(output_dir, split):
+    """output_dir/vis/<split>/{mask,bbox,att,gt} (engine_vg.py:86-94)."""
+    from pathlib import Path
+    if output_dir is None:
+        raise ValueError("evaluate(visualize=True) needs an output_dir")
+    root = Path(output_dir) / "vis" / str(split)
+    for sub in ("mask", "bbox", "att", "gt"):
+        (root / sub).mkdir(parents=True, exist_ok=True)
+    return root
+
+
+_VIS_PURPLE = (128, 0, 128)
+_VIS_YELLOW = (255, 255, 0)
+
+
+def _dump_visuals(root, dataset, dataset_id, mask_origin, pred_box, mask_att):
+    """The four image dumps of one evaluated sample (engine_vg.py:157-192): `mask_origin` uint8 / bool [H, W] at the original
+    image size (PostProcessSegm's 'masks_origin'), `pred_box` xyxy in original pixels, `mask_att` [heads, h, w] (the
+    segmentation head's attention maps).  Host-side, off the hot path; PIL / matplotlib are imported here only."""
+    import numpy as np
+    from PIL import Image, ImageDraw
+    import matplotlib
+    matplotlib.use("Agg", force=False)
+    import matplotlib.pyplot as plt
+    img, mask, _phrase, tgt_box, img_file = dataset.pull_item(dataset_id)
+    pm = (mask_origin.detach().cpu().numpy() != 0)
+    mask = np.asarray(mask)
+    assert pm.shape == mask.shape[:2], (pm.shape, mask.shape)
+    stem = str(img_file).split("/")[-1].split(".")[0]
+    tag = f"{stem}_{dataset_id:05d}"
+    purple = np.array(_VIS_PURPLE, dtype=np.uint8); yellow = np.array(_VIS_YELLOW, dtype=np.uint8)
+    Image.fromarray(np.where(pm[..., None], yellow, purple)).save(root / "mask" / f"{tag}.jpg")
+    Image.fromarray(np.where((mask != 0)[..., None], yellow, purple)).save(root / "gt" / f"{tag}.jpg")
+    canvas = Image.fromarray(np.asarray(img))
+    draw = ImageDraw.Draw(canvas)
+    draw.rectangle([float(v) for v in pred_box.detach().cpu().reshape(-1)], outline="blue", width=5)
+    draw.rectangle([float(v) for v in np.asarray(tgt_box).reshape(-1)], outline="red", width=5)
+    canvas.save(root / "bbox" / f"{tag}.jpg")
+    # attention maps: resized to 320 x 320 and cropped to the image's half size, heads 0, 1, 2 and 7 (:181-186)
+    att = torch.nn.functional.interpolate(mask_att.detach().float().cpu()[None], size=(320, 320), mode="bilinear")[0].numpy()
+    h, w = mask.shape[:2]
+    for head in (0, 1, 2, 7):
+        if head < att.shape[0]:
+            plt.imsave(root / "att" / f"{tag}_{head}.jpg", att[head, :h // 2, :w // 2], cmap="viridis")
+
+
 @torch.no_grad()
 def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=None, visualize=False):
-    """engine_vg.evaluate (engine_vg.py:82-225) without the image dumps of `visualize`: losses, Acc@0.5 / mean IoU of the
-    predicted boxes (:127-140), mask IoU when a 'segm' post-processor is present (:143-152), boxes scaled to the
-    original image size in the returned results dict (:141,203)."""
+    """engine_vg.evaluate (engine_vg.py:82-225): losses, Acc@0.5 / mean IoU of the predicted boxes (:127-140), mask IoU when a
+    'segm' post-processor is present (:143-152), boxes scaled to the original image size in the returned results dict (:141,203).
+    `visualize` (needs the 'segm' post-processor, `output_dir` and a dataset with `split` / `pull_item`, as in the reference):
+    per sample the predicted mask, the ground-truth mask, the image with both boxes and four attention maps under
+    output_dir/vis/<split>/{mask,gt,bbox,att} (:86-96,157-192)."""
     from .util.box_ops import mask_iou
     model.eval()
     criterion.eval()
@@ -878,6 +926,7 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
     sum_accu = torch.zeros((), device=device); sum_iou = torch.zeros((), device=device); cnt = torch.zeros((), device=device)
     seg_iou = torch.zeros((), device=device); cnt_seg = 0.0
     results_dict = {}
+    vis_dir = _vis_dirs(output_dir, data_loader.dataset.split) if visualize else None
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
     # the forward is replayed from a hipGraph per input shape (fixed-size evaluation sets; bit-identical outputs; up to four
@@ -912,9 +961,12 @@ def evaluate(model, criterion, postprocessors, data_loader, device, output_dir=N
         if "segm" in postprocessors:
             target_sizes = torch.stack([t["size"] for t in targets], dim=0)
             results = postprocessors["segm"](results, outputs, orig_sizes, target_sizes)
-            for res, tg in zip(results, targets):
+            for i, (res, tg) in enumerate(zip(results, targets)):
                 seg_iou += mask_iou(res["masks"][0][0], tg["masks"])
                 cnt_seg += 1
+                if vis_dir is not None:
+                    _dump_visuals(vis_dir, data_loader.dataset, int(tg["dataset_id"]), res["masks_origin"][0, 0],
+                                  results_scaled[i]["boxes"][0], outputs["mask_att"][i])
         for tg, res in zip(targets, results_scaled):
             if "image_id" in tg:
                 results_dict[int(tg["image_id"])] = res["boxes"].cpu().numpy().tolist()

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -303,6 +303,7 @@ _SIGNATURES = {
     "rt_img_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_stem_conv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rt_stem_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rt_bottleneck_fwd": (c_int, [POINTER(BottleneckDesc), c_void_p]),
     "rt_weight_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rt_weight_prep_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
@@ -849,6 +850,14 @@ def maxpool3x3s2(x):
     y = _new((B, Ho, Wo, C), torch.bfloat16, x)
     _check(lib().rt_maxpool3x3s2(_p(x), _p(y), B, H, W, C, Ho, Wo, _stream()), "rt_maxpool3x3s2")
     return y
+
+
+def stem_pool(xp, w, bias, Ho, Wo):
+    """conv1 7x7/2 + FrozenBN + ReLU + MaxPool2d(3, 2, 1) in one launch: the stem output is never written."""
+    B, Hp, Wp, _ = xp.shape
+    out = _new((B, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), torch.bfloat16, xp)
+    _check(lib().rt_stem_pool(_p(xp), _p(w), _p(bias), _p(out), B, Hp, Wp, Ho, Wo, _stream()), "rt_stem_pool")
+    return out
 
 
 def bottleneck_fwd(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out=None, form=0):

@@ -64,6 +64,7 @@ class ResNetBody:
         self.wg = H.SideStream(False)     # conv weight gradients stay inline (they fill the chip on their own)
         import os
         self.fuse_frozen = os.environ.get("REFTR_L1_FUSE", "1") == "1" and str(store.device).startswith("cuda")
+        self.fuse_stem = os.environ.get("REFTR_STEM_FUSE", "1") == "1"
         gc = int(os.environ.get("REFTR_GROUP_CONV", "1")) if str(store.device).startswith("cuda") else 0
         self.batch = H.WgradBatch(workspace_mb=1024) if gc else None
         self.wgs = H.SideStream(gc == 2)
@@ -122,15 +123,20 @@ class ResNetBody:
                            act=H.ACT_RELU if relu else H.ACT_NONE, dil=c.dil)
         return y, (B, Ho, Wo), geom
 
-    def forward(self, img, ready=None, before_trainable=None):
+    def forward(self, img, ready=None, before_trainable=None, after_stem=None):
         """img fp32 [B,3,H,W] -> (list of the 4 stage outputs as ([M, C] bf16, (B,h,w))), saved-for-backward).
         `ready`: event after which the TRAINABLE convolutions' operands are current (the frozen stem / layer1 do not wait)."""
         B, _, Hh, Ww = img.shape
         Ho, Wo, _, _ = H.stem_geometry(Hh, Ww)
         xp = H.img_pack(img)
-        y = H.stem_conv(xp, self.W["stem"], self.bn[self.PFX + "bn1."][1], Ho, Wo)
-        y = H.maxpool3x3s2(y)
+        if self.fuse_stem:                          # conv1 / bn1 / relu / maxpool are frozen: nothing of them is saved for backward
+            y = H.stem_pool(xp, self.W["stem"], self.bn[self.PFX + "bn1."][1], Ho, Wo)
+        else:
+            y = H.stem_conv(xp, self.W["stem"], self.bn[self.PFX + "bn1."][1], Ho, Wo)
+            y = H.maxpool3x3s2(y)
         H.mark("ResNet forward: stem + max-pool done")
+        if after_stem is not None:
+            after_stem()
         shp = (B, y.shape[1], y.shape[2])
         x = y.view(-1, 64)
         feats, saved = [], []

@@ -108,6 +108,7 @@ class RefTR(nn.Module):
         # streams share the chip; layer2 alone goes 469 -> 1004 us beside BERT's forward): 7.28-7.33 vs 7.01-7.04 ms.  Off.
         self._opt_pipe = os.environ.get("REFTR_OPT_PIPE", "0") != "0"
         self.opt_side = H.SideStream(self._opt_pipe)
+        self._stem_first = int(os.environ.get("REFTR_STEM_FIRST", "1"))
         self._bert_gates = None
         self._adam_done = None
         self._bb_ready = None
@@ -453,9 +454,16 @@ class RefTR(nn.Module):
             return (pos, kpm)
         self._adam_done = None
         late = self._late_hook
-        lang_out = net.side.run(_lang_branch, ids, smask_u8, mask_u8)
-        if self._adam_done is not None and net.side.enabled:
-            torch.cuda.current_stream().wait_event(self._adam_done)
+        # REFTR_STEM_FIRST=1: the language branch is forked BEHIND the frozen stem (rt_stem_pool: two 72-KB / 230-VGPR workgroups per
+        # CU, which find no room beside the BERT slice's AdamW pass once that has filled the chip) instead of in front of it
+        stem_first = self._stem_first if (late is None and self.body.fuse_stem) else 0       # 2: behind frozen layer1 as well
+        lang_box = []
+        def _fork_lang():
+            lang_box.append(net.side.run(_lang_branch, ids, smask_u8, mask_u8))
+            if self._adam_done is not None and net.side.enabled:
+                torch.cuda.current_stream().wait_event(self._adam_done)
+        if not stem_first:
+            _fork_lang()
         late_out = []
         def _late_main():
             # main stream, behind the frozen stem / layer1: the main slice's pending AdamW pass (it writes the bf16 operands), the
@@ -465,7 +473,12 @@ class RefTR(nn.Module):
             net._refresh_kv_cat()
             H.mark("AdamW (main slice) + operands done")
             late_out.append(net.side.run(_pos_work, mask_u8, smask_u8))
-        feats, bb_saved = self.body.forward(x, ready=self._bb_ready, before_trainable=_late_main if late is not None else None)
+        feats, bb_saved = self.body.forward(x, ready=self._bb_ready,
+                                            before_trainable=_late_main if late is not None else (_fork_lang if stem_first == 2 else None),
+                                            after_stem=_fork_lang if stem_first == 1 else None)
+        if not lang_box:                       # no trainable block fired the hook (--lr_backbone 0)
+            _fork_lang()
+        lang_out = lang_box[0]
         seq16, pooled16, bctx, pos, kpm = lang_out + late_out[0] if late is not None else lang_out
         c5, (_, h5, w5) = feats[-1]
         assert (h5, w5) == (h, w)

@@ -526,3 +526,40 @@ def test_data_parallel_boundary_clears_never_written_matrices_before_the_exchang
                     st.offset["lang_backbone.encoder.layer.0.output.dense.weight"][1]}
     # not armed (plain zero_grad): nothing to do
     log.clear(); st.finish_overwrite_range([(ma, mb)]); assert not log
+
+
+def test_evaluate_visualize_dumps(tmp_path):
+    """evaluate(visualize=True)'s image dumps (reference engine_vg.py:86-96,157-192): directory layout, file names, the two-colour
+    mask images, the boxes drawn on the image and the four attention maps at half the image size."""
+    import numpy as np
+    from PIL import Image
+    from reftr_amd.engine_vg import _vis_dirs, _dump_visuals
+
+    class DS:
+        split = "testA"
+        def pull_item(self, idx):
+            img = np.full((40, 60, 3), 200, dtype=np.uint8)
+            mask = np.zeros((40, 60), dtype=np.uint8); mask[10:30, 20:50] = 1
+            return img, mask, "the left one", np.array([20., 10., 50., 30.]), "images/coco/COCO_train2014_000000000009.jpg"
+
+    root = _vis_dirs(tmp_path, DS.split)
+    assert root == tmp_path / "vis" / "testA" and all((root / d).is_dir() for d in ("mask", "bbox", "att", "gt"))
+    pred = torch.zeros(40, 60, dtype=torch.uint8); pred[12:28, 22:48] = 1
+    att = torch.rand(8, 10, 10)
+    _dump_visuals(root, DS(), 7, pred, torch.tensor([28., 16., 44., 26.]), att)
+    tag = "COCO_train2014_000000000009_00007"
+    m = np.asarray(Image.open(root / "mask" / f"{tag}.jpg")).astype(int)
+    g = np.asarray(Image.open(root / "gt" / f"{tag}.jpg")).astype(int)
+    assert m.shape == (40, 60, 3) and g.shape == (40, 60, 3)
+    # JPEG is lossy: interior pixels are yellow-ish (255, 255, 0), far background purple-ish (128, 0, 128)
+    assert np.abs(m[20, 35] - np.array([255, 255, 0])).max() < 40 and np.abs(m[2, 2] - np.array([128, 0, 128])).max() < 40
+    assert np.abs(g[20, 35] - np.array([255, 255, 0])).max() < 40 and np.abs(g[35, 5] - np.array([128, 0, 128])).max() < 40
+    b = np.asarray(Image.open(root / "bbox" / f"{tag}.jpg")).astype(int)
+    assert b.shape == (40, 60, 3)
+    assert b[20, 21, 0] > 150 and b[20, 21, 2] < 120          # the target box's left edge (red, 5 px wide from x = 20)
+    assert b[20, 30, 2] > 150 and b[20, 30, 0] < 120          # the predicted box's left edge (blue, from x = 28)
+    for head in (0, 1, 2, 7):
+        a = np.asarray(Image.open(root / "att" / f"{tag}_{head}.jpg"))
+        assert a.shape[:2] == (20, 30)
+    with pytest.raises(ValueError):
+        _vis_dirs(None, "val")

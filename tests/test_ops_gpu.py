@@ -187,6 +187,25 @@ def test_stem_and_maxpool(hip):
     assert torch.equal(mp.float().cpu().permute(0, 3, 1, 2), ref_mp)          # max is exact
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 70, 52), (1, 64, 128), (3, 33, 47), (2, 130, 61), (1, 17, 16), (8, 640, 640)])
+def test_stem_pool_in_one_launch_is_bit_identical(hip, B, H, W):
+    """rt_stem_pool = rt_maxpool3x3s2(rt_stem_conv(x)) bit for bit: same products in the same K order, one bf16 rounding, and
+    max commutes with it (ragged tiles, odd sizes, pool padding on every side, one full-size case)."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    img = torch.randn(B, 3, H, W, generator=g).cuda()
+    w = (torch.randn(64, 7, 7, 3, generator=g) / 12).cuda()
+    scale = (torch.rand(64, generator=g) + 0.5).cuda(); shift = (torch.randn(64, generator=g) * 0.3).cuda()
+    Ho, Wo, Hp, Wp = hip.stem_geometry(H, W)
+    xp = hip.img_pack(img)
+    wk = torch.empty(64, 7, 8, 4, dtype=torch.bfloat16, device="cuda")
+    hip.stem_weight_prep(w, scale, wk)
+    two = hip.maxpool3x3s2(hip.stem_conv(xp, wk, shift, Ho, Wo))
+    one = hip.stem_pool(xp, wk, shift, Ho, Wo)
+    torch.cuda.synchronize()
+    assert one.shape == two.shape
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+
+
 def test_weight_prep_and_bn_fold(hip):
     g = torch.Generator().manual_seed(4)
     N, T, C = 24, 9, 16
