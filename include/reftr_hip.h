@@ -489,6 +489,7 @@ int rt_qenc_attn_bwd(const float* k, const float* qs, const float* vs, const flo
  * num_boxes: DEVICE fp32 scalar (already all-reduced / world, clamp >= 1 applied here).
  * losses[l*2+0] = loss_bbox of layer l, losses[l*2+1] = loss_giou; total = sum_l w_bbox*l1 + w_giou*giou;
  * dlogits = d total / d logits (0 for invalid phrases).  Selection/ordering is exact.
+ * Both outputs are cleared by the call (they are accumulated with atomics); total == losses + 2*NL (one buffer) costs one clear.
  * ------------------------------------------------------------------------------------------ */
 typedef struct rt_box_loss_desc {
     const float*   logits;

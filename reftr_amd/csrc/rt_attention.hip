@@ -510,6 +510,301 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const rt_attn_b
     else attn_bwd_dkv_body<DH, NW, true>(p, (int)blockIdx.y - ny_dq);
 }
 
+// ------------------------------------------------------------------------------------------------ long inner axes
+// Sequences whose K / V (forward, dQ) or Q / dO (dK, dV) rows do not fit the CU's 160 KB at once (--dilation at 640 x 640: c5 at
+// stride 16, S = 1600 + L): the inner axis is walked in chunks of LONG_CH rows, each staged into the same LDS region behind a
+// barrier.  Same lane <-> (query, key) assignment and the same key order per lane as the whole-axis kernels above -- the forward
+// is the two-pass kernel with each pass running over the chunks (pass 1 stages K only) -- so the results are bit-identical to
+// attn_fwd_kernel / the dq / dkv bodies wherever both apply (tests force this path on short sequences with a small chunk).
+template <int DH> struct LongGeo { static constexpr int CH = DH == 32 ? 768 : 448; };     // 2 * CH * RS + 8 * CH <= 160 KB
+
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const rt_attn_desc p, const int ch) {
+    constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Skp = (p.Sk + 31) & ~31;
+    unsigned char* sK = smem;
+    unsigned char* sV = sK + (size_t)ch * RS;
+    float* sBias = reinterpret_cast<float*>(sV + (size_t)ch * RS);
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const bf16_t* kbase = (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH;
+    const bf16_t* vbase = (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH;
+    const int q = blockIdx.y * (16 * NW) + wave * 16 + li;          // this lane's query (rows past Sq: zero fragments, never stored)
+    bf16x8 qf[Geo<DH>::KH];
+    load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
+
+    float m = -INFINITY, l = 0.f;
+    for (int c0 = 0; c0 < Skp; c0 += ch) {
+        const int rows = (Skp - c0 < ch) ? Skp - c0 : ch;
+        const int valid = (p.Sk - c0 < rows) ? p.Sk - c0 : rows;
+        __syncthreads();
+        stage_rows<DH>(sK, kbase + (size_t)c0 * p.ldk, valid, rows, p.ldk, threadIdx.x, 64 * NW);
+        for (int j = threadIdx.x; j < rows; j += 64 * NW)
+            sBias[j] = (c0 + j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + c0 + j])) ? 0.f : -INFINITY;
+        __syncthreads();
+        for (int blk = 0; blk < (rows >> 4); ++blk) {
+            const f32x4 acc = tile_dot<DH>(sK, blk * 16, li, lg, qf);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + blk * 16 + lg * 4);
+            float sc[4], mx = m;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = acc[r] * p.scale + bias[r]; mx = fmaxf(mx, sc[r]); }
+            const float ms = (mx == -INFINITY) ? 0.f : mx;
+            float add = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) add += __expf(sc[r] - ms);
+            l = l * __expf(m - ms) + add;
+            m = mx;
+        }
+    }
+    float M = fmaxf(m, __shfl_xor(m, 16, 64));
+    M = fmaxf(M, __shfl_xor(M, 32, 64));
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    l *= __expf(m - Ms);
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.f / l;
+
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
+    const uint32_t drop_row = (uint32_t)(((size_t)bh * p.Sq + q) * p.Sk);
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tr_r = 4 * lg + (li >> 2), tr_c = (li & 3) * 8;
+    for (int c0 = 0; c0 < Skp; c0 += ch) {
+        const int rows = (Skp - c0 < ch) ? Skp - c0 : ch;
+        const int valid = (p.Sk - c0 < rows) ? p.Sk - c0 : rows;
+        __syncthreads();
+        stage_rows2<DH>(sK, kbase + (size_t)c0 * p.ldk, p.ldk, sV, vbase + (size_t)c0 * p.ldv, p.ldv, valid, rows, threadIdx.x, 64 * NW);
+        for (int j = threadIdx.x; j < rows; j += 64 * NW)
+            sBias[j] = (c0 + j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + c0 + j])) ? 0.f : -INFINITY;
+        __syncthreads();
+        for (int c = 0; c < (rows >> 5); ++c) {
+            float pv[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int k0 = c * 32 + half * 16;
+                const f32x4 acc = tile_dot<DH>(sK, k0, li, lg, qf);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + k0 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = __expf(acc[r] * p.scale + bias[r] - Ms) * inv_l;
+                    if (do_drop) pr = (rt_hash32(dseed, drop_row + (uint32_t)(c0 + k0 + lg * 4 + r)) >= thresh) ? pr * ks : 0.f;
+                    pv[half * 4 + r] = pr;
+                }
+            }
+            const bf16x8 pf = pack8(pv);
+            const unsigned char* v0 = sV + (c * 32 + tr_r) * RS + tr_c;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const bf16x8 vf = tr_pair(v0 + t * 32, v0 + 16 * RS + t * 32);
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
+            }
+        }
+    }
+    if (q < p.Sq) {
+        bf16_t* orow = (bf16_t*)p.out + ((size_t)b * p.Sq + q) * p.ldo + h * DH;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)o[t][r];
+            *reinterpret_cast<bf16x4*>(orow + t * 16 + lg * 4) = ov;
+        }
+        if (lg == 0 && p.lse) p.lse[(size_t)bh * p.Sq + q] = M + __logf(l);
+    }
+}
+
+template <int DH, int NW>
+__device__ __forceinline__ void attn_bwd_dq_long_body(const rt_attn_bwd_desc& p, const int by, const int ch) {
+    constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Skp = (p.Sk + 31) & ~31;
+    unsigned char* sK = smem;
+    unsigned char* sV = sK + (size_t)ch * RS;
+    float* sBias = reinterpret_cast<float*>(sV + (size_t)ch * RS);
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const bf16_t* kbase = (const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH;
+    const bf16_t* vbase = (const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH;
+    const int q = by * (16 * NW) + wave * 16 + li;
+    bf16x8 qf[KH], dof[KH], of[KH];
+    load_bfrag<DH>((const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH, q, p.Sq, p.ldq, lg, qf);
+    load_bfrag<DH>((const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH, q, p.Sq, p.ldo, lg, dof);
+    load_bfrag<DH>((const bf16_t*)p.out + (size_t)b * p.Sq * p.ldo + h * DH, q, p.Sq, p.ldo, lg, of);
+    float delta = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) delta += (float)dof[kh][e] * (float)of[kh][e];
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = (q < p.Sq) ? p.lse[(size_t)bh * p.Sq + q] : INFINITY;
+    if (lg == 0 && q < p.Sq) p.delta[(size_t)bh * p.Sq + q] = delta;
+
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
+    const uint32_t drop_row = (uint32_t)(((size_t)bh * p.Sq + q) * p.Sk);
+    f32x4 dq[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tr_r = 4 * lg + (li >> 2), tr_c = (li & 3) * 8;
+    for (int c0 = 0; c0 < Skp; c0 += ch) {
+        const int rows = (Skp - c0 < ch) ? Skp - c0 : ch;
+        const int valid = (p.Sk - c0 < rows) ? p.Sk - c0 : rows;
+        __syncthreads();
+        stage_rows2<DH>(sK, kbase + (size_t)c0 * p.ldk, p.ldk, sV, vbase + (size_t)c0 * p.ldv, p.ldv, valid, rows, threadIdx.x, 64 * NW);
+        for (int j = threadIdx.x; j < rows; j += 64 * NW)
+            sBias[j] = (c0 + j < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + c0 + j])) ? 0.f : -INFINITY;
+        __syncthreads();
+        for (int c = 0; c < (rows >> 5); ++c) {
+            float dsv[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int k0 = c * 32 + half * 16;
+                const f32x4 sc = tile_dot<DH>(sK, k0, li, lg, qf);
+                const f32x4 dp = tile_dot<DH>(sV, k0, li, lg, dof);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + k0 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __expf(sc[r] * p.scale + bias[r] - lse);
+                    float d = dp[r];
+                    if (do_drop) d = (rt_hash32(dseed, drop_row + (uint32_t)(c0 + k0 + lg * 4 + r)) >= thresh) ? d * ks : 0.f;
+                    dsv[half * 4 + r] = pr * (d - delta) * p.scale;
+                }
+            }
+            const bf16x8 dsf = pack8(dsv);
+            const unsigned char* k0p = sK + (c * 32 + tr_r) * RS + tr_c;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const bf16x8 kf = tr_pair(k0p + t * 32, k0p + 16 * RS + t * 32);
+                dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[t], 0, 0, 0);
+            }
+        }
+    }
+    if (q < p.Sq) {
+        bf16_t* drow = (bf16_t*)p.dq + ((size_t)b * p.Sq + q) * p.lddq + h * DH;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)dq[t][r];
+            *reinterpret_cast<bf16x4*>(drow + t * 16 + lg * 4) = ov;
+        }
+    }
+}
+
+template <int DH, int NW>
+__device__ __forceinline__ void attn_bwd_dkv_long_body(const rt_attn_bwd_desc& p, const int by, const int ch) {
+    constexpr int RS = Geo<DH>::RS, DT = Geo<DH>::DT, KH = Geo<DH>::KH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Sqp = (p.Sq + 31) & ~31;
+    unsigned char* sQ = smem;
+    unsigned char* sD = sQ + (size_t)ch * RS;
+    float* sL = reinterpret_cast<float*>(sD + (size_t)ch * RS);
+    float* sDel = sL + ch;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const bf16_t* qbase = (const bf16_t*)p.q + (size_t)b * p.Sq * p.ldq + h * DH;
+    const bf16_t* dbase = (const bf16_t*)p.dout + (size_t)b * p.Sq * p.ldo + h * DH;
+    const int key = by * (16 * NW) + wave * 16 + li;
+    bf16x8 kf[KH], vf[KH];
+    load_bfrag<DH>((const bf16_t*)p.k + (size_t)b * p.Sk * p.ldk + h * DH, key, p.Sk, p.ldk, lg, kf);
+    load_bfrag<DH>((const bf16_t*)p.v + (size_t)b * p.Sk * p.ldv + h * DH, key, p.Sk, p.ldv, lg, vf);
+    const float kbias = (key < p.Sk && !(p.kpm && p.kpm[(size_t)b * p.Sk + key])) ? 0.f : -INFINITY;
+    const bool do_drop = p.drop_p > 0.f;
+    const uint32_t thresh = rt_drop_thresh(p.drop_p);
+    const float ks = do_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    const uint32_t dseed = rt_site_seed(p.seed_dev, p.drop_seed);
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int tr_r = 4 * lg + (li >> 2), tr_c = (li & 3) * 8;
+    for (int c0 = 0; c0 < Sqp; c0 += ch) {
+        const int rows = (Sqp - c0 < ch) ? Sqp - c0 : ch;
+        const int valid = (p.Sq - c0 < rows) ? p.Sq - c0 : rows;
+        __syncthreads();
+        stage_rows2<DH>(sQ, qbase + (size_t)c0 * p.ldq, p.ldq, sD, dbase + (size_t)c0 * p.ldo, p.ldo, valid, rows, threadIdx.x, 64 * NW);
+        for (int i = threadIdx.x; i < rows; i += 64 * NW) {
+            const int qi = c0 + i;
+            sL[i] = (qi < p.Sq) ? p.lse[(size_t)bh * p.Sq + qi] : INFINITY;
+            float del = 0.f;
+            if (qi < p.Sq) {                       // delta recomputed from the head's O / dO rows: independent of the dQ blocks
+                const bf16_t* orow = (const bf16_t*)p.out + ((size_t)b * p.Sq + qi) * p.ldo + h * DH;
+                const bf16_t* drow = dbase + (size_t)qi * p.ldo;
+#pragma unroll
+                for (int c = 0; c < DH; c += 8) {
+                    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + c), dv8 = *reinterpret_cast<const bf16x8*>(drow + c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) del += (float)dv8[e] * (float)ov[e];
+                }
+            }
+            sDel[i] = del;
+        }
+        __syncthreads();
+        for (int c = 0; c < (rows >> 5); ++c) {
+            float pv[8], dsv[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int q0 = c * 32 + half * 16;
+                const f32x4 sc = tile_dot<DH>(sQ, q0, li, lg, kf);
+                const f32x4 dp = tile_dot<DH>(sD, q0, li, lg, vf);
+                const f32x4 lse = *reinterpret_cast<const f32x4*>(sL + q0 + lg * 4);
+                const f32x4 del = *reinterpret_cast<const f32x4*>(sDel + q0 + lg * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __expf(sc[r] * p.scale + kbias - lse[r]);
+                    float d = dp[r], pd = pr;
+                    if (do_drop) {
+                        const int qq = c0 + q0 + lg * 4 + r;
+                        const bool keep = rt_hash32(dseed, (uint32_t)(((size_t)bh * p.Sq + qq) * p.Sk + key)) >= thresh;
+                        d = keep ? d * ks : 0.f; pd = keep ? pr * ks : 0.f;
+                    }
+                    pv[half * 4 + r] = pd;
+                    dsv[half * 4 + r] = pr * (d - del[r]) * p.scale;
+                }
+            }
+            const bf16x8 pf = pack8(pv), dsf = pack8(dsv);
+            const unsigned char* d0 = sD + (c * 32 + tr_r) * RS + tr_c;
+            const unsigned char* q0p = sQ + (c * 32 + tr_r) * RS + tr_c;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const bf16x8 dof = tr_pair(d0 + t * 32, d0 + 16 * RS + t * 32);
+                dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[t], 0, 0, 0);
+                const bf16x8 qtf = tr_pair(q0p + t * 32, q0p + 16 * RS + t * 32);
+                dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[t], 0, 0, 0);
+            }
+        }
+    }
+    if (key < p.Sk) {
+        bf16_t* kro = (bf16_t*)p.dk + ((size_t)b * p.Sk + key) * p.lddk + h * DH;
+        bf16_t* vro = (bf16_t*)p.dv + ((size_t)b * p.Sk + key) * p.lddv + h * DH;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            bf16x4 a, c2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[t][r]; c2[r] = (bf16_t)dv[t][r]; }
+            *reinterpret_cast<bf16x4*>(kro + t * 16 + lg * 4) = a;
+            *reinterpret_cast<bf16x4*>(vro + t * 16 + lg * 4) = c2;
+        }
+    }
+}
+
+// both halves in one launch, as attn_bwd_fused_kernel: blockIdx.y < ny_dq -> the dQ row blocks, the rest -> the dK / dV key blocks
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_long_kernel(const rt_attn_bwd_desc p, const int ny_dq, const int ch) {
+    if ((int)blockIdx.y < ny_dq) attn_bwd_dq_long_body<DH, NW>(p, (int)blockIdx.y, ch);
+    else attn_bwd_dkv_long_body<DH, NW>(p, (int)blockIdx.y - ny_dq, ch);
+}
+
 // Opt a kernel into the full 160 KiB of dynamic LDS once per kernel (not per launch: keeps launches capturable in a
 // hipGraph).  Keyed by the function pointer (kernels of equal signature share a C++ type).
 template <typename K>
@@ -528,6 +823,15 @@ int set_smem(K kernel, size_t bytes) {
 size_t smem_bytes(int inner, int dh) {
     const size_t ip = (size_t)((inner + 31) & ~31);
     return 2 * ip * (dh * 2 + 32) + 2 * sizeof(float) * ip;
+}
+
+// rows of the inner axis per LDS pass of the long-axis kernels; 0 = the whole-axis kernels apply.  REFTR_ATTN_CHUNK (a multiple of
+// 32) forces the long-axis kernels with that chunk on every shape (tests: bit-identity with the whole-axis kernels)
+int long_chunk(int inner, int dh) {
+    static const int env = getenv("REFTR_ATTN_CHUNK") ? atoi(getenv("REFTR_ATTN_CHUNK")) : 0;
+    const int cap = dh == 32 ? LongGeo<32>::CH : LongGeo<64>::CH;
+    if (env >= 32) return ((env < cap ? env : cap) + 31) & ~31;
+    return smem_bytes(inner, dh) > 160 * 1024 ? cap : 0;
 }
 
 }  // namespace
@@ -720,13 +1024,23 @@ extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
         RT_CHECK_LAUNCH();
         return RT_OK;
     }
+    int rc;
+    if (const int ch = long_chunk(d->Sk, d->dh)) {
+        const size_t lsmem = smem_bytes(ch, d->dh);
+        const dim3 lgrid(d->B * d->H, (d->Sq + 127) / 128);
+#define RT_ATTN_FWD_LONG(DHV) do { if ((rc = set_smem(attn_fwd_long_kernel<DHV, 8>, lsmem)) != RT_OK) return rc; \
+        hipLaunchKernelGGL((attn_fwd_long_kernel<DHV, 8>), lgrid, dim3(512), lsmem, (hipStream_t)stream, *d, ch); } while (0)
+        if (d->dh == 32) RT_ATTN_FWD_LONG(32); else RT_ATTN_FWD_LONG(64);
+#undef RT_ATTN_FWD_LONG
+        RT_CHECK_LAUNCH();
+        return RT_OK;
+    }
     const size_t smem = smem_bytes(d->Sk, d->dh);
     static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
     const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
     // (b, h) on grid.x: the row blocks of one head get ids bh, bh + B*H, ... -> the same XCD whenever B*H is a multiple of 8, so the
     // head's K / V rows cross the fabric once per XCD instead of once per block
     const dim3 grid(d->B * d->H, (d->Sq + 16 * nw - 1) / (16 * nw));
-    int rc;
 #define RT_ATTN_FWD(DHV, NWV) do { if ((rc = set_smem(attn_fwd_kernel<DHV, NWV>, smem)) != RT_OK) return rc; \
         hipLaunchKernelGGL((attn_fwd_kernel<DHV, NWV>), grid, dim3(64 * NWV), smem, (hipStream_t)stream, *d); } while (0)
     static const int reg_env = getenv("REFTR_ATTN_REG") ? atoi(getenv("REFTR_ATTN_REG")) : 1;
@@ -759,11 +1073,25 @@ extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
         RT_CHECK_LAUNCH();
         return RT_OK;
     }
+    int rc;
+    {
+        const int ch1 = long_chunk(d->Sk, d->dh), ch2 = long_chunk(d->Sq, d->dh);
+        if (ch1 || ch2) {          // either inner axis too long for one LDS pass: both halves walk their axis in chunks
+            const int ch = ch1 > ch2 ? ch1 : ch2;
+            const size_t lsmem = smem_bytes(ch, d->dh);
+            const int ny_dq = (d->Sq + 127) / 128, ny_kv = (d->Sk + 127) / 128;
+#define RT_ATTN_BWD_LONG(DHV) do { if ((rc = set_smem(attn_bwd_long_kernel<DHV, 8>, lsmem)) != RT_OK) return rc; \
+            hipLaunchKernelGGL((attn_bwd_long_kernel<DHV, 8>), dim3(d->B * d->H, ny_dq + ny_kv), dim3(512), lsmem, s, *d, ny_dq, ch); } while (0)
+            if (d->dh == 32) RT_ATTN_BWD_LONG(32); else RT_ATTN_BWD_LONG(64);
+#undef RT_ATTN_BWD_LONG
+            RT_CHECK_LAUNCH();
+            return RT_OK;
+        }
+    }
     const size_t smem1 = smem_bytes(d->Sk, d->dh), smem2 = smem_bytes(d->Sq, d->dh);
     static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
     const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
     const dim3 g1(d->B * d->H, (d->Sq + 16 * nw - 1) / (16 * nw)), g2(d->B * d->H, (d->Sk + 16 * nw - 1) / (16 * nw));
-    int rc;
     static const int fused_env = getenv("REFTR_ATTN_BWD_FUSED") ? atoi(getenv("REFTR_ATTN_BWD_FUSED")) : 1;
     if (fused_env && nw == 8) {
         const size_t smem = smem1 > smem2 ? smem1 : smem2;

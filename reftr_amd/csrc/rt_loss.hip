@@ -99,10 +99,14 @@ extern "C" int rt_box_loss(const rt_box_loss_desc* d, rt_stream_t stream) {
     if (!d || !d->logits || !d->valid || !d->targets || !d->tgt_off || !d->num_boxes || !d->losses || !d->total)
         return RT_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = rt_zero_f32(d->losses, 2 * (size_t)d->NL, s);
+    // both outputs are accumulated with atomics; a caller that hands them over as ONE buffer ([NL][2] losses | total) pays one clear
+    const bool joined = d->total == d->losses + 2 * (size_t)d->NL;
+    hipError_t e = rt_zero_f32(d->losses, 2 * (size_t)d->NL + (joined ? 1 : 0), s);
     if (e != hipSuccess) return (int)e;
-    e = rt_zero_f32(d->total, 1, s);
-    if (e != hipSuccess) return (int)e;
+    if (!joined) {
+        e = rt_zero_f32(d->total, 1, s);
+        if (e != hipSuccess) return (int)e;
+    }
     const int total = d->NL * d->B * d->P * d->K;
     hipLaunchKernelGGL(box_loss_kernel, dim3((total + 255) / 256), dim3(256), 0, s, *d);
     RT_CHECK_LAUNCH();

@@ -478,7 +478,37 @@ class CapturedTrainStep:
             k.append(tuple((n, tuple(v.shape)) for n, v in sorted(t.items()) if torch.is_tensor(v)))
         return tuple(k)
 
+    def _direct_loss_ok(self):
+        """The direct loss path applies when the total is the weighted sum of the box losses of THIS process's model: no wrapper
+        (the data-parallel schedules drive backward themselves), no mask / CEM terms, the fused total, aux weights as usual."""
+        inner, crit = self.inner, self.criterion
+        return (os.environ.get("REFTR_LOSS_DIRECT", "1") == "1" and self.model is inner and getattr(inner, "seg", 1) is None
+                and hasattr(crit, "loss_and_grad") and tuple(crit.losses) == ("boxes",) and not inner.dp_mode
+                and os.environ.get("REFTR_FUSED_TOTAL", "1") != "0")
+
+    def _fwd_bwd_direct(self, zero):
+        inner, crit = self.inner, self.criterion
+        dev = inner.store.device
+        side = inner.net.side
+        main = torch.cuda.current_stream()
+        prepared = side.run(lambda: crit.prepare(self.t, dev))            # reads the targets only: beside the step head, not behind the forward
+        logits = inner(self.s, _logits_only=True)                          # joins the side stream at its forward join
+        if side.enabled:
+            for t in prepared:
+                t.record_stream(main)
+        loss_dict, box, dl = crit.loss_and_grad(logits, inner._saved["phrase_mask"], prepared, inner.aux_loss)
+        # the weighted total is only logged (engine_vg.py:43,46-53): the same two torch kernels as in the autograd path.  On the main
+        # stream: forked to the side stream here (measured) the replayed graph's whole backward slows down by 0.25 ms
+        losses = crit.weighted_total(loss_dict)
+        if zero:
+            _zero_grad(self.optimizer)
+        inner._backward_impl(dl)                                           # ends with the side stream joined
+        self._last = (losses.detach(), {k: v.detach() for k, v in loss_dict.items()})
+        return self._last
+
     def _fwd_bwd(self, zero=True):
+        if self._direct_loss_ok():
+            return self._fwd_bwd_direct(zero)
         outputs = self.model(self.s)
         loss_dict = self.criterion(outputs, self.t)
         losses = _total(self.criterion, loss_dict)

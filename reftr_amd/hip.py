@@ -975,8 +975,8 @@ def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox=1.0, w_giou=1
     """logits fp32 [NL,B,P,K,4]; returns (losses [NL,2], total [1], dlogits | None).  `weights` (device fp32
     [NL,2]) overrides the scalar weights per layer."""
     NL, B, P, K, _ = logits.shape
-    losses = _new((NL, 2), torch.float32, logits)
-    total = _new((1,), torch.float32, logits)
+    buf = _new((NL * 2 + 1,), torch.float32, logits)        # [NL][2] losses | total: one clear inside rt_box_loss
+    losses, total = buf[:NL * 2].view(NL, 2), buf[NL * 2:]
     dl = _new(tuple(logits.shape), torch.float32, logits) if want_grad else None
     d = BoxLossDesc(_p(logits), _p(valid_u8), _p(targets), _p(tgt_off), _p(num_boxes), _p(losses), _p(total), _p(dl),
                     NL, B, P, K, w_bbox, w_giou, _p(weights))

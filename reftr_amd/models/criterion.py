@@ -77,6 +77,9 @@ class CriterionVGMultiPhrase(nn.Module):
         boxes, off = self._targets(targets, device)
         valid = outputs["phrase_mask"].to(torch.uint8).contiguous()
         losses = _BoxLossFunction.apply(logits, valid, boxes, off, num_boxes)     # [NL, 2]
+        return self._loss_dict(losses)
+
+    def _loss_dict(self, losses):
         self._last_box = losses
         nl = losses.shape[0]
         out = {"loss_bbox": losses[nl - 1, 0], "loss_giou": losses[nl - 1, 1]}
@@ -85,23 +88,52 @@ class CriterionVGMultiPhrase(nn.Module):
             out[f"loss_giou_{i}"] = losses[i, 1]
         return out
 
+    def prepare(self, targets, device):
+        """The part of `forward` that only reads the targets: (boxes [sum n_i, 4] fp32, offsets, num_boxes).  The captured
+        training step issues it at the head of the step on the side stream, off the chain the model's forward runs on."""
+        num_boxes = self.num_boxes(targets, device)
+        boxes, off = self._targets(targets, device)
+        return boxes, off, num_boxes
 
-def _weighted_total(crit, loss_dict):
-    """engine_vg.py:43 (`sum(loss_dict[k] * weight_dict[k] ...)`) as ONE weighted reduction over the loss tensors the
-    kernels produced, instead of ~4 tiny autograd kernels per loss key (12 keys with aux losses)."""
-    box = crit._last_box                                  # [NL, 2] = (loss_bbox, loss_giou) per decoder layer
-    nl = box.shape[0]
-    key = (nl, box.device)
+    def loss_and_grad(self, logits, phrase_mask, prepared, aux):
+        """Losses AND d total / d logits in one rt_box_loss launch, for a total that is the weighted sum of the box losses only
+        (`weighted_total` without mask / CEM terms): the gradient of that sum with respect to losses[i, j] IS weight[i, j], so the
+        launch is handed the weights the autograd path would have delivered (`_BoxLossFunction.backward`) -- same kernel, same
+        arguments, same bits -- without the forward-only launch and the five autograd kernels between the two.
+        Returns (loss_dict, losses [NL, 2], dlogits [as logits])."""
+        full = logits
+        if not aux:
+            logits = logits[-1:]
+        logits = logits.contiguous()
+        boxes, off, num_boxes = prepared
+        valid = phrase_mask.to(torch.uint8).contiguous()
+        w = _box_weights(self, logits.shape[0], logits.device)
+        losses, _, dl = H.box_loss(logits, valid, boxes, off, num_boxes, want_grad=True, weights=w)
+        if not aux and full.shape[0] > 1:          # only the last layer carries a loss: the other layers' gradient is zero
+            dl = torch.cat([torch.zeros_like(full[:-1]), dl], dim=0)
+        return self._loss_dict(losses), losses, dl
+
+
+def _box_weights(crit, nl, device):
+    """weight_dict's entries for the box losses as a device tensor [NL, 2] (cached per (NL, device))."""
+    key = (nl, device)
     if getattr(crit, "_wkey", None) != key:
         wd = crit.weight_dict
         w = torch.zeros(nl, 2)
         for i in range(nl):
             sfx = "" if i == nl - 1 else f"_{i}"
             w[i, 0] = wd.get("loss_bbox" + sfx, 0.0); w[i, 1] = wd.get("loss_giou" + sfx, 0.0)
-        crit._wbox = w.to(box.device)
-        crit._wmask = torch.tensor([wd.get("loss_mask", 0.0), wd.get("loss_dice", 0.0)], device=box.device)
+        crit._wbox = w.to(device)
+        crit._wmask = torch.tensor([wd.get("loss_mask", 0.0), wd.get("loss_dice", 0.0)], device=device)
         crit._wkey = key
-    total = (box * crit._wbox).sum()
+    return crit._wbox
+
+
+def _weighted_total(crit, loss_dict):
+    """engine_vg.py:43 (`sum(loss_dict[k] * weight_dict[k] ...)`) as ONE weighted reduction over the loss tensors the
+    kernels produced, instead of ~4 tiny autograd kernels per loss key (12 keys with aux losses)."""
+    box = crit._last_box                                  # [NL, 2] = (loss_bbox, loss_giou) per decoder layer
+    total = (box * _box_weights(crit, box.shape[0], box.device)).sum()
     if getattr(crit, "_last_mask", None) is not None and "loss_mask" in loss_dict:
         total = total + (crit._last_mask * crit._wmask).sum()
     if "loss_cem" in loss_dict and "loss_cem" in crit.weight_dict:

@@ -306,7 +306,10 @@ class RefTR(nn.Module):
         print("Missing keys: ", missing)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, samples):
+    def forward(self, samples, _logits_only=False):
+        """`_logits_only` (the captured training step's direct loss path, engine_vg.CapturedTrainStep._fwd_bwd): returns the
+        pre-sigmoid box logits [NL, B, P, K, 4] without an autograd node and without the sigmoid of `pred_boxes`, which nothing in
+        a training iteration reads (engine_vg.py:40-60 only consumes the criterion's losses); the caller owns the backward."""
         self._bb_ready = None
         self._late_hook = None
         H.mark("step start")
@@ -357,6 +360,10 @@ class RefTR(nn.Module):
         if self._late_hook is None:
             H.mark("AdamW (main slice) + operands done")
         pred_masks = None
+        if _logits_only:
+            assert self.seg is None
+            with torch.no_grad():
+                return self._forward_impl(samples)
         if self.seg is not None:
             assert "phrase" not in samples, "RefTRSeg is single-phrase (reftr_segmentation.py:101-103)"
             res = _RefTRSegFunction.apply(self._anchor, self, samples)

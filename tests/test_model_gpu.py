@@ -214,6 +214,40 @@ def test_captured_step_matches_eager(hip, two_phase):
     assert rel(p_g, p_e) < 2e-4             # after the trajectories may have separated (see above); step 1 is the tight check
 
 
+@pytest.mark.parametrize("aux", [True, False])
+def test_direct_loss_path_equals_the_autograd_path(hip, monkeypatch, aux):
+    """CapturedTrainStep's direct loss path (losses and d total / d logits from ONE rt_box_loss launch, targets prepared beside
+    the step head, no sigmoid, no autograd node) against the criterion + autograd path it replaces: the loss values are the
+    same kernel on the same logits -- bit-identical -- and the gradients differ by the order of the backward's atomics only."""
+    from reftr_amd.engine_vg import CapturedTrainStep
+    from reftr_amd.optim import FusedAdamW
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    out = {}
+    for direct in ("0", "1"):
+        monkeypatch.setenv("REFTR_LOSS_DIRECT", direct)
+        model, crit, P, ocfg = build(small=True)
+        model.eval()
+        if not aux:
+            model.aux_loss = False
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        p0, m0, v0 = model.store.flat_p.clone(), opt.m.clone(), opt.v.clone()
+        cap = CapturedTrainStep(model, crit, opt, 0.1, s, tg, warmup=1)
+        assert cap._direct_loss_ok() == (direct == "1")
+        cap.reset_pending()
+        model.store.flat_p.copy_(p0); opt.m.copy_(m0); opt.v.copy_(v0); opt.step_dev.zero_(); opt.step_count = 0
+        model.mark_dirty(full=True)
+        l, ld, gn = cap(s, tg)
+        torch.cuda.synchronize()
+        out[direct] = (float(l), {k: float(v) for k, v in ld.items()}, float(gn), model.store.flat_g.clone())
+    a, b = out["0"], out["1"]
+    assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+    assert sorted(a[1]) == (sorted(["loss_bbox", "loss_giou"] + [f"loss_{n}_{i}" for n in ("bbox", "giou") for i in range(ocfg.dec_layers - 1)])
+                            if aux else ["loss_bbox", "loss_giou"])
+    assert abs(a[2] - b[2]) < 1e-5 * a[2]
+    assert rel(b[3], a[3]) < 1e-6
+
+
 @pytest.mark.parametrize("two_phase", [False, True])
 def test_captured_deferred_update_follows_the_lr_schedule(hip, two_phase):
     """Deferred schedule: the update of iteration i is applied at the head of replay i+1 but must use the learning rates
@@ -494,6 +528,62 @@ def test_dilation_vs_reference_golden(hip):
         cos = lambda u, v: float((u * v).sum() / (u.norm() * v.norm()))
         assert 1 - cos(a, b) < max(4.0 * (1 - cos(c, b)), 1e-3), (name, cos(a, b), cos(c, b))     # (1 - cos ~ rel^2 / 2: twice the floor's rel)
         assert abs(float(mine.norm()) / float(g["gnorm." + name]) - 1) < max(2.0 * abs(float(q_.norm()) / float(g["gnorm." + name]) - 1), 2e-2), name
+
+
+def test_dilation_beyond_one_lds_pass_vs_oracle(hip):
+    """--dilation on an image large enough that a head's K / V no longer fit the CU's LDS at once (480 x 480: c5 30 x 30 at stride 16,
+    S = 900 + L = 912 tokens > ~830): the attention launches of the encoder and the decoder take the chunked kernels.  Forward
+    and selected gradients against the q-oracle (the HIP path's rounding points; pinned to the reference by
+    tests/golden/e2e_dilation.npz at the small size)."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), dilation=True)
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), dilation=True)
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda")
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    samples, targets = make_inputs("e2e_dilation_long", B=2, H=480, W=480, L=12)          # image 1 carries right / bottom padding
+    s, tg = to_cuda(samples, targets)
+    out = model(s)
+    keys = ["vl_transformer.encoder.layers.0.self_attn.in_proj_weight", "vl_transformer.encoder.layers.1.linear1.weight",
+            "vl_transformer.decoder.layers.0.multihead_attn.in_proj_weight", "input_proj.0.0.weight",
+            "img_backbone.0.body.layer4.2.conv2.weight", "txt_backbone.encoder.layer.1.output.dense.weight"]
+    keys = [k for k in keys if k in P]
+    assert len(keys) >= 4, [k for k in P if "in_proj" in k][:4]
+    Pq = {k: v.clone() for k, v in P.items()}
+    leaves = [Pq[k].requires_grad_(True) for k in keys]
+    oq = O.reftr_forward(Pq, samples, ocfg, q=True)
+    assert rel(out["pred_logits"].sigmoid().reshape(-1), oq["logits"].sigmoid().reshape(-1)) < 5e-3
+    assert rel(out["pred_boxes"], oq["pred_boxes"]) < 5e-3
+    lq = O.total_loss(O.criterion(oq, targets), O.weight_dict(ocfg))
+    gq = torch.autograd.grad(lq, leaves)
+    ld = crit(out, tg)
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    assert abs(float(total) - float(lq)) < 5e-3 * abs(float(lq))
+    model.store.flat_g.zero_()
+    total.backward()
+    # the yardstick: the same q-oracle with every contraction accumulated in fp64 -- identical operands and rounding points, another
+    # summation order (tests/test_parity_fullsize_gpu.py); the HIP gradients must sit within 1.5 x of what that alone moves
+    P2 = {k: v.clone() for k, v in P.items()}
+    leaves2 = [P2[k].requires_grad_(True) for k in keys]
+    with O.accumulate_fp64():
+        o2 = O.reftr_forward(P2, samples, ocfg, q=True)
+        g2 = torch.autograd.grad(O.total_loss(O.criterion(o2, targets), O.weight_dict(ocfg)), leaves2)
+    report = []
+    for name, q_, f_ in zip(keys, gq, g2):
+        mine = model.store.G[name].float().cpu().reshape(q_.shape)
+        cos = lambda u, v: float((u.reshape(-1) * v.reshape(-1)).sum() / (u.norm() * v.norm()))       # noqa: E731
+        got, floor = rel(mine, q_), rel(f_.float(), q_)
+        report.append((name, got, floor, cos(mine, q_), cos(f_.float(), q_)))
+    print("\n[--dilation 480x480, S = 912] gradient rel-L2 vs q-oracle (HIP | order floor), cosine (HIP | floor):")
+    for r in report:
+        print("   %-62s %.3e | %.3e   %.5f | %.5f" % r)
+    for name, got, floor, c_m, c_f in report:
+        assert got < max(1.5 * floor, 3e-2), (name, got, floor)
+        assert 1 - c_m < max(2.25 * (1 - c_f), 1e-3), (name, c_m, c_f)
 
 
 def test_clip_norm_with_the_bert_share_taken_on_the_language_stream(hip):

@@ -1,6 +1,7 @@
 """GPU parity of the non-GEMM kernels against plain torch fp32 references of the same op (floating point)
 or exact integer/bool expectations (masks, selection)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -97,7 +98,10 @@ def ref_attn(q, k, v, kpm, B, H, Sq, Sk, dh, scale):
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,dh", [(2, 8, 440, 440, 32), (3, 12, 40, 40, 64), (2, 8, 1, 440, 32),
-                                           (2, 8, 5, 5, 32), (1, 8, 130, 715, 32)])
+                                           (2, 8, 5, 5, 32), (1, 8, 130, 715, 32),
+                                           # inner axes that do not fit the CU's LDS at once: walked in chunks (--dilation at 640 x 640: S = 1640)
+                                           (2, 8, 1640, 1640, 32), (1, 8, 1, 1640, 32), (1, 8, 70, 1000, 32), (1, 12, 600, 600, 64),
+                                           (1, 8, 900, 33, 32)])
 def test_attention_fwd_bwd(hip, B, H, Sq, Sk, dh):
     g = torch.Generator().manual_seed(Sq + Sk)
     E = H * dh
@@ -120,6 +124,42 @@ def test_attention_fwd_bwd(hip, B, H, Sq, Sk, dh):
                             scale=scale, dk=dkv[:, :E], dv=dkv[:, E:])
     assert rel(dq, q.grad) < 1e-2
     assert rel(dkv, kv.grad) < 1e-2
+
+
+_CHUNK_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from reftr_amd import hip
+B, H, Sq, Sk, dh = 2, 8, 200, 600, 32
+E = H * dh
+g = torch.Generator().manual_seed(3)
+q = torch.randn(B * Sq, E, generator=g).bfloat16().cuda(); k = torch.randn(B * Sk, E, generator=g).bfloat16().cuda()
+v = torch.randn(B * Sk, E, generator=g).bfloat16().cuda(); do = torch.randn(B * Sq, E, generator=g).bfloat16().cuda()
+kpm = torch.zeros(B, Sk, dtype=torch.uint8); kpm[1, 500:] = 1; kpm[0, ::5] = 1
+hip.set_seed_dev(None)
+o, lse = hip.attn_fwd(q, k, v, kpm.cuda(), B=B, H=H, Sq=Sq, Sk=Sk, dh=dh, scale=dh ** -0.5, drop_p=0.1, drop_seed=77)
+dq, dk, dv = hip.attn_bwd(q, k, v, o, do, lse, kpm.cuda(), B=B, H=H, Sq=Sq, Sk=Sk, dh=dh, scale=dh ** -0.5, drop_p=0.1, drop_seed=77)
+torch.cuda.synchronize()
+torch.save({"o": o.cpu(), "lse": lse.cpu(), "dq": dq.cpu(), "dk": dk.cpu(), "dv": dv.cpu()}, sys.argv[2])
+"""
+
+
+def test_attention_long_axis_kernels_are_bit_identical_to_the_whole_axis_kernels(hip, tmp_path):
+    """REFTR_ATTN_CHUNK forces the chunked kernels (inner axis staged 64 rows at a time) on a shape the whole-axis kernels handle
+    (Sk = 600: the two-pass forward, the fused backward): same lane <-> element assignment, same key order per lane, dropout and
+    key-padding mask included -> identical bits.  One process per setting (the library reads the variable once)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for chunk in ("0", "64", "224"):
+        f = tmp_path / f"attn_{chunk}.pt"
+        env = dict(os.environ); env["REFTR_ATTN_CHUNK"] = chunk
+        subprocess.run([sys.executable, "-c", _CHUNK_SCRIPT, root, str(f)], check=True, env=env, timeout=600)
+        outs.append(torch.load(f))
+    for other in outs[1:]:
+        for key in ("o", "lse", "dq", "dk", "dv"):
+            a, b = outs[0][key], other[key]
+            assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), key
 
 
 def test_attention_dropout_mask(hip):

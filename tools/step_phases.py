@@ -15,7 +15,7 @@ cands = [(rows[ad[i + 1]][2] - rows[ad[i] + 1][1], ad[i] + 1, ad[i + 1] + 1) for
 _, a, b = min(cands)
 step = rows[a:b]
 t0 = step[0][1]
-marks = [("AdamW of the previous step (deferred) + weight prep + pack", "adamw_"), ("pack", "img_pack"), ("stem", "stem_conv"), ("ResNet fwd (+BERT if 1 stream)", "maxpool"), ("input_proj+GN", "gn_stats_kernel"),
+marks = [("AdamW of the previous step (deferred) + weight prep + pack", "adamw_"), ("pack", "img_pack"), ("stem", "stem_"), ("language branch inline (REFTR_STEM_FIRST: forked behind the stem): AdamW (BERT slice) + BERT fwd", "adamw_"), ("ResNet fwd (+BERT if 1 stream)", ("maxpool", "bottleneck_fwd")), ("input_proj+GN", "gn_stats_kernel"),
          ("encoder fwd", "gn_apply"), ("query encoder + decoder fwd + head", "qenc_attn_fwd"), ("loss", "box_loss"),
          ("head + decoder bwd", "box_loss"), ("qenc bwd + encoder bwd", "qenc_attn_bwd"), ("GN/input_proj bwd", "gn_bwd_stats"),
          ("ResNet bwd (+BERT bwd)", "gn_bwd_apply"), ("gradient norm", "sqnorm")]
@@ -23,7 +23,7 @@ idx, pos = [], 0
 for label, key in marks:
     rng = range(pos, len(step)) if key != "sqnorm" else range(len(step) - 1, pos - 1, -1)      # the step-ending norm launch
     for i in rng:
-        if (is_norm(step[i][0]) if key == "sqnorm" else key in step[i][0]):
+        if (is_norm(step[i][0]) if key == "sqnorm" else any(k in step[i][0] for k in ((key,) if isinstance(key, str) else key))):
             idx.append((label, i)); pos = i + 1; break
 print("step: %d kernels, %.2f ms (kernel-busy %.2f ms)" % (len(step), (step[-1][2] - t0) / 1e6, sum(r[2] - r[1] for r in step) / 1e6))
 for n, (label, i) in enumerate(idx):
@@ -45,3 +45,11 @@ if len(sys.argv) > 2:               # dump the kernel sequence of the phases who
             nm, st, en = step[k]
             gap = (st - step[k - 1][2]) / 1e3 if k > 0 else 0.0
             print("  %9.1f us  %6.1f us  gap %5.1f  %s" % ((st - t0) / 1e3, (en - st) / 1e3, gap, nm.replace("(anonymous namespace)::", "").replace("void ", "")[:100]))
+if len(sys.argv) > 2 and sys.argv[2] == "hist":     # per-kernel-name totals of the one step
+    agg = {}
+    for nm, st, en in step:
+        k = nm.replace("(anonymous namespace)::", "").replace("void ", "")[:120]
+        c, t = agg.get(k, (0, 0.0)); agg[k] = (c + 1, t + (en - st) / 1e3)
+    print("-- kernels of the step by total time: launches, total us, name")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("  %4d  %8.1f us  %s" % (c, t, k))
