@@ -109,6 +109,7 @@ class RefTR(nn.Module):
         self._opt_pipe = os.environ.get("REFTR_OPT_PIPE", "0") != "0"
         self.opt_side = H.SideStream(self._opt_pipe)
         self._stem_first = int(os.environ.get("REFTR_STEM_FIRST", "1"))
+        self._lang_tail = os.environ.get("REFTR_LANG_TAIL", "1") == "1"
         self._bert_gates = None
         self._adam_done = None
         self._bb_ready = None
@@ -415,6 +416,13 @@ class RefTR(nn.Module):
         M = B * S
         vt = "vl_transformer."
 
+        # the sequence buffers [B * S, E] (fp32 residual stream, its bf16 image, bf16 of x + pos): allocated in front of the fork so that
+        # the language branch can write its rows of them (map_sentence) while the ResNet still runs
+        x32 = torch.empty(M, E, dtype=torch.float32, device=dev)
+        x16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
+        xp16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
+        lang_tail = {}
+
         def _lang_branch():
             H.mark("lang: branch starts")
             if self._bert_gates is not None:
@@ -436,7 +444,20 @@ class RefTR(nn.Module):
             H.mark("lang: BERT forward done")
             if self._late_hook is not None:
                 return r                       # the positional work reads main-slice parameters: it is forked behind their update
-            return r + _pos_work()
+            res = r + _pos_work()
+            if self._lang_tail:
+                # what only BERT's outputs feed -- map_sentence into the language rows of the sequence, and with one phrase per image
+                # the context mask and map_phrase -- stays on this stream instead of opening the main stream's chain behind the
+                # forward join (5-6 launches; this branch has ~90 us of slack there).  Same order of the dropout sites as before.
+                sq16, pl16, _, pos_, _ = res
+                _, lang_tail["ms_ctx"] = net.mlp_fwd(sq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos_, rowmap=(Lq, S, 0))
+                if "phrase" not in samples:
+                    lang_tail["masks"] = H.context_mask(smask_u8)
+                    cat16_ = torch.empty(B, 2 * E, dtype=torch.bfloat16, device=dev)
+                    _, lang_tail["mp_ctx"] = net.mlp_fwd(pl16, "map_phrase.", y_bf16=cat16_.view(2 * B, E), want_f32=False, rowmap=(1, 2, 1))
+                    lang_tail["cat16"] = cat16_
+                H.mark("lang: map_sentence / map_phrase done")
+            return res
 
         def _pos_work():
             pos = torch.empty(M, E, dtype=torch.float32, device=dev)
@@ -489,9 +510,6 @@ class RefTR(nn.Module):
         seq16, pooled16, bctx, pos, kpm = lang_out + late_out[0] if late is not None else lang_out
         c5, (_, h5, w5) = feats[-1]
         assert (h5, w5) == (h, w)
-        x32 = torch.empty(M, E, dtype=torch.float32, device=dev)
-        x16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
-        xp16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
         H.mark("ResNet forward done")
         if self._bert_gates is not None:
             if self._bb_ready is not None:     # nothing trainable in the ResNet waited for the main piece (--lr_backbone 0)
@@ -506,7 +524,10 @@ class RefTR(nn.Module):
         elif self._zero_grad_side:
             # 607 MB of zeros: off the critical path, under the (latency-bound) encoder / decoder forward; backward joins
             net.side.run(st.flat_g.zero_)
-        _, ms_ctx = net.mlp_fwd(seq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos, rowmap=(Lq, S, 0))
+        if "ms_ctx" in lang_tail:
+            ms_ctx = lang_tail["ms_ctx"]
+        else:
+            _, ms_ctx = net.mlp_fwd(seq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos, rowmap=(Lq, S, 0))
         _, ip = net.lin_fwd("input_proj.0.0.", c5, out_bf16=False, out_f32=True)
         gn_stats = H.groupnorm_fwd(ip.view(B, HW, E), st.P["input_proj.0.1.weight"], st.P["input_proj.0.1.bias"], 32, 1e-5,
                                    y_f32=x32, y_bf16=x16, pos=pos, ypos_bf16=xp16, rows_per_img=S, row_off=Lq)
@@ -522,11 +543,15 @@ class RefTR(nn.Module):
         else:
             Pn = 1
             ph_pooled16 = pooled16
-            ctxmask, qmask = H.context_mask(smask_u8)
+            ctxmask, qmask = lang_tail["masks"] if "masks" in lang_tail else H.context_mask(smask_u8)
         N = B * Pn
-        cat16 = torch.empty(N, 2 * E, dtype=torch.bfloat16, device=dev)
-        cat_rows = cat16.view(2 * N, E)
-        _, mp_ctx = net.mlp_fwd(ph_pooled16, "map_phrase.", y_bf16=cat_rows, want_f32=False, rowmap=(1, 2, 1))
+        if "mp_ctx" in lang_tail:
+            cat16, mp_ctx = lang_tail["cat16"], lang_tail["mp_ctx"]
+            cat_rows = cat16.view(2 * N, E)
+        else:
+            cat16 = torch.empty(N, 2 * E, dtype=torch.bfloat16, device=dev)
+            cat_rows = cat16.view(2 * N, E)
+            _, mp_ctx = net.mlp_fwd(ph_pooled16, "map_phrase.", y_bf16=cat_rows, want_f32=False, rowmap=(1, 2, 1))
 
         src32 = x32                        # sequence buffer whose image rows hold input_proj + GroupNorm (img_src_proj)
         enc = []

@@ -113,7 +113,7 @@ def main():
             say("%10.1f us  %s  ->  %s" % (med[b] - med[a], a, b))
     # critical path: at each join the later arrival is the one that gates
     say()
-    fj, rf, lf = med.get("forward join (language branch in)"), med.get("ResNet forward done"), med.get("lang: positional / mask work done")
+    fj, rf, lf = med.get("forward join (language branch in)"), med.get("ResNet forward done"), med.get("lang: map_sentence / map_phrase done", med.get("lang: positional / mask work done"))
     if fj is not None and rf is not None and lf is not None:
         say(f"forward join at {fj:.1f} us: main stream arrives at {rf:.1f}, language stream at {lf:.1f} -> gated by the "
             f"{'language' if lf > rf else 'main'} stream (slack of the other: {abs(lf - rf):.1f} us)")
