@@ -109,7 +109,8 @@ class RefTR(nn.Module):
         self._opt_pipe = os.environ.get("REFTR_OPT_PIPE", "0") != "0"
         self.opt_side = H.SideStream(self._opt_pipe)
         self._stem_first = int(os.environ.get("REFTR_STEM_FIRST", "1"))
-        self._lang_tail = os.environ.get("REFTR_LANG_TAIL", "1") == "1"
+        self._lang_tail = os.environ.get("REFTR_LANG_TAIL", "1") != "0"
+        self._lang_tail_bwd_phrase = os.environ.get("REFTR_LANG_TAIL", "1") != "2"      # 2: map_phrase's backward stays on the main stream
         self._bert_gates = None
         self._adam_done = None
         self._bb_ready = None
@@ -808,11 +809,14 @@ class RefTR(nn.Module):
         _, dlang = net.lin_bwd(qe + "linear3.", dvs16, sv["lang16"], res_f32=dla, out_bf16=False, out_f32=True)
         H.rows_add(B * Lq, E, a_f32=dlang, out_f32=dmem, accumulate=True, o_map=(Lq, S, 0))
         # map_phrase: gradient rows 2r+1 of dcat; its input is BERT's pooled output (tanh) -> fold tanh'
-        if sv["pctx"] is None:
-            dpool = net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False, dtanh=sv["pooled16"])
-        else:
-            dpool = net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False,
-                                dtanh=sv["pctx"]["pooled"])
+        def _map_phrase_bwd():
+            return net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False,
+                               dtanh=sv["pooled16"] if sv["pctx"] is None else sv["pctx"]["pooled"])
+        # Single process with the language stream on: the backward of map_phrase and of map_sentence only feed BERT's backward, so
+        # they open THAT branch (language stream) instead of sitting in the main stream's chain (REFTR_LANG_TAIL, as in forward)
+        lang_head = self._lang_tail and net.side.enabled and not self.dp_mode
+        phrase_on_lang = lang_head and self._lang_tail_bwd_phrase
+        dpool = None if phrase_on_lang else _map_phrase_bwd()
 
         net.flush_wgrads_side(1)         # decoder / query-encoder / map_phrase / head weight gradients: grouped launches
 
@@ -836,7 +840,9 @@ class RefTR(nn.Module):
 
         H.mark("encoder backward done")
         # ---- sequence inputs: map_sentence (language rows) and input_proj + GroupNorm (image rows)
-        d_seq = net.mlp_bwd(sv["ms_ctx"], dxa, "map_sentence.", dy_rowmap=(Lq, S, 0), dy2=dxb)
+        def _map_sentence_bwd():
+            return net.mlp_bwd(sv["ms_ctx"], dxa, "map_sentence.", dy_rowmap=(Lq, S, 0), dy2=dxb)
+        d_seq = None if lang_head else _map_sentence_bwd()
         if seg_dsrc is not None:
             H.rows_add(B * HW, E, a_f32=seg_dsrc, out_f32=dxa, accumulate=True, o_map=(HW, S, Lq))
         _, dip16 = H.groupnorm_bwd(dxa, sv["ip"].view(B, HW, E), st.P["input_proj.0.1.weight"], sv["gn_stats"],
@@ -912,11 +918,13 @@ class RefTR(nn.Module):
         else:
             def _bert_bwd():
                 H.mark("lang: BERT backward starts")
+                d_seq_ = _map_sentence_bwd() if lang_head else d_seq          # (their weight gradients: queued, launched with BERT's)
+                dpool_ = _map_phrase_bwd() if phrase_on_lang else dpool
                 if sv["pctx"] is None:
-                    net.bert_bwd(sv["bctx"], d_seq, dpool)
+                    net.bert_bwd(sv["bctx"], d_seq_, dpool_)
                 else:
-                    net.bert_bwd(sv["bctx"], d_seq, None)
-                    net.bert_bwd(sv["pctx"], None, dpool)
+                    net.bert_bwd(sv["bctx"], d_seq_, None)
+                    net.bert_bwd(sv["pctx"], None, dpool_)
                 net.wg.flush()           # BERT weight gradients: queued, launched behind the BERT data chain
                 H.mark("lang: BERT backward (data + weight gradients) launched")
                 if self._norm_side and not net.wg.enabled:      # (REFTR_STREAMS=3: the weight gradients run on their own stream -- not ordered in front of this one)
@@ -929,7 +937,7 @@ class RefTR(nn.Module):
                     H.mark("lang: BERT slice's squared norm done")
             H.mark("input_proj backward done (ResNet backward starts)")
             net.flush_wgrads_side(4)     # encoder / map_sentence weight gradients: language stream, in front of the BERT branch
-            net.side.run(_bert_bwd, d_seq, dpool)
+            net.side.run(_bert_bwd, d_seq, dpool, dxa, dxb, dcat_rows)
         # ---- ResNet body (its gradients are the last to become final); data parallel: layer4's slice (64 % of the ResNet
         # bytes) is final -- and exchanged -- before layer3 / layer2 run
         for stage in (self.body.backward_stages(sv["bb_saved"], g_c5, seg_extra) if cfg.train_backbone else ()):
