@@ -180,6 +180,11 @@ class Net:
         the step (the ResNet backward no longer waits for it); the groups that would run BESIDE the latency-bound encoder
         chain slow that chain down by more than they save (+0.25 .. 0.3 ms) and stay on the main stream.
         The queued tensors stay referenced by the SideStream until the join at the end of backward."""
+        if bit == 1 and os.environ.get("REFTR_WG_MERGE_DEC", "1") == "1":
+            # the decoder / query-encoder / head jobs stay queued and ride with the encoder's first group (bit 2, or the end-of-encoder
+            # group when the encoder has one layer): six launches of ~90 us leave the chain between the query encoder's and the
+            # encoder's backward (-0.025 ms, profiles/r04bd_wgrad_merge_ab.txt)
+            return None
         if not self.side.enabled or not (int(os.environ.get("REFTR_WG_SIDE", "4")) & bit):
             return self.flush_wgrads() if bit != 2 else None
         keep = []
