@@ -295,3 +295,47 @@ def test_evaluate_rec_and_res_metrics(hip):
     sc = torch.tensor(results[10][0]); nb = box_ops.box_cxcywh_to_xyxy(out["pred_boxes"][0, 0]).cpu()[0]
     oh, ow = [float(v) for v in targets[0]["orig_size"]]
     assert torch.allclose(sc, nb * torch.tensor([ow, oh, ow, oh]), rtol=1e-4, atol=1e-3)
+
+
+def test_evaluate_visualize_end_to_end(hip, tmp_path):
+    """evaluate(..., visualize=True) (engine_vg.py:84-96,157-192) on the REC+RES model: one set of image dumps per evaluated sample
+    under output_dir/vis/<split>/{mask,gt,bbox,att}, the predicted mask at the ORIGINAL image size (PostProcessSegm's
+    'masks_origin'), metrics unchanged by the dumps."""
+    from PIL import Image
+    from reftr_amd.engine_vg import evaluate
+    from reftr_amd.models.post_process import PostProcessSegm, PostProcessVGMultiPhrase
+    from reftr_amd.util.misc import NestedTensor
+    g = np.load(os.path.join(GOLD, "seg_single.npz"))
+    model, crit, P, ocfg = build_seg()
+    samples, targets = seg_batch(g)
+    sizes = {}
+    for i, t in enumerate(targets):
+        h, w = t["masks"].shape[-2:]
+        t.update(size=torch.tensor([h, w]), orig_size=torch.tensor([2 * h + 1, 3 * w]), image_id=torch.tensor(10 + i),
+                 dataset_id=torch.tensor(i))
+        sizes[i] = (2 * h + 1, 3 * w)
+
+    class DS:
+        split = "val"
+        def pull_item(self, idx):
+            H_, W_ = sizes[idx]
+            m = np.zeros((H_, W_), dtype=np.uint8); m[H_ // 4: H_ // 2, W_ // 4: W_ // 2] = 1
+            return (np.full((H_, W_, 3), 90, dtype=np.uint8), m, "a phrase", np.array([W_ / 4, H_ / 4, W_ / 2, H_ / 2]),
+                    f"images/img_{idx:03d}.jpg")
+
+    class Loader(list):
+        dataset = DS()
+
+    s = {k: v for k, v in samples.items() if k not in ("img", "img_mask")}
+    s["img"] = NestedTensor(samples["img"], samples["img_mask"])
+    post = {"bbox": PostProcessVGMultiPhrase(), "segm": PostProcessSegm()}
+    plain, _ = evaluate(model, crit, post, Loader([(s, targets)]), torch.device("cuda"))
+    stats, _ = evaluate(model, crit, post, Loader([(s, targets)]), torch.device("cuda"), output_dir=tmp_path, visualize=True)
+    assert stats == plain
+    root = tmp_path / "vis" / "val"
+    for i in range(len(targets)):
+        tag = f"img_{i:03d}_{i:05d}"
+        for sub, name in (("mask", f"{tag}.jpg"), ("gt", f"{tag}.jpg"), ("bbox", f"{tag}.jpg"), ("att", f"{tag}_0.jpg"), ("att", f"{tag}_7.jpg")):
+            assert (root / sub / name).is_file(), (sub, name)
+        assert Image.open(root / "mask" / f"{tag}.jpg").size == (sizes[i][1], sizes[i][0])
+        assert Image.open(root / "att" / f"{tag}_1.jpg").size == (min(320, sizes[i][1] // 2), min(320, sizes[i][0] // 2))
