@@ -563,3 +563,39 @@ def test_evaluate_visualize_dumps(tmp_path):
         assert a.shape[:2] == (20, 30)
     with pytest.raises(ValueError):
         _vis_dirs(None, "val")
+
+
+def test_box_weights_and_direct_loss_gate(monkeypatch):
+    """Host side of the captured step's direct loss path: the weight tensor handed to rt_box_loss is weight_dict in the kernel's
+    [layer][bbox, giou] order (last layer = the un-suffixed keys, criterion.py / engine_vg.py:43), and the path is taken only for
+    box-loss-only totals of an unwrapped single-process model."""
+    from types import SimpleNamespace
+    from reftr_amd.engine_vg import CapturedTrainStep
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase, _box_weights
+    wd = {"loss_bbox": 5.0, "loss_giou": 2.0, "loss_bbox_0": 0.5, "loss_giou_0": 0.25, "loss_bbox_1": 3.0, "loss_giou_1": 4.0}
+    crit = CriterionVGMultiPhrase(wd, ["boxes"])
+    w = _box_weights(crit, 3, torch.device("cpu"))
+    assert w.tolist() == [[0.5, 0.25], [3.0, 4.0], [5.0, 2.0]]
+    assert _box_weights(crit, 1, torch.device("cpu")).tolist() == [[5.0, 2.0]]           # no aux outputs: the last layer only
+    losses = torch.tensor([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+    ld = crit._loss_dict(losses)
+    assert float(ld["loss_bbox"]) == 5.0 and float(ld["loss_giou_1"]) == 4.0 and float(ld["loss_bbox_0"]) == 1.0
+    total = crit.weighted_total(ld)
+    assert abs(float(total) - sum(float(ld[k]) * wd[k] for k in ld)) < 1e-5
+
+    def gate(**kw):
+        inner = SimpleNamespace(seg=kw.get("seg"), dp_mode=kw.get("dp", False))
+        cap = CapturedTrainStep.__new__(CapturedTrainStep)
+        cap.inner = inner
+        cap.model = inner if not kw.get("wrapped") else SimpleNamespace(module=inner)
+        cap.criterion = kw.get("crit", crit)
+        return cap._direct_loss_ok()
+    monkeypatch.delenv("REFTR_LOSS_DIRECT", raising=False)
+    monkeypatch.delenv("REFTR_FUSED_TOTAL", raising=False)
+    assert gate() is True
+    assert gate(wrapped=True) is False                       # a data-parallel wrapper drives backward itself
+    assert gate(dp=True) is False
+    assert gate(seg=object()) is False                       # REC+RES: the total has mask terms
+    assert gate(crit=CriterionVGMultiPhrase(wd, ["boxes", "masks"])) is False
+    monkeypatch.setenv("REFTR_LOSS_DIRECT", "0")
+    assert gate() is False
