@@ -762,7 +762,12 @@ static int sq_account(const rt_conv_wgrad_desc* descs, int n, bool after, hipStr
         const bool last = i == n;
         if (!last) {
             const rt_conv_wgrad_desc& d = descs[i];
-            if (!d.sqacc || (!after && d.overwrite)) continue;
+            if (!d.sqacc) continue;
+            // a dw that appears more than once in the group (shared weights, a second accumulate queued before the flush) is
+            // accounted ONCE, by its first occurrence: -|before|^2 unless that first launch overwrites, +|after|^2 behind them all
+            int first = i;
+            for (int j = 0; j < i; ++j) if (descs[j].sqacc && descs[j].dw == d.dw) { first = j; break; }
+            if (first != i || (!after && d.overwrite)) continue;
             if (slots && d.sqacc != slots) return RT_ERR_BADARG;     // one accumulator per call
             slots = d.sqacc;
             bufs[m] = d.dw; cnts[m] = (long long)d.N * d.KH * d.KW * d.SC; signs[m] = after ? 1.f : -1.f; ++m;

@@ -109,13 +109,15 @@ def _cooperative_failed(model):
     replayed loop carries the word in its per-iteration stats vector)."""
     inner = _inner(model)
     fw = inner.coop_failure_word() if hasattr(inner, "coop_failure_word") else None
-    if fw is None or getattr(inner.net, "dec_counters", None) is None:
+    if fw is None:                                     # no cooperative launches in this build / configuration: the same on every rank
         return False
+    launched = getattr(inner.net, "dec_counters", None) is not None      # rank-local (depends on this rank's batch shape)
     if utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1:
-        f = fw.to(torch.int32).clone()
+        # every rank enters the collective; a rank that has not launched the cooperative decoder yet contributes 0
+        f = fw.to(torch.int32).clone() if launched else torch.zeros_like(fw, dtype=torch.int32)
         torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MAX)
         return int(f) != 0
-    return int(fw) != 0
+    return launched and int(fw) != 0
 
 
 _COOP_LOGGED = False
@@ -791,6 +793,10 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
         # what the failed iteration advanced: host step count (the device counter was vetoed), dropout seed / step, learning rates
         _coop_fallback(model)
         optimizer.step_count -= 1
+        # The veto is a per-rank device word, the decision to run the iteration again is collective: a healthy rank's finish_step
+        # has advanced its device counter, the failing rank's was vetoed.  Every rank re-bases the device counter on the host count
+        # (the same on all ranks), otherwise the AdamW bias corrections of the replicas differ from here on.
+        optimizer.step_dev.fill_(optimizer.step_count)
         _restore_seed(model, seed_back)
         after = [g["lr"] for g in optimizer.param_groups]
         for g, lr in zip(optimizer.param_groups, lrs_now):

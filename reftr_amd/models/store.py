@@ -133,6 +133,13 @@ class ParamStore:
         else:
             self.disarm()                     # a backward that was abandoned half-way must not leave overwrite mode armed
             self.flat_g.zero_()
+            g16 = getattr(self, "flat_g16", None)
+            if g16 is not None:
+                # full-clear mode under the bf16 exchange: a matrix that no producer writes in this step has no producer for its
+                # twin either (the rounding pass of a slice skips registered matrices), and finish_overwrite(_range) only repairs
+                # twins while armed -- so the twins are cleared with the masters (the previous step's all-reduced values would
+                # otherwise be exchanged and applied again)
+                g16.zero_()
         self.begin_norm()                     # the producers' epilogues collect the clip norm from here on (rt_sqnorm_finish)
 
     def begin_norm(self):

@@ -189,6 +189,10 @@ class FusedAdamW(torch.optim.Optimizer):
                      max_norm=self._max_norm, beta1=b1, beta2=b2, eps=self.defaults["eps"], step_dev=self.step_dev,
                      active=self.active, lr_dev=self.lr_dev, span=span, sgd=self.SGD, **kw)
         self._last_emitted = tabs is not None
+        if tabs is None and self._sparse_flags and not torch.cuda.is_current_stream_capturing():
+            # the flat pass wrote m / v of the embedding tables through raw pointers: their "m and v are zero here" bytes are void
+            for f in self._sparse_flags.values():
+                f.fill_(1)
         return self._last_emitted
 
     @torch.no_grad()
@@ -197,7 +201,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._flush_pending()
         st = self.model.store
         self.step_count += 1
-        H.counter_add(self.step_dev, 1)
+        H.counter_add(self.step_dev, 1, unless=self.veto)      # a vetoed iteration does not advance the device counter either
         if not self._have_sq:
             H.sqnorm(self._grad_buffer(), self.sq)
         act, self.active = self.active, None          # an immediate step is never conditional ...

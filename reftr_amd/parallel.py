@@ -167,6 +167,11 @@ class DistributedDataParallel(nn.Module):
     def _launch(self, bounds):
         st = self.module.store
         g = st.flat_g
+        # an exchange touches the gradient buffer between backward and the clip: what the weight-gradient epilogues collected in
+        # the norm slots (and what the backward pre-reduced of the BERT slice) describes THIS rank's gradients, not the sums the
+        # buffer holds afterwards -- every schedule (overlap or not, bf16 or fp32) falls back to the pass over the exchanged buffer
+        st.norm_valid = False
+        self.module._norm_split = None
         if self.bf16:
             g16 = st.flat_g16
             if self.twin:
