@@ -68,8 +68,10 @@ def synth_batch(B, H, W, L, device, seed):
 
 
 def cpu_baseline(B, H, W, L, max_seconds=28.0, sample_batch=2, threads=32):
-    """Times the oracle's train_step (fp32, dropout on, clip 0.1, AdamW) on the host cores, on a bounded sample:
-    `sample_batch` images of the same workload (per-image cost of this path is batch-independent on CPU)."""
+    """Times the oracle's train_step (fp32, dropout on, clip 0.1, AdamW) on the host cores, on a bounded sample of the same workload:
+    the FULL batch (B images, like for like with the GPU step -- BASELINE.md section 3) when one warm-up step says that a warm-up + two
+    timed steps fit `max_seconds`, else `sample_batch` images (the per-image cost of this path is close to batch-independent on CPU).
+    The batch that was timed is reported in the result ("batch") and in the bench line's config."""
     from oracle import reftr_oracle as O
     from oracle.shapes import param_shapes
     from oracle.weights import formula_state
@@ -77,13 +79,24 @@ def cpu_baseline(B, H, W, L, max_seconds=28.0, sample_batch=2, threads=32):
     torch.set_num_threads(cores)
     cfg = O.Cfg()
     P = formula_state(param_shapes(cfg))
-    samples, targets = synth_batch(sample_batch, H, W, L, "cpu", 1234)
-    state = {}
     t_start = time.time()
-    step = 1
-    for _ in range(2):                                                                # warm-up (2)
-        O.train_step(P, samples, targets, cfg, state, step, max_norm=0.1, train=True)
-        step += 1
+
+    def run(batch, warm):
+        samples, targets = synth_batch(batch, H, W, L, "cpu", 1234)
+        state, step, warm_t = {}, 1, []
+        for _ in range(warm):
+            t0 = time.time()
+            O.train_step(P, samples, targets, cfg, state, step, max_norm=0.1, train=True)
+            warm_t.append(time.time() - t0)
+            step += 1
+        return samples, targets, state, step, warm_t
+
+    batch, warm = B, 1
+    samples, targets, state, step, warm_t = run(batch, warm)
+    if B > sample_batch and warm_t[0] * 3.0 > max_seconds:          # the full batch does not fit the budget: the small sample
+        batch, warm = sample_batch, 2
+        t_start = time.time()
+        samples, targets, state, step, warm_t = run(batch, warm)
     times = []
     while len(times) < 10 and (not times or time.time() - t_start + times[-1] < max_seconds):
         t0 = time.time()
@@ -91,8 +104,8 @@ def cpu_baseline(B, H, W, L, max_seconds=28.0, sample_batch=2, threads=32):
         times.append(time.time() - t0)
         step += 1
     med = sorted(times)[len(times) // 2]
-    return {"value": sample_batch / med, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"median of {len(times)} timed step(s) after 2 warm-ups on {sample_batch} images of the same workload "
+    return {"value": batch / med, "unit": "images/s", "cores": cores, "kind": "port", "batch": batch,
+            "sample": f"median of {len(times)} timed step(s) after {warm} warm-up(s) on {batch} images of the same workload "
                       f"({H}x{W}, L={L}, fp32, dropout on, clip 0.1, AdamW), torch CPU threads = {cores}"}
 
 
@@ -353,6 +366,7 @@ def main():
             out["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, S_, S_, Lq)
+            out["config"]["cpu_baseline_batch"] = out["cpu_baseline"]["batch"]     # B when the full batch fits the time budget
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

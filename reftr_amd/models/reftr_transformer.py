@@ -971,6 +971,15 @@ def build_config(args):
     if bool(getattr(args, "masks", False)) and getattr(args, "ablation", "none") == "cem_loss" and int(args.hidden_dim) != 256:
         raise NotImplementedError("--ablation cem_loss with hidden_dim != 256: the CEM kernels (rt_cem_fwd / rt_cem_bwd) are built for "
                                   "hidden_dim // 16 == 16 channels (every reference config uses hidden_dim 256)")
+    backbone = str(getattr(args, "backbone", "resnet50"))
+    if backbone not in ("resnet50", "resnet101"):
+        raise NotImplementedError(f"--backbone {backbone}: the reference takes any torchvision ResNet name (models/modeling/backbone.py:"
+                                  "119); this build has the bottleneck stacks of resnet50 (3, 4, 6, 3) and resnet101 (3, 4, 23, 3) only")
+    bert_name = str(getattr(args, "bert_model", "bert-base-uncased"))
+    if "base" not in bert_name.split("-"):
+        raise NotImplementedError(f"--bert_model {bert_name}: the reference reads hidden_size from the checkpoint's config "
+                                  "(models/reftr_transformer.py:84,315-318); this build has the base geometry (12 layers x 768, 12 heads) "
+                                  "of bert-base-* / roberta-base only")
     # models/reftr_transformer.py:315-318: RobertaModel when args.bert_model starts with 'roberta', BertModel otherwise
     bc = L.roberta_config() if str(getattr(args, "bert_model", "bert-base-uncased")).split("-")[0] == "roberta" else L.BertConfig()
     layers = (3, 4, 23, 3) if getattr(args, "backbone", "resnet50") == "resnet101" else (3, 4, 6, 3)

@@ -20,3 +20,27 @@ def hip():
     from reftr_amd import hip as H
     H.lib()
     return H
+
+
+# ---- measured-vs-gate table: parity tests call `record_parity(test, quantity, measured, gate)`; the rows are
+# printed as ONE table at the end of the run (GPU log: profiles/*_gpu_tests.log), so the distance to every gate is visible in one place.
+_PARITY_ROWS = []
+
+
+def record_parity(test, quantity, measured, gate):
+    _PARITY_ROWS.append((test, quantity, float(measured), float(gate)))
+
+
+@pytest.fixture()
+def parity_table():
+    return record_parity
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not _PARITY_ROWS:
+        return
+    tr = terminalreporter
+    tr.write_sep("=", "parity: measured vs gate (north_star states 1e-3 rel on bf16 logits; see README 'Parity, honestly')")
+    tr.write_line(f"{'test':58s} {'quantity':22s} {'measured':>10s} {'gate':>10s} {'measured/gate':>14s}")
+    for t, q, m, g in _PARITY_ROWS:
+        tr.write_line(f"{t[:58]:58s} {q[:22]:22s} {m:10.3e} {g:10.3e} {m / g if g else float('nan'):14.2f}")

@@ -237,3 +237,59 @@ def test_bf16_exchange_twin_is_written_by_the_gradient_producers(hip, single_ran
     bad = (st.flat_g16 != want)
     assert int(bad.sum()) == 0, ("first mismatch at", int(bad.nonzero()[0]), "of", int(bad.sum()))
     assert float(st.flat_g.abs().sum()) > 0
+
+
+def test_bf16_exchange_twin_in_full_clear_mode(hip, single_rank_group, monkeypatch):
+    """with REFTR_OVERWRITE=0 (or optimizer.zero_grad() with fast=False) the store is never armed, so the twins of the
+    matrices that no producer writes in a step (one query per image: the decoder's self-attention q / k projections) were left at
+    the previous step's all-reduced values.  The full clear now clears the twins with the masters."""
+    from reftr_amd.engine_vg import _total, _zero_grad
+    from reftr_amd.optim import FusedAdamW
+    from reftr_amd.parallel import DistributedDataParallel
+    monkeypatch.setenv("REFTR_DDP_DTYPE", "bf16")
+    monkeypatch.setenv("REFTR_OVERWRITE", "0")
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    model, crit, P, ocfg = build(small=True)
+    model.train()
+    opt = FusedAdamW(model)
+    runner = DistributedDataParallel(model)
+    assert runner.active and runner.bf16 and runner.twin
+    st = model.store
+    st.flat_g.normal_(); st.flat_g16.normal_()
+    out = runner(s)
+    total = _total(crit, crit(out, tg))
+    _zero_grad(opt)
+    assert not st._armed
+    total.backward()
+    torch.cuda.synchronize()
+    bad = (st.flat_g16 != st.flat_g.to(torch.bfloat16))
+    assert int(bad.sum()) == 0, ("first mismatch at", int(bad.nonzero()[0]), "of", int(bad.sum()))
+
+
+def test_clip_norm_after_a_non_overlapped_fp32_exchange(hip, single_rank_group, monkeypatch):
+    """DistributedDataParallel(overlap=False) with the fp32 exchange has neither stops nor phase hooks (dp_mode False) and
+    the clip read the norm slots the weight-gradient epilogues filled BEFORE the all-reduce.  Any exchange now voids the slots; with
+    one rank the norm must equal the plain loop's."""
+    from reftr_amd.engine_vg import train_step
+    from reftr_amd.optim import FusedAdamW
+    from reftr_amd.parallel import DistributedDataParallel
+    monkeypatch.setenv("REFTR_DDP_DTYPE", "fp32")
+    samples, targets = make_inputs("e2e_single", B=2, H=96, W=128, L=12)
+    s, tg = to_cuda(samples, targets)
+    norms = []
+    for wrap in (False, True):
+        model, crit, P, ocfg = build(small=True)
+        model.eval()
+        opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
+        runner = DistributedDataParallel(model, overlap=False) if wrap else model
+        if wrap:
+            assert runner.active and not runner.bf16 and not model.dp_mode
+        _, _, _, gn = train_step(runner, crit, s, tg, opt, None, max_norm=0.1)
+        torch.cuda.synchronize()
+        if wrap:
+            assert not model.store.norm_valid          # consumed / voided: the pass over the exchanged buffer ran
+        norms.append((float(gn), model.store.flat_g.clone()))
+    (n0, g0), (n1, g1) = norms
+    ref = float(g1.double().pow(2).sum().sqrt())
+    assert abs(n1 - ref) < 2e-5 * ref and abs(n1 - n0) < 2e-3 * n0      # two backward runs: atomics-order noise 4e-4

@@ -94,6 +94,11 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         build_reftr(ref_args(num_feature_levels=4))
     assert build_reftr(ref_args(bert_model="roberta-base"))[0].cfg.bert.pad_idx == 1
+    # a --backbone / --bert_model this build has no geometry for must not silently build ResNet-50 / the base config
+    for kw in (dict(backbone="resnet152"), dict(backbone="resnet34"), dict(bert_model="bert-large-uncased"), dict(bert_model="roberta-large")):
+        with pytest.raises(NotImplementedError):
+            build_reftr(ref_args(**kw))
+    assert build_reftr(ref_args(backbone="resnet101"))[0].cfg.resnet_layers == (3, 4, 23, 3)
     # --dilation is built (backbone.py:117-125): layer4 at stride 1, its later 3x3 convolutions dilated by 2 with padding 2
     m = build_reftr(ref_args(dilation=True))[0]
     l4 = m.body.blocks[3]

@@ -147,6 +147,61 @@ def test_cfg2_size_full_depth_forward_vs_oracle_and_its_order_floor(hip):
     assert got["boxes"] < 2.4e-3, got
 
 
+def test_cfg2_exact_B8_forward_and_losses_vs_oracle(hip, parity_table):
+    """configs[1] at its EXACT batch: 640 x 640, B = 8, L = 40, 12 + 6 + 6 layers, one fp32 oracle forward
+    (no rounding mirror, ~10 s of CPU): boxes, every loss term, the total, `phrase_mask` (exact).  The gates are the B = 2 test's
+    (bf16 operands against an fp32 reference: boxes 1.3e-3 measured -- north_star's 1e-3 on LOGITS is not met, see README)."""
+    samples, targets = make_inputs("e2e_single", B=8, H=640, W=640, L=40)
+    model, crit, P, ocfg = build_full()
+    s, tg = to_cuda(samples, targets)
+    with torch.no_grad():
+        out = model(s)
+        ld = crit(out, tg)
+        total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        o = O.reftr_forward(P, samples, ocfg, q=False)
+        losses = O.criterion(o, targets)
+        tot = O.total_loss(losses, O.weight_dict(ocfg))
+    assert np.array_equal(out["phrase_mask"].cpu().numpy(), o["phrase_mask"].numpy())          # exact
+    got = {"boxes": rel(out["pred_logits"].sigmoid(), o["logits"].sigmoid()), "logits": rel(out["pred_logits"], o["logits"]),
+           "loss": max(abs(float(ld[k]) - float(losses[k])) / max(abs(float(losses[k])), 1e-6) for k in losses),
+           "total": abs(float(total) - float(tot)) / float(tot)}
+    print("\n[cfg2 EXACT 640x640 B=8] HIP vs fp32 oracle " + "  ".join(f"{k}={v:.2e}" for k, v in got.items()))
+    gates = {"boxes": 2.4e-3, "logits": 1.1e-2, "loss": 5e-3, "total": 1e-3}
+    for k, g in gates.items():
+        parity_table("cfg2_exact_B8", k + " vs fp32 oracle", got[k], g)
+        assert got[k] < g, (k, got)
+
+
+def test_cfg5_exact_size_r101_800_elementwise_vs_oracle(hip, parity_table):
+    """configs[4] at its image size, element-wise: ResNet-101, 800 x 800, B = 2, L = 40, 16 phrase slots
+    (S = 40 + 625 rows), one fp32 oracle forward: boxes, losses, `phrase_mask`."""
+    from reftr_amd.models import layout as L
+    from reftr_amd.models.criterion import CriterionVGMultiPhrase
+    from reftr_amd.models.reftr_transformer import RefTR
+    ocfg = O.Cfg(resnet_layers=(3, 4, 23, 3))
+    cfg = L.ModelConfig(resnet_layers=(3, 4, 23, 3))
+    P = formula_state(param_shapes(ocfg))
+    model = RefTR(cfg, device="cuda", aux_loss=True)
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    crit = CriterionVGMultiPhrase(O.weight_dict(ocfg), ["boxes"])
+    samples, targets = make_inputs("cfg5_arch", B=2, H=800, W=800, L=40, n_phrase=16, Lp=12)
+    s, tg = to_cuda(samples, targets)
+    with torch.no_grad():
+        out = model(s)
+        ld = crit(out, tg)
+        o = O.reftr_forward(P, samples, ocfg, q=False)
+        losses = O.criterion(o, targets)
+    assert np.array_equal(out["phrase_mask"].cpu().numpy(), o["phrase_mask"].numpy())
+    got = {"boxes": rel(out["pred_logits"].sigmoid(), o["logits"].sigmoid()), "logits": rel(out["pred_logits"], o["logits"]),
+           "loss": max(abs(float(ld[k]) - float(losses[k])) / max(abs(float(losses[k])), 1e-6) for k in losses)}
+    print("\n[cfg5 EXACT SIZE R101 800x800 B=2 P=16] HIP vs fp32 oracle " + "  ".join(f"{k}={v:.2e}" for k, v in got.items()))
+    gates = {"boxes": 3e-3, "logits": 1.5e-2, "loss": 5e-3}
+    for k, g in gates.items():
+        parity_table("cfg5_exact_800_R101", k + " vs fp32 oracle", got[k], g)
+        assert got[k] < g, (k, got)
+
+
 def test_cfg5_architecture_r101_long_sentence_16_phrases_vs_oracle_and_its_order_floor(hip):
     """configs[4]'s ARCHITECTURE element-wise (VERDICT r02 'weak' item 2: ResNet-101 and the long-sequence attention had only
     property tests): ResNet-101 (3, 4, 23, 3), L = 90 tokens, 16 phrase slots with ragged validity (Lp = 22), 12 + 6 + 6 layers, at
