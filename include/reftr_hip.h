@@ -828,6 +828,83 @@ typedef struct rt_enc_tail_bwd_desc {
 } rt_enc_tail_bwd_desc;
 int rt_enc_tail_bwd(const rt_enc_tail_bwd_desc* d, rt_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * The few-row region between the encoder's forward and backward as three launches (round 5, csrc/rt_qregion.hip).
+ * Rows: N = B * P phrase rows (P <= 16 phrases per image), L <= 96 language tokens, E = 256.  Every workgroup works alone (no
+ * grid hand-off); the tensors listed as outputs are exactly what the launched chain (rt_conv_gemm + rt_layernorm_* + rt_rows_add +
+ * rt_qenc_attn_* + rt_box_loss + rt_small_dgrad) leaves behind, in the same formats, so forward / backward may mix fused and
+ * launched halves and the weight gradients stay with rt_small_wgrad_grouped / rt_conv_wgrad_grouped.
+ *
+ * rt_qenc_fwd  -- QueryEncoder.forward (models/reftr_transformer.py:41-66) + the query / query_pos split (:60-66), one workgroup
+ *                 per image.  cat16 [N, 2E]: columns E.. hold map_phrase's output on entry, columns ..E are written here.
+ * rt_head_loss -- decoder.norm on every layer's output (models/modeling/transformer.py:131-141), bbox_embed (models/modeling/
+ *                 backbone.py:26-38, models/reftr_transformer.py:287), CriterionVGMultiPhrase's box losses for all layers
+ *                 (models/criterion.py:113-153) with d total / d logits for the per-layer weights `weights` [NL][2], and the
+ *                 backward-data of the MLP and of the norm: one workgroup per decoder layer; losses [NL][2] are WRITTEN (no clear
+ *                 needed, no atomics: run-to-run reproducible).  Nothing is accumulated: the launch may run before the gradient clear.
+ * rt_qenc_bwd  -- backward-data of rt_qenc_fwd: from ga (+ gb) = d tgt and dqpos = d query_pos down to d memory (language rows and
+ *                 the CLS row of every image are accumulated in place; nothing else writes them while the launch runs), d
+ *                 query_embed (accumulated, n_q = 1), the bf16 dy operands of the six Linear weight gradients, and per-workgroup
+ *                 LayerNorm parameter-gradient partials [B][2][E] for rt_ln_param_grad_grouped.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rt_qenc_fwd_desc {
+    const void*  mem16;  const float* mem32;  const uint8_t* ctx;     /* memory bf16 / fp32 [B*S, E]; context mask [B, P, L] */
+    const void *W1, *W2, *W3, *Wc, *Wf0, *Wf4;                          /* bf16 [E][E] (Wf0: [E][2E]) */
+    const float *b1, *b2, *b3, *bc, *bf0, *bf4;
+    const float *gc, *betc, *g1, *bet1, *g5, *bet5;                     /* context_out.1, fuse_encoder_query.1 / .5 */
+    const float* qembed;                                                /* query_embed.weight [nq, 2E] */
+    const uint32_t* seed_dev;
+    void *cls16, *lang16;  float *kq, *qs, *vs, *qw;                    /* saved: bf16 [B,E], [B*L,E]; fp32 [B,E], [B*L,E] x 2, [B,P,L] */
+    void* c16;  float *co, *cmean, *crstd;                              /* bf16 [N,E]; fp32 [N,E], [N], [N] */
+    void* cat16;                                                        /* bf16 [N, 2E] */
+    float *t1, *m1, *r1;  void* a16;  float *t2, *m2, *r2;
+    float* tgt32;  void* tgt16;  float* qpos;  void* tgtq16;            /* [N*nq, E] */
+    int32_t B, S, L, P, nq, E;
+    float   eps, drop_p;
+    uint32_t drop_seed;  int32_t reserved;
+} rt_qenc_fwd_desc;
+int rt_qenc_fwd(const rt_qenc_fwd_desc* d, rt_stream_t stream);
+
+typedef struct rt_head_loss_desc {
+    const float* t3;                                                    /* fp32 [NL*N, E]: every decoder layer's output */
+    const float *gn, *betn;                                             /* decoder.norm */
+    const void *W0, *W1, *W2, *W0T, *W1T;                               /* bf16 [E][E], [E][E], [4][E]; backward-data operands [E][E] */
+    const float *b0, *b1, *b2, *w2_f32;                                 /* fp32 biases; fp32 master of the last Linear [4][E] */
+    const uint8_t* valid;  const float* targets;  const int32_t* tgt_off;  const float* num_boxes;  const float* weights;   /* as rt_box_loss */
+    void *hs16, *y1, *y2;  float *hmean, *hrstd;                        /* saved: bf16 [NL*N, E] x 3; fp32 [NL*N] x 2 */
+    float *logits, *losses, *dlogits;  void* dl16;                      /* fp32 [NL*N, 4], [NL][2], [NL*N, 4]; bf16 [NL*N, 4] */
+    void *dy2, *dy1;  float *dhs, *dnorm;                               /* bf16 [NL*N, E] x 2; fp32 [NL*N, E] x 2 */
+    float* db2_part;                                                    /* optional: [NL][2][4], row 0 of a pair = the layer's share of d bias of the last Linear (rt_ln_param_grad_grouped adds the pairs up) */
+    float* part_n;                                                      /* [NL][2][E] */
+    float* total;  int32_t* ticket;                                     /* optional: weighted total [1], written by the workgroup that draws the last ticket; *ticket must be 0 at the first launch and is left 0 */
+    int32_t NL, B, P, K, E;
+    float   eps;
+    int32_t invert_valid;  int32_t reserved;                            /* invert_valid: `valid` holds 1 = ignore (the model's query mask) */
+} rt_head_loss_desc;
+int rt_head_loss(const rt_head_loss_desc* d, rt_stream_t stream);
+
+typedef struct rt_qenc_bwd_desc {
+    const float *ga, *gb, *dqpos;                                       /* fp32 [N, E]; gb optional */
+    const float *t2, *m2, *r2, *g5, *bet5;
+    const float *t1, *m1, *r1, *g1, *bet1;
+    const float *co, *cmean, *crstd, *gc, *betc;
+    const float *kq, *qs, *vs, *qw;
+    const void *Wf4T, *Wf0T, *WcT, *W1T, *W2T, *W3T;                    /* bf16 backward-data operands [K][N] */
+    const uint32_t* seed_dev;
+    void *dt2b, *dt1b, *dcob, *dk16, *dqs16, *dvs16;                    /* bf16 dy operands of the weight gradients */
+    float *da, *dcat, *dc;                                              /* fp32 scratch / outputs: [N,E], [N,2E], [N,E] */
+    float* dmem;                                                        /* fp32 [B*S, E], accumulated */
+    float* dqembed;                                                     /* optional: fp32 [2, E], accumulated */
+    float *part5, *part1, *partc;                                       /* [B][2][E] each */
+    int32_t B, S, L, P, E;
+    float   drop_p;
+    uint32_t drop_seed;  int32_t reserved;
+} rt_qenc_bwd_desc;
+int rt_qenc_bwd(const rt_qenc_bwd_desc* d, rt_stream_t stream);
+/* Measurement aid: the stage stamps (100 MHz wall clock) workgroup 0 of the last rt_qenc_fwd / rt_head_loss / rt_qenc_bwd launch left,
+ * [3][24] values copied to HOST memory (synchronises with the device). */
+int rt_qregion_trace(unsigned long long* host_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,14 +494,26 @@ class CapturedTrainStep:
         side = inner.net.side
         main = torch.cuda.current_stream()
         prepared = side.run(lambda: crit.prepare(self.t, dev))            # reads the targets only: beside the step head, not behind the forward
-        logits = inner(self.s, _logits_only=True)                          # joins the side stream at its forward join
+        # round 5: with the fused head (rt_head_loss) the forward itself ends with the losses and the head's backward-data; it needs
+        # the prepared targets (ready at the forward join, where the side stream comes in)
+        inner.__dict__["_head_fused"] = (crit, prepared) if os.environ.get("REFTR_HEAD_FUSE", "1") != "0" else None
+        try:
+            logits = inner(self.s, _logits_only=True)                      # joins the side stream at its forward join
+        finally:
+            inner.__dict__["_head_fused"] = None
         if side.enabled:
             for t in prepared:
                 t.record_stream(main)
-        loss_dict, box, dl = crit.loss_and_grad(logits, inner._saved["phrase_mask"], prepared, inner.aux_loss)
-        # the weighted total is only logged (engine_vg.py:43,46-53): the same two torch kernels as in the autograd path.  On the main
-        # stream: forked to the side stream here (measured) the replayed graph's whole backward slows down by 0.25 ms
-        losses = crit.weighted_total(loss_dict)
+        head = inner._saved.get("head")
+        if head is not None:
+            box, dl = head["losses"], None                                 # backward starts behind the head (RefTR._backward_phases)
+            loss_dict = crit._loss_dict(box)
+            losses = head["total"][0]                                      # the weighted total (engine_vg.py:43), from the same launch
+        else:
+            loss_dict, box, dl = crit.loss_and_grad(logits, inner._saved["phrase_mask"], prepared, inner.aux_loss)
+            # the weighted total is only logged (engine_vg.py:43,46-53): the same two torch kernels as in the autograd path.  On the
+            # main stream: forked to the side stream here (measured) the replayed graph's whole backward slows down by 0.25 ms
+            losses = crit.weighted_total(loss_dict)
         if zero:
             _zero_grad(self.optimizer)
         inner._backward_impl(dl)                                           # ends with the side stream joined

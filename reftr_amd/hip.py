@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -288,6 +288,33 @@ class EncTailBwdDesc(Structure):
                                                  ("mode", c_int32), ("reserved", c_int32), ("dx1", c_void_p)]
 
 
+
+class QencFwdDesc(Structure):
+    _PTRS = ("mem16", "mem32", "ctx", "W1", "W2", "W3", "Wc", "Wf0", "Wf4", "b1", "b2", "b3", "bc", "bf0", "bf4",
+             "gc", "betc", "g1", "bet1", "g5", "bet5", "qembed", "seed_dev",
+             "cls16", "lang16", "kq", "qs", "vs", "qw", "c16", "co", "cmean", "crstd", "cat16",
+             "t1", "m1", "r1", "a16", "t2", "m2", "r2", "tgt32", "tgt16", "qpos", "tgtq16")
+    _fields_ = [(n, c_void_p) for n in _PTRS] + [("B", c_int32), ("S", c_int32), ("L", c_int32), ("P", c_int32), ("nq", c_int32),
+                                                 ("E", c_int32), ("eps", c_float), ("drop_p", c_float), ("drop_seed", c_uint32),
+                                                 ("reserved", c_int32)]
+
+
+class HeadLossDesc(Structure):
+    _PTRS = ("t3", "gn", "betn", "W0", "W1", "W2", "W0T", "W1T", "b0", "b1", "b2", "w2_f32",
+             "valid", "targets", "tgt_off", "num_boxes", "weights",
+             "hs16", "y1", "y2", "hmean", "hrstd", "logits", "losses", "dlogits", "dl16", "dy2", "dy1", "dhs", "dnorm", "db2_part", "part_n", "total", "ticket")
+    _fields_ = [(n, c_void_p) for n in _PTRS] + [("NL", c_int32), ("B", c_int32), ("P", c_int32), ("K", c_int32), ("E", c_int32),
+                                                 ("eps", c_float), ("invert_valid", c_int32), ("reserved", c_int32)]
+
+
+class QencBwdDesc(Structure):
+    _PTRS = ("ga", "gb", "dqpos", "t2", "m2", "r2", "g5", "bet5", "t1", "m1", "r1", "g1", "bet1", "co", "cmean", "crstd", "gc", "betc",
+             "kq", "qs", "vs", "qw", "Wf4T", "Wf0T", "WcT", "W1T", "W2T", "W3T", "seed_dev",
+             "dt2b", "dt1b", "dcob", "dk16", "dqs16", "dvs16", "da", "dcat", "dc", "dmem", "dqembed", "part5", "part1", "partc")
+    _fields_ = [(n, c_void_p) for n in _PTRS] + [("B", c_int32), ("S", c_int32), ("L", c_int32), ("P", c_int32), ("E", c_int32),
+                                                 ("drop_p", c_float), ("drop_seed", c_uint32), ("reserved", c_int32)]
+
+
 _SIGNATURES = {
     "rt_abi_version": (c_int, []),
     "rt_device_arch": (c_int, [c_int, c_char_p, c_int]),
@@ -361,6 +388,10 @@ _SIGNATURES = {
     "rt_stamp": (c_int, [c_void_p, c_int, c_void_p]),
     "rt_adamw_mat": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_int, c_void_p]),
     "rt_adamw_chunks": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_void_p]),
+    "rt_qenc_fwd": (c_int, [POINTER(QencFwdDesc), c_void_p]),
+    "rt_head_loss": (c_int, [POINTER(HeadLossDesc), c_void_p]),
+    "rt_qenc_bwd": (c_int, [POINTER(QencBwdDesc), c_void_p]),
+    "rt_qregion_trace": (c_int, [c_void_p]),
 }
 
 _lib = None
@@ -969,6 +1000,46 @@ def qenc_attn_bwd(k, qs, vs, w, dc):
     _check(lib().rt_qenc_attn_bwd(_p(k), _p(qs), _p(vs), _p(w), _p(dc), _p(dk), _p(dqs), _p(dvs), B, P, L, E, _stream()),
            "rt_qenc_attn_bwd")
     return dk, dqs, dvs
+
+
+def _fill(desc_cls, ptrs, **scalars):
+    """A descriptor whose pointer fields are named tensors (None -> NULL); unknown names are an error."""
+    d = desc_cls()
+    names = set(desc_cls._PTRS)
+    for k, v in ptrs.items():
+        if k not in names:
+            raise KeyError(f"{desc_cls.__name__}: no pointer field {k!r}")
+        setattr(d, k, _p(v))
+    for k, v in scalars.items():
+        setattr(d, k, v)
+    return d
+
+
+def qenc_fwd(*, B, S, L, P, nq, E, eps=1e-5, drop_p=0.0, drop_seed=0, **t):
+    """QueryEncoder forward + query / query_pos split as ONE launch (rt_qenc_fwd).  `t`: the named tensors of rt_qenc_fwd_desc."""
+    d = _fill(QencFwdDesc, dict(t, seed_dev=_SEED_DEV if drop_p > 0 else None), B=B, S=S, L=L, P=P, nq=nq, E=E, eps=eps,
+              drop_p=drop_p, drop_seed=drop_seed & 0xFFFFFFFF, reserved=0)
+    _check(lib().rt_qenc_fwd(ctypes.byref(d), _stream()), "rt_qenc_fwd")
+
+
+def head_loss(*, NL, B, P, K, E, eps=1e-5, invert_valid=False, **t):
+    """decoder.norm + bbox MLP + box losses + d total / d logits + their backward-data as ONE launch (rt_head_loss)."""
+    d = _fill(HeadLossDesc, t, NL=NL, B=B, P=P, K=K, E=E, eps=eps, invert_valid=int(bool(invert_valid)), reserved=0)
+    _check(lib().rt_head_loss(ctypes.byref(d), _stream()), "rt_head_loss")
+
+
+def qenc_bwd(*, B, S, L, P, E, drop_p=0.0, drop_seed=0, **t):
+    """Backward-data of rt_qenc_fwd as ONE launch (rt_qenc_bwd)."""
+    d = _fill(QencBwdDesc, dict(t, seed_dev=_SEED_DEV if drop_p > 0 else None), B=B, S=S, L=L, P=P, E=E, drop_p=drop_p,
+              drop_seed=drop_seed & 0xFFFFFFFF, reserved=0)
+    _check(lib().rt_qenc_bwd(ctypes.byref(d), _stream()), "rt_qenc_bwd")
+
+
+def qregion_trace():
+    """Stage stamps [3][24] (10 ns units) of workgroup 0 of the last rt_qenc_fwd / rt_head_loss / rt_qenc_bwd launches."""
+    buf = (ctypes.c_uint64 * 72)()
+    _check(lib().rt_qregion_trace(ctypes.cast(buf, c_void_p)), "rt_qregion_trace")
+    return [list(buf[i * 24:(i + 1) * 24]) for i in range(3)]
 
 
 def box_loss(logits, valid_u8, targets, tgt_off, num_boxes, w_bbox=1.0, w_giou=1.0, want_grad=True, weights=None):

@@ -566,37 +566,22 @@ class RefTR(nn.Module):
 
         # ---- QueryEncoder (models/reftr_transformer.py:41-66)
         qe = "query_encoder."
-        cls16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
-        lang16 = torch.empty(B * Lq, E, dtype=torch.bfloat16, device=dev)
-        H.rows_add(B, E, a_bf16=mem16, a_map=(1, S, 0), out_bf16=cls16)
-        H.rows_add(B * Lq, E, a_bf16=mem16, a_map=(Lq, S, 0), out_bf16=lang16)
-        _, kq = net.lin_fwd(qe + "linear1.", cls16, out_bf16=False, out_f32=True)
-        _, qs = net.lin_fwd(qe + "linear2.", lang16, out_bf16=False, out_f32=True)
-        _, vs = net.lin_fwd(qe + "linear3.", lang16, out_bf16=False, out_f32=True)
-        qw, qc = H.qenc_attn_fwd(kq, qs.view(B, Lq, E), vs.view(B, Lq, E), ctxmask)
-        c16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
-        H.rows_add(N, E, a_f32=qc.view(N, E), out_bf16=c16)
-        _, co = net.lin_fwd(qe + "context_out.0.", c16, out_bf16=False, out_f32=True)
-        cn32, _, _, cm, cr = net.ln_fwd(co, qe + "context_out.1.", want_bf16=False)
-        H.rows_add(N, E, a_f32=cn32, b_f32=mem32, b_map=(-Pn, S, 0), out_bf16=cat_rows, o_map=(1, 2, 0))
-        (f32, _, _, _, _), fq_ctx = net.mlp_fwd(cat16, qe + "fuse_encoder_query.", want_bf16=False)
-        # phrase_queries = fused.repeat(1, 1, 1, 2) + query_embed.view(1, 1, n_q, -1), phrase-major (:60-64): query row
-        # (b * Pn + ph) * n_q + q = fused[b, ph] + query_embed[q], first half -> tgt, second half -> query_pos
         nq = cfg.n_q
-        Nf, N = N, N * nq                                                  # fused phrase rows / query rows
-        tgt32 = torch.empty(N, E, dtype=torch.float32, device=dev); tgt16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
-        qpos = torch.empty(N, E, dtype=torch.float32, device=dev); tgtq16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
-        if nq == 1:
-            emb = st.P[qe + "query_embed.weight"].view(2, E)               # rows [tgt part | query_pos part]
-            H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 0), out_f32=tgt32, out_bf16=tgt16)
-            H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 1), out_f32=qpos)
+        Nf = N                                                              # fused phrase rows
+        qf = self._qfuse_ok(Lq, Pn)
+        if qf:
+            # round 5: the whole QueryEncoder + the query / query_pos split as ONE launch (rt_qenc_fwd), same saved tensors
+            q = self._qenc_fwd_fused(mem16, mem32, ctxmask, cat16, B, S, Lq, Pn)
+            cls16, lang16, kq, qs, vs, qw, c16, co = (q[k] for k in ("cls16", "lang16", "kq", "qs", "vs", "qw", "c16", "co"))
+            cm, cr, fq_ctx = q["cmean"], q["crstd"], q["fq_ctx"]
+            tgt32, tgt16, qpos, tgtq16 = q["tgt32"], q["tgt16"], q["qpos"], q["tgtq16"]
+            N = N * nq
+            if nq > 1:
+                qmask = qmask.view(B, Pn, 1).expand(B, Pn, nq).reshape(B, Pn * nq).contiguous()      # :237-238
         else:
-            emb2 = st.P[qe + "query_embed.weight"].view(nq, 2, E)
-            emb_t, emb_p = emb2[:, 0].contiguous(), emb2[:, 1].contiguous()       # [n_q, E] each (n_q x 1 KB of glue)
-            H.rows_add(N, E, a_f32=f32, a_map=(-nq, 1, 0), b_f32=emb_t, b_map=(nq, 0, 0), out_f32=tgt32, out_bf16=tgt16)
-            H.rows_add(N, E, a_f32=f32, a_map=(-nq, 1, 0), b_f32=emb_p, b_map=(nq, 0, 0), out_f32=qpos)
-            qmask = qmask.view(B, Pn, 1).expand(B, Pn, nq).reshape(B, Pn * nq).contiguous()      # :237-238
-        H.rows_add(N, E, a_f32=tgt32, b_f32=qpos, out_bf16=tgtq16)
+            cls16, lang16, kq, qs, vs, qw, c16, co, cm, cr, fq_ctx, tgt32, tgt16, qpos, tgtq16, qmask = self._qenc_fwd_chain(
+                mem16, mem32, ctxmask, cat16, cat_rows, qmask, B, S, Lq, Pn)
+            N = N * nq
 
         # ---- decoder (models/modeling/transformer.py:105-143) + shared norm on every layer's output
         T = Pn * cfg.n_q
@@ -617,19 +602,28 @@ class RefTR(nn.Module):
             dec.append(r)
         # decoder.norm on every layer's output (transformer.py:131-141, return_intermediate): ONE launch over the stack
         hm = hr = None
-        if NL:
-            _, _, _, hm, hr = net.ln_fwd(t3_all, vt + "decoder.norm.", y_bf16=hs16, want_f32=False)
+        head = None
+        hf = self.__dict__.get("_head_fused")
+        if hf is not None and NL and self.seg is None and self.aux_loss and self._qfuse_ok(Lq, Pn):
+            # round 5, captured step with the direct loss path: decoder.norm + box head + box losses + d total / d logits + the
+            # head's and the norm's backward-data as ONE launch (rt_head_loss); backward starts at the decoder
+            head = self._head_loss_fused(hf, t3_all, hs16, qmask.view(B, T), NL, B, Pn, nq, N, invert=True)
+            hm, hr, y1, y2, logits = head["hmean"], head["hrstd"], head["y1"], head["y2"], head["logits"]
+        else:
+            if NL:
+                _, _, _, hm, hr = net.ln_fwd(t3_all, vt + "decoder.norm.", y_bf16=hs16, want_f32=False)
+            y1, _ = net.lin_fwd("bbox_embed.layers.0.", hs16, act=RELU)
+            y2, _ = net.lin_fwd("bbox_embed.layers.1.", y1, act=RELU)
+            _, logits = net.lin_fwd("bbox_embed.layers.2.", y2, out_bf16=False, out_f32=True)
         hs_stats, t3s = (hm, hr), t3_all
-        y1, _ = net.lin_fwd("bbox_embed.layers.0.", hs16, act=RELU)
-        y2, _ = net.lin_fwd("bbox_embed.layers.1.", y1, act=RELU)
-        _, logits = net.lin_fwd("bbox_embed.layers.2.", y2, out_bf16=False, out_f32=True)
 
         self._saved = dict(
             B=B, S=S, Lq=Lq, HW=HW, Pn=Pn, N=N, Nf=Nf, T=T, NL=NL, bb_saved=bb_saved, c5=c5, bctx=bctx, pctx=pctx, ms_ctx=ms_ctx,
             mp_ctx=mp_ctx, ip=ip, gn_stats=gn_stats, kpm=kpm, qmask=qmask, ctxmask=ctxmask, enc=enc, mem16=mem16,
             memp16=memp16, mem32=mem32, cls16=cls16, lang16=lang16, kq=kq, qs=qs, vs=vs, qw=qw, c16=c16, co=co,
             cst=(cm, cr), fq_ctx=fq_ctx, dec=dec, hs_stats=hs_stats, t3s=t3s, hs16=hs16, y1=y1, y2=y2, pooled16=pooled16,
-            phrase_mask=(qmask == 0).view(B, T), memory=mem32, hw=(h, w))
+            # (the fused head reads the query mask itself and nothing in a captured training iteration reads the bool mask)
+            phrase_mask=(qmask == 0).view(B, T) if head is None else None, qmask_bt=qmask.view(B, T), memory=mem32, hw=(h, w), head=head)
         if self.seg is not None:            # RES head on the last decoder layer (reftr_segmentation.py:136-146)
             pad_u8 = kpm[:, Lq:].contiguous()
             pred_masks, mask_att, seg_sv = self.seg.forward(hs16[(NL - 1) * N:], mem16, mem32, src32, pad_u8, feats, B, S, Lq, h, w)
@@ -637,6 +631,183 @@ class RefTR(nn.Module):
         H.set_seed_dev(None)
         H.mark("query encoder + decoder + head forward done")
         return logits.view(NL, B, Pn, cfg.n_q, 4)
+
+    # ------------------------------------------------------------------ QueryEncoder forward: launched chain / one launch
+    def _qfuse_ok(self, Lq, Pn):
+        """rt_qenc_fwd / rt_qenc_bwd apply (hidden 256, <= 96 tokens, <= 16 phrases per image) and are switched on."""
+        return (os.environ.get("REFTR_QFUSE", "1") != "0" and self.cfg.hidden == 256 and Lq <= 96 and Pn <= 16
+                and self.net.small_wg is not None and self.net.ln_batch is not None)
+
+    def _qenc_fwd_chain(self, mem16, mem32, ctxmask, cat16, cat_rows, qmask, B, S, Lq, Pn):
+        cfg, net, st = self.cfg, self.net, self.store
+        dev, E = st.device, cfg.hidden
+        N = B * Pn
+        qe = "query_encoder."
+        cls16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
+        lang16 = torch.empty(B * Lq, E, dtype=torch.bfloat16, device=dev)
+        H.rows_add(B, E, a_bf16=mem16, a_map=(1, S, 0), out_bf16=cls16)
+        H.rows_add(B * Lq, E, a_bf16=mem16, a_map=(Lq, S, 0), out_bf16=lang16)
+        _, kq = net.lin_fwd(qe + "linear1.", cls16, out_bf16=False, out_f32=True)
+        _, qs = net.lin_fwd(qe + "linear2.", lang16, out_bf16=False, out_f32=True)
+        _, vs = net.lin_fwd(qe + "linear3.", lang16, out_bf16=False, out_f32=True)
+        qw, qc = H.qenc_attn_fwd(kq, qs.view(B, Lq, E), vs.view(B, Lq, E), ctxmask)
+        c16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
+        H.rows_add(N, E, a_f32=qc.view(N, E), out_bf16=c16)
+        _, co = net.lin_fwd(qe + "context_out.0.", c16, out_bf16=False, out_f32=True)
+        cn32, _, _, cm, cr = net.ln_fwd(co, qe + "context_out.1.", want_bf16=False)
+        H.rows_add(N, E, a_f32=cn32, b_f32=mem32, b_map=(-Pn, S, 0), out_bf16=cat_rows, o_map=(1, 2, 0))
+        (f32, _, _, _, _), fq_ctx = net.mlp_fwd(cat16, qe + "fuse_encoder_query.", want_bf16=False)
+        # phrase_queries = fused.repeat(1, 1, 1, 2) + query_embed.view(1, 1, n_q, -1), phrase-major (:60-64): query row
+        # (b * Pn + ph) * n_q + q = fused[b, ph] + query_embed[q], first half -> tgt, second half -> query_pos
+        nq = cfg.n_q
+        N = N * nq                                                          # query rows
+        tgt32 = torch.empty(N, E, dtype=torch.float32, device=dev); tgt16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
+        qpos = torch.empty(N, E, dtype=torch.float32, device=dev); tgtq16 = torch.empty(N, E, dtype=torch.bfloat16, device=dev)
+        if nq == 1:
+            emb = st.P[qe + "query_embed.weight"].view(2, E)               # rows [tgt part | query_pos part]
+            H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 0), out_f32=tgt32, out_bf16=tgt16)
+            H.rows_add(N, E, a_f32=f32, b_f32=emb, b_map=(-N, 0, 1), out_f32=qpos)
+        else:
+            emb2 = st.P[qe + "query_embed.weight"].view(nq, 2, E)
+            emb_t, emb_p = emb2[:, 0].contiguous(), emb2[:, 1].contiguous()       # [n_q, E] each (n_q x 1 KB of glue)
+            H.rows_add(N, E, a_f32=f32, a_map=(-nq, 1, 0), b_f32=emb_t, b_map=(nq, 0, 0), out_f32=tgt32, out_bf16=tgt16)
+            H.rows_add(N, E, a_f32=f32, a_map=(-nq, 1, 0), b_f32=emb_p, b_map=(nq, 0, 0), out_f32=qpos)
+            qmask = qmask.view(B, Pn, 1).expand(B, Pn, nq).reshape(B, Pn * nq).contiguous()      # :237-238
+        H.rows_add(N, E, a_f32=tgt32, b_f32=qpos, out_bf16=tgtq16)
+
+        return cls16, lang16, kq, qs, vs, qw, c16, co, cm, cr, fq_ctx, tgt32, tgt16, qpos, tgtq16, qmask
+
+    def _qenc_fwd_fused(self, mem16, mem32, ctxmask, cat16, B, S, Lq, Pn):
+        cfg, net, st = self.cfg, self.net, self.store
+        dev, E, nq = st.device, cfg.hidden, cfg.n_q
+        qe = "query_encoder."
+        N = B * Pn
+        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)       # noqa: E731
+        b16 = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=dev)      # noqa: E731
+        L1, L2, L3, Lc = (net.lins[qe + k] for k in ("linear1.", "linear2.", "linear3.", "context_out.0."))
+        F0, F4 = net.lins[qe + "fuse_encoder_query.0."], net.lins[qe + "fuse_encoder_query.4."]
+        dp, ds = net._drop(0.1)                                              # the site mlp_fwd would have drawn
+        o = dict(cls16=b16(B, E), lang16=b16(B * Lq, E), kq=f32(B, E), qs=f32(B * Lq, E), vs=f32(B * Lq, E), qw=f32(B, Pn, Lq),
+                 c16=b16(N, E), co=f32(N, E), cmean=f32(N), crstd=f32(N), t1=f32(N, E), m1=f32(N), r1=f32(N), a16=b16(N, E),
+                 t2=f32(N, E), m2=f32(N), r2=f32(N), tgt32=f32(N * nq, E), tgt16=b16(N * nq, E), qpos=f32(N * nq, E),
+                 tgtq16=b16(N * nq, E))
+        H.qenc_fwd(B=B, S=S, L=Lq, P=Pn, nq=nq, E=E, eps=1e-5, drop_p=dp, drop_seed=ds,
+                   mem16=mem16, mem32=mem32, ctx=ctxmask, cat16=cat16,
+                   W1=L1.W, W2=L2.W, W3=L3.W, Wc=Lc.W, Wf0=F0.W, Wf4=F4.W, b1=L1.b32, b2=L2.b32, b3=L3.b32, bc=Lc.b32, bf0=F0.b32, bf4=F4.b32,
+                   gc=st.P[qe + "context_out.1.weight"], betc=st.P[qe + "context_out.1.bias"],
+                   g1=st.P[qe + "fuse_encoder_query.1.weight"], bet1=st.P[qe + "fuse_encoder_query.1.bias"],
+                   g5=st.P[qe + "fuse_encoder_query.5.weight"], bet5=st.P[qe + "fuse_encoder_query.5.bias"],
+                   qembed=st.P[qe + "query_embed.weight"], **o)
+        o["fq_ctx"] = {"x16": cat16, "t1": o["t1"], "st1": (o["m1"], o["r1"], dp, ds), "a16": o["a16"], "t2": o["t2"],
+                       "st2": (o["m2"], o["r2"])}
+        return o
+
+    def _head_ticket(self):
+        """The persistent arrival counter of rt_head_loss (zero between launches)."""
+        t = self.__dict__.get("_head_ticket_buf")
+        if t is None:
+            t = self.__dict__["_head_ticket_buf"] = torch.zeros(1, dtype=torch.int32, device=self.store.device)
+        return t
+
+    def _head_loss_fused(self, hf, t3_all, hs16, mask, NL, B, Pn, nq, N, invert=False):
+        """rt_head_loss over the NL * N decoder-output rows; `hf` = (criterion, (boxes, offsets, num_boxes)) from the engine.
+        `mask` [B, T]: the bool phrase mask (True = a real phrase), or -- invert -- the model's uint8 query mask (1 = ignore)."""
+        from .criterion import _box_weights
+        crit, (boxes, off, num_boxes) = hf
+        net, st, E = self.net, self.store, self.cfg.hidden
+        dev = st.device
+        vt = "vl_transformer."
+        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)       # noqa: E731
+        b16 = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=dev)      # noqa: E731
+        l0, l1, l2 = (net.lins[f"bbox_embed.layers.{i}."] for i in range(3))
+        R = NL * N
+        o = dict(hs16=hs16, y1=b16(R, E), y2=b16(R, E), hmean=f32(R), hrstd=f32(R), logits=f32(R, 4), losses=f32(NL, 2),
+                 dlogits=f32(R, 4), dl16=b16(R, 4), dy2=b16(R, E), dy1=b16(R, E), dhs=f32(R, E), dnorm=f32(R, E), part_n=f32(NL, 2, E),
+                 db2_part=f32(NL, 2, 4), total=f32(1))
+        H.head_loss(NL=NL, B=B, P=Pn, K=nq, E=E, eps=1e-5, t3=t3_all,
+                    gn=st.P[vt + "decoder.norm.weight"], betn=st.P[vt + "decoder.norm.bias"],
+                    W0=l0.W, W1=l1.W, W2=l2.W, W0T=l0.WT, W1T=l1.WT, b0=l0.b32, b1=l1.b32, b2=l2.b32, w2_f32=l2.w32,
+                    valid=mask if mask.dtype == torch.uint8 else mask.to(torch.uint8).contiguous(), invert_valid=invert,
+                    targets=boxes, tgt_off=off, num_boxes=num_boxes, weights=_box_weights(crit, NL, t3_all.device),
+                    ticket=self._head_ticket(), **o)     # the device object rt_box_loss's path keys its cache with
+        return o
+
+    def _qenc_bwd_chain(self, sv, ga, gb, dqpos, dmem, B, S, Lq, Pn, N):
+        cfg, net, st = self.cfg, self.net, self.store
+        dev, E = st.device, cfg.hidden
+        qe = "query_encoder."
+        nq, Nf = cfg.n_q, sv["Nf"]
+        df = torch.empty(N, E, dtype=torch.float32, device=dev)
+        if nq == 1:
+            gqe = st.G[qe + "query_embed.weight"].view(2, E)
+            H.colsum(ga, gqe[0]); H.colsum(dqpos, gqe[1])
+        if gb is None:                  # trivial self-attention (one query per image): no gradient through t + query_pos
+            H.rows_add(N, E, a_f32=ga, b_f32=dqpos, out_f32=df)
+        else:
+            if nq == 1:
+                H.colsum(gb, gqe[0])
+            H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=df)
+            H.rows_add(N, E, a_f32=dqpos, out_f32=df, accumulate=True)
+        if nq > 1:
+            # query row (phrase, q): d query_embed[q] = sum over phrases, d fused[phrase] = sum over q (rows of a few KB: glue)
+            dt = (ga if gb is None else ga + gb).view(Nf, nq, E)
+            g2 = st.G[qe + "query_embed.weight"].view(nq, 2, E)
+            g2[:, 0] += dt.sum(0); g2[:, 1] += dqpos.view(Nf, nq, E).sum(0)
+            df = df.view(Nf, nq, E).sum(1).contiguous()
+        N = Nf                          # from here on: one row per phrase
+        dcat = net.mlp_bwd(sv["fq_ctx"], df, qe + "fuse_encoder_query.")            # fp32 [N, 2E]
+        dcat_rows = dcat.view(2 * N, E)
+        _, dcob = net.ln_bwd(dcat_rows, sv["co"], qe + "context_out.1.", *sv["cst"], rowmap=(1, 2, 0), want_f32=False)
+        _, dc = net.lin_bwd(qe + "context_out.0.", dcob, sv["c16"], out_bf16=False, out_f32=True)
+        if net.kv_dgrad_side:
+            net.side.join()             # REFTR_DEC_KV_SIDE=1: the decoder layers' memory-gradient products ran on the language stream
+        H.rows_add(N, E, a_f32=dcat_rows, a_map=(1, 2, 0), out_f32=dmem, accumulate=2, o_map=(-Pn, S, 0))
+        dk, dqs, dvs = H.qenc_attn_bwd(sv["kq"], sv["qs"].view(B, Lq, E), sv["vs"].view(B, Lq, E), sv["qw"], dc.view(B, Pn, E))
+        dk16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
+        dqs16 = torch.empty(B * Lq, E, dtype=torch.bfloat16, device=dev); dvs16 = torch.empty_like(dqs16)
+        H.rows_add(B, E, a_f32=dk, out_bf16=dk16)
+        H.rows_add(B * Lq, E, a_f32=dqs.view(B * Lq, E), out_bf16=dqs16)
+        H.rows_add(B * Lq, E, a_f32=dvs.view(B * Lq, E), out_bf16=dvs16)
+        _, dcls = net.lin_bwd(qe + "linear1.", dk16, sv["cls16"], out_bf16=False, out_f32=True)
+        H.rows_add(B, E, a_f32=dcls, out_f32=dmem, accumulate=True, o_map=(1, S, 0))
+        _, dla = net.lin_bwd(qe + "linear2.", dqs16, sv["lang16"], out_bf16=False, out_f32=True)
+        _, dlang = net.lin_bwd(qe + "linear3.", dvs16, sv["lang16"], res_f32=dla, out_bf16=False, out_f32=True)
+        H.rows_add(B * Lq, E, a_f32=dlang, out_f32=dmem, accumulate=True, o_map=(Lq, S, 0))
+        return dcat, dcat_rows
+
+    def _qenc_bwd_fused(self, sv, ga, gb, dqpos, dmem, B, S, Lq, Pn):
+        cfg, net, st = self.cfg, self.net, self.store
+        dev, E = st.device, cfg.hidden
+        qe = "query_encoder."
+        N = B * Pn
+        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)       # noqa: E731
+        b16 = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=dev)      # noqa: E731
+        L1, L2, L3, Lc = (net.lins[qe + k] for k in ("linear1.", "linear2.", "linear3.", "context_out.0."))
+        F0, F4 = net.lins[qe + "fuse_encoder_query.0."], net.lins[qe + "fuse_encoder_query.4."]
+        fq = sv["fq_ctx"]
+        m1, r1, dp, ds = fq["st1"]
+        m2, r2 = fq["st2"]
+        cm, cr = sv["cst"]
+        parts = f32(3, B, 2, E)
+        o = dict(dt2b=b16(N, E), dt1b=b16(N, E), dcob=b16(N, E), dk16=b16(B, E), dqs16=b16(B * Lq, E), dvs16=b16(B * Lq, E),
+                 da=f32(N, E), dcat=f32(N, 2 * E), dc=f32(N, E))
+        H.qenc_bwd(B=B, S=S, L=Lq, P=Pn, E=E, drop_p=dp, drop_seed=ds, ga=ga, gb=gb, dqpos=dqpos,
+                   t2=fq["t2"], m2=m2, r2=r2, g5=st.P[qe + "fuse_encoder_query.5.weight"], bet5=st.P[qe + "fuse_encoder_query.5.bias"],
+                   t1=fq["t1"], m1=m1, r1=r1, g1=st.P[qe + "fuse_encoder_query.1.weight"], bet1=st.P[qe + "fuse_encoder_query.1.bias"],
+                   co=sv["co"], cmean=cm, crstd=cr, gc=st.P[qe + "context_out.1.weight"], betc=st.P[qe + "context_out.1.bias"],
+                   kq=sv["kq"], qs=sv["qs"], vs=sv["vs"], qw=sv["qw"],
+                   Wf4T=F4.WT, Wf0T=F0.WT, WcT=Lc.WT, W1T=L1.WT, W2T=L2.WT, W3T=L3.WT,
+                   dmem=dmem, dqembed=st.G[qe + "query_embed.weight"], part5=parts[0], part1=parts[1], partc=parts[2], **o)
+        net._wgrad_only(qe + "fuse_encoder_query.4.", o["dt2b"], fq["a16"])
+        net._wgrad_only(qe + "fuse_encoder_query.0.", o["dt1b"], fq["x16"])
+        net._wgrad_only(qe + "context_out.0.", o["dcob"], sv["c16"])
+        net._wgrad_only(qe + "linear1.", o["dk16"], sv["cls16"])
+        net._wgrad_only(qe + "linear2.", o["dqs16"], sv["lang16"])
+        net._wgrad_only(qe + "linear3.", o["dvs16"], sv["lang16"])
+        for i, pfx in enumerate(("fuse_encoder_query.5.", "fuse_encoder_query.1.", "context_out.1.")):
+            net.ln_batch.jobs.append(H.LnPgJob(H._p(parts[i]), H._p(st.G[qe + pfx + "weight"]), H._p(st.G[qe + pfx + "bias"]), B, E))
+        net.ln_batch.keep.append(parts)
+        return o["dcat"]
 
     # ------------------------------------------------------------------ backward
     BOUNDARIES_SERIAL = ("main", "bert_hi", "bert_mid", "bert", "layer4")
@@ -730,16 +901,32 @@ class RefTR(nn.Module):
         f32z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)     # noqa: E731
 
         H.mark("loss done (backward starts)")
-        # ---- bbox head (backbone.py:26-38)
-        dl = dlogits.reshape(NL * N, 4)
-        dl16 = torch.empty(NL * N, 4, dtype=torch.bfloat16, device=dev)
-        H.rows_add(NL * N, 4, a_f32=dl, out_bf16=dl16)
+        head = sv.get("head")
         l2 = net.lins["bbox_embed.layers.2."]
-        H.linear_wgrad(dl16, sv["y2"], l2.gw, overwrite=st.claim(l2.gw))
-        H.colsum(dl, l2.gb)
-        dy2 = H.small_dgrad(dl, l2.w32, gate=sv["y2"])
-        dy1, _ = net.lin_bwd("bbox_embed.layers.1.", dy2, sv["y1"], gate=sv["y1"])
-        _, dhs = net.lin_bwd("bbox_embed.layers.0.", dy1, sv["hs16"], out_bf16=False, out_f32=True)
+        if head is not None:
+            # rt_head_loss ran the head's backward-data with the forward: what is left are the weight gradients (the last Linear's
+            # bias gradient was accumulated in the launch) and the norm's parameter gradients, all off the chain's data path
+            assert dlogits is None and dmasks is None
+            H.linear_wgrad(head["dl16"], sv["y2"], l2.gw, overwrite=st.claim(l2.gw))
+            net._wgrad_only("bbox_embed.layers.1.", head["dy2"], sv["y1"])
+            net._wgrad_only("bbox_embed.layers.0.", head["dy1"], sv["hs16"])
+            net.ln_batch.jobs.append(H.LnPgJob(H._p(head["part_n"]), H._p(st.G[vt + "decoder.norm.weight"]),
+                                               H._p(st.G[vt + "decoder.norm.bias"]), NL, E))
+            # the last Linear's bias gradient: the launch ran BEFORE the gradient clear (it sits in the forward), so it left per-layer
+            # partial sums and the grouped reduction adds them to the bias gradient like a LayerNorm's d gamma
+            net.ln_batch.jobs.append(H.LnPgJob(H._p(head["db2_part"]), H._p(l2.gb), None, NL, 4))
+            net.ln_batch.keep.append((head["part_n"], head["db2_part"]))
+            dhs = None
+        else:
+            # ---- bbox head (backbone.py:26-38)
+            dl = dlogits.reshape(NL * N, 4)
+            dl16 = torch.empty(NL * N, 4, dtype=torch.bfloat16, device=dev)
+            H.rows_add(NL * N, 4, a_f32=dl, out_bf16=dl16)
+            H.linear_wgrad(dl16, sv["y2"], l2.gw, overwrite=st.claim(l2.gw))
+            H.colsum(dl, l2.gb)
+            dy2 = H.small_dgrad(dl, l2.w32, gate=sv["y2"])
+            dy1, _ = net.lin_bwd("bbox_embed.layers.1.", dy2, sv["y1"], gate=sv["y1"])
+            _, dhs = net.lin_bwd("bbox_embed.layers.0.", dy1, sv["hs16"], out_bf16=False, out_f32=True)
         zz = f32z(2 * M + N, E)          # one clear for the three fp32 accumulators of the decoder backward
         dmem, dmemp, dqpos = zz[:M], zz[M:2 * M], zz[2 * M:]
 
@@ -752,7 +939,10 @@ class RefTR(nn.Module):
         # ---- decoder
         ga = gb = None
         hm, hr = sv["hs_stats"]
-        dnorm_all, _ = net.ln_bwd(dhs, sv["t3s"], vt + "decoder.norm.", hm, hr, want_bf16=False)     # all layers, one launch
+        if head is not None:
+            dnorm_all = head["dnorm"]
+        else:
+            dnorm_all, _ = net.ln_bwd(dhs, sv["t3s"], vt + "decoder.norm.", hm, hr, want_bf16=False)     # all layers, one launch
         coop_bwd = (NL > 0 and net.dec_coop_bwd and net.ln_batch is not None and net.small_wg is not None
                     and all(r.get("coop") for r in sv["dec"]))
         if coop_bwd:                    # the whole stack's backward chain as one cooperative launch (rt_decoder_bwd)
@@ -772,42 +962,17 @@ class RefTR(nn.Module):
         H.mark("head + decoder backward done")
         # ---- QueryEncoder backward
         nq, Nf = cfg.n_q, sv["Nf"]
-        df = torch.empty(N, E, dtype=torch.float32, device=dev)
-        if nq == 1:
-            gqe = st.G[qe + "query_embed.weight"].view(2, E)
-            H.colsum(ga, gqe[0]); H.colsum(dqpos, gqe[1])
-        if gb is None:                  # trivial self-attention (one query per image): no gradient through t + query_pos
-            H.rows_add(N, E, a_f32=ga, b_f32=dqpos, out_f32=df)
+        if nq == 1 and self._qfuse_ok(Lq, Pn):
+            # round 5: the backward-data chain as ONE launch (rt_qenc_bwd); the six Linear weight gradients and the three LayerNorms'
+            # parameter gradients are queued for the grouped launches as before
+            if net.kv_dgrad_side:
+                net.side.join()         # REFTR_DEC_KV_SIDE=1: the decoder layers' memory-gradient products ran on the language stream
+            dcat = self._qenc_bwd_fused(sv, ga, gb, dqpos, dmem, B, S, Lq, Pn)
+            N = Nf
+            dcat_rows = dcat.view(2 * N, E)
         else:
-            if nq == 1:
-                H.colsum(gb, gqe[0])
-            H.rows_add(N, E, a_f32=ga, b_f32=gb, out_f32=df)
-            H.rows_add(N, E, a_f32=dqpos, out_f32=df, accumulate=True)
-        if nq > 1:
-            # query row (phrase, q): d query_embed[q] = sum over phrases, d fused[phrase] = sum over q (rows of a few KB: glue)
-            dt = (ga if gb is None else ga + gb).view(Nf, nq, E)
-            g2 = st.G[qe + "query_embed.weight"].view(nq, 2, E)
-            g2[:, 0] += dt.sum(0); g2[:, 1] += dqpos.view(Nf, nq, E).sum(0)
-            df = df.view(Nf, nq, E).sum(1).contiguous()
-        N = Nf                          # from here on: one row per phrase
-        dcat = net.mlp_bwd(sv["fq_ctx"], df, qe + "fuse_encoder_query.")            # fp32 [N, 2E]
-        dcat_rows = dcat.view(2 * N, E)
-        _, dcob = net.ln_bwd(dcat_rows, sv["co"], qe + "context_out.1.", *sv["cst"], rowmap=(1, 2, 0), want_f32=False)
-        _, dc = net.lin_bwd(qe + "context_out.0.", dcob, sv["c16"], out_bf16=False, out_f32=True)
-        if net.kv_dgrad_side:
-            net.side.join()             # REFTR_DEC_KV_SIDE=1: the decoder layers' memory-gradient products ran on the language stream
-        H.rows_add(N, E, a_f32=dcat_rows, a_map=(1, 2, 0), out_f32=dmem, accumulate=2, o_map=(-Pn, S, 0))
-        dk, dqs, dvs = H.qenc_attn_bwd(sv["kq"], sv["qs"].view(B, Lq, E), sv["vs"].view(B, Lq, E), sv["qw"], dc.view(B, Pn, E))
-        dk16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
-        dqs16 = torch.empty(B * Lq, E, dtype=torch.bfloat16, device=dev); dvs16 = torch.empty_like(dqs16)
-        H.rows_add(B, E, a_f32=dk, out_bf16=dk16)
-        H.rows_add(B * Lq, E, a_f32=dqs.view(B * Lq, E), out_bf16=dqs16)
-        H.rows_add(B * Lq, E, a_f32=dvs.view(B * Lq, E), out_bf16=dvs16)
-        _, dcls = net.lin_bwd(qe + "linear1.", dk16, sv["cls16"], out_bf16=False, out_f32=True)
-        H.rows_add(B, E, a_f32=dcls, out_f32=dmem, accumulate=True, o_map=(1, S, 0))
-        _, dla = net.lin_bwd(qe + "linear2.", dqs16, sv["lang16"], out_bf16=False, out_f32=True)
-        _, dlang = net.lin_bwd(qe + "linear3.", dvs16, sv["lang16"], res_f32=dla, out_bf16=False, out_f32=True)
-        H.rows_add(B * Lq, E, a_f32=dlang, out_f32=dmem, accumulate=True, o_map=(Lq, S, 0))
+            dcat, dcat_rows = self._qenc_bwd_chain(sv, ga, gb, dqpos, dmem, B, S, Lq, Pn, N)
+            N = Nf
         # map_phrase: gradient rows 2r+1 of dcat; its input is BERT's pooled output (tanh) -> fold tanh'
         def _map_phrase_bwd():
             return net.mlp_bwd(sv["mp_ctx"], dcat_rows, "map_phrase.", dy_rowmap=(1, 2, 1), dx_f32=False,

@@ -16,8 +16,8 @@ _, a, b = min(cands)
 step = rows[a:b]
 t0 = step[0][1]
 marks = [("AdamW of the previous step (deferred) + weight prep + pack", "adamw_"), ("pack", "img_pack"), ("stem", "stem_"), ("language branch inline (REFTR_STEM_FIRST: forked behind the stem): AdamW (BERT slice) + BERT fwd", "adamw_"), ("ResNet fwd (+BERT if 1 stream)", ("maxpool", "bottleneck_fwd")), ("input_proj+GN", "gn_stats_kernel"),
-         ("encoder fwd", "gn_apply"), ("query encoder + decoder fwd + head", "qenc_attn_fwd"), ("loss", "box_loss"),
-         ("head + decoder bwd", "box_loss"), ("qenc bwd + encoder bwd", "qenc_attn_bwd"), ("GN/input_proj bwd", "gn_bwd_stats"),
+         ("encoder fwd", "gn_apply"), ("query encoder + decoder fwd + head", ("qenc_attn_fwd", "qenc_fwd_kernel")), ("loss", ("box_loss", "head_loss_kernel")),
+         ("head + decoder bwd", ("box_loss", "decoder_bwd_kernel", "layernorm_bwd")), ("qenc bwd + encoder bwd", ("qenc_attn_bwd", "qenc_bwd_kernel")), ("GN/input_proj bwd", "gn_bwd_stats"),
          ("ResNet bwd (+BERT bwd)", "gn_bwd_apply"), ("gradient norm", "sqnorm")]
 idx, pos = [], 0
 for label, key in marks:
