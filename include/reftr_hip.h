@@ -572,6 +572,12 @@ int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream);
  * timeout never arms its AdamW update (engine_vg.py:55-58 of the reference stops BEFORE the update when an iteration is bad; here
  * the decision is taken on the device, inside the captured graph). */
 int rt_counter_add_if_zero(int32_t* ctr, int32_t inc, const uint32_t* cond, int reset_else, rt_stream_t stream);
+/* rt_finish_step — both counters of an iteration's end in ONE launch, with the reference's second stop condition carried to the
+ * device as well: *step += 1 and *active += 1 unless (*cond != 0, cond optional) or (*loss is not finite, loss optional: the
+ * iteration's weighted total); otherwise *active = 0 and *step is left alone.  engine_vg.py:53-58 stops BEFORE the update when the
+ * loss is not finite; with the decision on the device the host may launch iteration i + 1 before it has read iteration i's numbers
+ * (reftr_amd.engine_vg.train_one_epoch, REFTR_PIPELINE): a bad iteration's update is never applied, the host stops one read later. */
+int rt_finish_step(int32_t* step, int32_t* active, const uint32_t* cond, const float* loss, rt_stream_t stream);
 /* rt_stamp — buf[idx] = the device's constant 100 MHz wall clock (s_memrealtime) when the stream reaches this point: a one-thread
  * kernel the measurement tools capture into the step's graph at phase boundaries of every stream (tools/concurrent_timeline.py),
  * because rocprofv3 serialises the graph's concurrent streams. */

@@ -397,6 +397,12 @@ __global__ void counter_add_if_zero_kernel(int32_t* c, int32_t inc, const uint32
     if (cond[0] == 0u) c[0] += inc; else if (reset_else) c[0] = 0;
 }
 __global__ void stamp_kernel(uint64_t* buf, int idx) { buf[idx] = wall_clock64(); }
+// the end of an iteration in deferred mode, decided on the device: the update is armed (and the step counter advanced) only when no
+// cooperative launch failed AND the iteration's total loss is finite
+__global__ void finish_step_kernel(int32_t* step, int32_t* active, const uint32_t* cond, const float* loss) {
+    const bool bad = (cond && cond[0] != 0u) || (loss && !isfinite(loss[0]));
+    if (!bad) { step[0] += 1; active[0] += 1; } else active[0] = 0;
+}
 
 }  // namespace
 
@@ -411,6 +417,13 @@ extern "C" int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream) {
 extern "C" int rt_counter_add_if_zero(int32_t* ctr, int32_t inc, const uint32_t* cond, int reset_else, rt_stream_t stream) {
     if (!ctr || !cond) return RT_ERR_BADARG;
     hipLaunchKernelGGL(counter_add_if_zero_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc, cond, reset_else);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_finish_step(int32_t* step, int32_t* active, const uint32_t* cond, const float* loss, rt_stream_t stream) {
+    if (!step || !active) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, active, cond, loss);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

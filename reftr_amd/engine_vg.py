@@ -425,7 +425,7 @@ class CapturedTrainStep:
         inner._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0" and not getattr(inner.store, "fused_norm", False)
         try:
             out = self._fwd_bwd(zero=not inner._zero_grad_side)
-            self.grad_norm = opt.finish_step(self.max_norm)
+            self.grad_norm = opt.finish_step(self.max_norm, loss=out[0])
             from . import hip as _H
             _H.mark("gradient norm done (step end)")
         finally:
@@ -541,6 +541,21 @@ class CapturedTrainStep:
         # layout: [losses (sorted by name) | cooperative-launch failure word (when the model can raise one) | gradient norm]
         fw = [self.fail_word.reshape(()).float()] if self.fail_word is not None else []
         self.stats = torch.stack([ld[k].reshape(()).float() for k in self.stat_names] + fw + [self.grad_norm.reshape(()).float()])
+
+    def queue_stats(self, stats=None):
+        """Enqueues the device -> host copy of this iteration's stats vector behind the replay, into one of TWO pinned buffers used
+        in turn (each with its event): with REFTR_PIPELINE the loop launches iteration i + 1 before it reads iteration i, so the two
+        copies in flight must not share a buffer.  Returns (host buffer, event)."""
+        stats = self.stats if stats is None else stats
+        if getattr(self, "_stats_host", None) is None:
+            self._stats_host = [torch.empty(stats.numel(), dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._stats_event = [torch.cuda.Event(), torch.cuda.Event()]
+            self._stats_flip = 0
+        i = self._stats_flip
+        self._stats_flip ^= 1
+        self._stats_host[i].copy_(stats, non_blocking=True)
+        self._stats_event[i].record()
+        return self._stats_host[i], self._stats_event[i]
 
     @staticmethod
     def _run(hooks):
@@ -669,13 +684,15 @@ class _EagerResult:
 class _ReplayInFlight:
     """A replayed step between its launch and its host read-out (`finish`)."""
 
-    def __init__(self, cap, criterion, retry=None):
+    def __init__(self, cap, criterion, retry=None, slot=None):
         self.cap, self.criterion, self.retry = cap, criterion, retry
+        self.slot = slot if slot is not None else (cap._stats_host[0], cap._stats_event[0])
 
     def finish(self):
         cap = self.cap
-        cap._stats_event.synchronize()
-        host = cap._stats_host.tolist()
+        host_buf, event = self.slot
+        event.synchronize()
+        host = host_buf.tolist()
         k = len(cap.stat_names)
         if cap.fail_word is not None and host[k] != 0:
             # A stage hand-off of the cooperative decoder launches timed out in this iteration (under data parallelism: on any
@@ -789,11 +806,7 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
         stats = stats.clone()
         torch.distributed.all_reduce(stats[:kf])
         stats[:k] /= utils.get_world_size()
-    if getattr(cap, "_stats_host", None) is None:
-        cap._stats_host = torch.empty(stats.numel(), dtype=torch.float32).pin_memory()
-        cap._stats_event = torch.cuda.Event()
-    cap._stats_host.copy_(stats, non_blocking=True)
-    cap._stats_event.record()
+    slot = cap.queue_stats(stats)
     if lr_scheduler is not None:
         lr_scheduler.step()          # host state only; the device reads the new rates when the next launch syncs them
     inner.__dict__["_staged_cap"] = None
@@ -818,7 +831,7 @@ def begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler
         finally:
             for g, lr in zip(optimizer.param_groups, after):
                 g["lr"] = lr
-    return _ReplayInFlight(cap, criterion, retry=_retry)
+    return _ReplayInFlight(cap, criterion, retry=_retry, slot=slot)
 
 
 def captured_train_step(model, criterion, samples, targets, optimizer, lr_scheduler=None, max_norm=0.0, max_shapes=4, lookahead=None):
@@ -843,20 +856,45 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
     booked = None
+    # REFTR_PIPELINE=1 (single process; default OFF): iteration i + 1 is LAUNCHED before iteration i is read out, meant to close the
+    # ~75 us between two replays (read-out + launch latency).  Measured: a hipGraph launched while its previous launch is still
+    # running starts LATER than one launched from an idle stream on this stack (bench.py +0.03 ... 0.11 ms per iteration, also with two
+    # instantiated graphs used in turn; profiles/r05_pipeline_negative_result.txt) -- kept as an option.  The reference reads the loss and
+    # stops BEFORE the update when it is not finite (engine_vg.py:53-58); here that decision is taken on the device (rt_finish_step:
+    # a non-finite total never arms the iteration's deferred AdamW pass, like a failed cooperative launch), the host reads the same
+    # numbers one launch later and stops then -- with the weights the reference would have stopped with.
+    pipeline = os.environ.get("REFTR_PIPELINE", "0") == "1" and not (utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1)
+    pending = None
+
+    def _read(step):
+        loss_value, scaled, unscaled, gnorm = step.finish()
+        if torch.is_tensor(gnorm):               # the eager step hands back the optimizer's device scalar, which the next step overwrites
+            gnorm = float(gnorm)
+        return dict(loss=loss_value, **scaled, **unscaled, lr=step.lr_logged, grad_norm=gnorm)
+
     for _ in board.log_every(range(len(data_loader)), 50, header):
         # the loop body of engine_vg.py:40-72 -- replayed from hipGraphs for fixed-shape data (RefCOCO: 640 x 640, L = 40);
-        # the replayed path hands back host numbers (one stacked copy per iteration), the eager one device scalars.  The
-        # iteration is read out (finite check included) BEFORE the next one is launched, as in the reference; only the meter
-        # bookkeeping of iteration i is done after iteration i+1 is on the device.
+        # the replayed path hands back host numbers (one stacked copy per iteration), the eager one device scalars.
         ahead = Lookahead(prefetcher.next)
         step = begin_train_step(model, criterion, samples, targets, optimizer, lr_scheduler, max_norm, lookahead=ahead)
+        step.lr_logged = optimizer.param_groups[0]["lr"]      # what the reference's meter shows: the rate after this iteration's scheduler step
         if booked is not None:
             board.add(**booked)
-        loss_value, scaled, unscaled, gnorm = step.finish()
-        booked = dict(loss=loss_value, **scaled, **unscaled, lr=optimizer.param_groups[0]["lr"], grad_norm=gnorm)
+            booked = None
+        if pipeline and isinstance(step, _ReplayInFlight):
+            if pending is not None:
+                booked = _read(pending)          # iteration i - 1, while iteration i runs
+            pending = step
+        else:
+            if pending is not None:              # an eager iteration behind a replayed one: drain in order
+                board.add(**_read(pending))
+                pending = None
+            booked = _read(step)
         samples, targets = ahead()
     if booked is not None:
         board.add(**booked)
+    if pending is not None:
+        board.add(**_read(pending))
     _check_cooperative(model)
     board.synchronize_between_processes()
     print("Averaged stats:", board)

@@ -386,6 +386,7 @@ _SIGNATURES = {
     "rt_decoder_set_spin": (c_int, [c_int]),
     "rt_counter_add_if_zero": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p]),
     "rt_stamp": (c_int, [c_void_p, c_int, c_void_p]),
+    "rt_finish_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rt_adamw_mat": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_int, c_void_p]),
     "rt_adamw_chunks": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_void_p]),
     "rt_qenc_fwd": (c_int, [POINTER(QencFwdDesc), c_void_p]),
@@ -1174,6 +1175,12 @@ def counter_add(ctr, inc=1, unless=None, reset_else=False):
         _check(lib().rt_counter_add_if_zero(_p(ctr), inc, _p(unless), int(bool(reset_else)), _stream()), "rt_counter_add_if_zero")
     else:
         _check(lib().rt_counter_add(_p(ctr), inc, _stream()), "rt_counter_add")
+
+
+def finish_step(step_dev, active, veto=None, loss=None):
+    """*step_dev += 1, *active += 1 unless the veto word is set or the loss is not finite; else *active = 0 (rt_finish_step)."""
+    _req(loss, torch.float32, "loss")
+    _check(lib().rt_finish_step(_p(step_dev), _p(active), _p(veto), _p(loss), _stream()), "rt_finish_step")
 
 
 def stamp(buf, idx):

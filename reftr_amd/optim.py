@@ -261,15 +261,19 @@ class FusedAdamW(torch.optim.Optimizer):
         return lrs
 
     @torch.no_grad()
-    def finish_step(self, max_norm):
+    def finish_step(self, max_norm, loss=None):
         """End of an iteration in deferred mode: total gradient norm, step counter, 'update pending' flag.  The weights
-        are NOT touched; grad_norm holds this iteration's (pre-clip) norm like clip_grad_norm_'s return value."""
+        are NOT touched; grad_norm holds this iteration's (pre-clip) norm like clip_grad_norm_'s return value.
+        `loss` (device fp32 scalar, optional): the iteration's weighted total -- a non-finite value vetoes the update like the
+        cooperative decoder's failure word does (engine_vg.py:53-58: the reference stops BEFORE the update)."""
         self._sqnorm_all()
         self._max_norm = float(max_norm)
         # `veto` (the cooperative decoder's failure word): an iteration whose launches reported a hand-off timeout neither advances
-        # the step counter nor arms its update -- decided on the device, so a replayed graph can never apply such an update
-        H.counter_add(self.step_dev, 1, unless=self.veto)
-        H.counter_add(self.active, 1, unless=self.veto, reset_else=True)     # `active` != 0 already (earlier iterations): a veto clears it
+        # the step counter nor arms its update -- decided on the device, so a replayed graph can never apply such an update; the
+        # same launch checks the loss.  `active` != 0 already (earlier iterations): a veto clears it
+        if loss is not None and not (torch.is_tensor(loss) and loss.is_cuda and loss.dtype == torch.float32):
+            loss = None
+        H.finish_step(self.step_dev, self.active, self.veto, loss.reshape(1) if loss is not None and loss.dim() == 0 else loss)
         torch.sqrt(self.sq, out=self.grad_norm)
         gs = getattr(self.model, "_grad_scale", 1.0)
         if gs != 1.0:

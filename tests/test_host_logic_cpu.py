@@ -480,15 +480,17 @@ def test_replayed_iteration_with_a_raised_failure_word_is_run_again_not_returned
         def synchronize(self):
             pass
     crit = types.SimpleNamespace(weight_dict={"loss_bbox": 5.0, "loss_giou": 2.0})
-    cap = types.SimpleNamespace(_stats_event=Ev(), stat_names=("loss_bbox", "loss_giou"), fail_word=object(),
-                                _stats_host=torch.tensor([0.5, 0.25, 0.0, 3.0]), model=None)
-    loss, scaled, unscaled, gn = E._ReplayInFlight(cap, crit, retry=lambda: "again").finish()
+    # (round 5: every handle reads ITS OWN (pinned buffer, event) pair -- two iterations may be in flight, REFTR_PIPELINE)
+    cap = types.SimpleNamespace(stat_names=("loss_bbox", "loss_giou"), fail_word=object(), model=None)
+    slot = (torch.tensor([0.5, 0.25, 0.0, 3.0]), Ev())
+    loss, scaled, unscaled, gn = E._ReplayInFlight(cap, crit, retry=lambda: "again", slot=slot).finish()
     assert abs(loss - 3.0) < 1e-6 and gn == 3.0 and scaled["loss_bbox"] == 2.5 and unscaled["loss_giou_unscaled"] == 0.25
-    cap._stats_host = torch.tensor([0.5, 0.25, 2.0, 3.0])                      # two ranks reported a timeout
-    assert E._ReplayInFlight(cap, crit, retry=lambda: "again").finish() == "again"
-    cap_nofail = types.SimpleNamespace(_stats_event=Ev(), stat_names=("loss_bbox", "loss_giou"), fail_word=None,
-                                       _stats_host=torch.tensor([0.5, 0.25, 3.0]), model=None)
-    assert E._ReplayInFlight(cap_nofail, crit).finish()[3] == 3.0             # models without the launches: [losses | norm]
+    slot2 = (torch.tensor([0.5, 0.25, 2.0, 3.0]), Ev())                        # two ranks reported a timeout
+    first = E._ReplayInFlight(cap, crit, retry=lambda: "again", slot=slot)
+    assert E._ReplayInFlight(cap, crit, retry=lambda: "again", slot=slot2).finish() == "again"
+    assert first.finish()[3] == 3.0                                            # the older handle still reads its own buffer
+    cap_nofail = types.SimpleNamespace(stat_names=("loss_bbox", "loss_giou"), fail_word=None, model=None)
+    assert E._ReplayInFlight(cap_nofail, crit, slot=(torch.tensor([0.5, 0.25, 3.0]), Ev())).finish()[3] == 3.0   # [losses | norm]
 
 
 def test_data_parallel_boundary_clears_never_written_matrices_before_the_exchange(monkeypatch):
