@@ -484,8 +484,13 @@ class CapturedTrainStep:
         """The direct loss path applies when the total is the weighted sum of the box losses of THIS process's model: no wrapper
         (the data-parallel schedules drive backward themselves), no mask / CEM terms, the fused total, aux weights as usual."""
         inner, crit = self.inner, self.criterion
-        return (os.environ.get("REFTR_LOSS_DIRECT", "1") == "1" and self.model is inner and getattr(inner, "seg", 1) is None
-                and hasattr(crit, "loss_and_grad") and tuple(crit.losses) == ("boxes",) and not inner.dp_mode
+        # (round 5: REFTR_LOSS_DIRECT_DP=1 takes this path under the data-parallel wrapper too -- its forward only forwards to the
+        # module, and RefTR._backward_impl honours the wrapper's exchange boundaries whoever calls it.  Measured through single-rank
+        # RCCL: 7.58-7.63 ms against 7.17-7.22 ms on the autograd path (the early fork of the target preparation costs the segment
+        # graphs more than the launches it removes; profiles/r05_ddp_direct_loss_negative_result.txt) -- off.)
+        dp_ok = (self.model is inner and not inner.dp_mode) or os.environ.get("REFTR_LOSS_DIRECT_DP", "0") == "1"
+        return (os.environ.get("REFTR_LOSS_DIRECT", "1") == "1" and dp_ok and getattr(inner, "seg", 1) is None
+                and hasattr(crit, "loss_and_grad") and tuple(crit.losses) == ("boxes",)
                 and os.environ.get("REFTR_FUSED_TOTAL", "1") != "0")
 
     def _fwd_bwd_direct(self, zero):
