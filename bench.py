@@ -312,10 +312,6 @@ def main():
         # across ranks -- and rank 0 reports its own events; the all-reduces are not among the timed launches.
         side_was = model.net.side.enabled
         model.net.side.enabled = False          # one stream for this pass: per-launch durations must be additive
-        opt_side = getattr(model, "opt_side", None)
-        opt_was = opt_side.enabled if opt_side is not None else False
-        if opt_side is not None:
-            opt_side.enabled = False
         if mode == "hipgraph" and not dp:
             torch.cuda.synchronize()
             torch.cuda._sleep(int(2.4e9 * 0.4))       # longer than the host needs to enqueue the whole eager step (~0.1-0.15 s of Python)
@@ -333,13 +329,11 @@ def main():
         torch.cuda.synchronize()
         hip.set_launch_timer(None)
         model.net.side.enabled = side_was
-        if opt_side is not None:
-            opt_side.enabled = opt_was
         fl = sum(r["flops"] for r in recs)
         tm = sum(r["start"].elapsed_time(r["end"]) for r in recs) * 1e-3
         ach = fl / tm / 1e12
         if rank == 0:
-            roof = {"bound": "mfma", "kernel": "rt_conv_gemm / rt_conv_wgrad(+_grouped) / rt_bottleneck_fwd kernels (conv_gemm_dma_kernel, w2_grouped_kernel + w2_reduce_kernel, conv_wgrad*_kernel, bottleneck_fwd_kernel, skinny / small-M; rt_enc_tail_* when REFTR_ENC_FUSE=1)",
+            roof = {"bound": "mfma", "kernel": "rt_conv_gemm / rt_conv_wgrad(+_grouped) / rt_bottleneck_fwd kernels (conv_gemm_dma_kernel, w2_grouped_kernel + w2_reduce_kernel, conv_wgrad*_kernel, bottleneck_fwd_kernel, skinny / small-M)",
                     "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                     "traffic": None, "launches_per_step": len(recs), "avg_launch_us": tm / max(len(recs), 1) * 1e6,
                     "algorithmic_gflop_per_step": fl / 1e9, "kernel_ms_per_step": tm * 1e3,

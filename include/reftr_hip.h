@@ -416,8 +416,7 @@ typedef struct rt_bottleneck_desc {
     const float* bd;       /* [256] or NULL */
     void*        out;      /* bf16 [B,H,W,256] */
     int32_t B, H, W, cin, planes;
-    int32_t form;          /* 0 = library default (REFTR_BNK_V, 1); 1 = one tile per workgroup, weights through an LDS ring;
-                              2 = persistent workgroups, weights in registers; 3 = one 8-wave workgroup per CU on an 8 x 32 tile, 8-slot ring */
+    int32_t form;          /* 0 or 1: one 8 x 16 tile per workgroup, weights through an LDS ring (the forms 2 / 3 of round 4 were removed: RT_ERR_UNSUPPORTED) */
 } rt_bottleneck_desc;
 int rt_bottleneck_fwd(const rt_bottleneck_desc* d, rt_stream_t stream);
 /* rt_weight_prep_batched — every per-step operand refresh in ONE launch.  table: DEVICE int64 [njobs][8] =
@@ -777,62 +776,6 @@ int rt_decoder_trace(uint32_t* out1024);
 int rt_decoder_supported(int F);
 int rt_decoder_set_spin(int spin);
 
-/* --------------------------------------------------------------------------------------------
- * rt_enc_tail_fwd / rt_enc_tail_bwd — everything of a TransformerEncoderLayer (models/modeling/transformer.py:168-181,
- * forward_post; width 256) between two attention launches, as ONE launch per direction: a workgroup owns 32 rows of the
- * [M = B*S, 256] sequence (the chain is row-local), weights stream through LDS, the feed-forward pair is walked in chunks of 256
- * hidden units (csrc/rt_encoder.hip).  Equivalent to the launched chain
- *   fwd:  rt_conv_gemm (out_proj: +bias, dropout seed_d1, + x32) -> rt_layernorm_fwd (norm1) -> rt_conv_gemm (linear1: ReLU,
- *         dropout seed_dh) -> rt_conv_gemm (linear2: +bias, dropout seed_d2, + norm1 output) -> rt_layernorm_fwd (norm2, + pos)
- *         [-> rt_conv_gemm_grouped (the next layer's q|k projection of x2 + pos and v projection of x2) when qk / v are given]
- *   bwd:  rt_layernorm_bwd (norm2; dy + dy2) -> rt_conv_gemm (linear2^T, gate hdn > 0, gate_scale) -> rt_conv_gemm (linear1^T,
- *         + dt2) -> rt_layernorm_bwd (norm1) -> rt_conv_gemm (out_proj^T)
- * with the same rounding points and dropout sites (index m * N + n of each product's output), so every tensor it writes can be
- * read by the chain's other half and by the weight-gradient launches, which stay outside:  linear2 <- (dt2b, hdn), linear1 <-
- * (dhdn, x1_16), out_proj <- (dtb, o); LayerNorm parameter gradients <- part1 / part2 ([ceil(M/32)][2][256] partial sums in
- * rt_ln_param_grad_grouped's format).  F % 256 == 0; anything else RT_ERR_UNSUPPORTED.
- * ------------------------------------------------------------------------------------------ */
-typedef struct rt_enc_tail_fwd_desc {
-    const void*  o;                       /* bf16 [M,256] attention output (heads side by side) */
-    const float* x32;                     /* [M,256] the layer's input (residual) */
-    const void *Wo, *W1, *W2;             /* bf16 [256][256], [F][256], [256][F] */
-    const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
-    const float* pos;                     /* [M,256] or NULL */
-    const void *Wqk, *Wv;                 /* next layer: bf16 [512][256] (q | k rows), [256][256]; or NULL */
-    const float *bqk, *bv;
-    float* t; float* mean1; float* rstd1; void* x1_16;          /* saved: norm1's input, statistics, bf16 output */
-    void*  hdn;                           /* bf16 [M,F] */
-    float* t2; float* mean2; float* rstd2;
-    float* x2_32; void* x2_16; void* x2p16;                     /* the layer's output: fp32, bf16, bf16(out + pos) (x2p16 may be NULL) */
-    void *qk, *v;                         /* bf16 [M,512], [M,256] or both NULL */
-    int32_t M, F;
-    float   eps, drop_p;
-    uint32_t seed_d1, seed_dh, seed_d2;
-    const uint32_t* seed_dev;             /* optional, see rt_conv_gemm_desc */
-    int32_t mode;                         /* 0: the whole tail; 1: out_proj + dropout1 + residual -> norm1 only (writes t, mean1, rstd1,
-                                             x1_16 and x1_32; the feed-forward pair stays with the caller's launches) */
-    int32_t reserved;
-    float*  x1_32;                        /* mode 1: norm1's fp32 output [M,256] (linear2's residual) */
-} rt_enc_tail_fwd_desc;
-int rt_enc_tail_fwd(const rt_enc_tail_fwd_desc* d, rt_stream_t stream);
-typedef struct rt_enc_tail_bwd_desc {
-    const float *dy, *dy2;                /* [M,256] gradient(s) w.r.t. the layer's output (dy2 optional, added) */
-    const float *t2, *mean2, *rstd2, *g2;
-    const void*  hdn;
-    const void *WT2, *WT1, *WTo;          /* bf16 backward-data operands: [F][256], [256][F], [256][256] */
-    const float *t, *mean1, *rstd1, *g1;
-    void *dt2b, *dhdn, *dtb, *d_o;        /* bf16 [M,256] ([M,F]): linear2 / linear1 / out_proj output gradients, attention-output gradient */
-    float* dt;                            /* fp32 [M,256]: gradient w.r.t. norm1's input (the residual path to the layer input) */
-    float *part2, *part1;                 /* [ceil(M/32)][2][256] or NULL */
-    int32_t M, F;
-    float   drop_p, gate_scale;
-    uint32_t seed_d1, seed_d2;
-    const uint32_t* seed_dev;
-    int32_t mode;                         /* 0: the whole tail; 1: norm1 backward -> out_proj^T only, from dx1 */
-    int32_t reserved;
-    const float* dx1;                     /* mode 1: fp32 [M,256] gradient w.r.t. norm1's output (linear1^T's result + the residual path) */
-} rt_enc_tail_bwd_desc;
-int rt_enc_tail_bwd(const rt_enc_tail_bwd_desc* d, rt_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * The few-row region between the encoder's forward and backward as three launches (round 5, csrc/rt_qregion.hip).

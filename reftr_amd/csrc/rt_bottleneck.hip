@@ -57,13 +57,10 @@ struct BnkArgs {
 constexpr int BK_TH = 8, BK_TW = 16, BK_HW = BK_TW + 2, BK_HALO = (BK_TH + 2) * BK_HW, BK_XROWS = 192;
 constexpr int BK_XSLOT = BK_XROWS * 128, BK_WSLOT = 64 * 128, BK_LDS = 2 * BK_XSLOT + 4 * BK_WSLOT;
 constexpr int BK_LX = BK_XROWS / 32, BK_LW = 2;            // DMA instructions per thread: one X chunk, one weight piece
-// persistent form: h1 row pitch (pixels), bytes of h1, LDS of a workgroup
-constexpr int BKP_PITCH = 24, BKP_T1_BYTES = (BK_TH + 2) * BKP_PITCH * 128, BKP_LDS = 4 * BK_XSLOT + BKP_T1_BYTES + BK_TH * BK_TW * 128;
 
-// TW / NW / R: tile width in pixels, waves, ring slots.  (16, 4, 4) = the first form: 8 x 16 tile, 80 KB of LDS, two workgroups per CU.
-// (32, 8, 8) = the third form: ONE 8-wave workgroup per CU on an 8 x 32 tile, all 160 KB -- the weight pieces are pulled once per 256
-// pixels instead of per 128, the halo is 1.33x instead of 1.41x, and the ring runs SEVEN pieces ahead instead of three (the first
-// form's workgroups spend most of their 23 us parked on ring pieces: an L2 round trip is longer than three pieces of compute).
+// TW / NW / R: tile width in pixels, waves, ring slots.  (16, 4, 4) is the only instantiation: 8 x 16 tile, 80 KB of LDS, two
+// workgroups per CU.  (Round 4 also measured (32, 8, 8) -- one 8-wave workgroup per CU on an 8 x 32 tile -- and a persistent form with
+// the weights in registers: both bit-identical and slower, removed in round 5; profiles/r04ac_bottleneck_bench_three_forms.txt.)
 template <int CIN, bool DOWN, int TW = 16, int NW = 4, int R = 4>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bottleneck_fwd_kernel(const BnkArgs p) {
     static_assert((R & (R - 1)) == 0 && R >= 4 && TW % 16 == 0 && NW * 2 == BK_TH * TW / 16, "8 rows x TW / 16 pixel tiles, two per wave");
@@ -350,241 +347,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bottleneck_fwd_kerne
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// Second form (REFTR_BNK_V=2 / desc.form = 2; measured, NOT the default): PERSISTENT workgroups with the weights in REGISTERS.  The first form pulls the
-// block's 136 KB of weights through every 128-pixel tile's LDS ring (more bytes than the tile's own 96 KB of input) and
-// parks on 17 ring pieces per tile; here a workgroup walks a contiguous range of tiles and its four waves split the OUTPUT
-// FEATURES instead of the pixels -- wave w owns features 16w .. 16w+15 of conv1 / conv2 and 64w .. 64w+63 of conv3 -- so each
-// wave's share of the weights is 34-36 MFMA A fragments (136-144 VGPRs) loaded once per workgroup, and the only operand
-// that streams is the haloed input tile: four 24-KB LDS slots, chunk k always in slot k, the NEXT tile's chunk k requested as soon
-// as this tile's chunk k is consumed (one 4-wave workgroup per CU: the weights need the 512-register budget).  h1 is kept with a
-// row pitch of 24 pixels (not 18): the swizzle phase of a fragment row then depends on (kw + lane) only, so the 144 fragment reads
-// of conv2 are 6 lane addresses + immediates (with pitch 18 they are 60 distinct loop-invariant addresses the compiler keeps in
-// registers across the tile loop -- the first build spilled).  Every wave reads every pixel row of the
-// staged tiles (4x the LDS fragment reads of the pixel-split form: 1024 ds_read_b128 per tile against 304 MFMAs per wave).
 template <int CIN, bool DOWN>
-__global__ __launch_bounds__(256, 1) void bottleneck_persist_kernel(const BnkArgs p, const int ntiles) {
-    constexpr int NK1 = CIN / 64, KS1 = CIN / 32;
-    static_assert(NK1 == 1 || NK1 == 4, "cin = 64 or 256");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
-    const int G = (int)gridDim.x, wg = rt_xcd_remap((int)blockIdx.x, G, 1);
-    // contiguous tile range of this workgroup (XCD x owns workgroups 64x .. 64x+63: neighbouring tiles share an L2)
-    const int t_begin = (int)((long long)wg * ntiles / G), t_end = (int)((long long)(wg + 1) * ntiles / G);
-    if (t_begin >= t_end) return;
-
-    // ---- this wave's weights, once
-    bf16x8 w1f[KS1], w2f[9][2], w3f[4][2], wdf[4][2];
-    {
-        const int r1 = 16 * wave + li;
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) w1f[ks] = *reinterpret_cast<const bf16x8*>(p.w1 + r1 * CIN + ks * 32 + lg * 8);
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) w2f[tp][kk] = *reinterpret_cast<const bf16x8*>(p.w2 + (r1 * 9 + tp) * 64 + kk * 32 + lg * 8);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int ch = 64 * wave + (li >> 2) * 16 + a * 4 + (li & 3);           // permuted feature order (see the header comment)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                w3f[a][kk] = *reinterpret_cast<const bf16x8*>(p.w3 + ch * 64 + kk * 32 + lg * 8);
-                if (DOWN) wdf[a][kk] = *reinterpret_cast<const bf16x8*>(p.wd + ch * 64 + kk * 32 + lg * 8);
-            }
-        }
-    }
-    const f32x4 b1v = *reinterpret_cast<const f32x4*>(p.b1 + 16 * wave + lg * 4), b2v = *reinterpret_cast<const f32x4*>(p.b2 + 16 * wave + lg * 4);
-    float b3v[16], bdv[16];
-#pragma unroll
-    for (int e = 0; e < 16; e += 4) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(p.b3 + 64 * wave + lg * 16 + e);
-        const f32x4 ud = DOWN ? *reinterpret_cast<const f32x4*>(p.bd + 64 * wave + lg * 16 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { b3v[e + r] = u[r]; bdv[e + r] = ud[r]; }
-    }
-
-    const int srow = t >> 3, chunk = (t & 7) ^ (srow & 7);
-    constexpr int OOB = 0x7fffffff;
-    const i32x4 rs_x = bk_rsrc(p.x, p.x_bytes);
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
-    const int per_img = p.tiles_x * p.tiles_y;
-    auto tile_pos = [&](int tile, int& b, int& oy0, int& ox0) __attribute__((always_inline)) {
-        b = tile / per_img; const int r = tile - b * per_img, ty = r / p.tiles_x;
-        oy0 = ty * BK_TH; ox0 = (r - ty * p.tiles_x) * BK_TW;
-    };
-    auto tile_offsets = [&](int tile, int (&off)[BK_LX]) __attribute__((always_inline)) {
-        int b, oy0, ox0; tile_pos(tile, b, oy0, ox0);
-#pragma unroll
-        for (int j = 0; j < BK_LX; ++j) {
-            const int hp = srow + 32 * j, hr = hp / BK_HW, hc = hp - hr * BK_HW;
-            const int y = oy0 - 1 + hr, x = ox0 - 1 + hc;
-            const bool ok = hp < BK_HALO && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            off[j] = ok ? (((b * p.H + y) * p.W + x) * CIN + chunk * 8) * 2 : OOB;
-        }
-    };
-    auto issue_x = [&](const int (&off)[BK_LX], int kc, int slot) __attribute__((always_inline)) {
-        const unsigned base = lds0 + (unsigned)slot * BK_XSLOT;
-#pragma unroll
-        for (int j = 0; j < BK_LX; ++j) bk_dma16(rs_x, base + j * 4096, off[j], kc * 128);
-    };
-    auto put4 = [&](unsigned slot_off, int row, const f32x4 v) __attribute__((always_inline)) {      // this wave's 4 features of one pixel row
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-        *reinterpret_cast<bf16x4*>(smem + slot_off + row * 128 + (((2 * wave + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o;
-    };
-
-    // LDS: X slots 0..3 | h1 [10 x 24 rows] | h2 [128 rows].  Identity: chunk k of every tile lives in slot k.  Downsample: the one
-    // chunk of a tile alternates between slots 0 and 1 (conv3 still reads the centre pixels while the next tile's is in flight).
-    constexpr unsigned T1 = 4 * BK_XSLOT, T2 = T1 + BKP_T1_BYTES;
-    int cur_off[BK_LX], nxt_off[BK_LX];
-    int par = 0;
-    tile_offsets(t_begin, cur_off);
-#pragma unroll
-    for (int kc = 0; kc < NK1; ++kc) issue_x(cur_off, kc, kc);
-
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        const bool more = tile + 1 < t_end;
-        if (more) tile_offsets(tile + 1, nxt_off);
-        int b, oy0, ox0; tile_pos(tile, b, oy0, ox0);
-
-        // ---- stage 1: conv1 over the haloed tile, this wave's 16 features x 12 pixel tiles
-        f32x4 acc1[12];
-#pragma unroll
-        for (int mt = 0; mt < 12; ++mt) acc1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kc = 0; kc < NK1; ++kc) {
-            // DMA order (identity): c0 c1 c2 c3 | c0' (after the barrier of step 1) | c1' (step 2) | c2' (step 3) | c3' (after conv1).
-            // A wait leaves exactly the requests younger than its chunk outstanding.
-            const int own = (NK1 - 1 - kc) * BK_LX, ahead = (kc >= 2 ? kc - 1 : 0) * BK_LX;
-            if (more) bk_wait(own + ahead); else bk_wait(own);
-            __syncthreads();                               // chunk kc visible; everyone is done with chunk kc-1 (and with the previous tile)
-            if (more) {
-                if (NK1 == 1) issue_x(nxt_off, 0, par ^ 1);
-                else if (kc >= 1) issue_x(nxt_off, kc - 1, kc - 1);
-            }
-            const unsigned char* xs = smem + (NK1 == 1 ? par : kc) * BK_XSLOT;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int mt = 0; mt < 12; ++mt) {
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + (mt * 16 + li) * 128 + (((kk * 4 + lg) ^ (li & 7)) << 4));
-                    acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[kc * 2 + kk], xf, acc1[mt], 0, 0, 0);
-                }
-        }
-#pragma unroll
-        for (int mt = 0; mt < 12; ++mt) {
-            const int hp = mt * 16 + li, hr = hp / BK_HW, hc = hp - hr * BK_HW;
-            const int y = oy0 - 1 + hr, x = ox0 - 1 + hc;
-            const bool in = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;      // conv2 pads h1 with zeros
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc1[mt][r] + b1v[r], 0.f) : 0.f;
-            if (hp < BK_HALO) put4(T1, hr * BKP_PITCH + hc, v);
-        }
-        __syncthreads();                                   // h1 complete; everyone is done with the last X chunk
-        if (NK1 > 1 && more) issue_x(nxt_off, 3, 3);
-
-        // ---- stage 2: conv2, this wave's 16 features x 8 pixel tiles, no operand but h1
-        f32x4 acc2[8];
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) acc2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-            const int kh = tp / 3, kw = tp % 3;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    // row (mt + kh) * 24 + kw + li: its swizzle phase is (kw + li) & 7 whatever mt + kh is
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(smem + T1 + (mt + kh) * (BKP_PITCH * 128) + (kw + li) * 128 + (((kk * 4 + lg) ^ ((kw + li) & 7)) << 4));
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[tp][kk], xf, acc2[mt], 0, 0, 0);
-                }
-        }
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc2[mt][r] + b2v[r], 0.f);
-            put4(T2, mt * 16 + li, v);
-        }
-        __syncthreads();                                   // h2 complete
-
-        // ---- stage 3: conv3 (+ downsample), this wave's 64 features, two pixel tiles at a time
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x8 hf[2][2], cf[2][2];
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int m = (2 * g + bb) * 16 + li;
-                    hf[bb][kk] = *reinterpret_cast<const bf16x8*>(smem + T2 + m * 128 + (((kk * 4 + lg) ^ (m & 7)) << 4));
-                    if (DOWN) {
-                        const int hp = (2 * g + bb + 1) * BK_HW + 1 + li;
-                        cf[bb][kk] = *reinterpret_cast<const bf16x8*>(smem + par * BK_XSLOT + hp * 128 + (((kk * 4 + lg) ^ (hp & 7)) << 4));
-                    }
-                }
-            int opix[2];
-            bool oin[2];
-            bf16x8 res[2][2];
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int oy = oy0 + 2 * g + bb, ox = ox0 + li;
-                oin[bb] = oy < p.H && ox < p.W;
-                opix[bb] = (b * p.H + oy) * p.W + ox;
-                if (!DOWN) {
-                    const bf16_t* rp = p.x + (size_t)(oin[bb] ? opix[bb] : 0) * 256 + 64 * wave + lg * 16;
-                    res[bb][0] = *reinterpret_cast<const bf16x8*>(rp);
-                    res[bb][1] = *reinterpret_cast<const bf16x8*>(rp + 8);
-                }
-            }
-            f32x4 acc3[4][2], accd[4][2];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[a][kk], hf[bb][kk], c, 0, 0, 0);
-                    acc3[a][bb] = c;
-                    if (DOWN) {                            // accumulators of its own: rounded to bf16 before it joins, like the one-tile form
-                        f32x4 dd = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdf[a][kk], cf[bb][kk], dd, 0, 0, 0);
-                        accd[a][bb] = dd;
-                    }
-                }
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                if (!oin[bb]) continue;
-                bf16x8 lo, hi;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int e = a * 4 + r;
-                        float v = acc3[a][bb][r] + b3v[e];
-                        if (!DOWN) v += (float)(e < 8 ? res[bb][0][e & 7] : res[bb][1][e & 7]);
-                        else v += (float)(bf16_t)(accd[a][bb][r] + bdv[e]);
-                        v = fmaxf(v, 0.f);
-                        if (e < 8) lo[e] = (bf16_t)v; else hi[e - 8] = (bf16_t)v;
-                    }
-                bf16_t* op = p.out + (size_t)opix[bb] * 256 + 64 * wave + lg * 16;
-                *reinterpret_cast<bf16x8*>(op) = lo;
-                *reinterpret_cast<bf16x8*>(op + 8) = hi;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < BK_LX; ++j) cur_off[j] = nxt_off[j];
-        par ^= (NK1 == 1);
-    }
-    bk_wait(0);
-}
-
-template <int CIN, bool DOWN>
-int launch_bottleneck(const BnkArgs& a, int want, hipStream_t s) {
+int launch_bottleneck(const BnkArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)bottleneck_fwd_kernel<CIN, DOWN>, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS);
@@ -592,36 +356,6 @@ int launch_bottleneck(const BnkArgs& a, int want, hipStream_t s) {
         attr_set = true;
     }
     const unsigned grid = (unsigned)(a.B * a.tiles_x * a.tiles_y);
-    static const int form_env = getenv("REFTR_BNK_V") ? atoi(getenv("REFTR_BNK_V")) : 1;
-    const int form = want ? want : form_env;
-    if (form == 2) {
-        static int slots = 0;
-        if (!slots) {
-            int dev = 0; hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RT_ERR_UNSUPPORTED;
-            hipError_t e = hipFuncSetAttribute((const void*)bottleneck_persist_kernel<CIN, DOWN>, hipFuncAttributeMaxDynamicSharedMemorySize, BKP_LDS);
-            if (e != hipSuccess) return (int)e;
-            slots = prop.multiProcessorCount;               // one 142-KB workgroup per CU
-        }
-        const unsigned g2 = grid < (unsigned)slots ? grid : (unsigned)slots;
-        hipLaunchKernelGGL((bottleneck_persist_kernel<CIN, DOWN>), dim3(g2), dim3(256), BKP_LDS, s, a, (int)grid);
-        RT_CHECK_LAUNCH();
-        return RT_OK;
-    }
-    if (form == 3) {
-        constexpr int LDS3 = 2 * (8 * 48 * 128) + 8 * BK_WSLOT;        // all 160 KB
-        static bool attr3 = false;
-        if (!attr3) {
-            hipError_t e = hipFuncSetAttribute((const void*)bottleneck_fwd_kernel<CIN, DOWN, 32, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3);
-            if (e != hipSuccess) return (int)e;
-            attr3 = true;
-        }
-        BnkArgs a3 = a;
-        a3.tiles_x = (a.W + 31) / 32;
-        hipLaunchKernelGGL((bottleneck_fwd_kernel<CIN, DOWN, 32, 8, 8>), dim3((unsigned)(a.B * a3.tiles_x * a.tiles_y)), dim3(512), LDS3, s, a3);
-        RT_CHECK_LAUNCH();
-        return RT_OK;
-    }
     hipLaunchKernelGGL((bottleneck_fwd_kernel<CIN, DOWN>), dim3(grid), dim3(256), BK_LDS, s, a);
     RT_CHECK_LAUNCH();
     return RT_OK;
@@ -631,7 +365,7 @@ int launch_bottleneck(const BnkArgs& a, int want, hipStream_t s) {
 
 extern "C" int rt_bottleneck_fwd(const rt_bottleneck_desc* d, rt_stream_t stream) {
     if (!d || !d->x || !d->w1 || !d->w2 || !d->w3 || !d->b1 || !d->b2 || !d->b3 || !d->out) return RT_ERR_BADARG;
-    if (d->planes != 64 || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->form < 0 || d->form > 3) return RT_ERR_UNSUPPORTED;
+    if (d->planes != 64 || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->form < 0 || d->form > 1) return RT_ERR_UNSUPPORTED;      // forms 2 / 3 (round 4: persistent / 8-wave, slower) were removed
     const long long in_bytes = (long long)d->B * d->H * d->W * d->cin * 2, out_elems = (long long)d->B * d->H * d->W * 256;
     if (in_bytes >= (1ll << 31) || out_elems >= (1ll << 31)) return RT_ERR_UNSUPPORTED;      // 32-bit buffer offsets / pixel indices
     BnkArgs a;
@@ -641,7 +375,7 @@ extern "C" int rt_bottleneck_fwd(const rt_bottleneck_desc* d, rt_stream_t stream
     a.tiles_x = (d->W + BK_TW - 1) / BK_TW; a.tiles_y = (d->H + BK_TH - 1) / BK_TH;
     a.x_bytes = (unsigned)in_bytes;
     hipStream_t s = (hipStream_t)stream;
-    if (d->cin == 64 && d->wd && d->bd) return launch_bottleneck<64, true>(a, d->form, s);
-    if (d->cin == 256 && !d->wd) return launch_bottleneck<256, false>(a, d->form, s);
+    if (d->cin == 64 && d->wd && d->bd) return launch_bottleneck<64, true>(a, s);
+    if (d->cin == 256 && !d->wd) return launch_bottleneck<256, false>(a, s);
     return RT_ERR_UNSUPPORTED;
 }

@@ -435,12 +435,6 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         case 31: return launch_gemm_dma<64, 64, 2, 4>(a, s);
         case 32: return launch_gemm_dma<64, 64, 4, 2>(a, s);
         case 33: return launch_gemm_dma<64, 64, 3, 3>(a, s);
-        // direct epilogue from the accumulators (permuted weight rows, rt_gemm_dma.h EPI = 1)
-        case 331: return launch_gemm_dma<64, 64, 2, 4, 4, 0, 1>(a, s);
-        case 333: return launch_gemm_dma<64, 64, 3, 3, 4, 0, 1>(a, s);
-        case 321: return launch_gemm_dma<128, 64, 2, 2, 4, 0, 1>(a, s);
-        case 351: return launch_gemm_dma<128, 128, 2, 2, 8, 0, 1>(a, s);
-        case 352: return launch_gemm_dma<128, 128, 3, 1, 8, 0, 1>(a, s);
         // 8-wave workgroups (2 x 4 waves) on the 128-row tiles
         case 51: return launch_gemm_dma<128, 128, 2, 2, 8>(a, s);
         case 52: return launch_gemm_dma<128, 128, 3, 1, 8>(a, s);
@@ -485,7 +479,7 @@ extern "C" int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_st
     return RT_OK;
 }
 
-extern "C" int rt_abi_version(void) { return 30; }
+extern "C" int rt_abi_version(void) { return 31; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

@@ -33,11 +33,8 @@ __device__ __forceinline__ void rt_dma16(const i32x4 rsrc, unsigned lds_base, in
 // problems of a grouped launch (conv_gemm_dma_grouped_kernel); bx / by / gx stand for blockIdx.x / blockIdx.y / gridDim.x.
 // NW = 4 waves arranged 2(n) x 2(m), or 8 waves 2(n) x 4(m): the same tile with smaller wave tiles and twice the waves per CU
 // PIPE = 1 (rt_gemm_pipe.hip): the software-pipelined K loop -- see the `if constexpr (PIPE)` block.
-// EPI = 1 (round 4): the weight rows of a wave's half tile are staged in a PERMUTED feature order -- LDS row a*16 + i of the half
-// holds feature (i >> 2) * 4 TN + a*4 + (i & 3) -- so that after the TN 16-feature MFMAs a lane holds 4 TN CONSECUTIVE features of
-// its pixel: the epilogue runs straight from the accumulators (no LDS staging pass, no barrier behind the K loop), every residual /
-// gate read and store a 16-B piece, 8 TN bytes contiguous per pixel and lane.
-template <int BM, int BN, int MODE, int NS, int NW = 4, int PIPE = 0, int EPI = 0>
+// (Round 4's direct epilogue from permuted weight rows -- EPI = 1 -- was measured neutral and removed in round 5: profiles/r04v_*.)
+template <int BM, int BN, int MODE, int NS, int NW = 4, int PIPE = 0>
 __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, const GemmArgs& p,
                                               const int bx, const int by, const int gx) {
     constexpr int NT = 64 * NW, WM = NW / 2, RPP = NT / 8;        // threads, waves along m, rows one DMA pass covers
@@ -82,10 +79,6 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         int n = n0 + srow + RPP * j;
-        if (EPI == 1) {
-            const int r = srow + RPP * j, h = r / (BN / 2), rl = r - h * (BN / 2), a = rl >> 4, i = rl & 15;
-            n = n0 + h * (BN / 2) + (i >> 2) * (4 * TN) + a * 4 + (i & 3);
-        }
         a_off[j] = n < p.N ? (n * p.K + chunk * 8) * 2 : OOB;
     }
     int b_off[BJ], b_y[BJ], b_x[BJ];
@@ -202,33 +195,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     constexpr bool RAGGED_PIECES = (ROWS * CPR) % NT != 0;
     constexpr bool CAN_PRE = HALVES == 1 && PIECES <= 4;
     const bool epi_lds = p.epi_lds && (p.N & 7) == 0;
-    static_assert(EPI == 0 || (TN == 2 || TN == 4), "the direct epilogue handles 8 or 16 consecutive features per lane");
-    constexpr int EG = EPI == 1 ? TN / 2 : 1;                      // 8-feature groups per lane and pixel
-    bf16x8 d_res[EPI == 1 ? TM : 1][EG], d_gate[EPI == 1 ? TM : 1][EG];
-    const bool d_pre = EPI == 1 && p.prefetch && (p.res_bf16 || p.gate);
-    auto direct_row = [&](int b, int& m) __attribute__((always_inline)) -> bool {
-        m = m0 + wm * (BM / WM) + b * 16 + li;
-        if (m >= Mloc) return false;
-        if (MODE == 3) {
-            const int xx = m % nx, tmp = m / nx, yy = tmp % ny, bb = tmp / ny;
-            m = (bb * p.DH + 2 * yy + cy) * p.DW + 2 * xx + cx;
-        }
-        return true;
-    };
-    if (EPI == 1 && d_pre) {
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-#pragma unroll
-            for (int e = 0; e < EG; ++e) {
-                int m;
-                const int n = n0 + wn * (BN / 2) + lg * (4 * TN) + e * 8;
-                const bool ok = direct_row(b, m) && n < p.N;
-                const size_t o = ok ? (size_t)m * p.N + n : 0;
-                d_res[b][e] = p.res_bf16 ? *reinterpret_cast<const bf16x8*>(p.res_bf16 + o) : bf16x8{};
-                d_gate[b][e] = p.gate ? *reinterpret_cast<const bf16x8*>(p.gate + o) : bf16x8{};
-            }
-    }
-    const bool pre = EPI == 0 && CAN_PRE && epi_lds && p.prefetch && (p.res_bf16 || p.gate);
+    const bool pre = CAN_PRE && epi_lds && p.prefetch && (p.res_bf16 || p.gate);
     bf16x8 pre_res[CAN_PRE ? PIECES : 1], pre_gate[CAN_PRE ? PIECES : 1];
     auto out_piece = [&](int idx, int& m, int& n) __attribute__((always_inline)) -> bool {
         const int rl = idx / CPR, cl = (idx - rl * CPR) * 8;
@@ -345,23 +312,6 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     // different rows per store instruction.  Staging the fp32 tile through LDS (the operand stages are dead now) turns every
     // residual / gate read and every store into 16-B pieces of ONE row per lane, 128+ contiguous bytes per row.
     static_assert((size_t)ROWS * EP_LD * 4 <= (size_t)NS * BUF_BYTES, "epilogue tile does not fit the LDS stages");
-    if (EPI == 1) {
-#pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            int m;
-            if (!direct_row(b, m)) continue;
-#pragma unroll
-            for (int e = 0; e < EG; ++e) {
-                const int n = n0 + wn * (BN / 2) + lg * (4 * TN) + e * 8;
-                if (n >= p.N) continue;
-                const f32x4 lo4 = acc[2 * e][b], hi4 = acc[2 * e + 1][b];
-                const f32x8 v8 = f32x8{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                if (d_pre) epilogue8<true>(p, m, n, v8, d_res[b][e], d_gate[b][e]);
-                else epilogue8(p, m, n, v8);
-            }
-        }
-        return;
-    }
     if (epi_lds) {
         float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -408,15 +358,14 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     }
 }
 
-template <int BM, int BN, int MODE, int NS, int MINB, int NW = 4, int PIPE = 0, int EPI = 0>
+template <int BM, int BN, int MODE, int NS, int MINB, int NW = 4, int PIPE = 0>
 __global__ __launch_bounds__(64 * NW, MINB) void conv_gemm_dma_kernel(const bf16_t* __restrict__ src,
                                                                       const bf16_t* __restrict__ wgt, const GemmArgs p) {
-    gemm_dma_body<BM, BN, MODE, NS, NW, PIPE, EPI>(src, wgt, p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+    gemm_dma_body<BM, BN, MODE, NS, NW, PIPE>(src, wgt, p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
-template <int BM, int BN, int NS, int MINB, int NW = 4, int PIPE = 0, int EPI = 0>
+template <int BM, int BN, int NS, int MINB, int NW = 4, int PIPE = 0>
 int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
-    if (EPI == 1 && (a.N & 7) != 0) return launch_gemm_dma<BM, BN, NS, MINB, NW, PIPE, 0>(a, s);     // 8-feature pieces
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const size_t smem = (size_t)NS * (BM + BN) * 128;
     const dim3 grid((unsigned)(mt * nt)), block(64 * NW);
@@ -426,27 +375,27 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
         if (smem > 65536) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     };
     if (dense) {
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW, PIPE, EPI>);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW, PIPE>);
         // distinct operand slabs an XCD's run of R tiles touches: R / n_tiles + min(R, n_tiles) (n fastest) vs the same with m_tiles
         static const int mfast_env = getenv("REFTR_MFAST") ? atoi(getenv("REFTR_MFAST")) : 1;
         GemmArgs am = a;
         const double R = (double)(mt * nt) / 8.0;
         const double cn = R / nt + (R < nt ? R : nt), cm = R / mt + (R < mt ? R : mt);
         am.mfast = (mfast_env && a.xcd && mt * nt >= 16 && cm < cn) ? 1 : 0;
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW, PIPE, EPI>), grid, block, smem, s, a.src, a.wgt, am);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW, PIPE>), grid, block, smem, s, a.src, a.wgt, am);
     } else if (!a.transposed) {
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW, PIPE, EPI>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW, PIPE, EPI>), grid, block, smem, s, a.src, a.wgt, a);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW, PIPE>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 1, NS, MINB, NW, PIPE>), grid, block, smem, s, a.src, a.wgt, a);
     } else if (a.stride == 2 && par_env) {
         const int m_cls = a.B * ((a.DH + 1) / 2) * ((a.DW + 1) / 2);           // largest parity class
         // grid.x padded to a multiple of 8: block (x, y) has linear id y * gridDim.x + x, so only then do the four parity classes
         // of a tile range (they gather from the same dy rows) sit on the same XCD as the tile map assumes (surplus blocks exit)
         const dim3 grid3((unsigned)(((((m_cls + BM - 1) / BM) * nt) + 7) / 8 * 8), 4);
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW, PIPE, EPI>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW, PIPE, EPI>), grid3, block, smem, s, a.src, a.wgt, a);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW, PIPE>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 3, NS, MINB, NW, PIPE>), grid3, block, smem, s, a.src, a.wgt, a);
     } else {
-        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 2, NS, MINB, NW, PIPE, EPI>);
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, NS, MINB, NW, PIPE, EPI>), grid, block, smem, s, a.src, a.wgt, a);
+        set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 2, NS, MINB, NW, PIPE>);
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<BM, BN, 2, NS, MINB, NW, PIPE>), grid, block, smem, s, a.src, a.wgt, a);
     }
     RT_CHECK_LAUNCH();
     return RT_OK;

@@ -350,19 +350,6 @@ class CapturedTrainStep:
         assert be == inner.store.flat_p.numel() or be > bb, "BERT is the last group of the flat buffers"
         self._hooks = ((lambda: opt.apply_pending(span=(0, bb)) if bb > 0 else None),
                        (lambda: opt.apply_pending(span=(bb, be))))
-        inner._late_ok = bool(getattr(opt, "_emit", False)) and bb > 0      # the late main-slice pass relies on the pass writing the operands
-        # pipelined schedule (REFTR_OPT_PIPE, reftr_transformer.forward): the BERT slice in pieces of three layers on a stream of its
-        # own, each piece gating only the BERT layers that read it -- BERT's forward starts behind the embeddings + layers 0-2
-        # instead of behind the whole 3.5 GB slice, the ResNet starts at once (stem / layer1 are frozen)
-        cuts = inner.bert_layer_offsets() if hasattr(inner, "bert_layer_offsets") else None
-        if cuts and bb > 0 and getattr(opt, "_emit", False):
-            step = int(os.environ.get("REFTR_OPT_PIPE_LAYERS", "3"))
-            marks = [bb] + [cuts[i] for i in range(step, len(cuts) - 1, step)] + [be]     # cuts[-1] = the pooler, kept with the last piece
-            pieces = [((lambda: opt.apply_pending(span=(0, bb))), "main")]
-            for k in range(len(marks) - 1):
-                sp = (marks[k], marks[k + 1])
-                pieces.append(((lambda sp=sp: opt.apply_pending(span=sp)), k * step))          # tag = first BERT layer that reads the piece
-            self._hooks = self._hooks + (pieces,)
 
     def _head_deferred(self):
         """[AdamW of the previous iteration | forward | loss | backward up to the first boundary]"""
@@ -414,23 +401,18 @@ class CapturedTrainStep:
         inner, opt = self.inner, self.optimizer
         self._set_flush(False)
         inner._pre_update = self._hooks
-        # REFTR_ZERO_SIDE: 0 = the clear between loss and backward on the main stream; 1 = a FULL clear on the language stream under
-        # the encoder (measured neutral in round 1); 2 = the fast clear (atomics' 4 % + norm slots: ~20 us of launches on the
-        # loss -> backward chain) there: 6.67-6.69 vs 6.66-6.68 ms over four interleaved pairs (profiles/r04ai_zero_side_ab.txt): the
-        # fork / join edges cost what the launches did.  0.
-        zs = int(os.environ.get("REFTR_ZERO_SIDE", "0"))
-        inner._zero_grad_side = zs if (zs in (1, 2) and inner.net.side.enabled) else 0
+        # (the gradient clear stays between loss and backward on the main stream: on the language stream under the encoder it was
+        # neutral, 6.67-6.69 vs 6.66-6.68 ms, profiles/r04ai_zero_side_ab.txt and again +0.06 ms in round 5 -- option removed)
         # backward and clip norm are one unit here (nothing touches the gradient buffer in between): the BERT slice's share of the
         # norm may be taken on the language stream as soon as that slice is final (reftr_transformer._backward_gen)
         inner._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0" and not getattr(inner.store, "fused_norm", False)
         try:
-            out = self._fwd_bwd(zero=not inner._zero_grad_side)
+            out = self._fwd_bwd(zero=True)
             self.grad_norm = opt.finish_step(self.max_norm, loss=out[0])
             from . import hip as _H
             _H.mark("gradient norm done (step end)")
         finally:
             inner._pre_update = None
-            inner._zero_grad_side = False
             inner._norm_side = False
             inner._norm_split = None
         self._pack_stats()

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -272,23 +272,6 @@ class DecoderFwdDesc(Structure):
                 ("drop_p", c_float), ("eps", c_float), ("scale", c_float)]
 
 
-class EncTailFwdDesc(Structure):
-    _PTRS = ("o", "x32", "Wo", "W1", "W2", "bo", "b1", "b2", "g1", "be1", "g2", "be2", "pos", "Wqk", "Wv", "bqk", "bv",
-             "t", "mean1", "rstd1", "x1_16", "hdn", "t2", "mean2", "rstd2", "x2_32", "x2_16", "x2p16", "qk", "v")
-    _fields_ = [(n, c_void_p) for n in _PTRS] + [("M", c_int32), ("F", c_int32), ("eps", c_float), ("drop_p", c_float),
-                                                 ("seed_d1", c_uint32), ("seed_dh", c_uint32), ("seed_d2", c_uint32),
-                                                 ("seed_dev", c_void_p), ("mode", c_int32), ("reserved", c_int32), ("x1_32", c_void_p)]
-
-
-class EncTailBwdDesc(Structure):
-    _PTRS = ("dy", "dy2", "t2", "mean2", "rstd2", "g2", "hdn", "WT2", "WT1", "WTo", "t", "mean1", "rstd1", "g1",
-             "dt2b", "dhdn", "dtb", "d_o", "dt", "part2", "part1")
-    _fields_ = [(n, c_void_p) for n in _PTRS] + [("M", c_int32), ("F", c_int32), ("drop_p", c_float), ("gate_scale", c_float),
-                                                 ("seed_d1", c_uint32), ("seed_d2", c_uint32), ("seed_dev", c_void_p),
-                                                 ("mode", c_int32), ("reserved", c_int32), ("dx1", c_void_p)]
-
-
-
 class QencFwdDesc(Structure):
     _PTRS = ("mem16", "mem32", "ctx", "W1", "W2", "W3", "Wc", "Wf0", "Wf4", "b1", "b2", "b3", "bc", "bf0", "bf4",
              "gc", "betc", "g1", "bet1", "g5", "bet5", "qembed", "seed_dev",
@@ -380,8 +363,6 @@ _SIGNATURES = {
     "rt_decoder_fwd": (c_int, [POINTER(DecoderFwdDesc), c_void_p]),
     "rt_decoder_bwd": (c_int, [POINTER(DecoderBwdDesc), c_void_p]),
     "rt_decoder_trace": (c_int, [c_void_p]),
-    "rt_enc_tail_fwd": (c_int, [POINTER(EncTailFwdDesc), c_void_p]),
-    "rt_enc_tail_bwd": (c_int, [POINTER(EncTailBwdDesc), c_void_p]),
     "rt_decoder_supported": (c_int, [c_int]),
     "rt_decoder_set_spin": (c_int, [c_int]),
     "rt_counter_add_if_zero": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p]),
@@ -1216,42 +1197,6 @@ def mark(name):
     if ent is None:
         ent = m["names"][name] = (len(m["names"]), torch.cuda.current_stream().cuda_stream)
     stamp(m["buf"], ent[0])
-
-
-def enc_tail_fwd(*, M, F, eps, drop_p, seeds, mode=0, x1_32=None, **t):
-    """rt_enc_tail_fwd: keyword tensors = EncTailFwdDesc._PTRS (missing / None = NULL); seeds = (d1, dh, d2) dropout sites;
-    mode 1: out_proj + residual + norm1 only (x1_32 = norm1's fp32 output)."""
-    d = EncTailFwdDesc()
-    for n in EncTailFwdDesc._PTRS:
-        setattr(d, n, _p(t.get(n)))
-    assert not (set(t) - set(EncTailFwdDesc._PTRS)), set(t) - set(EncTailFwdDesc._PTRS)
-    d.mode, d.x1_32 = mode, _p(x1_32)
-    d.M, d.F, d.eps, d.drop_p = M, F, eps, drop_p
-    d.seed_d1, d.seed_dh, d.seed_d2 = (x & 0xFFFFFFFF for x in seeds)
-    d.seed_dev = _seedp(drop_p)
-    nproj = 3 if (t.get("qk") is not None and mode == 0) else 0
-    # the launch belongs to the GEMM family of bench.py's roofline: out_proj + linear1 + linear2 (+ the next layer's projections);
-    # compulsory bytes = the weights once + the row tensors it reads / writes once
-    Fe = F if mode == 0 else 0
-    flops = 2.0 * M * 256 * (256 * (1 + nproj) + 2 * Fe)
-    nbytes = 2.0 * (256 * 256 * (1 + nproj) + 2 * 256 * Fe) + M * (2 * 256 + 4 * 256 + 2 * Fe + 3 * 2 * 256 + 3 * 4 * 256 + nproj * 2 * 256)
-    _timed("enc_tail_fwd", flops, lambda: _check(lib().rt_enc_tail_fwd(ctypes.byref(d), _stream()), "rt_enc_tail_fwd"), nbytes=nbytes)
-
-
-def enc_tail_bwd(*, M, F, drop_p, gate_scale, seeds, mode=0, dx1=None, **t):
-    """rt_enc_tail_bwd: keyword tensors = EncTailBwdDesc._PTRS; seeds = (d1, d2); mode 1: norm1 backward + out_proj^T from dx1."""
-    d = EncTailBwdDesc()
-    for n in EncTailBwdDesc._PTRS:
-        setattr(d, n, _p(t.get(n)))
-    assert not (set(t) - set(EncTailBwdDesc._PTRS)), set(t) - set(EncTailBwdDesc._PTRS)
-    d.mode, d.dx1 = mode, _p(dx1)
-    d.M, d.F, d.drop_p, d.gate_scale = M, F, drop_p, gate_scale
-    d.seed_d1, d.seed_d2 = (x & 0xFFFFFFFF for x in seeds)
-    d.seed_dev = _seedp(drop_p)
-    Fe = F if mode == 0 else 0
-    flops = 2.0 * M * 256 * (256 + 2 * Fe)
-    nbytes = 2.0 * (256 * 256 + 2 * 256 * Fe) + M * (3 * 4 * 256 + 2 * 2 * Fe + 3 * 2 * 256 + 4 * 256)
-    _timed("enc_tail_bwd", flops, lambda: _check(lib().rt_enc_tail_bwd(ctypes.byref(d), _stream()), "rt_enc_tail_bwd"), nbytes=nbytes)
 
 
 def decoder_supported(F=2048):

@@ -208,17 +208,13 @@ class Net:
                                self.G(pfx + "weight"), self.G(pfx + "bias"), pg_batch=self.ln_batch, **kw)
 
     # ------------------------------------------------------------------ BERT
-    def bert_fwd(self, ids, mask_u8, gates=None):
+    def bert_fwd(self, ids, mask_u8):
         """ids int64 [B, L], mask uint8 [B, L] (1 = token).  Returns (seq bf16 [B*L, Hd], pooled bf16 [B, Hd], ctx)."""
         bc = self.cfg.bert
         B, L = ids.shape
         M, Hd = B * L, bc.hidden
         pfx = "lang_backbone."
         e = pfx + "embeddings."
-        # gates {first layer: event}: the pipelined optimizer's piece that holds layers [i, next key) (and, for 0, the embeddings;
-        # for the last, the pooler) has been applied once the event has passed
-        if gates and 0 in gates:
-            torch.cuda.current_stream().wait_event(gates[0])
         kpm = (mask_u8 == 0).to(torch.uint8)
         pos_ids = H.roberta_pos_ids(ids, bc.pad_idx) if bc.pad_idx >= 0 else None
         emb = H.bert_embed_fwd(ids, self.P(e + "word_embeddings.weight"), self.P(e + "position_embeddings.weight"),
@@ -230,8 +226,6 @@ class Net:
         scale = 1.0 / math.sqrt(dh)
         for i in range(bc.layers):
             lp = f"{pfx}encoder.layer.{i}."
-            if gates and i > 0 and i in gates:
-                torch.cuda.current_stream().wait_event(gates[i])
             r = {"h16": h16}
             qkv, _ = self.lin_fwd(lp + "qkv", h16)
             r["qkv"] = qkv
@@ -327,26 +321,10 @@ class Net:
         return of if dx_f32 else ob
 
     # ------------------------------------------------------------------ encoder layer (transformer.py:168-181)
-    def enc_fuse_ok(self):
-        """The row-local part of an encoder layer as one launch per direction (rt_enc_tail_fwd / rt_enc_tail_bwd): the reference's
-        width, a feed-forward width in whole 256-unit chunks.  OFF by default (REFTR_ENC_FUSE=1 turns it on): measured slower than the
-        launched chain at configs[1]'s M = 3520 rows -- a row block's workgroup streams the layer's whole 2.6 MB of weights through ONE
-        compute unit's LDS-DMA path, which delivers ~32 KB/us: 80.5 / 71 us per layer against 78 / 72 us for the chain's 6 + 5 launches
-        (profiles/r04_enc_fused_negative_result.txt).  Kept: correct (tests/test_encoder_fused_gpu.py), and the right shape once a row
-        block can be split over compute units."""
-        cfg = self.cfg
-        return (os.environ.get("REFTR_ENC_FUSE", "0") == "1" and str(self.store.device).startswith("cuda")
-                and cfg.hidden == 256 and cfg.ffn >= 256 and cfg.ffn % 256 == 0)
-
-    def enc_fuse_attn_tail(self):
-        """REFTR_ENC_FUSE=2: only out_proj + residual + norm1 (forward) and norm1' + out_proj^T (backward) go through the fused launch
-        (mode 1: 128 KB of weights per row block instead of 2.6 MB); the feed-forward pair, norm2 and the projections stay launches."""
-        return (os.environ.get("REFTR_ENC_FUSE", "0") == "2" and str(self.store.device).startswith("cuda") and self.cfg.hidden == 256)
-
     def enc_layer_fwd(self, p, x32, x16, xp16, pos, kpm, B, S, qkv=None, next_p=None):
-        """One TransformerEncoderLayer (transformer.py:168-181).  `qkv`: this layer's (q|k, v) projections when the previous layer's
-        launch already produced them; `next_p`: the next layer's prefix, whose projections this layer's fused launch may produce.
-        Returns (x2_32, x2_16, x2p16, saved, next layer's (q|k, v) or None)."""
+        """One TransformerEncoderLayer (transformer.py:168-181).  `qkv` / `next_p`: unused since round 5 (they served the fused
+        row-local launch rt_enc_tail_*, measured at the launched chain's speed in round 4 and removed: LAB_NOTES.md); the fifth return
+        value is always None.  Returns (x2_32, x2_16, x2p16, saved, None)."""
         cfg = self.cfg
         E, Hh = cfg.hidden, cfg.nheads
         dh = E // Hh
@@ -363,45 +341,9 @@ class Net:
                             drop_p=r["ad"][0], drop_seed=r["ad"][1])
         r.update(qk=qk, v=v, o=o, lse=lse)
         r["d1"] = self._drop(cfg.dropout)
-        if self.enc_fuse_ok():
-            # out_proj + residual -> norm1 -> linear1 -> linear2 + residual -> norm2 (+ pos) [-> next layer's q|k, v]: ONE launch
-            r["dh"] = self._drop(cfg.dropout)
-            r["d2"] = self._drop(cfg.dropout)
-            M, F, dev = B * S, cfg.ffn, x32.device
-            f32, bf = torch.float32, torch.bfloat16
-            out32 = torch.empty(3, M, E, dtype=f32, device=dev)             # t, t2, x2
-            out16 = torch.empty(3, M, E, dtype=bf, device=dev)              # x1, x2, x2 + pos
-            stats = torch.empty(4, M, dtype=f32, device=dev)
-            hdn = torch.empty(M, F, dtype=bf, device=dev)
-            L = self.lins
-            kw = {}
-            nxt = None
-            if next_p is not None:
-                nxt = (torch.empty(M, 2 * E, dtype=bf, device=dev), torch.empty(M, E, dtype=bf, device=dev))
-                kw = dict(Wqk=L[next_p + "self_attn.qk"].W, Wv=L[next_p + "self_attn.v"].W, bqk=L[next_p + "self_attn.qk"].b32,
-                          bv=L[next_p + "self_attn.v"].b32, qk=nxt[0], v=nxt[1])
-            H.enc_tail_fwd(M=M, F=F, eps=1e-5, drop_p=r["d1"][0], seeds=(r["d1"][1], r["dh"][1], r["d2"][1]),
-                           o=o, x32=x32, Wo=L[p + "self_attn.out_proj."].W, W1=L[p + "linear1."].W, W2=L[p + "linear2."].W,
-                           bo=L[p + "self_attn.out_proj."].b32, b1=L[p + "linear1."].b32, b2=L[p + "linear2."].b32,
-                           g1=self.P(p + "norm1.weight"), be1=self.P(p + "norm1.bias"), g2=self.P(p + "norm2.weight"),
-                           be2=self.P(p + "norm2.bias"), pos=pos, t=out32[0], mean1=stats[0], rstd1=stats[1], x1_16=out16[0],
-                           hdn=hdn, t2=out32[1], mean2=stats[2], rstd2=stats[3], x2_32=out32[2], x2_16=out16[1], x2p16=out16[2], **kw)
-            r.update(t=out32[0], st1=(stats[0], stats[1]), x1_16=out16[0], hdn=hdn, t2=out32[1], st2=(stats[2], stats[3]), fused=True)
-            return out32[2], out16[1], out16[2], r, nxt
-        if self.enc_fuse_attn_tail():
-            M, dev = B * S, x32.device
-            o32 = torch.empty(2, M, E, dtype=torch.float32, device=dev); x1_16 = torch.empty(M, E, dtype=torch.bfloat16, device=dev)
-            st = torch.empty(2, M, dtype=torch.float32, device=dev)
-            L = self.lins
-            H.enc_tail_fwd(M=M, F=cfg.ffn, eps=1e-5, drop_p=r["d1"][0], seeds=(r["d1"][1], 0, 0), mode=1, o=o, x32=x32,
-                           Wo=L[p + "self_attn.out_proj."].W, bo=L[p + "self_attn.out_proj."].b32, g1=self.P(p + "norm1.weight"),
-                           be1=self.P(p + "norm1.bias"), t=o32[0], mean1=st[0], rstd1=st[1], x1_16=x1_16, x1_32=o32[1])
-            t, x1_32, m1, r1 = o32[0], o32[1], st[0], st[1]
-            r["fused_attn_tail"] = True
-        else:
-            _, t = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=x32,
-                                out_bf16=False, out_f32=True)
-            x1_32, x1_16, _, m1, r1 = self.ln_fwd(t, p + "norm1.")
+        _, t = self.lin_fwd(p + "self_attn.out_proj.", o, drop_p=r["d1"][0], drop_seed=r["d1"][1], res_f32=x32,
+                            out_bf16=False, out_f32=True)
+        x1_32, x1_16, _, m1, r1 = self.ln_fwd(t, p + "norm1.")
         r.update(t=t, st1=(m1, r1), x1_16=x1_16)
         r["dh"] = self._drop(cfg.dropout)
         hdn, _ = self.lin_fwd(p + "linear1.", x1_16, act=RELU, drop_p=r["dh"][0], drop_seed=r["dh"][1])
@@ -423,50 +365,11 @@ class Net:
         gs = 1.0 / (1.0 - r["dh"][0]) if r["dh"][0] > 0 else 1.0
         if getattr(self, "_dbg_enc", None) is not None:          # tests: the gradient that enters the layer
             self._dbg_enc.append((dx2 if dx2b is None else dx2 + dx2b).detach().clone())
-        if self.enc_fuse_ok() and self.ln_batch is not None and self.big_wg is not None:
-            # norm2 backward -> linear2^T (gate) -> linear1^T + residual -> norm1 backward -> out_proj^T: ONE launch (rt_enc_tail_bwd);
-            # it leaves the weight-gradient operands and the LayerNorm parameter-gradient partials for the grouped launches
-            F, dev = cfg.ffn, dx2.device
-            bf = torch.bfloat16
-            nb = (M + 31) // 32
-            g16 = torch.empty(3, M, E, dtype=bf, device=dev)               # dt2b, dtb, do
-            dhdn = torch.empty(M, F, dtype=bf, device=dev)
-            dt = torch.empty(M, E, dtype=torch.float32, device=dev)
-            parts = torch.empty(2, nb, 2, E, dtype=torch.float32, device=dev)
-            L = self.lins
-            H.enc_tail_bwd(M=M, F=F, drop_p=r["d1"][0], gate_scale=gs, seeds=(r["d1"][1], r["d2"][1]), dy=dx2, dy2=dx2b,
-                           t2=r["t2"], mean2=r["st2"][0], rstd2=r["st2"][1], g2=self.P(p + "norm2.weight"), hdn=r["hdn"],
-                           WT2=L[p + "linear2."].WT, WT1=L[p + "linear1."].WT, WTo=L[p + "self_attn.out_proj."].WT,
-                           t=r["t"], mean1=r["st1"][0], rstd1=r["st1"][1], g1=self.P(p + "norm1.weight"),
-                           dt2b=g16[0], dhdn=dhdn, dtb=g16[1], d_o=g16[2], dt=dt, part2=parts[0], part1=parts[1])
-            self._wgrad_only(p + "linear2.", g16[0], r["hdn"])
-            self._wgrad_only(p + "linear1.", dhdn, r["x1_16"])
-            self._wgrad_only(p + "self_attn.out_proj.", g16[1], r["o"])
-            for j, nm in ((0, "norm2."), (1, "norm1.")):
-                self.ln_batch.jobs.append(H.LnPgJob(parts[j].data_ptr(), self.G(p + nm + "weight").data_ptr(),
-                                                    self.G(p + nm + "bias").data_ptr(), nb, E))
-                self.ln_batch.keep.append(parts[j])
-            do = g16[2]
-        else:
-            dt2, dt2b = self.ln_bwd(dx2, r["t2"], p + "norm2.", *r["st2"], dy2=dx2b, drop2_p=r["d2"][0], drop2_seed=r["d2"][1])
-            dhdn, _ = self.lin_bwd(p + "linear2.", dt2b, r["hdn"], gate=r["hdn"], gate_scale=gs)
-            _, dx1 = self.lin_bwd(p + "linear1.", dhdn, r["x1_16"], res_f32=dt2, out_bf16=False, out_f32=True)
-            if self.enc_fuse_attn_tail() and self.ln_batch is not None and self.big_wg is not None:
-                nb = (M + 31) // 32
-                g16 = torch.empty(2, M, E, dtype=torch.bfloat16, device=dx1.device)               # dtb, do
-                dt = torch.empty(M, E, dtype=torch.float32, device=dx1.device)
-                part = torch.empty(nb, 2, E, dtype=torch.float32, device=dx1.device)
-                H.enc_tail_bwd(M=M, F=cfg.ffn, drop_p=r["d1"][0], gate_scale=1.0, seeds=(r["d1"][1], 0), mode=1, dx1=dx1, t=r["t"],
-                               mean1=r["st1"][0], rstd1=r["st1"][1], g1=self.P(p + "norm1.weight"),
-                               WTo=self.lins[p + "self_attn.out_proj."].WT, dtb=g16[0], d_o=g16[1], dt=dt, part1=part)
-                self._wgrad_only(p + "self_attn.out_proj.", g16[0], r["o"])
-                self.ln_batch.jobs.append(H.LnPgJob(part.data_ptr(), self.G(p + "norm1.weight").data_ptr(),
-                                                    self.G(p + "norm1.bias").data_ptr(), nb, E))
-                self.ln_batch.keep.append(part)
-                do = g16[1]
-            else:
-                dt, dtb = self.ln_bwd(dx1, r["t"], p + "norm1.", *r["st1"], drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
-                do, _ = self.lin_bwd(p + "self_attn.out_proj.", dtb, r["o"])
+        dt2, dt2b = self.ln_bwd(dx2, r["t2"], p + "norm2.", *r["st2"], dy2=dx2b, drop2_p=r["d2"][0], drop2_seed=r["d2"][1])
+        dhdn, _ = self.lin_bwd(p + "linear2.", dt2b, r["hdn"], gate=r["hdn"], gate_scale=gs)
+        _, dx1 = self.lin_bwd(p + "linear1.", dhdn, r["x1_16"], res_f32=dt2, out_bf16=False, out_f32=True)
+        dt, dtb = self.ln_bwd(dx1, r["t"], p + "norm1.", *r["st1"], drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
+        do, _ = self.lin_bwd(p + "self_attn.out_proj.", dtb, r["o"])
         qk, v = r["qk"], r["v"]
         dqk = torch.empty_like(qk)
         _, _, dv = H.attn_bwd(qk[:, :E], qk[:, E:], v, r["o"], do, r["lse"], kpm, B=B, H=Hh, Sq=S, Sk=S, dh=dh,

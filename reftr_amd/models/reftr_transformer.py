@@ -93,32 +93,17 @@ class RefTR(nn.Module):
         # single-process captured training step: the BERT slice's share of the gradient norm is taken on the language stream as
         # soon as that slice is final (see _backward_gen); (begin, end, device scalar) for the optimizer, None when not taken.
         # Anything that edits the gradient buffer between backward and the clip (gradient surgery, an exchange) must leave it off.
-        # measured (profiles/r03_side_stream_probes.txt): the main-slice AdamW pass beside the frozen stem / layer1 instead of in
-        # front of them changes nothing (7.295 vs 7.295 ms over four interleaved pairs) -- both are HBM-bound; off by default
-        self._pre_side = os.environ.get("REFTR_PRE_SIDE", "0") != "0"
-        self._opt_serial = os.environ.get("REFTR_OPT_SERIAL", "0") != "0"
-        # the main slice's deferred AdamW pass BEHIND the frozen stem / layer1 (in front of the first trainable convolution) instead
-        # of in front of the stem: the frozen prefix shares the memory system with the BERT slice's pass from t = 0.  Measured
-        # (profiles/r04z_opt_late_negative_result.txt): layer1 is done at 0.92 instead of 1.15 ms, but the pass then takes 0.33 ms
-        # beside BERT's forward and layer2 starts at 1.25 ms: 6.76-6.81 vs 6.66-6.72 ms.  Off.
-        self._opt_late = os.environ.get("REFTR_OPT_LATE", "0") != "0"
-        self._late_hook = None
-        # pipelined deferred optimizer: every AdamW piece on a third stream, consumers wait per piece (forward).  Measured
-        # (profiles/r04s_opt_pipe_negative_result.txt): BERT's forward then ends 0.5 ms earlier and the ResNet's 0.4 ms LATER (three
-        # streams share the chip; layer2 alone goes 469 -> 1004 us beside BERT's forward): 7.28-7.33 vs 7.01-7.04 ms.  Off.
-        self._opt_pipe = os.environ.get("REFTR_OPT_PIPE", "0") != "0"
-        self.opt_side = H.SideStream(self._opt_pipe)
+        # (Rounds 3-4 measured four other placements of the deferred AdamW passes -- beside the frozen prefix (REFTR_PRE_SIDE), behind it
+        # (REFTR_OPT_LATE), serialised in front of it (REFTR_OPT_SERIAL), in five pieces on a third stream (REFTR_OPT_PIPE) -- all
+        # neutral or slower (profiles/r03_side_stream_probes.txt, r04s_*, r04z_*); their code was removed in round 5, LAB_NOTES.md.)
         self._stem_first = int(os.environ.get("REFTR_STEM_FIRST", "1"))
         self._lang_tail = os.environ.get("REFTR_LANG_TAIL", "1") != "0"
         self._lang_tail_bwd_phrase = os.environ.get("REFTR_LANG_TAIL", "1") != "2"      # 2: map_phrase's backward stays on the main stream
-        self._bert_gates = None
-        self._adam_done = None
         self._bb_ready = None
         self._norm_side = False          # switched on by engine_vg.CapturedTrainStep around its own backward + clip-norm unit only
         self._norm_split = None
         self._sq_bert = torch.zeros(1, dtype=torch.float32, device=device)
         self._flush_pending = None
-        self._zero_grad_side = False      # engine-driven: clear the gradient buffer on the language stream under the encoder
         self._pending = None
         self.reset_parameters()
 
@@ -313,54 +298,16 @@ class RefTR(nn.Module):
         pre-sigmoid box logits [NL, B, P, K, 4] without an autograd node and without the sigmoid of `pred_boxes`, which nothing in
         a training iteration reads (engine_vg.py:40-60 only consumes the criterion's losses); the caller owns the backward."""
         self._bb_ready = None
-        self._late_hook = None
         H.mark("step start")
-        self._bert_gates = None
-        if self._pre_update is not None and self._opt_pipe and len(self._pre_update) > 2 and self.net.side.enabled \
-                and self.opt_side.enabled and not self._full_refresh and not self._operands_dirty:
-            # Deferred optimizer, pipelined: [main slice | BERT embeddings + layers 0-2 | 3-5 | 6-8 | 9-11 + pooler] on the optimizer
-            # stream.  Nothing on the main stream waits here: the frozen stem / layer1 start at once, the first trainable
-            # convolution waits for the main piece (body.forward `ready`), BERT layer i for the piece that holds it (_bert_gates).
-            gates, state = {}, {"ok": True}
-            def _chain():
-                for fn, tag in self._pre_update[2]:
-                    state["ok"] = bool(fn()) and state["ok"]
-                    if tag == "main":
-                        self.net._refresh_kv_cat()
-                    ev = torch.cuda.Event(); ev.record()
-                    gates[tag] = ev
-                    H.mark("opt: main slice done" if tag == "main" else f"opt: BERT piece from layer {tag} done")
-            self.opt_side.run(_chain)
-            if not state["ok"]:                 # a piece did not write its operands (not expected here): refresh behind the whole chain
-                self.opt_side.join()
+        if self._pre_update is not None:
+            # the pending (deferred) AdamW pass over the main / mask / ResNet slices; when it wrote the bf16 operands itself
+            # (rt_adamw_mat) nothing is dirty.  The BERT slice's pass opens the language branch (_forward_impl).
+            if not self._pre_update[0]():
                 self.mark_dirty()
-            else:
-                self._bb_ready = gates.pop("main")
-                self._bert_gates = gates
-        elif self._pre_update is not None and self._opt_late and self.net.side.enabled and not self._full_refresh \
-                and not self._operands_dirty and getattr(self, "_late_ok", True):
-            self._late_hook = self._pre_update[0]          # issued by body.forward in front of the first trainable block
-        elif self._pre_update is not None:
-            if self._pre_side and self.net.side.enabled and not self._full_refresh:
-                # Deferred optimizer: the pending AdamW pass over the main / mask / ResNet slices and the refresh of the trainable
-                # convolutions' operands go to the language stream (in front of the BERT slice's pass): the stem and layer1 are
-                # frozen, so the ResNet's forward starts at once and only its first trainable block waits (body.forward).
-                def _pre_main():
-                    if not self._pre_update[0]():
-                        self.mark_dirty()
-                    self.refresh_operands()
-                self.net.side.run(_pre_main)
-                self._bb_ready = torch.cuda.Event()
-                self._bb_ready.record(self.net.side.stream)
-            else:
-                # the pending AdamW pass; when it wrote the bf16 operands itself (rt_adamw_mat) nothing is dirty
-                if not self._pre_update[0]():
-                    self.mark_dirty()
         elif self._flush_pending is not None:
             self._flush_pending()
         self.refresh_operands()
-        if self._late_hook is None:
-            H.mark("AdamW (main slice) + operands done")
+        H.mark("AdamW (main slice) + operands done")
         pred_masks = None
         if _logits_only:
             assert self.seg is None
@@ -426,25 +373,14 @@ class RefTR(nn.Module):
 
         def _lang_branch():
             H.mark("lang: branch starts")
-            if self._bert_gates is not None:
-                pass                           # the optimizer stream holds every piece; bert_fwd waits per piece
-            elif self._pre_update is not None and self._pre_update[1]():
-                if self._late_hook is None:
-                    net._refresh_kv_cat()      # operands written by the AdamW passes (this one and the main stream's, which is ordered in front of this branch)
-            if self._pre_update is not None and self._opt_serial:
-                # the BERT slice's AdamW pass (3.5 GB) and the frozen stem / layer1 (HBM-bound too) do not share the memory system
-                # well: side by side they took 1080 + 1075 us against ~600 + ~85 us alone (profiles/r04a_concurrent_timeline.txt).
-                # The ResNet forward waits for this event; BERT's forward then runs beside it instead.
-                self._adam_done = torch.cuda.Event()
-                self._adam_done.record()
+            if self._pre_update is not None and self._pre_update[1]():
+                net._refresh_kv_cat()          # operands written by the AdamW passes (this one and the main stream's, which is ordered in front of this branch)
             if self._lin_refresh_pending:
                 net.refresh()
                 self._lin_refresh_pending = False
             H.mark("lang: AdamW (BERT slice) + operands done")
-            r = net.bert_fwd(ids, smask_u8, gates=self._bert_gates)
+            r = net.bert_fwd(ids, smask_u8)
             H.mark("lang: BERT forward done")
-            if self._late_hook is not None:
-                return r                       # the positional work reads main-slice parameters: it is forked behind their update
             res = r + _pos_work()
             if self._lang_tail:
                 # what only BERT's outputs feed -- map_sentence into the language rows of the sequence, and with one phrase per image
@@ -481,50 +417,24 @@ class RefTR(nn.Module):
                 pos.view(B, S, E)[:, Lq:, :] = pe
             H.mark("lang: positional / mask work done")
             return (pos, kpm)
-        self._adam_done = None
-        late = self._late_hook
         # REFTR_STEM_FIRST=1: the language branch is forked BEHIND the frozen stem (rt_stem_pool: two 72-KB / 230-VGPR workgroups per
         # CU, which find no room beside the BERT slice's AdamW pass once that has filled the chip) instead of in front of it
-        stem_first = self._stem_first if (late is None and self.body.fuse_stem) else 0       # 2: behind frozen layer1 as well
+        stem_first = self._stem_first if self.body.fuse_stem else 0       # 2: behind frozen layer1 as well
         lang_box = []
         def _fork_lang():
             lang_box.append(net.side.run(_lang_branch, ids, smask_u8, mask_u8))
-            if self._adam_done is not None and net.side.enabled:
-                torch.cuda.current_stream().wait_event(self._adam_done)
         if not stem_first:
             _fork_lang()
-        late_out = []
-        def _late_main():
-            # main stream, behind the frozen stem / layer1: the main slice's pending AdamW pass (it writes the bf16 operands), the
-            # K-concatenated copies, then the positional work -- forked here, it queues on the language stream behind BERT's forward
-            if not late():
-                raise RuntimeError("the deferred AdamW pass did not write the bf16 operands (REFTR_OPT_EMIT=0?): run with REFTR_OPT_LATE=0")
-            net._refresh_kv_cat()
-            H.mark("AdamW (main slice) + operands done")
-            late_out.append(net.side.run(_pos_work, mask_u8, smask_u8))
-        feats, bb_saved = self.body.forward(x, ready=self._bb_ready,
-                                            before_trainable=_late_main if late is not None else (_fork_lang if stem_first == 2 else None),
+        feats, bb_saved = self.body.forward(x, ready=self._bb_ready, before_trainable=_fork_lang if stem_first == 2 else None,
                                             after_stem=_fork_lang if stem_first == 1 else None)
         if not lang_box:                       # no trainable block fired the hook (--lr_backbone 0)
             _fork_lang()
-        lang_out = lang_box[0]
-        seq16, pooled16, bctx, pos, kpm = lang_out + late_out[0] if late is not None else lang_out
+        seq16, pooled16, bctx, pos, kpm = lang_box[0]
         c5, (_, h5, w5) = feats[-1]
         assert (h5, w5) == (h, w)
         H.mark("ResNet forward done")
-        if self._bert_gates is not None:
-            if self._bb_ready is not None:     # nothing trainable in the ResNet waited for the main piece (--lr_backbone 0)
-                torch.cuda.current_stream().wait_event(self._bb_ready)
-            self.opt_side.join()
         net.side.join()
         H.mark("forward join (language branch in)")
-        if self._zero_grad_side == 2:
-            # the clear in front of backward (the 4 % of the buffer that is accumulated with atomics + the norm slots: ~20 us of
-            # launches between the loss and the first backward kernel) on the idle language stream instead; backward joins
-            net.side.run(st.zero_for_backward)
-        elif self._zero_grad_side:
-            # 607 MB of zeros: off the critical path, under the (latency-bound) encoder / decoder forward; backward joins
-            net.side.run(st.flat_g.zero_)
         if "ms_ctx" in lang_tail:
             ms_ctx = lang_tail["ms_ctx"]
         else:
@@ -893,8 +803,6 @@ class RefTR(nn.Module):
         E = cfg.hidden
         dev = st.device
         H.set_seed_dev(self.seed_dev)
-        if self._zero_grad_side:
-            net.side.join()
         B, S, Lq, HW, Pn, N, T, NL = (sv[k] for k in ("B", "S", "Lq", "HW", "Pn", "N", "T", "NL"))
         vt, qe = "vl_transformer.", "query_encoder."
         M = B * S

@@ -58,7 +58,6 @@ def test_struct_layouts_match_header(built):
                "rt_small_wgrad_job": hip.SmallWgradJob, "rt_ln_pg_job": hip.LnPgJob,
                "rt_mask_post_desc": hip.MaskPostDesc, "rt_box_post_desc": hip.BoxPostDesc, "rt_cem_desc": hip.CemDesc,
                "rt_decoder_fwd_desc": hip.DecoderFwdDesc, "rt_decoder_bwd_desc": hip.DecoderBwdDesc,
-               "rt_enc_tail_fwd_desc": hip.EncTailFwdDesc, "rt_enc_tail_bwd_desc": hip.EncTailBwdDesc,
                "rt_bottleneck_desc": hip.BottleneckDesc, "rt_qenc_fwd_desc": hip.QencFwdDesc,
                "rt_head_loss_desc": hip.HeadLossDesc, "rt_qenc_bwd_desc": hip.QencBwdDesc}
     assert sorted(binding) == names

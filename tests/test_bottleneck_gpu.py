@@ -51,7 +51,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("form", [1, 2, 3])
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("B,H,W,cin,down", CASES)
 def test_fused_bottleneck_vs_torch(hip, B, H, W, cin, down, form):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + cin)
@@ -76,7 +76,7 @@ def test_fused_bottleneck_vs_torch(hip, B, H, W, cin, down, form):
     assert float((o[:, ring] - ref[:, ring]).norm() / ref[:, ring].norm()) < 4e-3
 
 
-@pytest.mark.parametrize("form", [1, 2, 3])
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("B,H,W,cin,down", [(2, 24, 40, 256, False), (2, 24, 40, 64, True), (8, 160, 160, 256, False), (8, 160, 160, 64, True),
                                             (5, 100, 100, 256, False), (5, 100, 100, 64, True)])
 def test_fused_bottleneck_vs_the_launches_it_replaces(hip, B, H, W, cin, down, form):
@@ -117,17 +117,16 @@ def test_fused_bottleneck_rejects_what_it_does_not_implement(hip):
 
 
 @pytest.mark.parametrize("B,H,W,cin,down", [(3, 37, 53, 256, False), (3, 37, 53, 64, True)])
-def test_the_forms_agree(hip, B, H, W, cin, down):
-    """Same MFMA shapes, same K order per output element, same rounding points: the three forms are
-    bit-identical (a tile's result does not depend on which workgroup computed it, nor on what the workgroup computed before)."""
+def test_two_launches_are_bit_identical_and_removed_forms_are_rejected(hip, B, H, W, cin, down):
+    """A tile's result does not depend on which workgroup computed it: two launches agree bit for bit.  The persistent / 8-wave
+    forms of round 4 (desc.form = 2, 3: correct, bit-identical, slower) were removed in round 5: asking for them is an error."""
     g = torch.Generator(device="cuda").manual_seed(11)
     x = torch.relu(torch.randn(B, H, W, cin, generator=g, device="cuda")).bfloat16()
     w1, b1, w2, b2, w3, b3, wd, bd = [t.cuda() if t is not None else None for t in make_block(cin, down, seed=5)]
     a = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=1)
-    b = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=2)
-    c = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=2)
-    d = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=3)
+    b = hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=0)
     torch.cuda.synchronize()
-    assert torch.equal(b, c)
     assert torch.equal(a, b)
-    assert torch.equal(a, d)
+    for form in (2, 3):
+        with pytest.raises(RuntimeError):
+            hip.bottleneck_fwd(x, w1, b1, w2.view(64, 9, 64), b2, w3, b3, wd=wd, bd=bd, form=form)

@@ -197,9 +197,13 @@ def test_dp_wrapper_on_the_c_abi_exchange_matches_the_torch_distributed_one(hip,
         opt = FusedAdamW(model, lr=1e-4, lr_backbone=1e-5, weight_decay=1e-4)
         runner = DistributedDataParallel(model)
         assert (runner.comm is not None) == (mode == "abi")
-        res = [train_step(runner, crit, s, tg, opt, None, max_norm=0.1) for _ in range(3)]
+        res, gn0 = [], None
+        for it in range(3):
+            res.append(train_step(runner, crit, s, tg, opt, None, max_norm=0.1))
+            if it == 0:
+                gn0 = float(res[0][3])        # the optimizer's device scalar: the next step overwrites it (read it now, not after step 3)
         torch.cuda.synchronize()
-        out[mode] = ([r[0] for r in res], float(res[0][3]), model.store.flat_p.clone())
+        out[mode] = ([r[0] for r in res], gn0, model.store.flat_p.clone())
         if runner.comm is not None:
             runner.comm.destroy()
     (lt, gt, pt), (la, ga, pa) = out["torch"], out["abi"]

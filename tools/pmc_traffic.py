@@ -13,7 +13,7 @@ bytes of wide coalesced reads (128-B requests tallied at 64 B), so fetch bytes =
 calibrates 1:1 on this run's own 607 MB gradient-buffer fill (592832 KB reported)."""
 import argparse, json, re, sqlite3
 
-FAMILY = re.compile(r"conv_gemm|conv_wgrad|wgrad_reduce|skinny_gemm|small_m_wgrad|w2_grouped|w2_reduce|enc_tail|bottleneck_")
+FAMILY = re.compile(r"conv_gemm|conv_wgrad|wgrad_reduce|skinny_gemm|small_m_wgrad|w2_grouped|w2_reduce|bottleneck_")
 
 
 def per_kernel(dbpath):
