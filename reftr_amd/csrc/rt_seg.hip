@@ -72,8 +72,12 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(const rt_gn_nhwc_des
     }
 }
 
-// backward, pass 1: bstats[b][g] = {sum g, sum g*xhat} with g = dy*gamma (dy through the ReLU mask); dgamma / dbeta
-__global__ __launch_bounds__(256) void gn_nhwc_bstats_kernel(const rt_gn_nhwc_bwd_desc p, int pix_per_block) {
+// backward, pass 1: bstats[b][g] = {sum g, sum g*xhat} with g = dy*gamma (dy through the ReLU mask); dgamma / dbeta.
+// Round 5: a thread OWNS its channel(s) -- lane = channel (coalesced rows), 256 / CP pixel rows per pass for narrow layers -- and keeps
+// the four sums of a channel in registers over the block's pixels; LDS sees one atomic per thread and sum at the end (round 4 issued
+// four LDS atomics per ELEMENT, two of them onto the group's pair of words: 93-103 us per layer whatever its size, 0.49 ms per step
+// of configs[3]).  CP = channels per pass: C when C divides 256, else 256 (wide layers walk their channels in passes of 256).
+__global__ __launch_bounds__(256) void gn_nhwc_bstats_kernel(const rt_gn_nhwc_bwd_desc p, int pix_per_block, int CP) {
     __shared__ float sm[2 * 64];
     extern __shared__ float dgb[];         // [2][C]
     const int b = blockIdx.y;
@@ -83,19 +87,24 @@ __global__ __launch_bounds__(256) void gn_nhwc_bstats_kernel(const rt_gn_nhwc_bw
     for (int i = threadIdx.x; i < 2 * p.G; i += 256) sm[i] = 0.f;
     for (int i = threadIdx.x; i < 2 * p.C; i += 256) dgb[i] = 0.f;
     __syncthreads();
-    const int total = (p1 - p0) * p.C;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int pix = e / p.C, c = e - pix * p.C;
+    const int cl = threadIdx.x % CP, prow = threadIdx.x / CP, rows = 256 / CP;
+    for (int c = cl; c < p.C; c += CP) {
         const int g = c / cpg;
-        const size_t row = (size_t)b * p.HW + p0 + pix;
         const float mean = p.stats[((size_t)b * p.G + g) * 2] * inv_n;
         const float var = fmaxf(p.stats[((size_t)b * p.G + g) * 2 + 1] * inv_n - mean * mean, 0.f);
-        const float xh = (p.x[row * p.ldx + c] - mean) * rsqrtf(var + p.eps);
-        float d = p.dy[row * p.lddy + c];
-        if (p.act == RT_ACT_RELU && xh * p.gamma[c] + p.beta[c] <= 0.f) d = 0.f;
-        atomicAdd(&dgb[c], d * xh); atomicAdd(&dgb[p.C + c], d);
-        const float gg = d * p.gamma[c];
-        atomicAdd(&sm[2 * g], gg); atomicAdd(&sm[2 * g + 1], gg * xh);
+        const float rstd = rsqrtf(var + p.eps), gam = p.gamma[c], bet = p.beta[c];
+        float a_dg = 0.f, a_db = 0.f, a_g = 0.f, a_gx = 0.f;
+        for (int pix = p0 + prow; pix < p1; pix += rows) {
+            const size_t row = (size_t)b * p.HW + pix;
+            const float xh = (p.x[row * p.ldx + c] - mean) * rstd;
+            float d = p.dy[row * p.lddy + c];
+            if (p.act == RT_ACT_RELU && xh * gam + bet <= 0.f) d = 0.f;
+            a_dg += d * xh; a_db += d;
+            const float gg = d * gam;
+            a_g += gg; a_gx += gg * xh;
+        }
+        atomicAdd(&dgb[c], a_dg); atomicAdd(&dgb[p.C + c], a_db);
+        atomicAdd(&sm[2 * g], a_g); atomicAdd(&sm[2 * g + 1], a_gx);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * p.G; i += 256) atomicAdd(p.bstats + (size_t)b * p.G * 2 + i, sm[i]);
@@ -311,36 +320,52 @@ __global__ void mask_loss_final_kernel(const float* __restrict__ sums, float* __
     losses[0] = f * inv_norm; losses[1] = d * inv_norm;
 }
 
-// dpred[b][y][x] += sum over target pixels of (w_focal * dfocal/dz + w_dice * ddice/dz) * bilinear weight
+// dpred[b][ys][xs] += sum over target pixels of (w_focal * dfocal/dz + w_dice * ddice/dz) * bilinear weight of (ys, xs) in that pixel.
+// Round 5: a GATHER -- one thread per SOURCE pixel walks the target pixels whose bilinear footprint contains it (a (2 / scale + 2)^2
+// window, each pixel's corners and weights recomputed with the same `bilin` as the forward, so exactly the scatter's terms) and
+// adds ONE value to dpred.  Round 4 scattered four global atomics per target pixel -- 13 M atomics, sixteen-fold contended at the
+// 4x upsample: 275 us per step of configs[3].
 __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const rt_mask_loss_desc p) {
     const int b = blockIdx.y;
+    const int src = blockIdx.x * 256 + threadIdx.x;
+    if (src >= p.h * p.w) return;
+    const int ys = src / p.w, xs = src - ys * p.w;
     const float sy = (float)p.h / (float)p.Ht, sx = (float)p.w / (float)p.Wt;
     const float* z = p.pred + (size_t)b * p.h * p.w * p.ldp;
     float* dz = p.dpred + (size_t)b * p.h * p.w * p.lddp;
     const int total = p.Ht * p.Wt;
     const float num = 2.f * p.sums[b * 4 + 1] + 1.f, den = p.sums[b * 4 + 2] + p.sums[b * 4 + 3] + 1.f;
     const float gf = p.g_focal[0] * p.inv_norm / (float)total, gd = p.g_dice[0] * p.inv_norm;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int y = i / p.Wt, x = i - y * p.Wt;
-        const Bilin bl = bilin(y, x, p.h, p.w, sy, sx);
-        const float v = (1.f - bl.wy) * ((1.f - bl.wx) * z[((size_t)bl.y0 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y0 * p.w + bl.x1) * p.ldp])
-                      + bl.wy * ((1.f - bl.wx) * z[((size_t)bl.y1 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y1 * p.w + bl.x1) * p.ldp]);
-        const float t = p.target[(size_t)b * total + i] ? 1.f : 0.f;
-        const float pr = 1.f / (1.f + __expf(-v));
-        const float ce = fmaxf(v, 0.f) - v * t + log1pf(__expf(-fabsf(v)));
-        const float pt = pr * t + (1.f - pr) * (1.f - t);
-        const float at = 0.25f * t + 0.75f * (1.f - t);
-        const float dpr = pr * (1.f - pr);
-        // d/dz [ce * (1-pt)^2] = (pr - t) * (1-pt)^2 - 2 ce (1-pt) * dpt/dz,  dpt/dz = (2t-1) * pr(1-pr)
-        const float dfocal = at * ((pr - t) * (1.f - pt) * (1.f - pt) - 2.f * ce * (1.f - pt) * (2.f * t - 1.f) * dpr);
-        // dice = 1 - num/den: d/dz = -(2 t den - num) / den^2 * pr(1-pr)
-        const float ddice = -(2.f * t * den - num) / (den * den) * dpr;
-        const float g = gf * dfocal + gd * ddice;
-        atomicAdd(dz + ((size_t)bl.y0 * p.w + bl.x0) * p.lddp, g * (1.f - bl.wy) * (1.f - bl.wx));
-        atomicAdd(dz + ((size_t)bl.y0 * p.w + bl.x1) * p.lddp, g * (1.f - bl.wy) * bl.wx);
-        atomicAdd(dz + ((size_t)bl.y1 * p.w + bl.x0) * p.lddp, g * bl.wy * (1.f - bl.wx));
-        atomicAdd(dz + ((size_t)bl.y1 * p.w + bl.x1) * p.lddp, g * bl.wy * bl.wx);
+    // target rows / columns whose y0 or y1 (x0 or x1) can be ys (xs): floor(f) in {s - 1, s}, one pixel of slack on both sides;
+    // the last source row / column also collects every target pixel clamped onto it
+    int ylo = (int)floorf(((float)ys - 0.5f) / sy - 0.5f) - 1, yhi = (int)ceilf(((float)ys + 1.5f) / sy - 0.5f) + 1;
+    int xlo = (int)floorf(((float)xs - 0.5f) / sx - 0.5f) - 1, xhi = (int)ceilf(((float)xs + 1.5f) / sx - 0.5f) + 1;
+    ylo = max(ylo, 0); xlo = max(xlo, 0);
+    yhi = ys == p.h - 1 ? p.Ht - 1 : min(yhi, p.Ht - 1); xhi = xs == p.w - 1 ? p.Wt - 1 : min(xhi, p.Wt - 1);
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+        for (int x = xlo; x <= xhi; ++x) {
+            const Bilin bl = bilin(y, x, p.h, p.w, sy, sx);
+            const float wyv = (bl.y0 == ys ? 1.f - bl.wy : 0.f) + (bl.y1 == ys ? bl.wy : 0.f);
+            const float wxv = (bl.x0 == xs ? 1.f - bl.wx : 0.f) + (bl.x1 == xs ? bl.wx : 0.f);
+            const float wgt = wyv * wxv;
+            if (wgt == 0.f) continue;
+            const float v = (1.f - bl.wy) * ((1.f - bl.wx) * z[((size_t)bl.y0 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y0 * p.w + bl.x1) * p.ldp])
+                          + bl.wy * ((1.f - bl.wx) * z[((size_t)bl.y1 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y1 * p.w + bl.x1) * p.ldp]);
+            const float t = p.target[(size_t)b * total + (size_t)y * p.Wt + x] ? 1.f : 0.f;
+            const float pr = 1.f / (1.f + __expf(-v));
+            const float ce = fmaxf(v, 0.f) - v * t + log1pf(__expf(-fabsf(v)));
+            const float pt = pr * t + (1.f - pr) * (1.f - t);
+            const float at = 0.25f * t + 0.75f * (1.f - t);
+            const float dpr = pr * (1.f - pr);
+            // d/dz [ce * (1-pt)^2] = (pr - t) * (1-pt)^2 - 2 ce (1-pt) * dpt/dz,  dpt/dz = (2t-1) * pr(1-pr)
+            const float dfocal = at * ((pr - t) * (1.f - pt) * (1.f - pt) - 2.f * ce * (1.f - pt) * (2.f * t - 1.f) * dpr);
+            // dice = 1 - num/den: d/dz = -(2 t den - num) / den^2 * pr(1-pr)
+            const float ddice = -(2.f * t * den - num) / (den * den) * dpr;
+            acc += (gf * dfocal + gd * ddice) * wgt;
+        }
     }
+    dz[(size_t)src * p.lddp] += acc;          // one owner per element
 }
 
 static inline int grid_for(size_t total, int cap = 4096) {
@@ -375,7 +400,8 @@ extern "C" int rt_gn_nhwc_bwd(const rt_gn_nhwc_bwd_desc* d, rt_stream_t stream) 
     hipError_t e = rt_zero_f32(d->bstats, 2 * (size_t)d->B * d->G, s);
     if (e != hipSuccess) return (int)e;
     int ppb = (int)((16384 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
-    hipLaunchKernelGGL(gn_nhwc_bstats_kernel, dim3((d->HW + ppb - 1) / ppb, d->B), dim3(256), 2 * d->C * sizeof(float), s, *d, ppb);
+    const int CP = (d->C <= 256 && 256 % d->C == 0) ? d->C : 256;
+    hipLaunchKernelGGL(gn_nhwc_bstats_kernel, dim3((d->HW + ppb - 1) / ppb, d->B), dim3(256), 2 * d->C * sizeof(float), s, *d, ppb, CP);
     RT_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_nhwc_bwd_apply_kernel, dim3(grid_for((size_t)d->B * d->HW * d->lddx)), dim3(256), 0, s, *d);
     RT_CHECK_LAUNCH();
@@ -442,7 +468,7 @@ extern "C" int rt_mask_loss(const rt_mask_loss_desc* d, rt_stream_t stream) {
         RT_CHECK_LAUNCH();
     } else {
         if (!d->g_focal || !d->g_dice || d->lddp <= 0) return RT_ERR_BADARG;
-        hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(gx, d->B), dim3(256), 0, s, *d);
+        hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3((d->h * d->w + 255) / 256, d->B), dim3(256), 0, s, *d);
         RT_CHECK_LAUNCH();
     }
     return RT_OK;
