@@ -337,6 +337,7 @@ typedef struct rt_mask_loss_desc {
     float* dpred; const float* g_focal; const float* g_dice;
     int32_t B, h, w, Ht, Wt, ldp, lddp;
     float inv_norm;
+    float* gbuf;           /* backward only: scratch fp32 [B, Ht, Wt] (the per-target-pixel gradient between the two passes) */
 } rt_mask_loss_desc;
 int rt_mask_loss(const rt_mask_loss_desc* d, rt_stream_t stream);
 

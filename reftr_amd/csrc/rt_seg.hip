@@ -321,21 +321,43 @@ __global__ void mask_loss_final_kernel(const float* __restrict__ sums, float* __
 }
 
 // dpred[b][ys][xs] += sum over target pixels of (w_focal * dfocal/dz + w_dice * ddice/dz) * bilinear weight of (ys, xs) in that pixel.
-// Round 5: a GATHER -- one thread per SOURCE pixel walks the target pixels whose bilinear footprint contains it (a (2 / scale + 2)^2
-// window, each pixel's corners and weights recomputed with the same `bilin` as the forward, so exactly the scatter's terms) and
-// adds ONE value to dpred.  Round 4 scattered four global atomics per target pixel -- 13 M atomics, sixteen-fold contended at the
-// 4x upsample: 275 us per step of configs[3].
-__global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const rt_mask_loss_desc p) {
+// Round 5: two passes without atomics.  Pass 1 (one thread per TARGET pixel, coalesced): g = w_focal * dfocal/dz + w_dice * ddice/dz
+// -> gbuf.  Pass 2 (one thread per SOURCE pixel): a gather over the target pixels whose bilinear footprint contains it -- a
+// (2 / scale + 2)^2 window, corners and weights recomputed with the forward's `bilin`, so exactly the scatter's terms -- and ONE add
+// to dpred.  Round 4 scattered four global atomics per target pixel (13 M atomics, sixteen-fold contended at the 4x upsample: 275 us
+// per step of configs[3]); a single-pass gather that re-evaluated the pixel function per corner took 143 us.
+__global__ __launch_bounds__(256) void mask_loss_grad_kernel(const rt_mask_loss_desc p) {
+    const int b = blockIdx.y;
+    const float sy = (float)p.h / (float)p.Ht, sx = (float)p.w / (float)p.Wt;
+    const float* z = p.pred + (size_t)b * p.h * p.w * p.ldp;
+    const int total = p.Ht * p.Wt;
+    const float num = 2.f * p.sums[b * 4 + 1] + 1.f, den = p.sums[b * 4 + 2] + p.sums[b * 4 + 3] + 1.f;
+    const float gf = p.g_focal[0] * p.inv_norm / (float)total, gd = p.g_dice[0] * p.inv_norm;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int y = i / p.Wt, x = i - y * p.Wt;
+        const Bilin bl = bilin(y, x, p.h, p.w, sy, sx);
+        const float v = (1.f - bl.wy) * ((1.f - bl.wx) * z[((size_t)bl.y0 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y0 * p.w + bl.x1) * p.ldp])
+                      + bl.wy * ((1.f - bl.wx) * z[((size_t)bl.y1 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y1 * p.w + bl.x1) * p.ldp]);
+        const float t = p.target[(size_t)b * total + i] ? 1.f : 0.f;
+        const float pr = 1.f / (1.f + __expf(-v));
+        const float ce = fmaxf(v, 0.f) - v * t + log1pf(__expf(-fabsf(v)));
+        const float pt = pr * t + (1.f - pr) * (1.f - t);
+        const float at = 0.25f * t + 0.75f * (1.f - t);
+        const float dpr = pr * (1.f - pr);
+        // d/dz [ce * (1-pt)^2] = (pr - t) * (1-pt)^2 - 2 ce (1-pt) * dpt/dz,  dpt/dz = (2t-1) * pr(1-pr)
+        const float dfocal = at * ((pr - t) * (1.f - pt) * (1.f - pt) - 2.f * ce * (1.f - pt) * (2.f * t - 1.f) * dpr);
+        // dice = 1 - num/den: d/dz = -(2 t den - num) / den^2 * pr(1-pr)
+        const float ddice = -(2.f * t * den - num) / (den * den) * dpr;
+        p.gbuf[(size_t)b * total + i] = gf * dfocal + gd * ddice;
+    }
+}
+__global__ __launch_bounds__(256) void mask_loss_gather_kernel(const rt_mask_loss_desc p) {
     const int b = blockIdx.y;
     const int src = blockIdx.x * 256 + threadIdx.x;
     if (src >= p.h * p.w) return;
     const int ys = src / p.w, xs = src - ys * p.w;
     const float sy = (float)p.h / (float)p.Ht, sx = (float)p.w / (float)p.Wt;
-    const float* z = p.pred + (size_t)b * p.h * p.w * p.ldp;
-    float* dz = p.dpred + (size_t)b * p.h * p.w * p.lddp;
-    const int total = p.Ht * p.Wt;
-    const float num = 2.f * p.sums[b * 4 + 1] + 1.f, den = p.sums[b * 4 + 2] + p.sums[b * 4 + 3] + 1.f;
-    const float gf = p.g_focal[0] * p.inv_norm / (float)total, gd = p.g_dice[0] * p.inv_norm;
+    const float* g = p.gbuf + (size_t)b * p.Ht * p.Wt;
     // target rows / columns whose y0 or y1 (x0 or x1) can be ys (xs): floor(f) in {s - 1, s}, one pixel of slack on both sides;
     // the last source row / column also collects every target pixel clamped onto it
     int ylo = (int)floorf(((float)ys - 0.5f) / sy - 0.5f) - 1, yhi = (int)ceilf(((float)ys + 1.5f) / sy - 0.5f) + 1;
@@ -344,28 +366,18 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const rt_mask_loss_d
     yhi = ys == p.h - 1 ? p.Ht - 1 : min(yhi, p.Ht - 1); xhi = xs == p.w - 1 ? p.Wt - 1 : min(xhi, p.Wt - 1);
     float acc = 0.f;
     for (int y = ylo; y <= yhi; ++y) {
+        const Bilin by = bilin(y, 0, p.h, p.w, sy, sx);
+        const float wyv = (by.y0 == ys ? 1.f - by.wy : 0.f) + (by.y1 == ys ? by.wy : 0.f);
+        if (wyv == 0.f) continue;
+        float row = 0.f;
         for (int x = xlo; x <= xhi; ++x) {
-            const Bilin bl = bilin(y, x, p.h, p.w, sy, sx);
-            const float wyv = (bl.y0 == ys ? 1.f - bl.wy : 0.f) + (bl.y1 == ys ? bl.wy : 0.f);
-            const float wxv = (bl.x0 == xs ? 1.f - bl.wx : 0.f) + (bl.x1 == xs ? bl.wx : 0.f);
-            const float wgt = wyv * wxv;
-            if (wgt == 0.f) continue;
-            const float v = (1.f - bl.wy) * ((1.f - bl.wx) * z[((size_t)bl.y0 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y0 * p.w + bl.x1) * p.ldp])
-                          + bl.wy * ((1.f - bl.wx) * z[((size_t)bl.y1 * p.w + bl.x0) * p.ldp] + bl.wx * z[((size_t)bl.y1 * p.w + bl.x1) * p.ldp]);
-            const float t = p.target[(size_t)b * total + (size_t)y * p.Wt + x] ? 1.f : 0.f;
-            const float pr = 1.f / (1.f + __expf(-v));
-            const float ce = fmaxf(v, 0.f) - v * t + log1pf(__expf(-fabsf(v)));
-            const float pt = pr * t + (1.f - pr) * (1.f - t);
-            const float at = 0.25f * t + 0.75f * (1.f - t);
-            const float dpr = pr * (1.f - pr);
-            // d/dz [ce * (1-pt)^2] = (pr - t) * (1-pt)^2 - 2 ce (1-pt) * dpt/dz,  dpt/dz = (2t-1) * pr(1-pr)
-            const float dfocal = at * ((pr - t) * (1.f - pt) * (1.f - pt) - 2.f * ce * (1.f - pt) * (2.f * t - 1.f) * dpr);
-            // dice = 1 - num/den: d/dz = -(2 t den - num) / den^2 * pr(1-pr)
-            const float ddice = -(2.f * t * den - num) / (den * den) * dpr;
-            acc += (gf * dfocal + gd * ddice) * wgt;
+            const Bilin bx = bilin(0, x, p.h, p.w, sy, sx);
+            const float wxv = (bx.x0 == xs ? 1.f - bx.wx : 0.f) + (bx.x1 == xs ? bx.wx : 0.f);
+            if (wxv != 0.f) row += g[(size_t)y * p.Wt + x] * wxv;
         }
+        acc += row * wyv;
     }
-    dz[(size_t)src * p.lddp] += acc;          // one owner per element
+    p.dpred[((size_t)b * p.h * p.w + src) * p.lddp] += acc;          // one owner per element
 }
 
 static inline int grid_for(size_t total, int cap = 4096) {
@@ -467,8 +479,10 @@ extern "C" int rt_mask_loss(const rt_mask_loss_desc* d, rt_stream_t stream) {
         hipLaunchKernelGGL(mask_loss_final_kernel, dim3(1), dim3(64), 0, s, d->sums, d->losses, d->B, d->Ht * d->Wt, d->inv_norm);
         RT_CHECK_LAUNCH();
     } else {
-        if (!d->g_focal || !d->g_dice || d->lddp <= 0) return RT_ERR_BADARG;
-        hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3((d->h * d->w + 255) / 256, d->B), dim3(256), 0, s, *d);
+        if (!d->g_focal || !d->g_dice || d->lddp <= 0 || !d->gbuf) return RT_ERR_BADARG;
+        hipLaunchKernelGGL(mask_loss_grad_kernel, dim3(grid_for((size_t)d->Ht * d->Wt, 1024), d->B), dim3(256), 0, s, *d);
+        RT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(mask_loss_gather_kernel, dim3((d->h * d->w + 255) / 256, d->B), dim3(256), 0, s, *d);
         RT_CHECK_LAUNCH();
     }
     return RT_OK;

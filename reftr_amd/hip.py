@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -235,7 +235,7 @@ class MaskLossDesc(Structure):
     _fields_ = [("pred", c_void_p), ("target", c_void_p), ("sums", c_void_p), ("losses", c_void_p),
                 ("dpred", c_void_p), ("g_focal", c_void_p), ("g_dice", c_void_p),
                 ("B", c_int32), ("h", c_int32), ("w", c_int32), ("Ht", c_int32), ("Wt", c_int32), ("ldp", c_int32),
-                ("lddp", c_int32), ("inv_norm", c_float)]
+                ("lddp", c_int32), ("inv_norm", c_float), ("gbuf", c_void_p)]
 
 
 DEC_MAX_LAYERS = 8
@@ -1403,12 +1403,13 @@ def mask_loss(pred, target_u8, B, h, w, Ht, Wt, ldp, norm, sums=None, dpred=None
     if dpred is None:
         sums = torch.empty((B, 4), dtype=torch.float32, device=pred.device)
         losses = torch.empty(2, dtype=torch.float32, device=pred.device)
-        d = MaskLossDesc(_p(pred), _p(target_u8), _p(sums), _p(losses), None, None, None, B, h, w, Ht, Wt, ldp, 0, 1.0 / norm)
+        d = MaskLossDesc(_p(pred), _p(target_u8), _p(sums), _p(losses), None, None, None, B, h, w, Ht, Wt, ldp, 0, 1.0 / norm, None)
         _check(lib().rt_mask_loss(ctypes.byref(d), _stream()), "rt_mask_loss")
         return losses, sums
     _req(dpred, torch.float32, "dpred"); _req(g_focal, torch.float32, "g_focal"); _req(g_dice, torch.float32, "g_dice")
+    gbuf = torch.empty(B * Ht * Wt, dtype=torch.float32, device=pred.device)
     d = MaskLossDesc(_p(pred), _p(target_u8), _p(sums), None, _p(dpred), _p(g_focal), _p(g_dice), B, h, w, Ht, Wt, ldp,
-                     dpred.shape[-1], 1.0 / norm)
+                     dpred.shape[-1], 1.0 / norm, _p(gbuf))
     _check(lib().rt_mask_loss(ctypes.byref(d), _stream()), "rt_mask_loss")
     return dpred
 
