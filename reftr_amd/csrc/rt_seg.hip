@@ -392,7 +392,7 @@ extern "C" int rt_gn_nhwc_fwd(const rt_gn_nhwc_desc* d, rt_stream_t stream) {
     if (d->C <= 0 || d->G <= 0 || d->G > 64 || (d->C % d->G) || d->ldx < d->C || d->ldy < d->C || d->B <= 0 || d->HW <= 0) return RT_ERR_UNSUPPORTED;
     if (d->G > 16) return RT_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    int ppb = (int)((16384 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
+    int ppb = (int)((4096 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
     const int nblk = (d->HW + ppb - 1) / ppb;
     if (!d->partials || d->partial_blocks < nblk) return RT_ERR_BADARG;
     hipLaunchKernelGGL(gn_nhwc_stats_kernel, dim3(nblk, d->B), dim3(256), 2 * d->G * 256 * sizeof(float), s,
@@ -411,7 +411,7 @@ extern "C" int rt_gn_nhwc_bwd(const rt_gn_nhwc_bwd_desc* d, rt_stream_t stream) 
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = rt_zero_f32(d->bstats, 2 * (size_t)d->B * d->G, s);
     if (e != hipSuccess) return (int)e;
-    int ppb = (int)((16384 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
+    int ppb = (int)((4096 + d->C - 1) / d->C); if (ppb < 1) ppb = 1;
     const int CP = (d->C <= 256 && 256 % d->C == 0) ? d->C : 256;
     hipLaunchKernelGGL(gn_nhwc_bstats_kernel, dim3((d->HW + ppb - 1) / ppb, d->B), dim3(256), 2 * d->C * sizeof(float), s, *d, ppb, CP);
     RT_CHECK_LAUNCH();

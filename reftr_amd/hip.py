@@ -1322,7 +1322,7 @@ def gn_nhwc_fwd(x, gamma, beta, B, HW, C, G=8, ldy=None, act=ACT_RELU, eps=1e-5)
     assert x.numel() == B * HW * ldx and gamma.numel() >= C
     y = torch.empty((B * HW, ldy), dtype=torch.bfloat16, device=x.device)
     stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
-    ppb = max(1, (16384 + C - 1) // C)
+    ppb = max(1, (4096 + C - 1) // C)          # rt_gn_nhwc_fwd cuts the pixels the same way
     nblk = (HW + ppb - 1) // ppb
     partials = torch.empty((B, nblk, G, 2), dtype=torch.float32, device=x.device)
     d = GnNhwcDesc(_p(x), _p(gamma), _p(beta), _p(stats), _p(y), B, HW, C, G, ldx, ldy, act, eps, _p(partials), nblk)
