@@ -378,6 +378,8 @@ def main():
                    "global_batch": B * world, "batch_per_gpu": B, "image_size": S_, "parallelism": f"dp{world}", "launch": mode + ("+dp-overlap" if (world > 1 or force_dist) else ""),
                    **({"grad_exchange": "bf16" if getattr(runner, "bf16", False) else "fp32"} if (world > 1 or force_dist) else {})},
         "loss": loss_value, "build_id": bid,
+        # every switch of this package found in the environment: a run with any of them set is not the default configuration
+        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("REFTR_", "BENCH_"))},
         "ms_per_step_median": sorted(per_step)[len(per_step) // 2] * 1e3,
     }
     if rank == 0:

@@ -1,3 +1,4 @@
+export REFTR_LAB=1   # kernel tuning switches live in the lab library only (benchmarks/README.md): build it with REFTR_LAB=1 first
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 for abl in 0 1; do
 rm -rf $R/gpurun_out/pmc_w2_$abl

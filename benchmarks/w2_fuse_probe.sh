@@ -1,3 +1,4 @@
+export REFTR_LAB=1   # kernel tuning switches live in the lab library only (benchmarks/README.md): build it with REFTR_LAB=1 first
 cd benchmarks
 for w in "4,2,2,1,3" "4,2.25,2.25,1.5,4"; do echo "== WTS=$w"; REFTR_W2_WTS=$w python wgrad_group_bench.py 2>&1 | tail -7 | cut -c1-70 | tr '\n' ';'; echo; done
 cd ..

@@ -12,12 +12,20 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
-OBJ_DIR = os.path.join(_HERE, "build", "obj")
-LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
+# REFTR_LAB=1 selects the LAB library: the same sources compiled with -DRT_LAB, in which the kernels' tuning switches (RT_TUNE in
+# csrc/rt_common.h: tile heuristics, split targets, ablation probes ...) are read from the environment.  The product library fixes
+# every one of them at its measured-best value and cannot be re-tuned (or put into a wrong-results probe mode) from outside.
+LAB = os.environ.get("REFTR_LAB", "0") == "1"
+OBJ_DIR = os.path.join(_HERE, "build", "obj_lab" if LAB else "obj")
+LIB_PATH = os.path.join(_HERE, "libreftr_hip_lab.so" if LAB else "libreftr_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+if LAB:
+    FLAGS.append("-DRT_LAB")
 
 
 def _sources():

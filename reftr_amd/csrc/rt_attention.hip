@@ -1018,7 +1018,7 @@ extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
     if (!d || !d->q || !d->k || !d->v || !d->out) return RT_ERR_BADARG;
     if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sq <= 0) return RT_ERR_UNSUPPORTED;
     if ((d->ldq | d->ldk | d->ldv | d->ldo) & 7) return RT_ERR_UNSUPPORTED;
-    static const int q1_env = getenv("REFTR_ATTN_Q1") ? atoi(getenv("REFTR_ATTN_Q1")) : 1;
+    static const int q1_env = RT_TUNE("REFTR_ATTN_Q1", 1);
     if (q1_env && d->Sq == 1 && d->dh == 32 && d->Sk <= 256 * Q1_MAXK) {
         hipLaunchKernelGGL(attn_q1_fwd_kernel, dim3(d->B * d->H), dim3(256), 0, (hipStream_t)stream, *d);
         RT_CHECK_LAUNCH();
@@ -1036,14 +1036,14 @@ extern "C" int rt_attn_fwd(const rt_attn_desc* d, rt_stream_t stream) {
         return RT_OK;
     }
     const size_t smem = smem_bytes(d->Sk, d->dh);
-    static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
+    static const int nw_env = RT_TUNE("REFTR_ATTN_NW", 8);
     const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
     // (b, h) on grid.x: the row blocks of one head get ids bh, bh + B*H, ... -> the same XCD whenever B*H is a multiple of 8, so the
     // head's K / V rows cross the fabric once per XCD instead of once per block
     const dim3 grid(d->B * d->H, (d->Sq + 16 * nw - 1) / (16 * nw));
 #define RT_ATTN_FWD(DHV, NWV) do { if ((rc = set_smem(attn_fwd_kernel<DHV, NWV>, smem)) != RT_OK) return rc; \
         hipLaunchKernelGGL((attn_fwd_kernel<DHV, NWV>), grid, dim3(64 * NWV), smem, (hipStream_t)stream, *d); } while (0)
-    static const int reg_env = getenv("REFTR_ATTN_REG") ? atoi(getenv("REFTR_ATTN_REG")) : 1;
+    static const int reg_env = RT_TUNE("REFTR_ATTN_REG", 1);
     const int tiles = ((d->Sk + 31) & ~31) >> 4;
     if (reg_env && nw == 8 && tiles <= 28) {          // 28 tiles = 180 VGPRs; 48 would spill: longer rows keep the two-pass kernel
 #define RT_ATTN_FWD_REG(DHV, NTV) do { if ((rc = set_smem(attn_fwd_reg_kernel<DHV, 8, NTV>, smem)) != RT_OK) return rc; \
@@ -1067,7 +1067,7 @@ extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
     if ((d->dh != 32 && d->dh != 64) || d->Sk <= 0 || d->Sq <= 0) return RT_ERR_UNSUPPORTED;
     if ((d->ldq | d->ldk | d->ldv | d->ldo | d->lddq | d->lddk | d->lddv) & 7) return RT_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    static const int q1_env = getenv("REFTR_ATTN_Q1") ? atoi(getenv("REFTR_ATTN_Q1")) : 1;
+    static const int q1_env = RT_TUNE("REFTR_ATTN_Q1", 1);
     if (q1_env && d->Sq == 1 && d->dh == 32 && d->Sk <= 256 * Q1_MAXK) {
         hipLaunchKernelGGL(attn_q1_bwd_kernel, dim3(d->B * d->H), dim3(256), 0, s, *d);
         RT_CHECK_LAUNCH();
@@ -1089,10 +1089,10 @@ extern "C" int rt_attn_bwd(const rt_attn_bwd_desc* d, rt_stream_t stream) {
         }
     }
     const size_t smem1 = smem_bytes(d->Sk, d->dh), smem2 = smem_bytes(d->Sq, d->dh);
-    static const int nw_env = getenv("REFTR_ATTN_NW") ? atoi(getenv("REFTR_ATTN_NW")) : 8;
+    static const int nw_env = RT_TUNE("REFTR_ATTN_NW", 8);
     const int nw = nw_env == 4 ? 4 : (nw_env == 16 ? 16 : 8);
     const dim3 g1(d->B * d->H, (d->Sq + 16 * nw - 1) / (16 * nw)), g2(d->B * d->H, (d->Sk + 16 * nw - 1) / (16 * nw));
-    static const int fused_env = getenv("REFTR_ATTN_BWD_FUSED") ? atoi(getenv("REFTR_ATTN_BWD_FUSED")) : 1;
+    static const int fused_env = RT_TUNE("REFTR_ATTN_BWD_FUSED", 1);
     if (fused_env && nw == 8) {
         const size_t smem = smem1 > smem2 ? smem1 : smem2;
         const dim3 g(d->B * d->H, g1.y + g2.y);

@@ -15,6 +15,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define RT_WAVE 64
 
+// Tuning switches of the A/B sessions recorded in LAB_NOTES.md.  The product library fixes every one at its measured-best value
+// (the second argument); the lab library (REFTR_LAB=1 at build and at import: -DRT_LAB, libreftr_hip_lab.so) reads them from the
+// environment, once, at the first launch that consults them.
+#ifdef RT_LAB
+#include <stdlib.h>
+#define RT_TUNE(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define RT_TUNE_SET(name) (getenv(name) != nullptr)
+#else
+#define RT_TUNE(name, dflt) (dflt)
+#define RT_TUNE_SET(name) false
+#endif
+
 __device__ __forceinline__ float rt_bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t rt_f2bf(float v) { return (bf16_t)v; }
 

@@ -328,15 +328,19 @@ static int fill_gemm_args(const rt_conv_gemm_desc* d, GemmArgs& a) {
     // 32-bit element offsets inside the kernel
     if ((long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL || (long long)d->N * d->KH * d->KW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.K = d->KH * d->KW * d->SC; a.sshift = d->stride == 2 ? 1 : 0;
-    static const int xcd_env = getenv("REFTR_XCD") ? atoi(getenv("REFTR_XCD")) : 1;
+    static const int xcd_env = RT_TUNE("REFTR_XCD", 1);
     a.xcd = xcd_env;
-    static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
+    static const int early_env = RT_TUNE("REFTR_EARLY", 3);
     a.early = early_env & 1;
-    static const int epi_env = getenv("REFTR_EPI") ? atoi(getenv("REFTR_EPI")) : 3;
+    static const int epi_env = RT_TUNE("REFTR_EPI", 3);
     a.epi_lds = epi_env & 1;
-    static const int abl_env = getenv("REFTR_GEMM_ABL") ? atoi(getenv("REFTR_GEMM_ABL")) : 0;   // 1 no loads, 2 no MFMA, 4 no epilogue
+#ifdef RT_LAB                                      // lab builds only (hipcc -DRT_LAB): 1 no loads, 2 no MFMA, 4 no epilogue -- wrong results
+    static const int abl_env = RT_TUNE("REFTR_GEMM_ABL", 0);
     a.abl = abl_env;
-    static const int pre_env = getenv("REFTR_EPI_PREFETCH") ? atoi(getenv("REFTR_EPI_PREFETCH")) : 1;
+#else
+    a.abl = 0;
+#endif
+    static const int pre_env = RT_TUNE("REFTR_EPI_PREFETCH", 1);
     a.prefetch = pre_env;
     a.mfast = 0;
     a.src_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
@@ -354,7 +358,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
     if (d->tile_hint == 0 && dense && a.M <= 16) {
         const dim3 grid((unsigned)((a.N + 15) / 16));
         const int per = ((a.K >> 5) + 3) >> 2;          // k-steps per wave: the whole slice in flight when it fits 8 steps
-        static const int skinny_v = getenv("REFTR_SKINNY_V") ? atoi(getenv("REFTR_SKINNY_V")) : 2;
+        static const int skinny_v = RT_TUNE("REFTR_SKINNY_V", 2);
         if (skinny_v == 1) hipLaunchKernelGGL(skinny_gemm_kernel_v1, grid, dim3(256), 0, s, a.src, a.wgt, a);
         else if (per <= 2) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, dim3(256), 0, s, a.src, a.wgt, a);
         else if (per <= 4) hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, s, a.src, a.wgt, a);
@@ -369,13 +373,13 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         // best through many 64x64 workgroups; 128x128 needs >= 1.5 waves of tiles over the 256 CUs to pay off.
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         const long long t12864 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64);
-        static const int smallk = getenv("REFTR_SMALLK") ? atoi(getenv("REFTR_SMALLK")) : 256;
-        static const int dma = getenv("REFTR_DMA") ? atoi(getenv("REFTR_DMA")) : 1;
+        static const int smallk = RT_TUNE("REFTR_SMALLK", 256);
+        static const int dma = RT_TUNE("REFTR_DMA", 1);
         if (a.K <= smallk) hint = 3;
         else if (a.N > 64 && t128 >= 384) hint = 1;
         else if (t12864 >= 256) hint = 2;
         else hint = 3;
-        static const int tilev = getenv("REFTR_TILEV") ? atoi(getenv("REFTR_TILEV")) : 3;
+        static const int tilev = RT_TUNE("REFTR_TILEV", 3);
         if (dma && tilev >= 3) {
             // round 3 (profiles/r03_tile_sweep_warm.txt / _cold.txt, r03_instep_ab.txt).  Two lessons: (1) back-to-back launches of
             // one shape on warm caches are a misleading yardstick -- the software-pipelined K loop (hints 2xx: fragments of tile
@@ -385,13 +389,13 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
             // 128 x 128 at ONE workgroup per CU where the tiles do not fill two per CU anyway: layer3's 3x3).  (2) The M = B * L
             // Linears of the language branch (<= 96 tiles of 64 x 64: 60 CUs pulling at ~50 GB/s each) run on 32 x 32 tiles
             // (4x the workgroups), the other few-tile products on the 3-stage 64 x 64 tile also for K < 1024.
-            static const int smallt = getenv("REFTR_SMALLT") ? atoi(getenv("REFTR_SMALLT")) : 1;
-            static const int pipe = getenv("REFTR_PIPE") ? atoi(getenv("REFTR_PIPE")) : 3;         // bit 0: 128x128 / 3 stages, bit 1: 64x64 / 3 stages
+            static const int smallt = RT_TUNE("REFTR_SMALLT", 1);
+            static const int pipe = RT_TUNE("REFTR_PIPE", 3);         // bit 0: 128x128 / 3 stages, bit 1: 64x64 / 3 stages
             const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
             const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
             // round 4 (profiles/r04o_deep_stage_cold.txt): at <= 1 workgroup per CU the 32 x 32 form is bound by the K tiles it keeps in
             // flight -- 6 stages instead of 3 take the cold K >= 768 products from 17.3 / 14.6 / 7.8 us to 11.1 / 9.9 / 5.8 (8 stages: no better)
-            static const int deep = getenv("REFTR_DEEP") ? atoi(getenv("REFTR_DEEP")) : 1;
+            static const int deep = RT_TUNE("REFTR_DEEP", 1);
             if (dense && smallt && a.M <= 1024 && t64 < 256 && (a.N & 7) == 0) hint = t64 <= 96 ? ((deep && a.K >= 512) ? 285 : 281) : 33;
             else if (a.K < 1024) hint = (a.N >= 128 && t128 >= 384 && t128 <= 512) ? 51 : 31;
             else if (dense && a.K >= 2048 && a.N >= 128 && t256 >= 512) hint = 262;     // big products only; none in the step
@@ -452,7 +456,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
 extern "C" int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_stream_t stream) {
     if (!descs || n <= 0) return RT_ERR_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    static const int grp_env = getenv("REFTR_GEMM_GROUP") ? atoi(getenv("REFTR_GEMM_GROUP")) : 1;
+    static const int grp_env = RT_TUNE("REFTR_GEMM_GROUP", 1);
     // groupable: dense products the single-launch heuristic would give the 64x64 / 2-stage / 4-per-CU variant (K < 1024, M > 16)
     bool ok = grp_env && n >= 2 && n <= 12;
     GemmGroup g;

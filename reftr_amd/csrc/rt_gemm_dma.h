@@ -370,14 +370,14 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t s) {
     const size_t smem = (size_t)NS * (BM + BN) * 128;
     const dim3 grid((unsigned)(mt * nt)), block(64 * NW);
     const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.SH == a.DH && a.SW == a.DW);
-    static const int par_env = getenv("REFTR_S2PARITY") ? atoi(getenv("REFTR_S2PARITY")) : 1;
+    static const int par_env = RT_TUNE("REFTR_S2PARITY", 1);
     auto set_smem = [&](const void* f) {
         if (smem > 65536) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     };
     if (dense) {
         set_smem((const void*)conv_gemm_dma_kernel<BM, BN, 0, NS, MINB, NW, PIPE>);
         // distinct operand slabs an XCD's run of R tiles touches: R / n_tiles + min(R, n_tiles) (n fastest) vs the same with m_tiles
-        static const int mfast_env = getenv("REFTR_MFAST") ? atoi(getenv("REFTR_MFAST")) : 1;
+        static const int mfast_env = RT_TUNE("REFTR_MFAST", 1);
         GemmArgs am = a;
         const double R = (double)(mt * nt) / 8.0;
         const double cn = R / nt + (R < nt ? R : nt), cm = R / mt + (R < mt ? R : mt);

@@ -472,7 +472,7 @@ extern "C" int rt_layernorm_fwd(const rt_layernorm_desc* d, rt_stream_t stream) 
     if (!d || !d->x || !d->gamma || !d->beta) return RT_ERR_BADARG;
     if (d->D <= 0 || d->D > 64 * LN_MAX_PER_LANE || d->M <= 0) return RT_ERR_UNSUPPORTED;
     if (d->ypos_bf16 && !d->pos) return RT_ERR_BADARG;
-    static const int vec = getenv("REFTR_LNVEC") ? atoi(getenv("REFTR_LNVEC")) : 1;
+    static const int vec = RT_TUNE("REFTR_LNVEC", 1);
     const dim3 grid((d->M + 3) / 4);
     if (vec && d->D == 256)      hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, *d);
     else if (vec && d->D == 768) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *d);
@@ -487,14 +487,14 @@ extern "C" int rt_layernorm_bwd(const rt_layernorm_bwd_desc* d, rt_stream_t stre
     if (d->act == RT_ACT_RELU && !d->beta) return RT_ERR_BADARG;
     // few, fat workgroups: every block ends with D atomics per parameter vector, so contention (not bandwidth)
     // is what scales with the block count
-    static const int lnb = getenv("REFTR_LNB") ? atoi(getenv("REFTR_LNB")) : 256;   // A/B on the step: 64..1024, the per-block dgamma/dbeta atomics dominate
+    static const int lnb = RT_TUNE("REFTR_LNB", 256);   // A/B on the step: 64..1024, the per-block dgamma/dbeta atomics dominate
     int blocks = (d->M + 3) / 4;
     if (blocks > lnb) blocks = lnb;
     if (!d->dgamma && !d->dbeta && !d->partials) { blocks = (d->M + 3) / 4; if (blocks > 1024) blocks = 1024; }
-    static const int lnpb = getenv("REFTR_LNPB") ? atoi(getenv("REFTR_LNPB")) : 880;
+    static const int lnpb = RT_TUNE("REFTR_LNPB", 880);
     if (d->partials) { blocks = (d->M + 3) / 4; if (blocks > lnpb) blocks = lnpb; }
     if (d->partials && d->n_blocks_out) *d->n_blocks_out = blocks;
-    static const int vec = getenv("REFTR_LNVEC") ? atoi(getenv("REFTR_LNVEC")) : 1;
+    static const int vec = RT_TUNE("REFTR_LNVEC", 1);
     if (vec && d->D == 256)      hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
     else if (vec && d->D == 768) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
     else                         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);

@@ -542,7 +542,7 @@ extern "C" int rt_adamw_flat(const rt_adamw_desc* d, rt_stream_t stream) {
     if (a.span_begin == 0 && a.span_end == 0) a.span_end = a.n;
     if (a.span_begin < 0 || a.span_end > a.n || a.span_begin >= a.span_end || (a.span_begin & 3) || (a.span_end & 3)) return RT_ERR_BADARG;
     int blocks = (int)(((size_t)(a.span_end - a.span_begin) / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    static const int nt_env = getenv("REFTR_ADAMW_NT") ? atoi(getenv("REFTR_ADAMW_NT")) : 1;
+    static const int nt_env = RT_TUNE("REFTR_ADAMW_NT", 1);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, nt_env);
     RT_CHECK_LAUNCH();
     return RT_OK;

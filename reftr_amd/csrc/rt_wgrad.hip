@@ -686,10 +686,10 @@ int launch_wgrad_dma(WgradArgs a, int msplit, float* ws, long long ws_bytes, hip
     const int total_chunks = (a.M + CR - 1) / CR;
     const long long base_blocks = (long long)nt * a.c_tiles * taps;
     if (msplit <= 0) {
-        static const int target = getenv("REFTR_WG_TARGET") ? atoi(getenv("REFTR_WG_TARGET")) : 512;
+        static const int target = RT_TUNE("REFTR_WG_TARGET", 512);
         // each split costs one more partial tile through the workspace: small outputs take >= 256-row splits, larger
         // ones >= 512 (benchmarks/wgrad_probe.py)
-        static const int minrows_env = getenv("REFTR_WG_MINROWS") ? atoi(getenv("REFTR_WG_MINROWS")) : 0;
+        static const int minrows_env = RT_TUNE("REFTR_WG_MINROWS", 0);
         const int minrows = minrows_env ? minrows_env : ((long long)a.N * taps * a.SC * 4 <= (512 << 10) ? 256 : 512);
         long long want = (target + base_blocks - 1) / base_blocks;
         long long maxs = (long long)total_chunks * CR / minrows;
@@ -737,7 +737,7 @@ static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a);
 bool rt_w2_eligible(const rt_conv_wgrad_desc& d);
 int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* workspace, long long workspace_bytes, hipStream_t s);
 static int w2_enabled() {
-    static const int e = getenv("REFTR_WG2") ? atoi(getenv("REFTR_WG2")) : 1;
+    static const int e = RT_TUNE("REFTR_WG2", 1);
     return e;
 }
 
@@ -869,7 +869,7 @@ static int wgrad_grouped_v1(const rt_conv_wgrad_desc* descs, int n, float* works
         const long long base_blocks = (long long)nt * a.c_tiles;
         const long long out_elems = (long long)a.N * a.SC;
         const int minrows = out_elems * 4 <= (512 << 10) ? 256 : 512;
-        static const int gtarget = getenv("REFTR_WG_TARGET") ? atoi(getenv("REFTR_WG_TARGET")) : 512;
+        static const int gtarget = RT_TUNE("REFTR_WG_TARGET", 512);
         long long want = (gtarget + base_blocks - 1) / base_blocks, maxs = (long long)total_chunks * CR / minrows;
         if (maxs < 1) maxs = 1;
         if (want > maxs) want = maxs;
@@ -909,11 +909,11 @@ static int fill_wgrad_args(const rt_conv_wgrad_desc* d, WgradArgs& a) {
     if (M > 0x7fffffffLL / 4) return RT_ERR_UNSUPPORTED;
     if (M * d->N >= 0x3fffffffLL || (long long)d->B * d->SH * d->SW * d->SC >= 0x3fffffffLL) return RT_ERR_UNSUPPORTED;
     a.M = (int)M; a.chunks_per_block = 0; a.c_tiles = 0; a.part = nullptr; a.out_elems = 0; a.overwrite = d->overwrite ? 1 : 0;
-    static const int xcd_env = getenv("REFTR_XCD") ? atoi(getenv("REFTR_XCD")) : 1;
+    static const int xcd_env = RT_TUNE("REFTR_XCD", 1);
     a.xcd = xcd_env;
-    static const int early_env = getenv("REFTR_EARLY") ? atoi(getenv("REFTR_EARLY")) : 3;
+    static const int early_env = RT_TUNE("REFTR_EARLY", 3);
     a.early = early_env & 2 ? 1 : 0;
-    static const int epi_env = getenv("REFTR_EPI") ? atoi(getenv("REFTR_EPI")) : 3;
+    static const int epi_env = RT_TUNE("REFTR_EPI", 3);
     a.epi_lds = epi_env & 2 ? 1 : 0;
     a.dy_bytes = (unsigned)(M * d->N * 2);
     a.x_bytes = (unsigned)((long long)d->B * d->SH * d->SW * d->SC * 2);
@@ -924,7 +924,7 @@ extern "C" int rt_conv_wgrad(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
     if (!d) return RT_ERR_BADARG;
     if (!d->sqacc && !d->g16) return conv_wgrad_impl(d, stream);
     const long long M = (long long)d->B * d->DH * d->DW;
-    const bool v2 = w2_enabled() && rt_w2_eligible(*d) && !getenv("REFTR_WGV") &&
+    const bool v2 = w2_enabled() && rt_w2_eligible(*d) && !RT_TUNE_SET("REFTR_WGV") &&
                     !(M <= 16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->SC & 3) == 0);
     if (v2) return conv_wgrad_impl(d, stream);           // the second-generation kernels account in their epilogues
     int rc = sq_account(d, 1, false, (hipStream_t)stream);
@@ -946,15 +946,15 @@ static int conv_wgrad_impl(const rt_conv_wgrad_desc* d, rt_stream_t stream) {
         RT_CHECK_LAUNCH();
         return RT_OK;
     }
-    if (w2_enabled() && rt_w2_eligible(*d) && !getenv("REFTR_WGV")) {       // a group of one
+    if (w2_enabled() && rt_w2_eligible(*d) && !RT_TUNE_SET("REFTR_WGV")) {       // a group of one
         const int zero = 0;
         return rt_w2_run(d, &zero, 1, d->workspace, d->workspace ? (long long)d->workspace_bytes : 0, s);
     }
     // variant: 0 = LDS-DMA kernels (default), 9 = register-staged kernel, 1..5 = pinned 128x128 DMA staging shapes
-    static const int wgv_env = getenv("REFTR_WGV") ? atoi(getenv("REFTR_WGV")) : 0;
+    static const int wgv_env = RT_TUNE("REFTR_WGV", 0);
     const int wgv = d->variant > 0 ? d->variant : wgv_env;
     float* ws = d->workspace; long long wsb = d->workspace ? d->workspace_bytes : 0;
-    static const int no_ws = getenv("REFTR_WG_NOWS") ? atoi(getenv("REFTR_WG_NOWS")) : 0;
+    static const int no_ws = RT_TUNE("REFTR_WG_NOWS", 0);
     if (no_ws) { ws = nullptr; wsb = 0; }
     if (wgv != 9 && (a.N & 7) == 0) {
         if (a.N >= 128 && a.SC >= 128) {

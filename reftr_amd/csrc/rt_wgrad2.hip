@@ -569,7 +569,7 @@ int w2_launch(const W2Group& g, int blocks, hipStream_t s) {
 
 // Eligibility: channel counts the DMA path can address in 16-B pieces, enough rows for the pipeline to matter.
 bool rt_w2_eligible(const rt_conv_wgrad_desc& d) {
-    static const int minm_env = getenv("REFTR_W2_MINM") ? atoi(getenv("REFTR_W2_MINM")) : 256;
+    static const int minm_env = RT_TUNE("REFTR_W2_MINM", 256);
     const long long M = (long long)d.B * d.DH * d.DW;
     if (M < minm_env || (d.N & 7) || (d.SC & 7) || d.N < 64 || d.SC < 64) return false;
     if (d.variant != 0 || d.msplit > 0) return false;
@@ -579,9 +579,9 @@ bool rt_w2_eligible(const rt_conv_wgrad_desc& d) {
 }
 
 static int w2_cfg_of(const rt_conv_wgrad_desc& d) {       // 0: 256x256, 1: 128x256, 2: 256x128, 3: 128x128, 4: 128x128 x 3 taps
-    static const int fuse_env = getenv("REFTR_W2_FUSE3") ? atoi(getenv("REFTR_W2_FUSE3")) : 1;
-    static const int fuse_minw = getenv("REFTR_W2_FUSE3_MINW") ? atoi(getenv("REFTR_W2_FUSE3_MINW")) : 8;
-    static const int fuse_maxc = getenv("REFTR_W2_FUSE3_MAXC") ? atoi(getenv("REFTR_W2_FUSE3_MAXC")) : 128;
+    static const int fuse_env = RT_TUNE("REFTR_W2_FUSE3", 1);
+    static const int fuse_minw = RT_TUNE("REFTR_W2_FUSE3_MINW", 8);
+    static const int fuse_maxc = RT_TUNE("REFTR_W2_FUSE3_MAXC", 128);
     // fused taps where the per-tap tile could not be wider than 128 x 128 anyway (layer2, the RES head): 2.3x on those; with 256
     // channels a side the per-tap 256 x 256 tile is as good (layer3: equal), and at W = 20 the row masks cost more than the taps
     // save (layer4: 150 -> 169 us) -- REFTR_W2_FUSE3_MAXC / _MINW widen the choice
@@ -593,17 +593,23 @@ static int w2_cfg_of(const rt_conv_wgrad_desc& d) {       // 0: 256x256, 1: 128x
 
 // Launches every descriptor of `idx` (all eligible) as grouped v2 launches.  Split policy: see the file header.
 int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* workspace, long long workspace_bytes, hipStream_t s) {
-    static const int target_env = getenv("REFTR_W2_TARGET") ? atoi(getenv("REFTR_W2_TARGET")) : 0;
-    static const int xcd_env = getenv("REFTR_W2_XCD") ? atoi(getenv("REFTR_W2_XCD")) : 2;      // 0 linear, 1 per-XCD table (round-robin units), 2 contiguous runs
-    static const int minrows_env = getenv("REFTR_W2_MINROWS") ? atoi(getenv("REFTR_W2_MINROWS")) : 256;
-    static const int abl_env = getenv("REFTR_W2_ABL") ? atoi(getenv("REFTR_W2_ABL")) : 0;      // ablation probes (wrong results)
-    static const int pf_env = getenv("REFTR_W2_PF") ? atoi(getenv("REFTR_W2_PF")) : 0;
+    static const int target_env = RT_TUNE("REFTR_W2_TARGET", 0);
+    static const int xcd_env = RT_TUNE("REFTR_W2_XCD", 2);      // 0 linear, 1 per-XCD table (round-robin units), 2 contiguous runs
+    static const int minrows_env = RT_TUNE("REFTR_W2_MINROWS", 256);
+#ifdef RT_LAB                                      // lab builds only (hipcc -DRT_LAB): ablation probes, wrong results
+    static const int abl_env = RT_TUNE("REFTR_W2_ABL", 0);
+#else
+    constexpr int abl_env = 0;
+#endif
+    static const int pf_env = RT_TUNE("REFTR_W2_PF", 0);
     constexpr int CR = 32;
     static const int BNs[5] = {256, 128, 256, 128, 128}, BCs[5] = {256, 256, 128, 128, 128};
     static double wts[5] = {4, 2, 2, 1, 3};                   // cost of one chunk of a tile task, in 128x128-tile units (REFTR_W2_WTS="a,b,c,d,e")
     static bool wts_done = false;
     if (!wts_done) {
+#ifdef RT_LAB
         if (const char* e = getenv("REFTR_W2_WTS")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &wts[0], &wts[1], &wts[2], &wts[3], &wts[4]);
+#endif
         wts_done = true;
     }
     static const int slots[4] = {256, 256, 256, 512};         // resident workgroups on the chip (LDS: 130 / 98 / 98 / 66 KB each)
@@ -625,7 +631,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
         // The per-problem rounding of the split counts must not push the launch over the resident slots: a 257th workgroup of
         // a long task is a whole extra task time for everybody (measured: a layer3 stage went from 288 to 352 us).  Coarsen
         // per_wg until the rounded counts fit.
-        static const int fit_env = getenv("REFTR_W2_FIT") ? atoi(getenv("REFTR_W2_FIT")) : 1;
+        static const int fit_env = RT_TUNE("REFTR_W2_FIT", 1);
         if (fit_env && tiles_total < target) {
             for (int it = 0; it < 24; ++it) {
                 long long total = 0;
@@ -723,7 +729,7 @@ int rt_w2_run(const rt_conv_wgrad_desc* descs, const int* idx, int n, float* wor
                 xcount[x] += cnt * p.tiles; xload[x] += (double)cnt * p.tiles * p.chunks_per_split;
                 g.cum[x][g.n + 1] = xcount[x];
             }
-            static const int dbg_env = getenv("REFTR_W2_DEBUG") ? atoi(getenv("REFTR_W2_DEBUG")) : 0;
+            static const int dbg_env = RT_TUNE("REFTR_W2_DEBUG", 0);
             if (dbg_env) fprintf(stderr, "[w2] M=%d N=%d C=%d k=%d s=%d cfg=%d tiles=%d splits=%d chunks/split=%d  (group tiles %lld, per_wg %.0f)\n",
                                  p.M, p.N, p.SC, p.KH, p.stride, p.cfg, p.tiles, p.splits, p.chunks_per_split, tiles_total, per_wg);
             lin_total += p.tiles * p.splits;

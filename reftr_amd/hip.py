@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreftr_hip.so")
+LIB_PATH = os.path.join(_HERE, "libreftr_hip_lab.so" if os.environ.get("REFTR_LAB", "0") == "1" else "libreftr_hip.so")   # _build.py
 ABI_VERSION = 32
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
