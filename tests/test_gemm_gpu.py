@@ -51,9 +51,6 @@ def hash_keep(seed, idx, p):
     (129, 64, 68, 231), (200, 256, 256, 231), (3520, 2048, 256, 233), (320, 768, 3072, 233), (333, 192, 72, 221), (333, 320, 72, 221),
     (320, 768, 3072, 81), (320, 3072, 768, 281), (333, 192, 72, 281), (129, 64, 68, 282), (320, 768, 768, 282), (333, 320, 72, 283),
     (320, 3072, 768, 284), (50, 128, 40, 281),
-    # direct epilogue from the accumulators (permuted weight rows): ragged M, N a multiple of 8 but not of the tile, N not a multiple of 8 (falls back)
-    (200, 256, 256, 331), (333, 192, 72, 331), (129, 64, 68, 331), (3520, 256, 2048, 333), (333, 320, 264, 321), (12800, 256, 1024, 351),
-    (700, 256, 264, 351), (3520, 2048, 256, 352),
     # deep-stage forms: fewer K tiles than stages (64, 192), as many, and many more
     (320, 3072, 768, 285), (333, 192, 72, 285), (50, 64, 40, 285), (320, 384, 768, 285), (320, 768, 768, 286), (129, 64, 68, 286),
     (333, 320, 72, 287), (320, 2304, 768, 288), (3520, 2048, 256, 234), (129, 64, 68, 234), (3520, 2048, 256, 236), (200, 256, 256, 236),
@@ -101,24 +98,6 @@ def test_linear_epilogue(hip):
     assert abs(float(keep.float().mean()) - 0.9) < 0.01
 
 
-@pytest.mark.parametrize("hint", [331, 333, 321, 351, 352])
-def test_direct_epilogue_operands(hip, hint):
-    """EPI = 1 forms: bias + residual (fp32 and bf16, prefetched) + ReLU + gate through the accumulator-side epilogue."""
-    g = torch.Generator().manual_seed(hint)
-    M, K, N = 333, 192, 200
-    x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
-    b = torch.randn(N, generator=g); rf = torch.randn(M, N, generator=g); rb = bf(torch.randn(M, N, generator=g))
-    gate = bf(torch.randn(M, N, generator=g))
-    lin = x.float() @ w.float().T + b
-    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
-    ob, of = hip.linear(xc, wc, bias=bc, res_bf16=rb.cuda(), res_first=True, act=hip.ACT_RELU, out_bf16=True, out_f32=True, tile_hint=hint)
-    ref = torch.relu(lin + rb.float())
-    assert rel(of, ref) < TOL_F32 and rel(ob, ref) < TOL_BF16
-    _, of = hip.linear(xc, wc, bias=bc, res_f32=rf.cuda(), res_bf16=rb.cuda(), gate=gate.cuda(), gate_scale=0.5, out_bf16=False, out_f32=True,
-                       tile_hint=hint)
-    assert rel(of, (lin + rf + rb.float()) * (gate.float() > 0) * 0.5) < TOL_F32
-
-
 CONV_CASES = [
     # B, H, W, Cin, Cout, k, stride, pad
     (2, 20, 20, 64, 64, 3, 1, 1),
@@ -130,7 +109,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54, 61, 62, 63, 211, 221, 231, 233, 251, 252, 331, 333, 321, 351, 352])
+@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54, 61, 62, 63, 211, 221, 231, 233, 251, 252])
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", [CONV_CASES[1], CONV_CASES[4], CONV_CASES[2]])
 def test_conv_dma_variants(hip, hint, B, H, W, Ci, Co, k, s, p):
     """The LDS-DMA tile variants against torch fp32: forward gather and transposed (backward-data) gather."""
