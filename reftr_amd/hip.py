@@ -462,6 +462,15 @@ def _timed(kind, flops, fn, tag=None, nbytes=None, epi_bytes=0.0):
     return r
 
 
+def as_u8(t):
+    """A mask as the uint8 bytes the kernels read: bool tensors are re-typed in place (same bytes, no launch -- `.to(torch.uint8)` is a
+    converting copy: 12 us for the [8, 640, 640] padding mask at the head of every step), everything else is converted."""
+    t = t.contiguous()
+    if t.dtype == torch.bool:
+        return t.view(torch.uint8)
+    return t if t.dtype == torch.uint8 else t.to(torch.uint8)
+
+
 def _req(t, dtype, name):
     if t is None:
         return

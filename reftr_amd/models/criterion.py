@@ -75,7 +75,7 @@ class CriterionVGMultiPhrase(nn.Module):
         device = logits.device
         num_boxes = self.num_boxes(targets, device)
         boxes, off = self._targets(targets, device)
-        valid = outputs["phrase_mask"].to(torch.uint8).contiguous()
+        valid = H.as_u8(outputs["phrase_mask"])
         losses = _BoxLossFunction.apply(logits, valid, boxes, off, num_boxes)     # [NL, 2]
         return self._loss_dict(losses)
 
@@ -106,7 +106,7 @@ class CriterionVGMultiPhrase(nn.Module):
             logits = logits[-1:]
         logits = logits.contiguous()
         boxes, off, num_boxes = prepared
-        valid = phrase_mask.to(torch.uint8).contiguous()
+        valid = H.as_u8(phrase_mask)
         w = _box_weights(self, logits.shape[0], logits.device)
         losses, _, dl = H.box_loss(logits, valid, boxes, off, num_boxes, want_grad=True, weights=w)
         if not aux and full.shape[0] > 1:          # only the last layer carries a loss: the other layers' gradient is zero

@@ -215,7 +215,7 @@ class Net:
         M, Hd = B * L, bc.hidden
         pfx = "lang_backbone."
         e = pfx + "embeddings."
-        kpm = (mask_u8 == 0).to(torch.uint8)
+        kpm = (mask_u8 == 0).view(torch.uint8)
         pos_ids = H.roberta_pos_ids(ids, bc.pad_idx) if bc.pad_idx >= 0 else None
         emb = H.bert_embed_fwd(ids, self.P(e + "word_embeddings.weight"), self.P(e + "position_embeddings.weight"),
                                self.P(e + "token_type_embeddings.weight"), L, pos_ids=pos_ids)

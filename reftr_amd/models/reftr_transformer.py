@@ -341,7 +341,7 @@ class RefTR(nn.Module):
             img = nested_tensor_from_tensor_list(img)
         x, mask = img.decompose()
         x = x.to(dev, torch.float32).contiguous()
-        mask_u8 = mask.to(dev).to(torch.uint8).contiguous()
+        mask_u8 = H.as_u8(mask.to(dev))
         B = x.shape[0]
         self._step += 1
         net.begin_step(self.training)
@@ -350,7 +350,17 @@ class RefTR(nn.Module):
             H.counter_add(self.seed_dev, 1)
 
         ids = samples["sentence"].to(dev).contiguous()
-        smask_u8 = samples["sentence_mask"].to(dev).to(torch.uint8).contiguous()
+        # the sentence mask arrives as int64 (BERT's attention mask): its uint8 image is first needed by the language branch, which
+        # converts it on ITS stream (one launch less on the main stream's head); readers behind the forward join find it there
+        smask_src = samples["sentence_mask"].to(dev)
+        smask_box = []
+
+        def _smask():
+            if not smask_box:
+                smask_box.append(H.as_u8(smask_src))
+            elif smask_box[0] is not smask_src and smask_box[0].is_cuda:
+                smask_box[0].record_stream(torch.cuda.current_stream())
+            return smask_box[0]
         Lq = ids.shape[1]
         # language branch (BERT) on the side stream, concurrently with the ResNet branch below
         # c5 geometry from the image size (stem 7x7/2, maxpool 3x3/2, three stride-2 stages): the positional / mask work below
@@ -379,7 +389,7 @@ class RefTR(nn.Module):
                 net.refresh()
                 self._lin_refresh_pending = False
             H.mark("lang: AdamW (BERT slice) + operands done")
-            r = net.bert_fwd(ids, smask_u8)
+            r = net.bert_fwd(ids, _smask())
             H.mark("lang: BERT forward done")
             res = r + _pos_work()
             if self._lang_tail:
@@ -389,7 +399,7 @@ class RefTR(nn.Module):
                 sq16, pl16, _, pos_, _ = res
                 _, lang_tail["ms_ctx"] = net.mlp_fwd(sq16, "map_sentence.", y_f32=x32, y_bf16=x16, ypos_bf16=xp16, pos=pos_, rowmap=(Lq, S, 0))
                 if "phrase" not in samples:
-                    lang_tail["masks"] = H.context_mask(smask_u8)
+                    lang_tail["masks"] = H.context_mask(_smask())
                     cat16_ = torch.empty(B, 2 * E, dtype=torch.bfloat16, device=dev)
                     _, lang_tail["mp_ctx"] = net.mlp_fwd(pl16, "map_phrase.", y_bf16=cat16_.view(2 * B, E), want_f32=False, rowmap=(1, 2, 1))
                     lang_tail["cat16"] = cat16_
@@ -399,7 +409,7 @@ class RefTR(nn.Module):
         def _pos_work():
             pos = torch.empty(M, E, dtype=torch.float32, device=dev)
             kpm = torch.empty(B, S, dtype=torch.uint8, device=dev)
-            kpm[:, :Lq] = (smask_u8 == 0)                                   # models/reftr.py:92
+            kpm[:, :Lq] = (_smask() == 0)                                   # models/reftr.py:92
             H.rows_add(B * Lq, E, a_f32=st.P[vt + "lang_pos_embeddings.weight"], a_map=(Lq, 0, 0),
                        b_f32=st.P[vt + "token_type_embeddings.weight"], b_map=(-(B * Lq), 0, 0),
                        out_f32=pos, o_map=(Lq, S, 0))
@@ -422,7 +432,7 @@ class RefTR(nn.Module):
         stem_first = self._stem_first if self.body.fuse_stem else 0       # 2: behind frozen layer1 as well
         lang_box = []
         def _fork_lang():
-            lang_box.append(net.side.run(_lang_branch, ids, smask_u8, mask_u8))
+            lang_box.append(net.side.run(_lang_branch, ids, smask_src, mask_u8))
         if not stem_first:
             _fork_lang()
         feats, bb_saved = self.body.forward(x, ready=self._bb_ready, before_trainable=_fork_lang if stem_first == 2 else None,
@@ -447,14 +457,14 @@ class RefTR(nn.Module):
         if "phrase" in samples:
             ph = samples["phrase"].to(dev)
             Pn, Lp = ph.shape[1], ph.shape[2]
-            pm_u8 = samples["phrase_mask"].to(dev).to(torch.uint8).contiguous()
+            pm_u8 = H.as_u8(samples["phrase_mask"].to(dev))
             _, ph_pooled16, pctx = net.bert_fwd(ph.reshape(B * Pn, Lp).contiguous(), pm_u8.view(B * Pn, Lp))
-            ctxmask, qmask = H.context_mask(smask_u8, pm_u8, samples["phrase_pos_l"].to(dev).contiguous(),
+            ctxmask, qmask = H.context_mask(_smask(), pm_u8, samples["phrase_pos_l"].to(dev).contiguous(),
                                             samples["phrase_pos_r"].to(dev).contiguous())
         else:
             Pn = 1
             ph_pooled16 = pooled16
-            ctxmask, qmask = lang_tail["masks"] if "masks" in lang_tail else H.context_mask(smask_u8)
+            ctxmask, qmask = lang_tail["masks"] if "masks" in lang_tail else H.context_mask(_smask())
         N = B * Pn
         if "mp_ctx" in lang_tail:
             cat16, mp_ctx = lang_tail["cat16"], lang_tail["mp_ctx"]
@@ -637,7 +647,7 @@ class RefTR(nn.Module):
         H.head_loss(NL=NL, B=B, P=Pn, K=nq, E=E, eps=1e-5, t3=t3_all,
                     gn=st.P[vt + "decoder.norm.weight"], betn=st.P[vt + "decoder.norm.bias"],
                     W0=l0.W, W1=l1.W, W2=l2.W, W0T=l0.WT, W1T=l1.WT, b0=l0.b32, b1=l1.b32, b2=l2.b32, w2_f32=l2.w32,
-                    valid=mask if mask.dtype == torch.uint8 else mask.to(torch.uint8).contiguous(), invert_valid=invert,
+                    valid=H.as_u8(mask), invert_valid=invert,
                     targets=boxes, tgt_off=off, num_boxes=num_boxes, weights=_box_weights(crit, NL, t3_all.device),
                     ticket=self._head_ticket(), **o)     # the device object rt_box_loss's path keys its cache with
         return o
