@@ -216,37 +216,12 @@ def main():
         try:
             cap = CapturedTrainStep(runner, crit, opt, 0.1, s, tg)
 
-            # the batch is resident: it lives in the graphs' static input buffers (an input pipeline writes there); with
-            # REFTR_BENCH_STAGE_COPY=1 every step first copies it in from other tensors (one small copy per field)
-            sb, tb = (s, tg) if os.environ.get("REFTR_BENCH_STAGE_COPY") == "1" else cap.batch
-
-            # The loop body as reftr_amd.engine_vg.train_one_epoch drives it (REFTR_PIPELINE, single process): iteration i + 1 is
-            # launched BEFORE iteration i's numbers are read on the host -- every iteration's loss is still read (engine_vg.py:53),
-            # one launch later, from its own pinned buffer; the stop-before-update on a non-finite loss is decided on the device
-            # (rt_finish_step).  Measured SLOWER than reading each iteration before launching the next (+0.03 ... 0.11 ms, also with two
-            # instantiated graphs used in turn: profiles/r05_pipeline_negative_result.txt), so it is off: BENCH_PIPELINE=1 turns it on.
-            pipelined = os.environ.get("BENCH_PIPELINE", "0") == "1" and not (world > 1 or force_dist)
-            inflight = []
-
-            def _read(slot):
-                host, ev = slot
-                ev.synchronize()
-                vals = host.tolist()
-                k = len(cap.stat_names)
-                wd = crit.weight_dict
-                return sum(v * wd[n] for n, v in zip(cap.stat_names, vals[:k]) if n in wd)
+            # the batch is resident: it lives in the graphs' static input buffers (an input pipeline writes there)
+            sb, tb = cap.batch
 
             def step():
-                if not pipelined:
-                    losses, _, gn = cap(sb, tb)
-                    return (losses.item(), None, None, gn)   # same host sync as the reference loop (engine_vg.py:53)
-                cap(sb, tb)
-                inflight.append(cap.queue_stats())
-                loss_value = _read(inflight.pop(0)) if len(inflight) > 1 else float("nan")
-                return (loss_value, None, None, None)
-
-            def drain():
-                return _read(inflight.pop(0)) if inflight else None
+                losses, _, gn = cap(sb, tb)
+                return (losses.item(), None, None, gn)   # same host sync as the reference loop (engine_vg.py:53)
             mode = "hipgraph"
         except Exception as e:                               # capture unsupported in this environment: stay eager
             if rank == 0:
@@ -254,8 +229,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if mode == "hipgraph" and not args.no_graph and pipelined:
-        drain()                            # nothing of the warm-up is left in flight when the clock starts
     dp = world > 1 or force_dist
     if dp:
         runner.timing = []                 # (event, event) around the end-of-backward waits: the exposed part of the exchange
@@ -273,10 +246,6 @@ def main():
         print("[bench] losses:", " ".join("%.4g" % v for v in trace), file=sys.stderr)
         print("[bench] step_dev", int(opt.step_dev), "seed_dev", int(model.seed_dev), "gnorm", float(opt.grad_norm),
               "|p|", float(model.store.flat_p.norm()), "|g|", float(model.store.flat_g.norm()), "dirty", model._operands_dirty, file=sys.stderr)
-    if not args.no_graph and mode == "hipgraph" and pipelined:
-        last = drain()                     # the last iteration's numbers (inside the timed region)
-        if last is not None:
-            loss_value = last
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

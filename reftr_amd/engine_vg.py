@@ -293,8 +293,8 @@ class CapturedTrainStep:
         # data parallel (round 3): the same deferred schedule across the segment graphs -- the AdamW pass of iteration i sits at
         # the head of iteration i+1's FIRST graph (its BERT slice on the language stream under the ResNet forward, reading the
         # all-reduced bf16 gradients of iteration i, which nothing rewrites before this iteration's first exchange boundary), the
-        # last graph ends with the gradient norm.  REFTR_DEFER_DP=0: clip + AdamW in the last graph (round 2).
-        self.deferred_dp = can_defer and not self.deferred and os.environ.get("REFTR_DEFER_DP", "1") == "1"
+        # last graph ends with the gradient norm.  (Optimizers without the deferred interface: clip + step in the last graph.)
+        self.deferred_dp = can_defer and not self.deferred
         self._pending = False
         self._staged = None
         if self.deferred:
@@ -405,7 +405,7 @@ class CapturedTrainStep:
         # neutral, 6.67-6.69 vs 6.66-6.68 ms, profiles/r04ai_zero_side_ab.txt and again +0.06 ms in round 5 -- option removed)
         # backward and clip norm are one unit here (nothing touches the gradient buffer in between): the BERT slice's share of the
         # norm may be taken on the language stream as soon as that slice is final (reftr_transformer._backward_gen)
-        inner._norm_side = os.environ.get("REFTR_NORM_SPLIT", "1") != "0" and not getattr(inner.store, "fused_norm", False)
+        inner._norm_side = not getattr(inner.store, "fused_norm", False)
         try:
             out = self._fwd_bwd(zero=True)
             self.grad_norm = opt.finish_step(self.max_norm, loss=out[0])
@@ -466,11 +466,10 @@ class CapturedTrainStep:
         """The direct loss path applies when the total is the weighted sum of the box losses of THIS process's model: no wrapper
         (the data-parallel schedules drive backward themselves), no mask / CEM terms, the fused total, aux weights as usual."""
         inner, crit = self.inner, self.criterion
-        # (round 5: REFTR_LOSS_DIRECT_DP=1 takes this path under the data-parallel wrapper too -- its forward only forwards to the
-        # module, and RefTR._backward_impl honours the wrapper's exchange boundaries whoever calls it.  Measured through single-rank
-        # RCCL: 7.58-7.63 ms against 7.17-7.22 ms on the autograd path (the early fork of the target preparation costs the segment
-        # graphs more than the launches it removes; profiles/r05_ddp_direct_loss_negative_result.txt) -- off.)
-        dp_ok = (self.model is inner and not inner.dp_mode) or os.environ.get("REFTR_LOSS_DIRECT_DP", "0") == "1"
+        # (round 5 built this path under the data-parallel wrapper too and measured it through single-rank RCCL: 7.58-7.63 ms against
+        # 7.17-7.22 ms on the autograd path -- the early fork of the target preparation costs the segment graphs more than the launches it
+        # removes; profiles/r05_ddp_direct_loss_negative_result.txt.  Removed.)
+        dp_ok = self.model is inner and not inner.dp_mode
         return (os.environ.get("REFTR_LOSS_DIRECT", "1") == "1" and dp_ok and getattr(inner, "seg", 1) is None
                 and hasattr(crit, "loss_and_grad") and tuple(crit.losses) == ("boxes",)
                 and os.environ.get("REFTR_FUSED_TOTAL", "1") != "0")
@@ -531,7 +530,7 @@ class CapturedTrainStep:
 
     def queue_stats(self, stats=None):
         """Enqueues the device -> host copy of this iteration's stats vector behind the replay, into one of TWO pinned buffers used
-        in turn (each with its event): with REFTR_PIPELINE the loop launches iteration i + 1 before it reads iteration i, so the two
+        in turn (each with its event): a caller may launch iteration i + 1 before it reads iteration i, so the two
         copies in flight must not share a buffer.  Returns (host buffer, event)."""
         stats = self.stats if stats is None else stats
         if getattr(self, "_stats_host", None) is None:
@@ -843,15 +842,11 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
     prefetcher = data_prefetcher(data_loader, device, prefetch=True)
     samples, targets = prefetcher.next()
     booked = None
-    # REFTR_PIPELINE=1 (single process; default OFF): iteration i + 1 is LAUNCHED before iteration i is read out, meant to close the
-    # ~75 us between two replays (read-out + launch latency).  Measured: a hipGraph launched while its previous launch is still
-    # running starts LATER than one launched from an idle stream on this stack (bench.py +0.03 ... 0.11 ms per iteration, also with two
-    # instantiated graphs used in turn; profiles/r05_pipeline_negative_result.txt) -- kept as an option.  The reference reads the loss and
-    # stops BEFORE the update when it is not finite (engine_vg.py:53-58); here that decision is taken on the device (rt_finish_step:
-    # a non-finite total never arms the iteration's deferred AdamW pass, like a failed cooperative launch), the host reads the same
-    # numbers one launch later and stops then -- with the weights the reference would have stopped with.
-    pipeline = os.environ.get("REFTR_PIPELINE", "0") == "1" and not (utils.is_dist_avail_and_initialized() and utils.get_world_size() > 1)
-    pending = None
+    # The loop reads iteration i before it launches iteration i + 1 (engine_vg.py:53-58 stops on a non-finite loss BEFORE the update).
+    # Launching i + 1 first was built in round 5 on the device-side veto that is still there (rt_finish_step never arms the update of
+    # an iteration whose total is not finite) and measured SLOWER: a hipGraph launched while its previous launch is still running
+    # starts later than one launched from an idle stream on this stack (+0.03 ... 0.11 ms per iteration, also with two instantiated
+    # graphs used in turn; profiles/r05_pipeline_negative_result.txt).  Removed.
 
     def _read(step):
         loss_value, scaled, unscaled, gnorm = step.finish()
@@ -868,20 +863,10 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_scheduler, devi
         if booked is not None:
             board.add(**booked)
             booked = None
-        if pipeline and isinstance(step, _ReplayInFlight):
-            if pending is not None:
-                booked = _read(pending)          # iteration i - 1, while iteration i runs
-            pending = step
-        else:
-            if pending is not None:              # an eager iteration behind a replayed one: drain in order
-                board.add(**_read(pending))
-                pending = None
-            booked = _read(step)
+        booked = _read(step)
         samples, targets = ahead()
     if booked is not None:
         board.add(**booked)
-    if pending is not None:
-        board.add(**_read(pending))
     _check_cooperative(model)
     board.synchronize_between_processes()
     print("Averaged stats:", board)

@@ -62,12 +62,11 @@ class ResNetBody:
                 inpl = planes * 4
             self.blocks.append(stage)
         self.wg = H.SideStream(False)     # conv weight gradients stay inline (they fill the chip on their own)
-        import os
-        self.fuse_frozen = os.environ.get("REFTR_L1_FUSE", "1") == "1" and str(store.device).startswith("cuda")
-        self.fuse_stem = os.environ.get("REFTR_STEM_FUSE", "1") == "1"
-        gc = int(os.environ.get("REFTR_GROUP_CONV", "1")) if str(store.device).startswith("cuda") else 0
-        self.batch = H.WgradBatch(workspace_mb=1024) if gc else None
-        self.wgs = H.SideStream(gc == 2)
+        on_gpu = str(store.device).startswith("cuda")
+        self.fuse_frozen = on_gpu         # frozen layer1 bottlenecks as one launch each (rt_bottleneck_fwd)
+        self.fuse_stem = True             # frozen stem + max-pool as one launch (rt_stem_pool)
+        self.batch = H.WgradBatch(workspace_mb=1024) if on_gpu else None      # conv weight gradients: grouped launches per stage
+        self.wgs = H.SideStream(False)
         self.W = {}      # bf16 operands: name -> [N][T][C]; name + '.t' -> [C][T][N]
         self.bn = {}     # bn prefix -> (scale, shift) fp32
         self.all_convs = [c for st in self.blocks for b in st for c in (b.conv1, b.conv2, b.conv3, b.down) if c is not None]
@@ -123,7 +122,7 @@ class ResNetBody:
                            act=H.ACT_RELU if relu else H.ACT_NONE, dil=c.dil)
         return y, (B, Ho, Wo), geom
 
-    def forward(self, img, ready=None, before_trainable=None, after_stem=None):
+    def forward(self, img, ready=None, after_stem=None):
         """img fp32 [B,3,H,W] -> (list of the 4 stage outputs as ([M, C] bf16, (B,h,w))), saved-for-backward).
         `ready`: event after which the TRAINABLE convolutions' operands are current (the frozen stem / layer1 do not wait)."""
         B, _, Hh, Ww = img.shape
@@ -142,9 +141,6 @@ class ResNetBody:
         feats, saved = [], []
         for stage in self.blocks:
             for b in stage:
-                if before_trainable is not None and b.trainable:
-                    before_trainable()              # the deferred optimizer pass over the main slice, behind the frozen prefix
-                    before_trainable = None
                 if ready is not None and b.trainable:
                     torch.cuda.current_stream().wait_event(ready)
                     ready = None
@@ -170,8 +166,6 @@ class ResNetBody:
                 x, shp = out, s3
             feats.append((x, shp))
             H.mark(f"ResNet forward: layer{len(feats)} done")
-        if before_trainable is not None:            # nothing trainable in the body (--lr_backbone 0)
-            before_trainable()
         return feats, saved
 
     # ------------------------------------------------------------------ backward

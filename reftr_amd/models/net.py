@@ -47,13 +47,9 @@ class Net:
         on = int(os.environ.get("REFTR_STREAMS", "1")) if str(store.device).startswith("cuda") else 0
         self.wg = H.SideStream(bool(on & 2), defer=True)
         self.side = H.SideStream(bool(on & 1))
-        self.small_wg = H.SmallWgradBatch() if os.environ.get("REFTR_GROUP_SMALL", "1") != "0" else None
-        self.trivial_sa = os.environ.get("REFTR_TRIVIAL_SA", "1") != "0"
+        self.small_wg = H.SmallWgradBatch()
+        self.trivial_sa = True            # one-key self-attention (one query per image): softmax == 1, the attention launch is skipped
         self.fold_sa = os.environ.get("REFTR_FOLD_SA", "1") != "0"
-        # measured (profiles/r03_side_stream_probes.txt): the decoder layers' memory-gradient products on the language stream beside
-        # the decoder's backward chain cost +0.2 ms -- a 440-workgroup launch beside the chain's 1-16-workgroup kernels delays them
-        # more than leaving the chain saves; off by default
-        self.kv_dgrad_side = os.environ.get("REFTR_DEC_KV_SIDE", "0") != "0"
         # the decoder's forward chain as one cooperative launch (csrc/rt_decoder.hip) whenever its shape allows
         self.dec_coop = os.environ.get("REFTR_DEC_COOP", "1") != "0"
         self.dec_coop_bwd = os.environ.get("REFTR_DEC_COOP_BWD", "1") != "0"
@@ -63,8 +59,8 @@ class Net:
         # allocated (and zeroed) NOW, outside any stream capture: a zero-fill captured into a graph would reset the launch epoch on
         # every replay and make the previous replay's hand-off tags look current
         self._dec_handoff = H.decoder_handoff(store.device) if str(store.device).startswith("cuda") else None
-        self.ln_batch = H.LnGradBatch() if os.environ.get("REFTR_GROUP_LN", "1") != "0" and str(store.device).startswith("cuda") else None
-        self.big_wg = H.WgradBatch() if os.environ.get("REFTR_GROUP_WGRAD", "1") != "0" and str(store.device).startswith("cuda") else None
+        self.ln_batch = H.LnGradBatch() if str(store.device).startswith("cuda") else None
+        self.big_wg = H.WgradBatch() if str(store.device).startswith("cuda") else None
         self._build_lins()
 
     # ------------------------------------------------------------------ operand bank
@@ -174,19 +170,11 @@ class Net:
         if self.ln_batch is not None:
             self.ln_batch.run()
 
-    def flush_wgrads_side(self, bit=1):
-        """The same launches on the language stream (REFTR_WG_SIDE bit mask: 1 decoder section, 2 first half of the encoder,
-        4 end of the encoder; default 4).  Measured: the end-of-encoder group in front of the BERT branch takes 0.07 ms off
-        the step (the ResNet backward no longer waits for it); the groups that would run BESIDE the latency-bound encoder
-        chain slow that chain down by more than they save (+0.25 .. 0.3 ms) and stay on the main stream.
-        The queued tensors stay referenced by the SideStream until the join at the end of backward."""
-        if bit == 1 and os.environ.get("REFTR_WG_MERGE_DEC", "1") == "1":
-            # the decoder / query-encoder / head jobs stay queued and ride with the encoder's first group (bit 2, or the end-of-encoder
-            # group when the encoder has one layer): six launches of ~90 us leave the chain between the query encoder's and the
-            # encoder's backward (-0.025 ms, profiles/r04bd_wgrad_merge_ab.txt)
-            return None
-        if not self.side.enabled or not (int(os.environ.get("REFTR_WG_SIDE", "4")) & bit):
-            return self.flush_wgrads() if bit != 2 else None
+    def flush_wgrads_side(self):
+        """The same launches on the language stream, in front of the BERT-backward branch: the ResNet backward does not wait for them
+        (-0.07 ms).  The queued tensors stay referenced by the SideStream until the join at the end of backward."""
+        if not self.side.enabled:
+            return self.flush_wgrads()
         keep = []
         for b in (self.small_wg, self.big_wg, self.ln_batch):
             for tup in getattr(b, "keep", []) if b is not None else []:
@@ -635,13 +623,9 @@ class Net:
         grp = H.GemmGroup()                      # two accumulators, two independent products, one launch
         self.lin_bwd(p + "multihead_attn.v", dv2, mem16, res_f32=dmem_acc, out_bf16=False, out_f32=dmem_acc, group=grp)
         self.lin_bwd(p + "multihead_attn.k", dk2, memp16, res_f32=dmemp_acc, out_bf16=False, out_f32=dmemp_acc, group=grp)
-        # Nothing on the decoder's chain reads the memory gradients, so the M = B*S launch COULD leave the chain (a ~12 us node per
-        # layer) for the language stream, which is idle until BERT's backward (REFTR_DEC_KV_SIDE=1; the accumulations stay ordered
-        # on that one stream and the caller joins before its first own write to the accumulators) -- measured slower, see __init__.
-        if self.kv_dgrad_side and self.side.enabled:
-            self.side.run(grp.run, dv2, dk2, mem16, memp16)
-        else:
-            grp.run()
+        # (on the language stream, which idles here, this M = B*S launch delays the chain's 1-16-workgroup kernels by more than leaving
+        # the chain saves: +0.2 ms, profiles/r03_side_stream_probes.txt)
+        grp.run()
         _, dt1q = self.lin_bwd(p + "multihead_attn.q", dq2, r["t1q16"], out_bf16=False, out_f32=True, acc2_f32=dqpos_acc)
         du, dub = self.ln_bwd(du2, r["u"], p + "norm1.", *r["st1"], dy2=dt1q, drop2_p=r["d1"][0], drop2_seed=r["d1"][1])
         if r["fold"]:           # the head-dropout mask of the forward, applied by the backward-data product's epilogue

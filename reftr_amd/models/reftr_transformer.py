@@ -96,9 +96,7 @@ class RefTR(nn.Module):
         # (Rounds 3-4 measured four other placements of the deferred AdamW passes -- beside the frozen prefix (REFTR_PRE_SIDE), behind it
         # (REFTR_OPT_LATE), serialised in front of it (REFTR_OPT_SERIAL), in five pieces on a third stream (REFTR_OPT_PIPE) -- all
         # neutral or slower (profiles/r03_side_stream_probes.txt, r04s_*, r04z_*); their code was removed in round 5, LAB_NOTES.md.)
-        self._stem_first = int(os.environ.get("REFTR_STEM_FIRST", "1"))
-        self._lang_tail = os.environ.get("REFTR_LANG_TAIL", "1") != "0"
-        self._lang_tail_bwd_phrase = os.environ.get("REFTR_LANG_TAIL", "1") != "2"      # 2: map_phrase's backward stays on the main stream
+        self._lang_tail = True            # map_sentence / map_phrase (forward and backward) on the language stream (r04ax, r04az)
         self._bb_ready = None
         self._norm_side = False          # switched on by engine_vg.CapturedTrainStep around its own backward + clip-norm unit only
         self._norm_split = None
@@ -244,8 +242,6 @@ class RefTR(nn.Module):
         # the Linear operands (BERT + transformer, 85 % of the bytes) are refreshed at the head of the BERT side stream
         # inside _forward_impl, concurrently with the stem / layer1 of the ResNet
         self._lin_refresh_pending = True
-        if os.environ.get("REFTR_PREP_SIDE", "1") == "0" and self._pre_update is None:
-            self.net.refresh(); self._lin_refresh_pending = False
         if self.seg is not None:
             self.seg.refresh()
         self._operands_dirty, self._full_refresh = False, False
@@ -429,16 +425,13 @@ class RefTR(nn.Module):
             return (pos, kpm)
         # REFTR_STEM_FIRST=1: the language branch is forked BEHIND the frozen stem (rt_stem_pool: two 72-KB / 230-VGPR workgroups per
         # CU, which find no room beside the BERT slice's AdamW pass once that has filled the chip) instead of in front of it
-        stem_first = self._stem_first if self.body.fuse_stem else 0       # 2: behind frozen layer1 as well
+        stem_first = 1 if self.body.fuse_stem else 0                        # (behind frozen layer1 as well, or in front of the stem: slower, r04al)
         lang_box = []
         def _fork_lang():
             lang_box.append(net.side.run(_lang_branch, ids, smask_src, mask_u8))
         if not stem_first:
             _fork_lang()
-        feats, bb_saved = self.body.forward(x, ready=self._bb_ready, before_trainable=_fork_lang if stem_first == 2 else None,
-                                            after_stem=_fork_lang if stem_first == 1 else None)
-        if not lang_box:                       # no trainable block fired the hook (--lr_backbone 0)
-            _fork_lang()
+        feats, bb_saved = self.body.forward(x, ready=self._bb_ready, after_stem=_fork_lang if stem_first else None)
         seq16, pooled16, bctx, pos, kpm = lang_box[0]
         c5, (_, h5, w5) = feats[-1]
         assert (h5, w5) == (h, w)
@@ -679,8 +672,6 @@ class RefTR(nn.Module):
         dcat_rows = dcat.view(2 * N, E)
         _, dcob = net.ln_bwd(dcat_rows, sv["co"], qe + "context_out.1.", *sv["cst"], rowmap=(1, 2, 0), want_f32=False)
         _, dc = net.lin_bwd(qe + "context_out.0.", dcob, sv["c16"], out_bf16=False, out_f32=True)
-        if net.kv_dgrad_side:
-            net.side.join()             # REFTR_DEC_KV_SIDE=1: the decoder layers' memory-gradient products ran on the language stream
         H.rows_add(N, E, a_f32=dcat_rows, a_map=(1, 2, 0), out_f32=dmem, accumulate=2, o_map=(-Pn, S, 0))
         dk, dqs, dvs = H.qenc_attn_bwd(sv["kq"], sv["qs"].view(B, Lq, E), sv["vs"].view(B, Lq, E), sv["qw"], dc.view(B, Pn, E))
         dk16 = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
@@ -883,8 +874,6 @@ class RefTR(nn.Module):
         if nq == 1 and self._qfuse_ok(Lq, Pn):
             # round 5: the backward-data chain as ONE launch (rt_qenc_bwd); the six Linear weight gradients and the three LayerNorms'
             # parameter gradients are queued for the grouped launches as before
-            if net.kv_dgrad_side:
-                net.side.join()         # REFTR_DEC_KV_SIDE=1: the decoder layers' memory-gradient products ran on the language stream
             dcat = self._qenc_bwd_fused(sv, ga, gb, dqpos, dmem, B, S, Lq, Pn)
             N = Nf
             dcat_rows = dcat.view(2 * N, E)
@@ -898,11 +887,12 @@ class RefTR(nn.Module):
         # Single process with the language stream on: the backward of map_phrase and of map_sentence only feed BERT's backward, so
         # they open THAT branch (language stream) instead of sitting in the main stream's chain (REFTR_LANG_TAIL, as in forward)
         lang_head = self._lang_tail and net.side.enabled and not self.dp_mode
-        phrase_on_lang = lang_head and self._lang_tail_bwd_phrase
+        phrase_on_lang = lang_head
         dpool = None if phrase_on_lang else _map_phrase_bwd()
 
-        net.flush_wgrads_side(1)         # decoder / query-encoder / map_phrase / head weight gradients: grouped launches
-
+        # (the decoder / query-encoder / map_phrase / head weight gradients stay queued: they ride with the encoder's group on the
+        # language stream below -- launched here, or beside the encoder's chain, they cost the chain more than they save:
+        # profiles/r04bd_wgrad_merge_ab.txt, r03_side_stream_probes.txt)
         H.mark("query encoder backward done")
         # ---- encoder
         H.rows_add(M, E, a_f32=dmemp, out_f32=dmem, accumulate=True)      # K-side input of every cross-attention = memory + pos
@@ -911,8 +901,6 @@ class RefTR(nn.Module):
         dxa, dxb = dmem, None
         for i in reversed(range(cfg.enc_layers)):
             dxa, dxb = net.enc_layer_bwd(f"{vt}encoder.layers.{i}.", sv["enc"][i], dxa, dxb, sv["kpm"], B, S, dpos)
-            if i == cfg.enc_layers // 2:
-                net.flush_wgrads_side(2) # first half of the encoder's weight gradients, beside the second half's chain
         H.pos_grad(dpos, st.G[vt + "lang_pos_embeddings.weight"], st.G[vt + "token_type_embeddings.weight"],
                    st.G[vt + "level_embed"], B, S, Lq)
         if cfg.pos_learned:             # d col_embed[x] = sum over images and rows, d row_embed[y] = sum over images and columns
@@ -1019,7 +1007,7 @@ class RefTR(nn.Module):
                     self._norm_split = (b0, b1, self._sq_bert)
                     H.mark("lang: BERT slice's squared norm done")
             H.mark("input_proj backward done (ResNet backward starts)")
-            net.flush_wgrads_side(4)     # encoder / map_sentence weight gradients: language stream, in front of the BERT branch
+            net.flush_wgrads_side()      # every transformer-side weight gradient queued so far: language stream, in front of the BERT branch
             net.side.run(_bert_bwd, d_seq, dpool, dxa, dxb, dcat_rows)
         # ---- ResNet body (its gradients are the last to become final); data parallel: layer4's slice (64 % of the ResNet
         # bytes) is final -- and exchanged -- before layer3 / layer2 run

@@ -76,7 +76,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # 0 = "m and v of the piece are zero"; such a piece with an all-zero gradient is skipped without reading p / m / v (exact: see
         # the kernel).  The bytes describe m / v as THIS optimizer's kernels left them: any write to them from outside (a restored
         # snapshot, load_state_dict) is noticed through the tensors' version counters and resets every byte to "unknown" (1).
-        self._sparse = os.environ.get("REFTR_OPT_SPARSE", "1") != "0"
+        self._sparse = True
         self._sparse_flags = {}
         self._mv_version = None
         # device word that vetoes an iteration's update (the cooperative decoder's failure word): see finish_step / step

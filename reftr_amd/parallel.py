@@ -41,9 +41,9 @@ class DistributedDataParallel(nn.Module):
         # REFTR_DDP_FORCE=1: run the exchange schedule (single-rank RCCL all-reduces) even with one process, so the
         # multi-GPU code path can be exercised on a one-GPU box
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("REFTR_DDP_FORCE") == "1")
-        # pieces per exchange are at most 1/n_chunks of the buffer (REFTR_DDP_CHUNKS): fewer, larger all-reduces cost fewer
-        # launches beside the backward and suit the ring's per-message latency; more pieces start moving earlier
-        self.n_chunks = int(os.environ.get("REFTR_DDP_CHUNKS", "2")) if n_chunks is None else n_chunks
+        # pieces per exchange are at most 1/n_chunks of the buffer: fewer, larger all-reduces cost fewer launches beside the
+        # backward and suit the ring's per-message latency; more pieces start moving earlier
+        self.n_chunks = 2 if n_chunks is None else n_chunks
         self.overlap = overlap
         self._works = []
         self.timing = None        # a list: reduce_late appends (event before the waits, event after) = exposed exchange time
@@ -57,8 +57,8 @@ class DistributedDataParallel(nn.Module):
             module.store.flat_g16 = torch.zeros_like(module.store.flat_g, dtype=torch.bfloat16)
             # Round 4: the weight-gradient launches write the bf16 twin of every registered matrix themselves (rt_conv_wgrad_desc.g16),
             # so a slice's rounding pass only touches what they do not produce (biases, norm parameters, embeddings: 4 % of the
-            # buffer) instead of reading 607 MB and writing 304 MB per step.  REFTR_DDP_TWIN=0: the full rounding copy.
-            self.twin = os.environ.get("REFTR_DDP_TWIN", "1") != "0" and module.store.flat_g.is_cuda
+            # buffer) instead of reading 607 MB and writing 304 MB per step (CPU tensors: the full rounding copy).
+            self.twin = module.store.flat_g.is_cuda
             if self.twin:
                 from . import hip as H
                 st = module.store

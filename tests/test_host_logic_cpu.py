@@ -480,7 +480,7 @@ def test_replayed_iteration_with_a_raised_failure_word_is_run_again_not_returned
         def synchronize(self):
             pass
     crit = types.SimpleNamespace(weight_dict={"loss_bbox": 5.0, "loss_giou": 2.0})
-    # (round 5: every handle reads ITS OWN (pinned buffer, event) pair -- two iterations may be in flight, REFTR_PIPELINE)
+    # (round 5: every handle reads ITS OWN (pinned buffer, event) pair -- two iterations may be in flight)
     cap = types.SimpleNamespace(stat_names=("loss_bbox", "loss_giou"), fail_word=object(), model=None)
     slot = (torch.tensor([0.5, 0.25, 0.0, 3.0]), Ev())
     loss, scaled, unscaled, gn = E._ReplayInFlight(cap, crit, retry=lambda: "again", slot=slot).finish()
