@@ -78,20 +78,22 @@ __global__ __launch_bounds__(NT) void dma_kernel(const unsigned char* __restrict
 // the region; what changes is which L2 channels the simultaneously issued lines fall into.
 template <int NT, int S>
 __global__ __launch_bounds__(NT) void dma_rows_kernel(const unsigned char* __restrict__ base, int R, int pitch, int kbytes, size_t wg_stride, int passes,
-                                                      unsigned* sink) {
+                                                      unsigned* sink, int seg = 128) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned char* reg = base + (size_t)blockIdx.x * wg_stride;
     const i32x4 rsrc = make_rsrc(reg, (unsigned)(R * pitch));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
-    const int rows_per_pass = NT / 8;                       // rows one instruction of every wave covers together
+    const int lpr = seg >> 4;                               // lanes per row segment (seg bytes of a row per instruction)
+    const int rpw = 64 / lpr;                               // rows one wave instruction covers
+    const int rows_per_pass = (NT / 64) * rpw;              // rows one instruction of every wave covers together
     int slot = 0;
     for (int p = 0; p < passes; ++p)
-        for (int k = 0; k < kbytes; k += 128)
+        for (int k = 0; k < kbytes; k += seg)
             for (int r0 = 0; r0 < R; r0 += rows_per_pass) {
-                const int row = r0 + wave * 8 + (lane >> 3);
-                dma16(rsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((slot * NT + wave * 64) * 16))), row * pitch + k + (lane & 7) * 16);
+                const int row = r0 + wave * rpw + lane / lpr;
+                dma16(rsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((slot * NT + wave * 64) * 16))), row * pitch + k + (lane % lpr) * 16);
                 slot = (slot + 1 == S) ? 0 : slot + 1;
                 wait_vmcnt<S - 1>();
             }
@@ -156,6 +158,17 @@ int main() {
             const float us = time_us([&] { hipLaunchKernelGGL((dma_rows_kernel<256, 8>), dim3(256), dim3(256), 8 * 256 * 16, 0, buf, R, pitch, kbytes, wgs, passes, sink); });
             char name[64]; snprintf(name, 64, "pitch %5d B, %4d B of each row", pitch, kbytes);
             printf("%-44s %12.1f %10.2f\n", name, bytes / 256 / us * 1e-3, bytes / us * 1e-6);
+        }
+        // how many bytes of a row one instruction takes: 128 (8 rows per instruction, the GEMM kernels' K tile of 64 bf16) ... 1024 (one row)
+        for (int seg = 128; seg <= 1024; seg *= 2) {
+            const int pitch = 4096;
+            const double bytes = 256.0 * R * kb * passes;
+            const float us = time_us([&] { hipLaunchKernelGGL((dma_rows_kernel<256, 8>), dim3(256), dim3(256), 8 * 256 * 16, 0, buf, R, pitch, kb, (size_t)R * pitch, passes, sink, seg); });
+            char name[64]; snprintf(name, 64, "pitch  4096 B, %4d B of a row per instr", seg);
+            printf("%-44s %12.1f %10.2f\n", name, bytes / 256 / us * 1e-3, bytes / us * 1e-6);
+            const float us2 = time_us([&] { hipLaunchKernelGGL((dma_rows_kernel<512, 8>), dim3(256), dim3(512), 8 * 512 * 16, 0, buf, R, pitch, kb, (size_t)R * pitch, passes, sink, seg); });
+            snprintf(name, 64, "   same, 512 threads");
+            printf("%-44s %12.1f %10.2f\n", name, bytes / 256 / us2 * 1e-3, bytes / us2 * 1e-6);
         }
         // the same rows, but every workgroup of a run of 4 reads the SAME tile (an operand shared by the n tiles of a GEMM)
         for (int pi = 0; pi < 2; ++pi) {
