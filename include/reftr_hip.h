@@ -576,8 +576,20 @@ int rt_counter_add_if_zero(int32_t* ctr, int32_t inc, const uint32_t* cond, int 
  * device as well: *step += 1 and *active += 1 unless (*cond != 0, cond optional) or (*loss is not finite, loss optional: the
  * iteration's weighted total); otherwise *active = 0 and *step is left alone.  engine_vg.py:53-58 stops BEFORE the update when the
  * loss is not finite; with the decision on the device the host may launch iteration i + 1 before it has read iteration i's numbers
- * (reftr_amd.engine_vg.train_one_epoch, REFTR_PIPELINE): a bad iteration's update is never applied, the host stops one read later. */
+ * (a pipelined loop): a bad iteration's update is never applied, the host stops one read later. */
 int rt_finish_step(int32_t* step, int32_t* active, const uint32_t* cond, const float* loss, rt_stream_t stream);
+/* rt_finish_stats — rt_finish_step plus everything else the loop reads from an iteration, in the same one-thread launch: the total
+ * gradient norm grad_norm[0] = sqrt(sq[0]) * norm_scale (clip_grad_norm_'s return value, engine_vg.py:62-66) and the iteration's stats
+ * vector stats = [*src[0] ... *src[n_src-1] | float(*cond) if cond_in_stats | grad_norm] -- the unweighted losses the meters log
+ * (engine_vg.py:46-53, util/misc.py:156-160) as device scalars wherever the criterion left them.  Replaces four launches at the end of
+ * every replayed step (counters, sqrt, a dtype conversion, a concatenation). */
+#define RT_STATS_MAX 40
+typedef struct {
+    int32_t *step, *active;  const uint32_t* cond;  const float* loss;          /* as rt_finish_step */
+    const float* sq;  float norm_scale;  float* grad_norm;                      /* optional (sq = NULL: grad_norm untouched) */
+    const float* src[RT_STATS_MAX];  int n_src;  int cond_in_stats;  float* stats;   /* optional (stats = NULL) */
+} rt_finish_desc;
+int rt_finish_stats(const rt_finish_desc* d, rt_stream_t stream);
 /* rt_stamp — buf[idx] = the device's constant 100 MHz wall clock (s_memrealtime) when the stream reaches this point: a one-thread
  * kernel the measurement tools capture into the step's graph at phase boundaries of every stream (tools/concurrent_timeline.py),
  * because rocprofv3 serialises the graph's concurrent streams. */

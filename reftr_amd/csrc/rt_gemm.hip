@@ -483,7 +483,7 @@ extern "C" int rt_conv_gemm_grouped(const rt_conv_gemm_desc* descs, int n, rt_st
     return RT_OK;
 }
 
-extern "C" int rt_abi_version(void) { return 32; }
+extern "C" int rt_abi_version(void) { return 33; }
 
 extern "C" int rt_device_arch(int dev, char* buf, int buflen) {
     hipDeviceProp_t prop;

@@ -404,6 +404,20 @@ __global__ void finish_step_kernel(int32_t* step, int32_t* active, const uint32_
     if (!bad) { step[0] += 1; active[0] += 1; } else active[0] = 0;
 }
 
+__global__ void finish_stats_kernel(const rt_finish_desc d) {
+    const uint32_t cw = d.cond ? d.cond[0] : 0u;
+    const bool bad = cw != 0u || (d.loss && !isfinite(d.loss[0]));
+    if (!bad) { d.step[0] += 1; d.active[0] += 1; } else d.active[0] = 0;
+    float gn = d.grad_norm ? d.grad_norm[0] : 0.f;
+    if (d.sq) { gn = sqrtf(d.sq[0]) * d.norm_scale; if (d.grad_norm) d.grad_norm[0] = gn; }
+    if (d.stats) {
+        int o = 0;
+        for (int i = 0; i < d.n_src; ++i) d.stats[o++] = d.src[i][0];
+        if (d.cond_in_stats) d.stats[o++] = (float)cw;
+        d.stats[o] = gn;
+    }
+}
+
 }  // namespace
 
 extern "C" int rt_counter_add(int32_t* ctr, int32_t inc, rt_stream_t stream) {
@@ -424,6 +438,14 @@ extern "C" int rt_counter_add_if_zero(int32_t* ctr, int32_t inc, const uint32_t*
 extern "C" int rt_finish_step(int32_t* step, int32_t* active, const uint32_t* cond, const float* loss, rt_stream_t stream) {
     if (!step || !active) return RT_ERR_BADARG;
     hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, active, cond, loss);
+    RT_CHECK_LAUNCH();
+    return RT_OK;
+}
+
+extern "C" int rt_finish_stats(const rt_finish_desc* d, rt_stream_t stream) {
+    if (!d || !d->step || !d->active || d->n_src < 0 || d->n_src > RT_STATS_MAX) return RT_ERR_BADARG;
+    for (int i = 0; i < d->n_src; ++i) if (!d->src[i]) return RT_ERR_BADARG;
+    hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, *d);
     RT_CHECK_LAUNCH();
     return RT_OK;
 }

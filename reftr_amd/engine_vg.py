@@ -408,7 +408,7 @@ class CapturedTrainStep:
         inner._norm_side = not getattr(inner.store, "fused_norm", False)
         try:
             out = self._fwd_bwd(zero=True)
-            self.grad_norm = opt.finish_step(self.max_norm, loss=out[0])
+            self.grad_norm = opt.finish_step(self.max_norm, loss=out[0], stats=self._stats_spec())
             from . import hip as _H
             _H.mark("gradient norm done (step end)")
         finally:
@@ -518,10 +518,29 @@ class CapturedTrainStep:
         self._last = (losses.detach(), {k: v.detach() for k, v in loss_dict.items()})
         return self._last
 
+    def _stats_spec(self):
+        """The stats vector as rt_finish_stats writes it (deferred single-process schedule): (loss scalars sorted by name, whether the
+        failure word rides along, the static output vector) -- or None when a loss is not an fp32 device scalar (then _pack_stats)."""
+        ld = self._last[1]
+        names = tuple(sorted(ld))
+        srcs = [ld[k].reshape(1) for k in names]
+        if len(srcs) > 40 or any(not (t.is_cuda and t.dtype == torch.float32) for t in srcs):
+            self._stats_fused = False
+            return None
+        n = len(srcs) + (1 if self.fail_word is not None else 0) + 1
+        if getattr(self, "stats", None) is None or self.stats.numel() != n or not self.stats.is_cuda:
+            self.stats = torch.empty(n, dtype=torch.float32, device=srcs[0].device)
+        self.stat_names = names
+        self._stats_fused = True
+        return srcs, self.fail_word is not None, self.stats
+
     def _pack_stats(self):
         """Every scalar the loop reads from an iteration -- the unweighted losses (sorted by name) and the gradient norm -- in
         ONE static device vector (a single small kernel at the end of the graph): the engine fetches it with one device -> host
         copy per iteration instead of one .item() per meter (the reference: engine_vg.py:46-53,69-72, util/misc.py:156-160)."""
+        if getattr(self, "_stats_fused", False):      # rt_finish_stats wrote them (this iteration's finish_step)
+            self._stats_fused = False
+            return
         ld = self._last[1]
         self.stat_names = tuple(sorted(ld))
         # layout: [losses (sorted by name) | cooperative-launch failure word (when the model can raise one) | gradient norm]

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreftr_hip_lab.so" if os.environ.get("REFTR_LAB", "0") == "1" else "libreftr_hip.so")   # _build.py
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 _c_float_p = POINTER(c_float)
@@ -368,6 +368,7 @@ _SIGNATURES = {
     "rt_counter_add_if_zero": (c_int, [c_void_p, c_int32, c_void_p, c_int, c_void_p]),
     "rt_stamp": (c_int, [c_void_p, c_int, c_void_p]),
     "rt_finish_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rt_finish_stats": (c_int, [c_void_p, c_void_p]),
     "rt_adamw_mat": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_int, c_void_p]),
     "rt_adamw_chunks": (c_int, [POINTER(AdamWDesc), c_void_p, c_int, c_void_p]),
     "rt_qenc_fwd": (c_int, [POINTER(QencFwdDesc), c_void_p]),
@@ -1171,6 +1172,32 @@ def finish_step(step_dev, active, veto=None, loss=None):
     """*step_dev += 1, *active += 1 unless the veto word is set or the loss is not finite; else *active = 0 (rt_finish_step)."""
     _req(loss, torch.float32, "loss")
     _check(lib().rt_finish_step(_p(step_dev), _p(active), _p(veto), _p(loss), _stream()), "rt_finish_step")
+
+
+RT_STATS_MAX = 40
+
+
+class FinishDesc(Structure):
+    _fields_ = [("step", c_void_p), ("active", c_void_p), ("cond", c_void_p), ("loss", c_void_p),
+                ("sq", c_void_p), ("norm_scale", c_float), ("grad_norm", c_void_p),
+                ("src", c_void_p * RT_STATS_MAX), ("n_src", c_int), ("cond_in_stats", c_int), ("stats", c_void_p)]
+
+
+def finish_stats(step_dev, active, veto, loss, sq, norm_scale, grad_norm, srcs=(), cond_in_stats=False, stats=None):
+    """rt_finish_stats: the iteration's counters (as finish_step), grad_norm = sqrt(sq) * norm_scale and the stats vector
+    [*srcs | float(veto word) | grad_norm] in one launch.  `srcs`: fp32 device scalars (tensors of one element)."""
+    assert len(srcs) <= RT_STATS_MAX
+    for t in list(srcs) + [loss, sq, grad_norm, stats]:
+        _req(t, torch.float32, "finish_stats operand")
+    d = FinishDesc()
+    d.step, d.active, d.cond, d.loss = _p(step_dev), _p(active), _p(veto), _p(loss)
+    d.sq, d.norm_scale, d.grad_norm = _p(sq), float(norm_scale), _p(grad_norm)
+    for i, t in enumerate(srcs):
+        d.src[i] = _p(t)
+    d.n_src, d.cond_in_stats, d.stats = len(srcs), int(bool(cond_in_stats)), _p(stats)
+    if stats is not None:
+        assert stats.numel() == len(srcs) + int(bool(cond_in_stats)) + 1
+    _check(lib().rt_finish_stats(ctypes.byref(d), _stream()), "rt_finish_stats")
 
 
 def stamp(buf, idx):

@@ -816,7 +816,9 @@ class RefTR(nn.Module):
             # rt_head_loss ran the head's backward-data with the forward: what is left are the weight gradients (the last Linear's
             # bias gradient was accumulated in the launch) and the norm's parameter gradients, all off the chain's data path
             assert dlogits is None and dmasks is None
-            H.linear_wgrad(head["dl16"], sv["y2"], l2.gw, overwrite=st.claim(l2.gw))
+            # (the last Linear's [4, E] weight gradient rides with the grouped launches too: inline it was two launches on the loss ->
+            # decoder-backward chain)
+            net.big_wg.add(head["dl16"], sv["y2"], l2.gw, None, overwrite=st.claim(l2.gw))
             net._wgrad_only("bbox_embed.layers.1.", head["dy2"], sv["y1"])
             net._wgrad_only("bbox_embed.layers.0.", head["dy1"], sv["hs16"])
             net.ln_batch.jobs.append(H.LnPgJob(H._p(head["part_n"]), H._p(st.G[vt + "decoder.norm.weight"]),

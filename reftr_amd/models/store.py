@@ -86,6 +86,7 @@ class ParamStore:
         self.G = {n: self._view(self.flat_g, n, o) for n, (b, o) in self.offset.items() if b == "p"}
         # overwrite-mode bookkeeping (see the module docstring): registered matrices {data_ptr: (offset, numel)}
         self._ow, self._ow_table, self._armed, self._written, self._stale_tables = {}, None, False, set(), {}
+        self._zero_tab = None
         self.last_stale = ()
         # gradient-norm accumulator (hip._SQACC_MAP, rt_sqnorm_finish): the weight-gradient launches into the registered matrices add
         # |after|^2 - |before|^2 to these slots; `norm_valid` = the slots were cleared together with the gradients (optimizer.zero_grad)
@@ -103,7 +104,7 @@ class ParamStore:
         off = (gw.data_ptr() - self.flat_g.data_ptr()) // 4
         assert 0 <= off and off + gw.numel() <= self.flat_g.numel()
         self._ow[gw.data_ptr()] = (off, gw.numel())
-        self._ow_table, self._stale_tables = None, {}
+        self._ow_table, self._stale_tables, self._zero_tab = None, {}, None
         if self.fused_norm:
             from .. import hip as H
             import weakref
@@ -122,6 +123,24 @@ class ParamStore:
             self._ow_table = (torch.tensor(chunks, dtype=torch.int64, device=self.device), len(chunks) // 2)
         return self._ow_table
 
+    def _zero_table(self):
+        """The complement table plus the clip-norm accumulator slots (addressed relative to the gradient buffer: rt_zero_chunks takes
+        64-bit element offsets, both allocations are 512-byte aligned): ONE launch clears everything a backward accumulates into."""
+        if self._zero_tab is None:
+            table, n = self._complement_table()
+            extra = []
+            if self.fused_norm:
+                d = self.sq_slots.data_ptr() - self.flat_g.data_ptr()
+                assert d % 16 == 0
+                a, tot = 0, self.sq_slots.numel()
+                while a < tot:
+                    c = min(16384, tot - a)
+                    extra += [d // 4 + a, c]; a += c
+            if extra:
+                table = torch.cat([table, torch.tensor(extra, dtype=torch.int64, device=self.device)])
+            self._zero_tab = (table, n + len(extra) // 2)
+        return self._zero_tab
+
     def zero_for_backward(self, fast=True):
         """What optimizer.zero_grad does to the gradient buffer in front of a backward (fast: only the atomically-accumulated tensors
         are cleared, the weight matrices are overwritten by their first producer; REFTR_OVERWRITE=0 / a CPU store: the full clear),
@@ -129,7 +148,10 @@ class ParamStore:
         join (engine_vg: REFTR_ZERO_SIDE=2), off the loss -> backward chain."""
         import os
         if fast and os.environ.get("REFTR_OVERWRITE", "1") != "0" and self.flat_g.is_cuda:
-            self.arm_overwrite()
+            self.arm_overwrite()              # clears the norm accumulator in the same launch
+            if self.fused_norm:
+                self.norm_valid = True
+            return
         else:
             self.disarm()                     # a backward that was abandoned half-way must not leave overwrite mode armed
             self.flat_g.zero_()
@@ -152,7 +174,7 @@ class ParamStore:
         """Start of a training backward: clear the atomically-accumulated tensors only; until `finish_overwrite` the first
         `claim` of every registered matrix answers True (its producer overwrites)."""
         from .. import hip as H
-        table, n = self._complement_table()
+        table, n = self._zero_table()
         if n:
             H.zero_chunks(self.flat_g, table, n)
         self._armed, self._written = True, set()

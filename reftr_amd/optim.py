@@ -261,7 +261,7 @@ class FusedAdamW(torch.optim.Optimizer):
         return lrs
 
     @torch.no_grad()
-    def finish_step(self, max_norm, loss=None):
+    def finish_step(self, max_norm, loss=None, stats=None):
         """End of an iteration in deferred mode: total gradient norm, step counter, 'update pending' flag.  The weights
         are NOT touched; grad_norm holds this iteration's (pre-clip) norm like clip_grad_norm_'s return value.
         `loss` (device fp32 scalar, optional): the iteration's weighted total -- a non-finite value vetoes the update like the
@@ -273,9 +273,17 @@ class FusedAdamW(torch.optim.Optimizer):
         # same launch checks the loss.  `active` != 0 already (earlier iterations): a veto clears it
         if loss is not None and not (torch.is_tensor(loss) and loss.is_cuda and loss.dtype == torch.float32):
             loss = None
-        H.finish_step(self.step_dev, self.active, self.veto, loss.reshape(1) if loss is not None and loss.dim() == 0 else loss)
-        torch.sqrt(self.sq, out=self.grad_norm)
+        loss1 = loss.reshape(1) if loss is not None and loss.dim() == 0 else loss
         gs = getattr(self.model, "_grad_scale", 1.0)
+        if stats is not None:
+            # (srcs, with_veto_word, out): the loop's stats vector [losses | failure word | norm] written by the same launch
+            # (rt_finish_stats) -- the counters, the square root and the packing were four launches at the end of every replay
+            srcs, with_veto, out = stats
+            H.finish_stats(self.step_dev, self.active, self.veto, loss1, self.sq, gs, self.grad_norm, srcs=srcs,
+                           cond_in_stats=with_veto and self.veto is not None, stats=out)
+            return self.grad_norm
+        H.finish_step(self.step_dev, self.active, self.veto, loss1)
+        torch.sqrt(self.sq, out=self.grad_norm)
         if gs != 1.0:
             self.grad_norm.mul_(gs)
         return self.grad_norm

@@ -59,7 +59,7 @@ def test_struct_layouts_match_header(built):
                "rt_mask_post_desc": hip.MaskPostDesc, "rt_box_post_desc": hip.BoxPostDesc, "rt_cem_desc": hip.CemDesc,
                "rt_decoder_fwd_desc": hip.DecoderFwdDesc, "rt_decoder_bwd_desc": hip.DecoderBwdDesc,
                "rt_bottleneck_desc": hip.BottleneckDesc, "rt_qenc_fwd_desc": hip.QencFwdDesc,
-               "rt_head_loss_desc": hip.HeadLossDesc, "rt_qenc_bwd_desc": hip.QencBwdDesc}
+               "rt_head_loss_desc": hip.HeadLossDesc, "rt_qenc_bwd_desc": hip.QencBwdDesc, "rt_finish_desc": hip.FinishDesc}
     assert sorted(binding) == names
     prog = '#include <stdio.h>\n#include "reftr_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"

@@ -433,3 +433,32 @@ def test_a_non_finite_loss_never_arms_its_update(coop_env, monkeypatch, head_fus
     cap.flush()
     torch.cuda.synchronize()
     assert not torch.equal(model.store.flat_p, p0)
+
+
+def test_finish_stats_is_finish_step_plus_the_loops_numbers(hip):
+    """rt_finish_stats against the four launches it replaces (rt_finish_step, sqrt, dtype conversion, concatenation): counters and
+    veto behaviour identical, grad_norm = sqrt(sq) * scale, stats = [losses | failure word | norm] bit for bit."""
+    H = hip
+    dev = "cuda"
+    losses = torch.tensor([0.25, 1.5, 3.0, 0.125, 7.0], dtype=torch.float32, device=dev)
+    srcs = [losses[i:i + 1] for i in (3, 0, 4)]                           # scalars wherever they live, in any order
+    for veto_word, loss_val, expect_armed in ((0, 2.0, True), (3, 2.0, False), (0, float("nan"), False), (0, float("inf"), False)):
+        step = torch.tensor([7], dtype=torch.int32, device=dev); active = torch.tensor([1], dtype=torch.int32, device=dev)
+        veto = torch.tensor([veto_word], dtype=torch.int32, device=dev)
+        loss = torch.tensor([loss_val], dtype=torch.float32, device=dev)
+        sq = torch.tensor([6.25], dtype=torch.float32, device=dev); gn = torch.zeros(1, dtype=torch.float32, device=dev)
+        stats = torch.full((5,), -1.0, dtype=torch.float32, device=dev)
+        H.finish_stats(step, active, veto, loss, sq, 0.5, gn, srcs=srcs, cond_in_stats=True, stats=stats)
+        torch.cuda.synchronize()
+        assert int(step) == (8 if expect_armed else 7) and int(active) == (2 if expect_armed else 0)
+        assert float(gn) == 1.25
+        assert stats.tolist() == [0.125, 0.25, 7.0, float(veto_word), 1.25]
+        # the reference behaviour of the single launches
+        step2 = torch.tensor([7], dtype=torch.int32, device=dev); active2 = torch.tensor([1], dtype=torch.int32, device=dev)
+        H.finish_step(step2, active2, veto, loss)
+        assert int(step2) == int(step) and int(active2) == int(active)
+    # no veto word, no stats: counters and norm only
+    step = torch.tensor([0], dtype=torch.int32, device=dev); active = torch.tensor([0], dtype=torch.int32, device=dev)
+    sq = torch.tensor([4.0], dtype=torch.float32, device=dev); gn = torch.zeros(1, dtype=torch.float32, device=dev)
+    H.finish_stats(step, active, None, None, sq, 1.0, gn)
+    assert int(step) == 1 and int(active) == 1 and float(gn) == 2.0
