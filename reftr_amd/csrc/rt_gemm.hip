@@ -402,6 +402,13 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
             else if (a.N > 64 && (t128 >= 384 || (a.K >= 2048 && t128 >= 192))) hint = (!dense && (pipe & 1) && a.K >= 2048 && t128 <= 256) ? 252 : 51;
             else if (t12864 >= 256) hint = 21;
             else hint = (!dense && (pipe & 2)) ? 233 : 33;
+            // round 6 (profiles/r06c_sweep_*.txt): the K-parity ping-pong 128 x 128 form where ONE round of <= 256 tiles walks a long
+            // reduction -- layer3's 3 x 3 convolutions (K = 2304: 252 before) and its 1024 -> 256 products (K = 1024, 200 tiles: 21 before)
+            static const int pp = RT_TUNE("REFTR_PP", 0);      // off: loses 0.07-0.2 ms inside the step (profiles/r06_pingpong_gemm.txt)
+            if ((a.N & 7) == 0 && a.epi_lds && a.N >= 128) {
+                if ((pp & 1) && hint == 252) hint = (pp & 4) ? 351 : 352;
+                else if ((pp & 2) && dense && a.K >= 1024 && t128 >= 128 && t128 <= 256) hint = (pp & 4) ? 351 : 352;
+            }
         } else if (dma && tilev >= 2) {
             // round 2 (profiles/r02_tile_sweep_8wave.txt): the 128x128 tile runs on 8-wave workgroups (2 x 4 waves, 16 waves per CU
             // at two workgroups: beats the 4-wave form on every shape); it takes over the long reductions with >= 1.5 rounds of
@@ -449,6 +456,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         case 63: return launch_gemm_dma<128, 256, 2, 1, 8>(a, s);
         case 211: case 221: case 231: case 233: case 251: case 252: case 261: case 262:
         case 81: case 281: case 282: case 283: case 284: case 285: case 286: case 287: case 288: case 234: case 236: return rt_launch_gemm_pipe(a, hint, s);
+        case 351: case 321: case 323: case 331: case 352: case 322: case 332: return rt_launch_gemm_pp(a, hint, s);
         default: return RT_ERR_BADARG;
     }
 }

@@ -185,3 +185,5 @@ static __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n
 
 // rt_gemm_pipe.hip: software-pipelined LDS-DMA variants (hints 2xx)
 int rt_launch_gemm_pipe(const GemmArgs& a, int hint, hipStream_t s);
+// rt_gemm_pp.hip: K-parity ping-pong LDS-DMA variants (hints 3xx)
+int rt_launch_gemm_pp(const GemmArgs& a, int hint, hipStream_t s);

@@ -3,6 +3,7 @@
 #pragma once
 #include "rt_gemm_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -37,17 +38,23 @@ __device__ __forceinline__ void rt_dma16(const i32x4 rsrc, unsigned lds_base, in
 template <int BM, int BN, int MODE, int NS, int NW = 4, int PIPE = 0>
 __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, const bf16_t* __restrict__ wgt, const GemmArgs& p,
                                               const int bx, const int by, const int gx) {
-    constexpr int NT = 64 * NW, WM = NW / 2, RPP = NT / 8;        // threads, waves along m, rows one DMA pass covers
+    // PIPE = 2 (rt_gemm_pp.hip): the 8 waves are TWO 4-wave groups that each own the whole tile for every other K tile
+    // (K-parity ping-pong): staging and wave-tile geometry are those of a 4-wave workgroup, the epilogue is shared by all 8.
+    constexpr bool PP = PIPE == 2;                                 // the ping-pong form
+    constexpr int NWG = PP ? NW / 2 : NW;                  // waves of one compute group
+    constexpr int NT = 64 * NW, GT = 64 * NWG, WM = NWG / 2, RPP = GT / 8;   // threads, group threads, waves along m, rows one DMA pass covers
     constexpr int TM = BM / (16 * WM), TN = BN / 32;
     constexpr int AJ = BN / RPP, BJ = BM / RPP;
     static_assert(NW == 4 || NW == 8, "4 or 8 waves"); static_assert(AJ >= 1 && BJ >= 1 && TM >= 1, "tile too small for the wave count");
+    static_assert(!PP || (NW == 8 && (NS == 3 || NS == 4)), "ping-pong form: 8 waves, 3 or 4 stages");
     constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int LPT = AJ + BJ;                   // DMA instructions per thread per K tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = (t >> 6) % NWG;               // wave inside its compute group
+    const int grp = PP ? __builtin_amdgcn_readfirstlane(t >> 6) / NWG : 0;
     const int wn = wave & 1, wm = wave >> 1;
     const int li = lane & 15, lg = lane >> 4;
 
@@ -71,7 +78,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
         if (m0 >= Mloc) return;
     }
 
-    const int srow = t >> 3;
+    const int srow = (t % GT) >> 3;
     const int chunk = (t & 7) ^ (srow & 7);        // source-side swizzle
     constexpr int OOB = 0x7fffffff;
 
@@ -117,35 +124,7 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     const i32x4 rs_w = rt_make_rsrc(wgt, p.wgt_bytes), rs_x = rt_make_rsrc(src, p.src_bytes);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
 
-    auto issue_tile = [&](int buf) __attribute__((always_inline)) {
-        const unsigned bA = lds0 + buf * BUF_BYTES;      // this wave's 8-row group of each 32-row slab
-        const unsigned bB = bA + A_BYTES;
-        const int k0b = MODE == 3 ? ((kh * p.KW + kw) * p.SC + c0) * 2 : lk << 7;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) rt_dma16(rs_w, bA + j * (RPP * 128), a_off[j], k0b);
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            if (MODE == 0) {
-                rt_dma16(rs_x, bB + j * (RPP * 128), b_off[j], k0b);
-            } else {
-                bool ok;
-                int sy, sx;
-                if (MODE == 1) { sy = b_y[j] + kh * p.dil; sx = b_x[j] + kw * p.dil; ok = true; }
-                else if (MODE == 3) {
-                    const int ny_ = b_y[j] - kh, nx_ = b_x[j] - kw;      // even by construction of the class
-                    ok = (ny_ | nx_) >= 0;
-                    sy = ny_ >> 1; sx = nx_ >> 1;
-                } else {
-                    const int ny = b_y[j] - kh * p.dil, nx = b_x[j] - kw * p.dil;
-                    const int msk = p.stride - 1;
-                    ok = ((ny | nx) >= 0) && (((ny | nx) & msk) == 0);
-                    sy = ny >> p.sshift; sx = nx >> p.sshift;
-                }
-                ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
-                const int off = (b_off[j] + (sy * p.SW + sx) * p.SC) * 2;
-                rt_dma16(rs_x, bB + j * (RPP * 128), ok ? off : OOB, c0 * 2);
-            }
-        }
+    auto advance_k = [&]() __attribute__((always_inline)) {      // the K-tile cursor (lk, kh, kw, c0) one tile on; saturates at the last tile
         if (lk + 1 < nk) {
             ++lk;
             if (MODE == 3) {
@@ -157,6 +136,39 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
             }
         }
     };
+    // piece i of the current K tile: i < AJ -> 8-row group (this wave's) of weight slab i, else of activation slab i - AJ
+    auto issue_piece = [&](int buf, int i) __attribute__((always_inline)) {
+        const unsigned bA = lds0 + buf * BUF_BYTES;      // this wave's 8-row group of each 32-row slab
+        const unsigned bB = bA + A_BYTES;
+        const int k0b = MODE == 3 ? ((kh * p.KW + kw) * p.SC + c0) * 2 : lk << 7;
+        if (i < AJ) { rt_dma16(rs_w, bA + i * (RPP * 128), a_off[i], k0b); return; }
+        const int j = i - AJ;
+        if (MODE == 0) {
+            rt_dma16(rs_x, bB + j * (RPP * 128), b_off[j], k0b);
+        } else {
+            bool ok;
+            int sy, sx;
+            if (MODE == 1) { sy = b_y[j] + kh * p.dil; sx = b_x[j] + kw * p.dil; ok = true; }
+            else if (MODE == 3) {
+                const int ny_ = b_y[j] - kh, nx_ = b_x[j] - kw;      // even by construction of the class
+                ok = (ny_ | nx_) >= 0;
+                sy = ny_ >> 1; sx = nx_ >> 1;
+            } else {
+                const int ny = b_y[j] - kh * p.dil, nx = b_x[j] - kw * p.dil;
+                const int msk = p.stride - 1;
+                ok = ((ny | nx) >= 0) && (((ny | nx) & msk) == 0);
+                sy = ny >> p.sshift; sx = nx >> p.sshift;
+            }
+            ok = ok && (unsigned)sy < (unsigned)p.SH && (unsigned)sx < (unsigned)p.SW;
+            const int off = (b_off[j] + (sy * p.SW + sx) * p.SC) * 2;
+            rt_dma16(rs_x, bB + j * (RPP * 128), ok ? off : OOB, c0 * 2);
+        }
+    };
+    auto issue_only = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) issue_piece(buf, i);
+    };
+    auto issue_tile = [&](int buf) __attribute__((always_inline)) { issue_only(buf); advance_k(); };
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* bA = smem + buf * BUF_BYTES;
         const unsigned char* bB = bA + A_BYTES;
@@ -218,7 +230,117 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
         }
     }
 
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 2) {
+        // K-parity ping-pong (round 6).  At one workgroup per CU (the 200-tile convolutions at B = 8) the loops below run the operand
+        // DMA (0.33 us per K tile alone) and the MFMA side (0.49 us alone: barrier -> ds_read latency -> MFMAs, every wave in
+        // lockstep) one after the other (0.65-0.72 us together, profiles/r05_gemm_abl_conv128.txt).  Here the two waves of a SIMD are
+        // never in the same kind of segment: group g (waves 4g .. 4g+3, one per SIMD) owns the K tiles of parity g with the WHOLE
+        // output tile as 2 x 2 wave tiles of (BM/2) x (BN/2), and the workgroup's timeline is a sequence of INTERVALS separated by
+        // one raw s_barrier each,
+        //     interval i:   group i&1      M(i):   per DMA piece of tile i+NS-1 two ds_read_b128 of tile i's fragments, counted waits
+        //                   other group    X(i-1): the 2 * TN * TM MFMAs of tile i-1, nothing else
+        // so every SIMD's matrix pipe has one wave issuing back-to-back MFMAs while its partner reads LDS and feeds the DMA queue:
+        // one barrier per K tile (not two), 64 KB of fragment reads per 128 x 128 x 64 tile (64 x 64 wave tiles) instead of 96 KB,
+        // no over-fetch past the last tile.  The groups' partial sums meet once, in the LDS-staged epilogue.
+        //   NS = 4: tile k is issued in M(k-3) by the OTHER group, which waits for its pieces in M(k-1) (vmcnt leaves tile k+2 out).
+        //   NS = 3: tile k is issued in M(k-2) by its OWN group, which waits for its pieces (vmcnt 0) behind the MFMAs of X(k-2).
+        //   RAW  either way the wait precedes the barrier that ends interval k-1, and M(k) reads the tile after that barrier.
+        //   WAR  stage (i+NS-1) % NS held tile i-1: read in M(i-1), RETIRED (lgkmcnt(0)) before the barrier ending interval i-1.
+        // Measured (profiles/r06*_pp_*, LAB_NOTES.md round 6): MFMA segment 544-690 cycles, memory segment ~1050 (16 reads at ~23 + 8
+        // pieces at ~85, additive in one in-order wave whether interleaved or not) -- 1.5-5 % faster than the pipelined form on the
+        // layer3 shapes back to back, SLOWER inside the step at 4 stages (128 KB: no other stream's workgroup fits beside it).
+        constexpr int DEPTH = NS - 1;
+#ifdef RT_LAB       // probes (REFTR_GEMM_ABL): 1 no operand DMA, 2 no MFMAs, 8 no fragment reads (wrong results); 32 no priority raise (correct)
+#define PP_ABL(bit) (p.abl & (bit))
+#else
+#define PP_ABL(bit) false
+#endif
+        auto bar = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+        };
+        auto issue_adv = [&](int stage) __attribute__((always_inline)) { issue_only(stage); advance_k(); advance_k(); };
+        bf16x8 fa[2][TN], fb[2][TM];
+        if (PP_ABL(8)) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a) fa[kk][a] = bf16x8{};
+#pragma unroll
+                for (int b = 0; b < TM; ++b) fb[kk][b] = bf16x8{};
+            }
+        }
+        // the prologue stands in for the memory segments before interval 0
+        if (!PP_ABL(1)) {
+            if constexpr (NS == 4) {                                           // group g issues the tiles of parity g ^ 1
+                if (grp == 0) {
+                    advance_k();
+                    if (1 < nk) issue_adv(1);
+                } else {
+                    issue_adv(0);
+                    if (2 < nk) { issue_adv(2); rt_wait_vmcnt<LPT>(); } else rt_wait_vmcnt<0>();        // tile 0 landed
+                }
+            } else {                                                           // group g issues its own tiles
+                if (grp) advance_k();
+                if (grp < nk) issue_adv(grp);
+                rt_wait_vmcnt<0>();
+            }
+        }
+        bar();                                                                 // ... everyone's pieces
+        const int iters = (nk >> 1) + (grp == 0 ? 1 : 0);
+        if (grp) bar();                                                        // group 1 idles through interval 0
+        int rs = grp, ws = (grp + DEPTH) % NS;                                 // stage of tile j / of tile j + DEPTH
+        for (int it = 0, j = grp; it < iters; ++it, j += 2) {
+            if (j < nk) {                                                      // M(j)
+                const unsigned char* rA = smem + rs * BUF_BYTES;
+                const unsigned char* rB = rA + A_BYTES;
+                auto m_body = [&](auto with_dma) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = 0; i < LPT; ++i) {
+                        if constexpr (decltype(with_dma)::value) issue_piece(ws, i);
+                        if (!PP_ABL(8)) {
+#pragma unroll
+                            for (int r = 2 * i; r < 2 * i + 2; ++r) {          // read r of the tile: kk-major, weights then activations
+                                const int kk = r / LPT, q = r % LPT;
+                                const int slot = ((kk * 4 + lg) ^ (li & 7)) << 4;
+                                if (q < TN) fa[kk][q] = *reinterpret_cast<const bf16x8*>(rA + (wn * (BN / 2) + q * 16 + li) * 128 + slot);
+                                else fb[kk][q - TN] = *reinterpret_cast<const bf16x8*>(rB + (wm * (BM / WM) + (q - TN) * 16 + li) * 128 + slot);
+                            }
+                        }
+                    }
+                };
+                if (!PP_ABL(1) && j + DEPTH < nk) { m_body(std::true_type{}); advance_k(); advance_k(); }
+                else m_body(std::false_type{});
+                if (NS == 4 && !PP_ABL(1)) { if (j + DEPTH < nk) rt_wait_vmcnt<LPT>(); else rt_wait_vmcnt<0>(); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            bar();
+            if (j < nk) {                                                      // X(j)
+                if (!PP_ABL(2)) {
+                    if (!PP_ABL(32)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int a = 0; a < TN; ++a)
+#pragma unroll
+                            for (int b = 0; b < TM; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][a], fb[kk][b], acc[a][b], 0, 0, 0);
+                    if (!PP_ABL(32)) __builtin_amdgcn_s_setprio(0);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                        for (int a = 0; a < TN; ++a) asm volatile("" ::"v"(fa[kk][a]));
+#pragma unroll
+                        for (int b = 0; b < TM; ++b) asm volatile("" ::"v"(fb[kk][b]));
+                    }
+                }
+                if (NS == 3) rt_wait_vmcnt<0>();                               // this group's tile j+2 has landed (its pieces)
+            }
+            bar();
+            rs = (rs + 2) % NS; ws = (ws + 2) % NS;
+        }
+        if (grp) bar();
+    } else if constexpr (PIPE == 1) {
         // Software-pipelined K loop (round 3).  The loop above is a DEPENDENT chain per K tile -- barrier -> fragment reads
         // (ds_read latency) -> MFMAs -> barrier, ~800 cycles for 128-256 cycles of MFMA work per wave -- that only other
         // resident workgroups hide (profiles/r02_tile_sweep_8wave.txt).  Here the MFMA fragments of tile kt+1 are read from LDS
@@ -314,10 +436,31 @@ __device__ __forceinline__ void gemm_dma_body(const bf16_t* __restrict__ src, co
     static_assert((size_t)ROWS * EP_LD * 4 <= (size_t)NS * BUF_BYTES, "epilogue tile does not fit the LDS stages");
     if (epi_lds) {
         float* tile = reinterpret_cast<float*>(smem);
+        if constexpr (PP) {
+            // the two groups' partial sums (odd / even K tiles) meet here: group 1 parks its accumulators in the fp32 tile, group 0
+            // adds them to its own at the same lane positions (same wave tiling in both groups) and carries on as the tile's one owner
+            static_assert(HALVES == 1, "ping-pong form: the fp32 tile must fit the stages");
+            __syncthreads();
+            if (grp == 1) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        *reinterpret_cast<f32x4*>(tile + (wm * (BM / WM) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4) = acc[a][b];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] += *reinterpret_cast<const f32x4*>(tile + (wm * (BM / WM) + b * 16 + li) * EP_LD + wn * (BN / 2) + a * 16 + lg * 4);
+            }
+        }
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
             __syncthreads();    // every wave has drained its own DMA tail (vmcnt 0 above) and finished reading the stages / tile
-            if (HALVES == 1 || wm / (WM / 2) == h) {
+            if (PP ? grp == 0 : (HALVES == 1 || wm / (WM / 2) == h)) {
 #pragma unroll
                 for (int a = 0; a < TN; ++a)
 #pragma unroll

@@ -56,6 +56,19 @@ def hash_keep(seed, idx, p):
     (333, 320, 72, 287), (320, 2304, 768, 288), (3520, 2048, 256, 234), (129, 64, 68, 234), (3520, 2048, 256, 236), (200, 256, 256, 236),
     (700, 256, 264, 261), (3520, 2048, 256, 262),
     (200, 256, 256, 211), (700, 320, 264, 251), (3520, 2048, 256, 252), (129, 64, 68, 251), (12800, 256, 1024, 251),
+    # K-parity ping-pong forms (two 4-wave groups alternate memory / MFMA segments, 4 stages, 3 tiles in flight): 1, 2, 3, 4, 5, 6
+    # K tiles (prologue-only, first steady iteration, odd and even counts, the empty trailing iteration of group 0) and many;
+    # ragged M and N (N a multiple of 8: the groups' partial sums meet in the LDS-staged epilogue)
+    (129, 64, 72, 351), (200, 128, 256, 351), (333, 192, 264, 351), (200, 256, 256, 351), (700, 320, 264, 351), (333, 384, 136, 351),
+    (3520, 2048, 256, 351), (12800, 256, 1024, 351), (320, 3072, 768, 351), (1000, 2304, 256, 351),
+    (129, 64, 72, 331), (333, 192, 72, 331), (200, 256, 256, 331), (320, 768, 3072, 331), (3520, 2048, 256, 331), (50, 320, 40, 331),
+    (129, 64, 72, 321), (333, 320, 72, 321), (3520, 2048, 256, 321), (700, 128, 264, 321),
+    (129, 64, 72, 323), (333, 320, 72, 323), (3520, 2048, 256, 323), (700, 128, 264, 323),
+    # three-stage ping-pong forms (the issuing group waits behind its MFMA segment)
+    (129, 64, 72, 352), (200, 128, 256, 352), (333, 192, 264, 352), (200, 256, 256, 352), (700, 320, 264, 352), (333, 384, 136, 352),
+    (3520, 2048, 256, 352), (12800, 256, 1024, 352), (320, 3072, 768, 352), (1000, 2304, 256, 352),
+    (129, 64, 72, 332), (333, 192, 72, 332), (320, 768, 3072, 332), (3520, 2048, 256, 332), (50, 320, 40, 332),
+    (129, 64, 72, 322), (333, 320, 72, 322), (3520, 2048, 256, 322), (700, 128, 264, 322),
 ])
 def test_linear_fwd(hip, M, K, N, hint):
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -70,7 +83,8 @@ def test_linear_fwd(hip, M, K, N, hint):
     assert torch.allclose(of.cpu()[M - 1, N - 1], ref[M - 1, N - 1], rtol=1e-4, atol=1e-4)
 
 
-def test_linear_epilogue(hip):
+@pytest.mark.parametrize("hint", [0, 351, 331, 321, 352, 332])
+def test_linear_epilogue(hip, hint):
     g = torch.Generator().manual_seed(5)
     M, K, N = 333, 128, 192
     x = bf(torch.randn(M, K, generator=g)); w = bf(torch.randn(N, K, generator=g) / K ** 0.5)
@@ -80,19 +94,19 @@ def test_linear_epilogue(hip):
     lin = x.float() @ w.float().T + b
     xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
     for act, fn in [(hip.ACT_RELU, torch.relu), (hip.ACT_GELU, F.gelu), (hip.ACT_TANH, torch.tanh)]:
-        _, of = hip.linear(xc, wc, bias=bc, act=act, out_bf16=False, out_f32=True)
+        _, of = hip.linear(xc, wc, bias=bc, act=act, out_bf16=False, out_f32=True, tile_hint=hint)
         assert rel(of, fn(lin)) < 1e-4, act
-    _, of = hip.linear(xc, wc, bias=bc, res_f32=rf.cuda(), res_bf16=rb.cuda(), out_bf16=False, out_f32=True)
+    _, of = hip.linear(xc, wc, bias=bc, res_f32=rf.cuda(), res_bf16=rb.cuda(), out_bf16=False, out_f32=True, tile_hint=hint)
     assert rel(of, lin + rf + rb.float()) < TOL_F32
-    _, of = hip.linear(xc, wc, bias=bc, gate=gate.cuda(), gate_scale=1.25, out_bf16=False, out_f32=True)
+    _, of = hip.linear(xc, wc, bias=bc, gate=gate.cuda(), gate_scale=1.25, out_bf16=False, out_f32=True, tile_hint=hint)
     assert rel(of, lin * (gate.float() > 0) * 1.25) < TOL_F32
-    _, of = hip.linear(xc, wc, bias=bc, preact=pre.cuda(), out_bf16=False, out_f32=True)
+    _, of = hip.linear(xc, wc, bias=bc, preact=pre.cuda(), out_bf16=False, out_f32=True, tile_hint=hint)
     u = pre.float().requires_grad_(True)
     F.gelu(u).sum().backward()
     assert rel(of, lin * u.grad) < 1e-4
     # dropout: mask must be the documented hash of (seed, m*N+n)
     p, seed = 0.1, 1234
-    _, of = hip.linear(xc, wc, bias=bc, drop_p=p, drop_seed=seed, out_bf16=False, out_f32=True)
+    _, of = hip.linear(xc, wc, bias=bc, drop_p=p, drop_seed=seed, out_bf16=False, out_f32=True, tile_hint=hint)
     keep = torch.from_numpy(hash_keep(seed, np.arange(M * N, dtype=np.uint64), p).reshape(M, N))
     assert rel(of, lin * keep / (1 - np.float32(p))) < TOL_F32
     assert abs(float(keep.float().mean()) - 0.9) < 0.01
@@ -109,7 +123,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54, 61, 62, 63, 211, 221, 231, 233, 251, 252])
+@pytest.mark.parametrize("hint", [11, 12, 13, 21, 22, 31, 32, 33, 51, 52, 53, 54, 61, 62, 63, 211, 221, 231, 233, 251, 252, 351, 321, 323, 331, 352, 322, 332])
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", [CONV_CASES[1], CONV_CASES[4], CONV_CASES[2]])
 def test_conv_dma_variants(hip, hint, B, H, W, Ci, Co, k, s, p):
     """The LDS-DMA tile variants against torch fp32: forward gather and transposed (backward-data) gather."""
