@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 
 GF_PER_IMG = 219.56          # fwd+bwd matmul+conv GFLOP per image, cfg2 (SURVEY.md §8d / BASELINE.md §4)
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_BYTES_PER_S = 8.0e12  # HBM3E peak (MI355X_MICROARCH.md; ~6.3e12 achievable)
 
 
 def synth_batch(B, H, W, L, device, seed):
@@ -103,8 +104,10 @@ def cpu_baseline(B, H, W, L, max_seconds=28.0, sample_batch=2, threads=32):
         O.train_step(P, samples, targets, cfg, state, step, max_norm=0.1, train=True)
         times.append(time.time() - t0)
         step += 1
-    med = sorted(times)[len(times) // 2]
+    import statistics
+    med = statistics.median(times)                  # true median (mean of the middle two for an even count: ADVICE r05)
     return {"value": batch / med, "unit": "images/s", "cores": cores, "kind": "port", "batch": batch,
+            "timed_steps_s": [round(t, 3) for t in times], "warmup_steps_s": [round(t, 3) for t in warm_t],
             "sample": f"median of {len(times)} timed step(s) after {warm} warm-up(s) on {batch} images of the same workload "
                       f"({H}x{W}, L={L}, fp32, dropout on, clip 0.1, AdamW), torch CPU threads = {cores}"}
 
@@ -333,6 +336,12 @@ def main():
             roof["traffic"] = fam["hbm_bytes_per_step"] / max(len(recs), 1)
             roof["traffic_bytes_per_step"] = fam["hbm_bytes_per_step"]
             roof["traffic_kernel_dispatches_per_step"] = fam["kernel_dispatches_per_step"]
+            # the other roofline, side by side: the family's HBM bytes over the family's time against 8 TB/s
+            roof["hbm_frac"] = fam["hbm_bytes_per_step"] / (roof["kernel_ms_per_step"] * 1e-3) / PEAK_HBM_BYTES_PER_S
+            if fam.get("kernel_only_ms_per_step"):
+                # kernel durations only (rocprofv3 --kernel-trace of the same command under graph replay): no inter-launch gaps
+                roof["kernel_only_ms_per_step"] = fam["kernel_only_ms_per_step"]
+                roof["kernel_only_frac"] = fl / (fam["kernel_only_ms_per_step"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
             note = (f"HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) of the family's kernel dispatches per step / launches_per_step "
                     f"({os.path.basename(pmc)}, same build; one launch = one rt_conv_gemm / rt_conv_wgrad(_grouped) call, which may "
                     f"dispatch several kernels: tile kernel + split reduction)")

@@ -25,7 +25,7 @@ for step in "$@"; do
     region)    bash benchmarks/region_trace.sh $TAG 60; python benchmarks/qregion_trace.py 2>&1 | grep "^rt_" | tee $O/${TAG}_qregion_stages.txt ;;
     shapes)    timeout 600 python benchmarks/step_breakdown.py > $O/${TAG}_shape_breakdown.txt 2>&1; head -30 $O/${TAG}_shape_breakdown.txt ;;
     wgrad)     timeout 600 python benchmarks/wgrad_group_bench.py > $O/${TAG}_wgrad_group_bench.txt 2>&1; tail -8 $O/${TAG}_wgrad_group_bench.txt ;;
-    tiles)     FLUSH=1 ONLY=lin HINTS=0,31,33,51,21 timeout 600 python benchmarks/tile_sweep.py > $O/${TAG}_tile_sweep_cold.txt 2>&1; head -24 $O/${TAG}_tile_sweep_cold.txt ;;
+    tiles)     REFTR_LAB=1 FLUSH=1 ONLY=lin HINTS=0,31,33,51,21 timeout 600 python benchmarks/tile_sweep.py > $O/${TAG}_tile_sweep_cold.txt 2>&1; head -24 $O/${TAG}_tile_sweep_cold.txt ;;
     configs)   ( timeout 300 python benchmarks/cfg4_seg.py 2>&1 | grep hipgraph; timeout 300 python benchmarks/cfg5_stress.py 2>&1 | grep hipgraph; timeout 300 python benchmarks/eval_throughput.py 2>&1 | grep hipgraph ) > $O/${TAG}_other_configs.txt; cat $O/${TAG}_other_configs.txt ;;
     epoch)     timeout 600 python benchmarks/epoch_throughput.py 2>&1 | tail -1 > $O/${TAG}_epoch_throughput.json; cut -c1-400 $O/${TAG}_epoch_throughput.json ;;
     ab:*)      kv=${step#ab:}; VAR=${kv%%=*} VALS="$(echo ${kv#*=} | tr ',' ' ')" bash benchmarks/ab_env.sh | tee $O/${TAG}_ab_${kv%%=*}.txt ;;

@@ -15,17 +15,23 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 # REFTR_LAB=1 selects the LAB library: the same sources compiled with -DRT_LAB, in which the kernels' tuning switches (RT_TUNE in
 # csrc/rt_common.h: tile heuristics, split targets, ablation probes ...) are read from the environment.  The product library fixes
 # every one of them at its measured-best value and cannot be re-tuned (or put into a wrong-results probe mode) from outside.
+# The lab library also carries every tile / stage / schedule variant of rt_conv_gemm that was built and measured but is not chosen by the
+# product heuristics (reachable through tile_hint: tests/test_gemm_gpu.py, benchmarks/tile_sweep.py); the product library instantiates
+# only what it can launch.
 LAB = os.environ.get("REFTR_LAB", "0") == "1"
-OBJ_DIR = os.path.join(_HERE, "build", "obj_lab" if LAB else "obj")
-LIB_PATH = os.path.join(_HERE, "libreftr_hip_lab.so" if LAB else "libreftr_hip.so")
 ARCH = "gfx950"
+
+
+def _paths(lab):
+    return (os.path.join(_HERE, "build", "obj_lab" if lab else "obj"),
+            os.path.join(_HERE, "libreftr_hip_lab.so" if lab else "libreftr_hip.so"))
+
+
+OBJ_DIR, LIB_PATH = _paths(LAB)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-inline-asm"]
 
-
-if LAB:
-    FLAGS.append("-DRT_LAB")
 
 
 def _sources():
@@ -38,12 +44,12 @@ def _deps_mtime():
     return max(os.path.getmtime(d) for d in deps)
 
 
-def _compile_one(src, hdr_mtime, force):
-    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+def _compile_one(src, hdr_mtime, force, lab):
+    obj = os.path.join(_paths(lab)[0], os.path.basename(src)[:-4] + ".o")
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= hdr_mtime):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DRT_LAB"] if lab else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -52,13 +58,16 @@ def _compile_one(src, hdr_mtime, force):
     return obj, True
 
 
-def build(force=False, verbose=False):
-    """Compile every csrc/*.hip for gfx950 and link libreftr_hip.so.  Returns the library path."""
+def build(force=False, verbose=False, lab=None):
+    """Compile every csrc/*.hip for gfx950 and link libreftr_hip.so (lab=True: libreftr_hip_lab.so; None: what REFTR_LAB selects).
+    Returns the library path."""
+    lab = LAB if lab is None else bool(lab)
+    OBJ_DIR, LIB_PATH = _paths(lab)
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = _sources()
     hdr_mtime = _deps_mtime()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile_one(s, hdr_mtime, force), srcs))
+        results = list(ex.map(lambda s: _compile_one(s, hdr_mtime, force, lab), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(ch for _, ch in results)
     stale = os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs)   # interrupted link
@@ -90,4 +99,4 @@ def build_id():
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, lab=True if "--lab" in sys.argv else None)

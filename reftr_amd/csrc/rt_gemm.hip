@@ -14,6 +14,7 @@
 
 namespace {
 
+#ifdef RT_LAB      // the register-staged tiles of round 1 (hints 1-3): A/B baseline of the sweeps, lab library only
 // MODE 0: dense rows (1x1, stride 1, pad 0: every Linear and most bottleneck convs)
 // MODE 1: forward conv gather       MODE 2: transposed (backward-data) gather
 template <int BM, int BN, int MODE>
@@ -192,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const bf16_t* __restr
     }
 }
 
+#endif  // RT_LAB
+
 // Several independent dense products in ONE launch (descriptors by value in the kernel arguments: graph-safe, no device
 // tables): the q/k and v projections of an encoder layer, the twelve cross-attention K / V projections of the decoder, pairs
 // of backward-data products.  On the latency-bound transformer chains every launch costs ~4.5 us whatever it computes.
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel_v1(const bf16_t* __res
     if (n < p.N && li < p.M) epilogue4(p, li, n, acc);
 }
 
+#ifdef RT_LAB
 template <int BM, int BN>
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
@@ -303,6 +307,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     RT_CHECK_LAUNCH();
     return RT_OK;
 }
+
+#endif  // RT_LAB
 
 }  // namespace
 
@@ -433,30 +439,36 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         }
     }
     if (a.dil > 1 && hint >= 1 && hint <= 3) return RT_ERR_UNSUPPORTED;      // (REFTR_DMA=0)
+    // The product library instantiates only the variants its (constant) heuristics can choose; every other tile / stage / schedule
+    // variant that was built and measured (LAB_NOTES.md, profiles/*tile_sweep*) lives in the LAB library (-DRT_LAB), where the
+    // sweeps and tests/test_gemm_gpu.py reach it through tile_hint.  (Round 6: libreftr_hip.so 16.3 MB -> see DESIGN.md section 5.)
     switch (hint) {
-        case 1: return launch_gemm<128, 128>(a, s);
+        // LDS-DMA variants (tile, stages, min workgroups / CU[, waves])
+        case 21: return launch_gemm_dma<128, 64, 2, 2>(a, s);
+        case 31: return launch_gemm_dma<64, 64, 2, 4>(a, s);
+        case 33: return launch_gemm_dma<64, 64, 3, 3>(a, s);
+        case 51: return launch_gemm_dma<128, 128, 2, 2, 8>(a, s);
+        case 233: case 252: case 262: case 281: case 285: return rt_launch_gemm_pipe(a, hint, s);
+#ifdef RT_LAB
+        case 1: return launch_gemm<128, 128>(a, s);          // register-staged tiles (round 1)
         case 2: return launch_gemm<128, 64>(a, s);
         case 3: return launch_gemm<64, 64>(a, s);
-        // LDS-DMA variants (tile, stages, min workgroups / CU)
         case 11: return launch_gemm_dma<128, 128, 2, 2>(a, s);
         case 12: return launch_gemm_dma<128, 128, 3, 2>(a, s);
         case 13: return launch_gemm_dma<128, 128, 4, 2>(a, s);
-        case 21: return launch_gemm_dma<128, 64, 2, 2>(a, s);
         case 22: return launch_gemm_dma<128, 64, 3, 2>(a, s);
-        case 31: return launch_gemm_dma<64, 64, 2, 4>(a, s);
         case 32: return launch_gemm_dma<64, 64, 4, 2>(a, s);
-        case 33: return launch_gemm_dma<64, 64, 3, 3>(a, s);
         // 8-wave workgroups (2 x 4 waves) on the 128-row tiles
-        case 51: return launch_gemm_dma<128, 128, 2, 2, 8>(a, s);
         case 52: return launch_gemm_dma<128, 128, 3, 1, 8>(a, s);
         case 53: return launch_gemm_dma<128, 64, 2, 2, 8>(a, s);
         case 54: return launch_gemm_dma<128, 64, 3, 2, 8>(a, s);
         case 61: return launch_gemm_dma<256, 128, 2, 1, 8>(a, s);
         case 62: return launch_gemm_dma<256, 128, 3, 1, 8>(a, s);
         case 63: return launch_gemm_dma<128, 256, 2, 1, 8>(a, s);
-        case 211: case 221: case 231: case 233: case 251: case 252: case 261: case 262:
-        case 81: case 281: case 282: case 283: case 284: case 285: case 286: case 287: case 288: case 234: case 236: return rt_launch_gemm_pipe(a, hint, s);
+        case 211: case 221: case 231: case 251: case 261:
+        case 81: case 282: case 283: case 284: case 286: case 287: case 288: case 234: case 236: return rt_launch_gemm_pipe(a, hint, s);
         case 351: case 321: case 323: case 331: case 352: case 322: case 332: return rt_launch_gemm_pp(a, hint, s);
+#endif
         default: return RT_ERR_BADARG;
     }
 }

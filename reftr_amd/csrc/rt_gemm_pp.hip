@@ -3,6 +3,7 @@
 // barrier per K tile, four LDS stages, three tiles in flight.  Own translation unit so that it compiles beside rt_gemm.hip.
 #include "rt_gemm_dma.h"
 
+#ifdef RT_LAB        // measured slower inside the step than the pipelined forms (profiles/r06_pingpong_gemm.txt): lab library only
 int rt_launch_gemm_pp(const GemmArgs& a, int hint, hipStream_t s) {
     if ((a.N & 7) || !a.epi_lds) return RT_ERR_UNSUPPORTED;       // the groups' partial sums meet in the LDS-staged epilogue
     switch (hint) {
@@ -18,3 +19,6 @@ int rt_launch_gemm_pp(const GemmArgs& a, int hint, hipStream_t s) {
         default: return RT_ERR_BADARG;
     }
 }
+#else
+int rt_launch_gemm_pp(const GemmArgs&, int, hipStream_t) { return RT_ERR_BADARG; }
+#endif

@@ -444,9 +444,10 @@ __global__ __launch_bounds__(QT) void head_loss_kernel(const rt_head_loss_desc p
     }
     if (p.total && p.ticket && threadIdx.x == 0) {
         // the weighted total (engine_vg.py:43) by the LAST workgroup to get here, in layer order (reproducible): the loss stores above
-        // are write-through and drained, the ticket is an agent-scope atomic, the reads bypass this compute unit's L1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int old = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // are write-through, the reads bypass this compute unit's L1
+        // ordering at the language level: the ticket is an acquire-release agent-scope RMW -- this workgroup's loss
+        // stores happen-before the increment, and the workgroup that draws the last ticket sees every earlier one's stores
+        const int old = __hip_atomic_fetch_add(p.ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (old == p.NL - 1) {
             float tot = 0.f;
             for (int i = 0; i < p.NL; ++i) {

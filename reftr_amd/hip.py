@@ -4,6 +4,7 @@ PyTorch is used here only as the owner of device memory and of the HIP stream th
 on (torch.cuda.current_stream()).  There is NO fallback: if the library is missing or a kernel reports
 an error, a RuntimeError is raised.
 """
+import contextlib
 import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
@@ -378,26 +379,52 @@ _SIGNATURES = {
 }
 
 _lib = None
+LAB_LIB_PATH = os.path.join(_HERE, "libreftr_hip_lab.so")
+# rt_conv_gemm tile hints the PRODUCT library instantiates (what its heuristics can choose; csrc/rt_gemm.hip); every other measured
+# variant lives in the lab library only
+PRODUCT_TILE_HINTS = frozenset({0, 21, 31, 33, 51, 233, 252, 262, 281, 285})
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP kernel library is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc; no CPU fallback exists).")
+    L = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    v = L.rt_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"{os.path.basename(path)} ABI {v} != binding ABI {ABI_VERSION}; rebuild")
+    return L
 
 
 def lib():
     """Load libreftr_hip.so (once).  Fails loudly when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} not found: the HIP kernel library is not built. Run "
-                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc; no CPU fallback exists).")
-        L = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        v = L.rt_abi_version()
-        if v != ABI_VERSION:
-            raise RuntimeError(f"libreftr_hip.so ABI {v} != binding ABI {ABI_VERSION}; rebuild")
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+_lab_lib = None
+
+
+@contextlib.contextmanager
+def lab_library():
+    """Route this module's calls to the LAB build (libreftr_hip_lab.so, the same sources with -DRT_LAB) inside the block: tests and
+    sweeps of the rt_conv_gemm variants the product library does not instantiate.  Never used by the product path."""
+    global _lib, _lab_lib
+    if _lab_lib is None:
+        _lab_lib = _load(LAB_LIB_PATH)
+    prev = lib()
+    _lib = _lab_lib
+    try:
+        yield
+    finally:
+        _lib = prev
 
 
 def exported_symbols():

@@ -211,25 +211,6 @@ class RefTR(nn.Module):
             return None
         return net._dec_handoff[1:2]
 
-    def bert_layer_offsets(self):
-        """Flat-buffer offsets at which BERT encoder layer 0, 1, ... start, then the pooler's: piece boundaries of the pipelined
-        optimizer pass.  None when the layout is not layer-contiguous."""
-        st, nl = self.store, self.cfg.bert.layers
-        firsts = []
-        for pfx in [f"lang_backbone.encoder.layer.{i}." for i in range(nl)] + ["lang_backbone.pooler."]:
-            offs = [o for n, (b, o) in st.offset.items() if b == "p" and n.startswith(pfx)]
-            if not offs:
-                return None
-            firsts.append(min(offs))
-        bb, be = st.group_range[L.GROUP_BERT]
-        ok = all(a < b for a, b in zip(firsts, firsts[1:])) and bb < firsts[0] and firsts[-1] < be
-        # every parameter of layer i lies in [firsts[i], firsts[i+1])
-        for i, pfx in enumerate([f"lang_backbone.encoder.layer.{i}." for i in range(nl)]):
-            for n, (b, o) in st.offset.items():
-                if b == "p" and n.startswith(pfx) and not (firsts[i] <= o < firsts[i + 1]):
-                    ok = False
-        return firsts if ok else None
-
     def operands_emitted(self):
         """The optimizer's pass wrote every bf16 operand itself: nothing to rebuild except the K-concatenated copies."""
         self.net._refresh_kv_cat()

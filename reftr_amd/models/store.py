@@ -126,7 +126,12 @@ class ParamStore:
     def _zero_table(self):
         """The complement table plus the clip-norm accumulator slots (addressed relative to the gradient buffer: rt_zero_chunks takes
         64-bit element offsets, both allocations are 512-byte aligned): ONE launch clears everything a backward accumulates into."""
+        # the table bakes sq_slots' address RELATIVE to flat_g in (ADVICE r05): it is only valid for this pair of allocations
+        key = (self.flat_g.data_ptr(), self.sq_slots.data_ptr() if self.fused_norm else 0)
+        if self._zero_tab is not None and getattr(self, "_zero_tab_key", None) != key:
+            self._zero_tab = None
         if self._zero_tab is None:
+            self._zero_tab_key = key
             table, n = self._complement_table()
             extra = []
             if self.fused_norm:
@@ -142,16 +147,16 @@ class ParamStore:
         return self._zero_tab
 
     def zero_for_backward(self, fast=True):
-        """What optimizer.zero_grad does to the gradient buffer in front of a backward (fast: only the atomically-accumulated tensors
-        are cleared, the weight matrices are overwritten by their first producer; REFTR_OVERWRITE=0 / a CPU store: the full clear),
-        plus the clip-norm accumulator.  A method of the store so that the model can issue it on the language stream at the forward
-        join (engine_vg: REFTR_ZERO_SIDE=2), off the loss -> backward chain."""
+        """What optimizer.zero_grad does to the gradient buffer in front of a backward, plus the clip-norm accumulator.  fast: only
+        the atomically-accumulated tensors are cleared (the weight matrices are overwritten by their first producer) and the
+        accumulator slots go in the same launch; REFTR_OVERWRITE=0 or a CPU store: the full clear.  A method of the store so that
+        the model can issue it on the language stream at the forward join, off the loss -> backward chain.  Both branches end with
+        the norm accumulator cleared and marked valid."""
         import os
         if fast and os.environ.get("REFTR_OVERWRITE", "1") != "0" and self.flat_g.is_cuda:
-            self.arm_overwrite()              # clears the norm accumulator in the same launch
+            self.arm_overwrite()              # one launch: the accumulated tensors AND the norm accumulator slots
             if self.fused_norm:
                 self.norm_valid = True
-            return
         else:
             self.disarm()                     # a backward that was abandoned half-way must not leave overwrite mode armed
             self.flat_g.zero_()
@@ -162,7 +167,7 @@ class ParamStore:
                 # twins while armed -- so the twins are cleared with the masters (the previous step's all-reduced values would
                 # otherwise be exchanged and applied again)
                 g16.zero_()
-        self.begin_norm()                     # the producers' epilogues collect the clip norm from here on (rt_sqnorm_finish)
+            self.begin_norm()                 # the producers' epilogues collect the clip norm from here on (rt_sqnorm_finish)
 
     def begin_norm(self):
         """The gradients are (about to be) cleared / re-armed: clear the norm accumulator with them."""

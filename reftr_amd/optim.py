@@ -271,8 +271,11 @@ class FusedAdamW(torch.optim.Optimizer):
         # `veto` (the cooperative decoder's failure word): an iteration whose launches reported a hand-off timeout neither advances
         # the step counter nor arms its update -- decided on the device, so a replayed graph can never apply such an update; the
         # same launch checks the loss.  `active` != 0 already (earlier iterations): a veto clears it
-        if loss is not None and not (torch.is_tensor(loss) and loss.is_cuda and loss.dtype == torch.float32):
-            loss = None
+        # a device tensor of another dtype is converted (it used to be dropped silently, and with it the on-device
+        # "non-finite loss never arms the update" check); a host number cannot be checked on the device -- the loop's own
+        # math.isfinite exit (engine_vg.py:53-58) covers it, as it does for the data-parallel schedules, which pass no loss
+        if loss is not None:
+            loss = loss.detach().float() if (torch.is_tensor(loss) and loss.is_cuda) else None
         loss1 = loss.reshape(1) if loss is not None and loss.dim() == 0 else loss
         gs = getattr(self.model, "_grad_scale", 1.0)
         if stats is not None:

@@ -41,6 +41,6 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         return
     tr = terminalreporter
     tr.write_sep("=", "parity: measured vs gate (north_star states 1e-3 rel on bf16 logits; see README 'Parity, honestly')")
-    tr.write_line(f"{'test':58s} {'quantity':22s} {'measured':>10s} {'gate':>10s} {'measured/gate':>14s}")
+    tr.write_line(f"{'test':58s} {'quantity':64s} {'measured':>10s} {'gate':>10s} {'measured/gate':>14s}")
     for t, q, m, g in _PARITY_ROWS:
-        tr.write_line(f"{t[:58]:58s} {q[:22]:22s} {m:10.3e} {g:10.3e} {m / g if g else float('nan'):14.2f}")
+        tr.write_line(f"{t[:58]:58s} {q[:64]:64s} {m:10.3e} {g:10.3e} {m / g if g else float('nan'):14.2f}")

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, required=True, help="training steps the profiled command ran (warm-up included)")
     ap.add_argument("--json", default="")
     ap.add_argument("--bench-json", default="", help="bench.py's JSON line of the same build (build_id, launches_per_step)")
+    ap.add_argument("--stats-md", default="", help="tools/rocpd_stats.py table of the same build's `rocprofv3 --kernel-trace --stats -- python bench.py` run: "
+                    "the family's kernel-only time per step goes into the output (bench.py: roofline.kernel_only_frac)")
     a = ap.parse_args()
     f, w = per_kernel(a.fetch_db), per_kernel(a.write_db)
     rows, fam = [], dict(launches=0, fetch=0.0, write=0.0)
@@ -56,6 +58,20 @@ def main():
         "excluded_init_bytes": sum(r[2] + r[3] for r in rows if init.search(r[0])),
         "corrections": "fetch = 2 x FETCH_SIZE KB (gfx950 128-B requests tallied at 64 B); write = WRITE_SIZE KB",
     }
+    if a.stats_md:
+        # | kernel | calls | total ms | ... ; a step = one decoder_fwd_kernel dispatch (one cooperative launch per forward)
+        fam_ms, steps = 0.0, 0
+        for line in open(a.stats_md):
+            c = [x.strip() for x in line.split("|")]
+            if len(c) < 5 or not c[2].isdigit():
+                continue
+            if c[1].startswith("decoder_fwd_kernel"):
+                steps = int(c[2])
+            if FAMILY.search(c[1]):
+                fam_ms += float(c[3])
+        if steps:
+            res["gemm_family"]["kernel_only_ms_per_step"] = fam_ms / steps
+            res["gemm_family"]["kernel_only_source"] = "rocprofv3 --kernel-trace --stats of `python bench.py` (graph replay), sum of the family's kernel durations / steps"
     if a.bench_json:
         import os
         b = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
