@@ -415,6 +415,13 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
                 if ((pp & 1) && hint == 252) hint = (pp & 4) ? 351 : 352;
                 else if ((pp & 2) && dense && a.K >= 1024 && t128 >= 128 && t128 <= 256) hint = (pp & 4) ? 351 : 352;
             }
+#ifdef RT_LAB
+            // round 6: the short-K / wide-N dense products (a bottleneck's conv3 and the backward-data of its conv1, the encoder's
+            // linear1 and the backward-data of its linear2) are epilogue-bound; the activation-stationary form (rt_gemm_astat.hip) was
+            // built for them and is SLOWER (28.2 vs 25.0 us cold on layer3's 256 -> 1024, +0.17 ms in the step): lab switch, off
+            static const int astat = RT_TUNE("REFTR_ASTAT", 0);
+            if (astat && rt_gemm_astat_ok(a) && a.M >= 1024 && a.N >= 2 * a.K && a.N >= 256) hint = 501;
+#endif
         } else if (dma && tilev >= 2) {
             // round 2 (profiles/r02_tile_sweep_8wave.txt): the 128x128 tile runs on 8-wave workgroups (2 x 4 waves, 16 waves per CU
             // at two workgroups: beats the 4-wave form on every shape); it takes over the long reductions with >= 1.5 rounds of
@@ -450,6 +457,7 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         case 51: return launch_gemm_dma<128, 128, 2, 2, 8>(a, s);
         case 233: case 252: case 262: case 281: case 285: return rt_launch_gemm_pipe(a, hint, s);
 #ifdef RT_LAB
+        case 501: return rt_launch_gemm_astat(a, s);
         case 1: return launch_gemm<128, 128>(a, s);          // register-staged tiles (round 1)
         case 2: return launch_gemm<128, 64>(a, s);
         case 3: return launch_gemm<64, 64>(a, s);

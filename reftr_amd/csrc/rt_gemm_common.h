@@ -185,5 +185,8 @@ static __device__ __forceinline__ void epilogue8(const GemmArgs& p, int m, int n
 
 // rt_gemm_pipe.hip: software-pipelined LDS-DMA variants (hints 2xx)
 int rt_launch_gemm_pipe(const GemmArgs& a, int hint, hipStream_t s);
+// rt_gemm_astat.hip: activation-stationary form of the short-K / wide-N dense products (hint 501)
+bool rt_gemm_astat_ok(const GemmArgs& a);
+int rt_launch_gemm_astat(const GemmArgs& a, hipStream_t s);
 // rt_gemm_pp.hip: K-parity ping-pong LDS-DMA variants (hints 3xx)
 int rt_launch_gemm_pp(const GemmArgs& a, int hint, hipStream_t s);

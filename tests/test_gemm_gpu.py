@@ -71,6 +71,9 @@ def hash_keep(seed, idx, p):
     (129, 64, 72, 331), (333, 192, 72, 331), (200, 256, 256, 331), (320, 768, 3072, 331), (3520, 2048, 256, 331), (50, 320, 40, 331),
     (129, 64, 72, 321), (333, 320, 72, 321), (3520, 2048, 256, 321), (700, 128, 264, 321),
     (129, 64, 72, 323), (333, 320, 72, 323), (3520, 2048, 256, 323), (700, 128, 264, 323),
+    # activation-stationary form (rt_gemm_astat.hip: K = 128 / 256 only): ragged rows / columns, one column tile, split column ranges
+    (129, 128, 72, 501), (333, 256, 264, 501), (64, 128, 512, 501), (1000, 256, 1024, 501), (12800, 256, 1024, 501), (3520, 256, 2048, 501),
+    (51200, 128, 512, 501), (200, 256, 256, 501), (50, 256, 40, 501),
     # three-stage ping-pong forms (the issuing group waits behind its MFMA segment)
     (129, 64, 72, 352), (200, 128, 256, 352), (333, 192, 264, 352), (200, 256, 256, 352), (700, 320, 264, 352), (333, 384, 136, 352),
     (3520, 2048, 256, 352), (12800, 256, 1024, 352), (320, 3072, 768, 352), (1000, 2304, 256, 352),
@@ -91,7 +94,7 @@ def test_linear_fwd(hip, M, K, N, hint):
     assert torch.allclose(of.cpu()[M - 1, N - 1], ref[M - 1, N - 1], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("hint", [0, 351, 331, 321, 352, 332])
+@pytest.mark.parametrize("hint", [0, 501, 351, 331, 321, 352, 332])
 def test_linear_epilogue(hip, hint):
     with lib_for(hip, hint):
         _linear_epilogue(hip, hint)
