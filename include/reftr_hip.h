@@ -78,7 +78,8 @@ typedef struct rt_conv_gemm_desc {
     float    gate_scale;
     float    drop_p;
     uint32_t drop_seed;
-    int32_t  tile_hint;     /* 0 = auto; otherwise 1: 128x128, 2: 128(m)x64(n), 3: 64x64 */
+    int32_t  tile_hint;     /* 0 = auto (the product path); otherwise a tile / stage / schedule variant by number (csrc/rt_gemm.hip): the product library
+                               answers RT_ERR_BADARG for the variants only the lab library (-DRT_LAB) instantiates */
     void*    out_preact;    /* bf16 [M, N] or NULL: value after +bias, BEFORE act (saved for GELU backward) */
     const void* dtanh;      /* bf16 [M, N] or NULL: out *= (1 - dtanh^2)  (backward of a tanh output, BERT pooler) */
     int32_t  res_first;     /* 1: add res_* BEFORE act (bottleneck tail relu(bn(conv) + identity)); 0: after dropout */
