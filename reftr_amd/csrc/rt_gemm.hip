@@ -11,6 +11,7 @@
 // zero) -> XOR-swizzled LDS (slot ^= row&7, conflict-free for ds_read_b128 fragment reads), LDS double
 // buffered with ONE barrier per K tile; next tile's global loads are in flight under the MFMAs.
 #include "rt_gemm_dma.h"
+#include <stdio.h>
 
 namespace {
 
@@ -402,10 +403,12 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
             // round 4 (profiles/r04o_deep_stage_cold.txt): at <= 1 workgroup per CU the 32 x 32 form is bound by the K tiles it keeps in
             // flight -- 6 stages instead of 3 take the cold K >= 768 products from 17.3 / 14.6 / 7.8 us to 11.1 / 9.9 / 5.8 (8 stages: no better)
             static const int deep = RT_TUNE("REFTR_DEEP", 1);
+            static const int k1024 = RT_TUNE("REFTR_K1024", 1);
             if (dense && smallt && a.M <= 1024 && t64 < 256 && (a.N & 7) == 0) hint = t64 <= 96 ? ((deep && a.K >= 512) ? 285 : 281) : 33;
             else if (a.K < 1024) hint = (a.N >= 128 && t128 >= 384 && t128 <= 512) ? 51 : 31;
             else if (dense && a.K >= 2048 && a.N >= 128 && t256 >= 512) hint = 262;     // big products only; none in the step
             else if (a.N > 64 && (t128 >= 384 || (a.K >= 2048 && t128 >= 192))) hint = (!dense && (pipe & 1) && a.K >= 2048 && t128 <= 256) ? 252 : 51;
+            else if (k1024 && dense && a.N > 64 && a.K >= 1024 && t128 >= 192) hint = 51;      // layer3's 1024 -> 256 (200 tiles): 18.6-19.1 us cold against 21.7-22.9 on hint 21
             else if (t12864 >= 256) hint = 21;
             else hint = (!dense && (pipe & 2)) ? 233 : 33;
             // round 6 (profiles/r06c_sweep_*.txt): the K-parity ping-pong 128 x 128 form where ONE round of <= 256 tiles walks a long
@@ -446,6 +449,22 @@ extern "C" int rt_conv_gemm(const rt_conv_gemm_desc* d, rt_stream_t stream) {
         }
     }
     if (a.dil > 1 && hint >= 1 && hint <= 3) return RT_ERR_UNSUPPORTED;      // (REFTR_DMA=0)
+#ifdef RT_LAB
+    // in-step autotune (benchmarks/instep_autotune.py): REFTR_HINT_OVERRIDE = "transposed,KH,stride,M,K,N=hint;..." replaces the heuristic's
+    // choice for exactly those launches; read on every call so that the script can re-capture the step with another table
+    if (d->tile_hint == 0) {
+        const char* ov = getenv("REFTR_HINT_OVERRIDE");
+        while (ov && *ov) {
+            int t_, kh_, s_, m_, k_, n_, h_, used = 0;
+            if (sscanf(ov, "%d,%d,%d,%d,%d,%d=%d%n", &t_, &kh_, &s_, &m_, &k_, &n_, &h_, &used) == 7) {
+                if (t_ == (a.transposed ? 1 : 0) && kh_ == a.KH && s_ == a.stride && m_ == a.M && k_ == a.K && n_ == a.N) { hint = h_; break; }
+                ov += used;
+            }
+            while (*ov && *ov != ';') ++ov;
+            if (*ov == ';') ++ov;
+        }
+    }
+#endif
     // The product library instantiates only the variants its (constant) heuristics can choose; every other tile / stage / schedule
     // variant that was built and measured (LAB_NOTES.md, profiles/*tile_sweep*) lives in the LAB library (-DRT_LAB), where the
     // sweeps and tests/test_gemm_gpu.py reach it through tile_hint.  (Round 6: libreftr_hip.so 16.3 MB -> see DESIGN.md section 5.)
