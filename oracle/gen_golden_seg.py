@@ -29,7 +29,9 @@ def seg_targets(targets, B, H, W):
     return out
 
 
-def main():
+def main(dilation=False, tag="seg_single"):
+    """dilation=True (python oracle/gen_golden_seg.py --dilation): the same fixture for --masks with --dilation (DC5: layer4 keeps stride 16,
+    backbone.py:117-125 + reftr_segmentation.py:343-384) -> tests/golden/seg_dilation.npz."""
     torch.manual_seed(0); torch.set_num_threads(8)
     rt, crit, bb, vl, pp, misc = import_reference()
     import models.reftr_segmentation as seg
@@ -39,7 +41,7 @@ def main():
     from oracle.synth import make_inputs
     from oracle.weights import fill_state_dict
 
-    args = ref_args(enc_layers=2, dec_layers=2, masks=True, aux_loss=False)
+    args = ref_args(enc_layers=2, dec_layers=2, masks=True, aux_loss=False, dilation=dilation)
     with redirect_stdout(io.StringIO()):
         model = seg.RefTRSeg(bb.build_backbone(args), BertModel(BertConfig(num_hidden_layers=2, attn_implementation="eager")),
                              vl.build_vl_transformer(args), num_feature_levels=1, num_queries_per_phrase=1)
@@ -57,7 +59,7 @@ def main():
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
-    cfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False)
+    cfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False, dilation=dilation)
     shp = param_shapes(cfg)
     ref_shp = {k: tuple(v.shape) for k, v in sd.items() if torch.is_floating_point(v)}
     assert shp == ref_shp, (set(shp) ^ set(ref_shp), [k for k in shp if k in ref_shp and shp[k] != ref_shp[k]])
@@ -96,13 +98,16 @@ def main():
         g = grads[k]
         fixture["grad." + k] = (g[:8] if g.dim() > 1 and g.shape[0] > 8 else g).numpy()
     fixture.update({"loss." + k: np.float32(float(v)) for k, v in losses.items()})
-    np.savez_compressed(os.path.join(GOLD, "seg_single.npz"), **fixture)
+    np.savez_compressed(os.path.join(GOLD, tag + ".npz"), **fixture)
     print("oracle vs imported reference RefTRSeg (rel. error):")
     for k, v in report.items():
         print(f"  {k:14s} {v:.3e}")
     assert all(v < 2e-4 for v in report.values()), report
-    print("written", os.path.join(GOLD, "seg_single.npz"), {k: float(v) for k, v in losses.items()})
+    print("written", os.path.join(GOLD, tag + ".npz"), {k: float(v) for k, v in losses.items()})
 
 
 if __name__ == "__main__":
-    main()
+    if "--dilation" in sys.argv:
+        main(dilation=True, tag="seg_dilation")
+    else:
+        main()

@@ -1016,9 +1016,8 @@ def build_config(args):
     # main_vg.py but have NO effect in the reference either: freeze_lang_backbone is stored and never used,
     # reftr_transformer.py:128,152-157; freeze_backbone is never read; build_reftr_seg hard-codes freeze_reftr=False,
     # reftr_segmentation.py:375.  They are accepted and ignored here for the same behaviour.)
-    if getattr(args, "dilation", False) and bool(getattr(args, "masks", False)):
-        raise NotImplementedError("--dilation with --masks: the RES head's FPN assumes the stride-32 layer4 output "
-                                  "(models/reftr_segmentation.py:196-227); not built")
+    # (--dilation with --masks: built since round 6 -- the RES head takes its geometry from the feature maps it is given;
+    # tests/golden/seg_dilation.npz, tests/test_seg_gpu.py)
     pe = getattr(args, "position_embedding", "sine")
     if pe not in ("v2", "sine"):
         raise ValueError(f"not supported {pe}")                     # as position_encoding.py:95

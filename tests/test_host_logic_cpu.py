@@ -104,8 +104,9 @@ def test_unsupported_options_raise():
     l4 = m.body.blocks[3]
     assert m.cfg.dilation and [(b.conv2.stride, b.conv2.dil, b.conv2.pad) for b in l4] == [(1, 1, 1), (1, 2, 2), (1, 2, 2)]
     assert l4[0].down.stride == 1 and all(b.conv2.dil == 1 for st in m.body.blocks[:3] for b in st)
-    with pytest.raises(NotImplementedError):
-        build_reftr(ref_args(dilation=True, masks=True, aux_loss=False, reftr_type="transformer_single_phrase", dice_loss_coef=1.0, mask_loss_coef=1.0))
+    # --dilation with --masks builds since round 6 (reftr_segmentation.py:343-384): RefTRSeg on the dilated backbone
+    ms = build_reftr(ref_args(dilation=True, masks=True, aux_loss=False, reftr_type="transformer_single_phrase", dice_loss_coef=1.0, mask_loss_coef=1.0))[0]
+    assert ms.cfg.dilation and ms.cfg.masks and ms.seg is not None
 
 
 def test_oracle_post_process_segm_matches_reference_golden_exactly():

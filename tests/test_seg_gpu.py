@@ -22,12 +22,12 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def build_seg():
+def build_seg(dilation=False):
     from reftr_amd.models import layout as L
     from reftr_amd.models.criterion import CriterionVGOnePhraseSeg
     from reftr_amd.models.reftr_transformer import RefTR
-    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False)
-    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), masks=True)
+    ocfg = O.Cfg(enc_layers=2, dec_layers=2, bert=O.BertCfg(layers=2), masks=True, aux_loss=False, dilation=dilation)
+    cfg = L.ModelConfig(enc_layers=2, dec_layers=2, bert=L.BertConfig(layers=2), masks=True, dilation=dilation)
     P = formula_state(param_shapes(ocfg))
     model = RefTR(cfg, device="cuda", aux_loss=False)
     model.load_state_dict(P, strict=True)
@@ -56,9 +56,13 @@ def test_eval_forward_is_bit_reproducible(hip):
                 assert torch.equal(a[k], b[k]), k
 
 
-def test_refer_segmentation_vs_reference_golden(hip):
-    g = np.load(os.path.join(GOLD, "seg_single.npz"))
-    model, crit, P, ocfg = build_seg()
+@pytest.mark.parametrize("fixture", ["seg_single", "seg_dilation"])
+def test_refer_segmentation_vs_reference_golden(hip, fixture):
+    """seg_dilation (round 6): --masks with --dilation -- layer4 at stride 16 (/root/reference/models/modeling/backbone.py:117-125), the mask
+    head's first FPN level the same size as its input (/root/reference/models/reftr_segmentation.py:243-280, 343-384); golden vectors
+    minted from the imported reference by `oracle/gen_golden_seg.py --dilation`."""
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    model, crit, P, ocfg = build_seg(dilation=fixture == "seg_dilation")
     model.eval()
     samples, targets = seg_batch(g)
     s, tg = to_cuda(samples, targets)
@@ -106,9 +110,10 @@ def test_refer_segmentation_vs_reference_golden(hip):
         assert float(same) > 0.99
 
 
-def test_seg_gradients_vs_oracle_global(hip):
-    g = np.load(os.path.join(GOLD, "seg_single.npz"))
-    model, crit, P, ocfg = build_seg()
+@pytest.mark.parametrize("fixture", ["seg_single", "seg_dilation"])
+def test_seg_gradients_vs_oracle_global(hip, fixture):
+    g = np.load(os.path.join(GOLD, fixture + ".npz"))
+    model, crit, P, ocfg = build_seg(dilation=fixture == "seg_dilation")
     model.eval()
     samples, targets = seg_batch(g)
     names = [k for k in P if O.is_trainable(k) and torch.is_floating_point(P[k])]
