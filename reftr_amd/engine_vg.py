@@ -7,6 +7,7 @@ Differences that are deliberate and documented in INTEGRATION.md:
     torch.cuda.Stream() unconditionally, engine_vg.py:240).
 """
 import math
+import contextlib
 import os
 import sys
 
@@ -236,6 +237,25 @@ def _copy_batch(dst_s, dst_t, samples, targets):
 _CAPTURE_MODE = "thread_local"
 
 
+@contextlib.contextmanager
+def _capture(graph, **kw):
+    """`torch.cuda.graph(...)` with Python's cyclic garbage collector switched OFF for the duration of the capture.  A step's capture
+    runs ~1500 Python-level launches; a generation-2 collection in the middle of it can finalize an OLDER CapturedTrainStep (its graphs,
+    its private pool, its events) -- device frees and graph destruction inside an open capture.  Seen in round 6 as `Fatal Python error:
+    Aborted` with `Garbage-collecting` on the stack inside `flush_wgrads_side` during a capture, and as segfaults in later replays, once the
+    GPU suite held enough dead captures; torch's own context collects BEFORE the capture but does not stop a collection during it."""
+    import gc
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class CapturedTrainStep:
     """The loop body (engine_vg.py:40-72) captured into HIP graphs for one input shape.
 
@@ -319,18 +339,18 @@ class CapturedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()     # no collective in flight while capturing (see _CAPTURE_MODE)
             self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb, capture_error_mode=_CAPTURE_MODE):
+            with _capture(self.g_fb):
                 self.out = head()
             self.g_seg = []
             for name in self.phases:                 # the segment that FOLLOWS boundary `name`
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
+                with _capture(g, pool=self.g_fb.pool()):
                     stopped = inner.continue_backward()
                 self.g_seg.append(g)
             assert inner._bwd_gen is None, "backward did not run to its end during capture"
             self.g_bb = self.g_seg[-1] if self.g_seg else None
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
+            with _capture(self.g_opt, pool=self.g_fb.pool()):
                 tail()
             if self.deferred_dp:
                 self.grad_norm = optimizer.grad_norm
@@ -377,7 +397,7 @@ class CapturedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb, capture_error_mode=_CAPTURE_MODE):
+            with _capture(self.g_fb):
                 self.out = self._step_deferred()
             self.g_bb = self.g_opt = None
             self.grad_norm = opt.grad_norm
@@ -643,7 +663,7 @@ class CapturedTrainStep:
         self._lrs = [g["lr"] for g in self.optimizer.param_groups]
         self.g_opt = torch.cuda.CUDAGraph()
         sc = self.optimizer.step_count
-        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode=_CAPTURE_MODE):
+        with _capture(self.g_opt, pool=self.g_fb.pool()):
             self._opt()
         self.optimizer.step_count = sc
 
@@ -927,7 +947,7 @@ class CapturedForward:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+            with _capture(g):
                 out = self.model(s)
             ent = self.graphs[key] = (g, s, out)
         g, s, out = ent

@@ -22,6 +22,21 @@ def hip():
     return H
 
 
+@pytest.fixture(autouse=True)
+def _release_captures_between_tests():
+    """Dead CapturedTrainStep objects (hipGraphs + their private memory pools) are released BETWEEN tests, with the device idle, instead
+    of whenever the cyclic collector happens to run (round 6: collections inside a later test's capture / replay brought the suite down)."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
 # ---- measured-vs-gate table (VERDICT r04 item 7): parity tests call `record_parity(test, quantity, measured, gate)`; the rows are
 # printed as ONE table at the end of the run (GPU log: profiles/*_gpu_tests.log), so the distance to every gate is visible in one place.
 _PARITY_ROWS = []
@@ -36,7 +51,18 @@ def parity_table():
     return record_parity
 
 
+_NOTES = []
+
+
+@pytest.fixture()
+def suite_note():
+    """Lines a test wants in the run's terminal summary (e.g. the summary line of a child pytest process)."""
+    return _NOTES.append
+
+
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    for line in _NOTES:
+        terminalreporter.write_line(line)
     if not _PARITY_ROWS:
         return
     tr = terminalreporter

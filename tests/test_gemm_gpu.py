@@ -28,7 +28,7 @@ def lib_for(hip, hint):
     return contextlib.nullcontext()
 
 
-def test_lab_variants_in_child_process():
+def test_lab_variants_in_child_process(suite_note):
     """Every tile / stage / schedule variant of rt_conv_gemm that is not in the product library, against torch fp32, in a process of its own."""
     import subprocess, sys
     if LAB_CHILD:
@@ -38,6 +38,7 @@ def test_lab_variants_in_child_process():
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     tail = "\n".join(r.stdout.strip().splitlines()[-5:])
     print("\n[lab-library child] " + tail)
+    suite_note("[tests/test_gemm_gpu.py, lab-library child process (REFTR_LAB=1): the variants skipped above] " + r.stdout.strip().splitlines()[-1])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in tail and "skipped" not in tail, tail     # nothing is skipped under the lab library
 
