@@ -23,10 +23,13 @@ def hip():
 
 
 @pytest.fixture(autouse=True)
-def _release_captures_between_tests():
+def _release_captures_between_tests(request):
     """Dead CapturedTrainStep objects (hipGraphs + their private memory pools) are released BETWEEN tests, with the device idle, instead
-    of whenever the cyclic collector happens to run (round 6: collections inside a later test's capture / replay brought the suite down)."""
+    of whenever the cyclic collector happens to run (round 6: collections inside a later test's capture / replay brought the suite down).
+    (The kernel-level files never capture: skipped there, they are 450 of the suite's tests.)"""
     yield
+    if os.path.basename(str(request.node.fspath)) in ("test_gemm_gpu.py", "test_ops_gpu.py", "test_seg_ops_gpu.py", "test_post_gpu.py", "test_abi.py"):
+        return
     import gc
     gc.collect()
     try:
